@@ -1,0 +1,194 @@
+/*
+ * api.c — the exported h264bsd* C API (include/h264bsd_decoder.h) on top of the host parser and
+ * the HIP engine.  Mirrors the reference's public functions one to one
+ * (src/h264bsd_decoder.c:90-1370); see the header for the per-function citations.
+ *
+ * There is no CPU pixel path in this library: h264bsdInit() binds the instance to the HIP engine
+ * and fails loudly (stderr + HANTRO_NOK) when no gfx950 device is usable.  The only GPU-less mode is
+ * h264bsdmiInitCapture(), which produces frame jobs and never pixels.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/h264bsd_mi355x.h"
+#include "hostdec.h"
+#include "engine.h"
+
+HostDec *hd_create(int no_output_reordering);
+void hd_destroy(HostDec *d);
+int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes);
+
+typedef struct ApiDec {
+    HostDec *hd;
+    h264bsdmi_job_cb cb;
+    void *cb_user;
+} ApiDec;
+
+static ApiDec *dec_of(storage_t *s) { return s ? (ApiDec *)s->opaque : NULL; }
+
+/* ---- capture sink ---- */
+static int cap_configure(void *u, uint32_t w, uint32_t h, uint32_t n) { (void)u; (void)w; (void)h; (void)n; return 0; }
+static int cap_submit(void *u, const uint8_t *blob, uint32_t bytes)
+{
+    ApiDec *a = (ApiDec *)u;
+    if (a->cb) a->cb(a->cb_user, blob, bytes);
+    return 0;
+}
+
+static u32 init_common(storage_t *s, u32 no_reorder, h264bsdmi_job_cb cb, void *user, int capture)
+{
+    if (!s) return HANTRO_NOK;
+    memset(s, 0, sizeof(*s));
+    ApiDec *a = (ApiDec *)calloc(1, sizeof(ApiDec));
+    if (!a) return HANTRO_NOK;
+    a->hd = hd_create((int)no_reorder);
+    if (!a->hd) { free(a); return HANTRO_NOK; }
+    if (capture) {
+        a->cb = cb;
+        a->cb_user = user;
+        a->hd->sink.user = a;
+        a->hd->sink.configure = cap_configure;
+        a->hd->sink.submit = cap_submit;
+    } else if (eng_attach(&a->hd->sink)) {
+        fprintf(stderr, "h264bsd-mi355x: h264bsdInit failed: no usable HIP device (this library has no CPU pixel path)\n");
+        hd_destroy(a->hd);
+        free(a);
+        return HANTRO_NOK;
+    }
+    s->opaque = a;
+    return HANTRO_OK;
+}
+
+u32 h264bsdInit(storage_t *s, u32 noOutputReordering) { return init_common(s, noOutputReordering, NULL, NULL, 0); }
+u32 h264bsdmiInitCapture(storage_t *s, u32 noOutputReordering, h264bsdmi_job_cb cb, void *user)
+{
+    return init_common(s, noOutputReordering, cb, user, 1);
+}
+
+void h264bsdShutdown(storage_t *s)
+{
+    ApiDec *a = dec_of(s);
+    if (!a) return;
+    hd_destroy(a->hd);
+    free(a);
+    s->opaque = NULL;
+}
+
+storage_t *h264bsdAlloc(void) { return (storage_t *)calloc(1, sizeof(storage_t)); }
+void h264bsdFree(storage_t *s) { free(s); }
+
+u32 h264bsdDecode(storage_t *s, u8 *byteStrm, u32 len, u32 picId, u32 *readBytes)
+{
+    ApiDec *a = dec_of(s);
+    if (!a || !byteStrm || !len || !readBytes) return H264BSD_ERROR;
+    return (u32)hd_decode(a->hd, byteStrm, len, picId, readBytes);
+}
+
+static const OutPic *pop_output(ApiDec *a, u32 *picId, u32 *isIdrPic, u32 *numErrMbs)
+{
+    const OutPic *o = hd_dpb_next_output(&a->hd->dpb);
+    if (!o) return NULL;
+    if (picId) *picId = o->pic_id;
+    if (isIdrPic) *isIdrPic = o->is_idr;
+    if (numErrMbs) *numErrMbs = o->num_err_mbs;
+    return o;
+}
+
+u8 *h264bsdNextOutputPicture(storage_t *s, u32 *picId, u32 *isIdrPic, u32 *numErrMbs)
+{
+    ApiDec *a = dec_of(s);
+    if (!a) return NULL;
+    const OutPic *o = pop_output(a, picId, isIdrPic, numErrMbs);
+    if (!o || !a->hd->sink.fetch) return NULL;
+    return a->hd->sink.fetch(a->hd->sink.user, o->slot);
+}
+
+static u32 *next_converted(storage_t *s, u32 *picId, u32 *isIdrPic, u32 *numErrMbs, int fmt)
+{
+    ApiDec *a = dec_of(s);
+    if (!a) return NULL;
+    const OutPic *o = pop_output(a, picId, isIdrPic, numErrMbs);
+    if (!o || !a->hd->sink.fetch_converted) return NULL;
+    return a->hd->sink.fetch_converted(a->hd->sink.user, o->slot, fmt);
+}
+u32 *h264bsdNextOutputPictureRGBA(storage_t *s, u32 *p, u32 *i, u32 *n) { return next_converted(s, p, i, n, 0); }
+u32 *h264bsdNextOutputPictureBGRA(storage_t *s, u32 *p, u32 *i, u32 *n) { return next_converted(s, p, i, n, 1); }
+u32 *h264bsdNextOutputPictureYCbCrA(storage_t *s, u32 *p, u32 *i, u32 *n) { return next_converted(s, p, i, n, 2); }
+
+static const Sps *active_sps(storage_t *s)
+{
+    ApiDec *a = dec_of(s);
+    return a ? a->hd->active_sps : NULL;
+}
+
+u32 h264bsdPicWidth(storage_t *s) { const Sps *p = active_sps(s); return p ? p->width_mbs : 0; }
+u32 h264bsdPicHeight(storage_t *s) { const Sps *p = active_sps(s); return p ? p->height_mbs : 0; }
+u32 h264bsdProfile(storage_t *s) { const Sps *p = active_sps(s); return p ? p->profile_idc : 0; }
+
+u32 h264bsdVideoRange(storage_t *s)
+{
+    const Sps *p = active_sps(s);
+    return (p && p->vui_present && p->video_signal_type_present && p->video_full_range) ? 1 : 0;
+}
+u32 h264bsdMatrixCoefficients(storage_t *s)
+{
+    const Sps *p = active_sps(s);
+    if (p && p->vui_present && p->video_signal_type_present && p->colour_description_present)
+        return p->matrix_coefficients;
+    return 2;   /* unspecified */
+}
+
+void h264bsdCroppingParams(storage_t *s, u32 *croppingFlag, u32 *left, u32 *width, u32 *top, u32 *height)
+{
+    const Sps *p = active_sps(s);
+    if (p && p->cropping) {
+        *croppingFlag = 1;
+        *left = 2 * p->crop_left;
+        *width = 16 * p->width_mbs - 2 * (p->crop_left + p->crop_right);
+        *top = 2 * p->crop_top;
+        *height = 16 * p->height_mbs - 2 * (p->crop_top + p->crop_bottom);
+    } else {
+        *croppingFlag = 0;
+        *left = *width = *top = *height = 0;
+    }
+}
+
+void h264bsdSampleAspectRatio(storage_t *s, u32 *sarWidth, u32 *sarHeight)
+{
+    /* Table E-1 */
+    static const u8 sar[14][2] = { { 0, 0 }, { 1, 1 }, { 12, 11 }, { 10, 11 }, { 16, 11 }, { 40, 33 }, { 24, 11 },
+        { 20, 11 }, { 32, 11 }, { 80, 33 }, { 18, 11 }, { 15, 11 }, { 64, 33 }, { 160, 99 } };
+    const Sps *p = active_sps(s);
+    u32 w = 1, h = 1;
+    if (p && p->vui_present && p->aspect_ratio_present) {
+        if (p->aspect_ratio_idc < 14) { w = sar[p->aspect_ratio_idc][0]; h = sar[p->aspect_ratio_idc][1]; }
+        else if (p->aspect_ratio_idc == 255) {
+            w = p->sar_width; h = p->sar_height;
+            if (!w || !h) w = h = 0;
+        } else w = h = 0;
+    }
+    *sarWidth = w;
+    *sarHeight = h;
+}
+
+/* 1 when at least one PPS with its SPS is stored and consistent (reference storage.c:793-829) */
+u32 h264bsdCheckValidParamSets(storage_t *s)
+{
+    ApiDec *a = dec_of(s);
+    if (!a) return 0;
+    for (int i = 0; i < HD_MAX_PPS; i++) {
+        const Pps *p = a->hd->pps[i];
+        if (p && a->hd->sps[p->sps_id]) return 1;
+    }
+    return 0;
+}
+
+void h264bsdFlushBuffer(storage_t *s)
+{
+    ApiDec *a = dec_of(s);
+    if (a) hd_dpb_flush(&a->hd->dpb);
+}
+
+void h264bsdConvertToRGBA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(0, width, height, data, pOutput); }
+void h264bsdConvertToBGRA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(1, width, height, data, pOutput); }
+void h264bsdConvertToYCbCrA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(2, width, height, data, pOutput); }

@@ -1,0 +1,111 @@
+/*
+ * framejob.h — the packed per-picture work description ("frame job") that crosses the
+ * host → device boundary.
+ *
+ * The host parser (hostdec_*.c) turns one coded picture into ONE contiguous blob: a fixed header,
+ * a 32-byte record per macroblock, 16 motion vectors per macroblock, the intra dependency-level
+ * schedule and a dense stream of 4x4 coefficient blocks.  The HIP kernels (kernels.hip) and the
+ * CPU test oracle (oracle/pixel_oracle.c) both consume exactly this format, so a blob captured on
+ * the host can be replayed on either.
+ *
+ * What the blob replaces in the reference: the per-MB hand-off at seam A/B of SURVEY.md §1 —
+ * macroblockLayer_t + mbStorage_t (reference src/h264bsd_macroblock_layer.h:140-185) as consumed by
+ * h264bsdDecodeMacroblock (src/h264bsd_macroblock_layer.c:965) and h264bsdFilterPicture
+ * (src/h264bsd_deblocking.c:575).  All indices inside a record are RASTER 4x4-block indices
+ * (blk = 4*by + bx), not the H.264 zig-zag block order the reference uses.
+ *
+ * All integers little-endian; every section starts 32-byte aligned.
+ */
+#ifndef H264BSD_AMD_FRAMEJOB_H
+#define H264BSD_AMD_FRAMEJOB_H
+
+#include <stdint.h>
+
+#define FJ_MAGIC      0x314A4648u /* "HFJ1" */
+#define FJ_MAX_SLOTS  17          /* max_dec_frame_buffering(16) + the picture being decoded */
+
+/* FjMbRec.kind */
+#define FJ_MB_INTER   0   /* P_Skip and all P partitions: per-4x4 mv + per-8x8 reference slot   */
+#define FJ_MB_I4x4    1
+#define FJ_MB_I16x16  2
+#define FJ_MB_IPCM    3
+#define FJ_MB_ABSENT  255 /* macroblock not covered by any decoded slice: pixels left untouched */
+
+/* FjMbRec.avail bits: neighbour usable for intra prediction (in picture, same slice, and not an
+ * inter MB when constrained_intra_pred is on) — reference src/h264bsd_neighbour.c:370-381,
+ * src/h264bsd_intra_prediction.c:644-655 */
+#define FJ_AVAIL_A 1  /* left       */
+#define FJ_AVAIL_B 2  /* above      */
+#define FJ_AVAIL_C 4  /* above-right*/
+#define FJ_AVAIL_D 8  /* above-left */
+
+/* FjMbRec.dbk bits — reference GetMbFilteringFlags, src/h264bsd_deblocking.c:289-320 */
+#define FJ_DBK_LEFT  1
+#define FJ_DBK_TOP   2
+#define FJ_DBK_INNER 4
+
+/* FjMbRec.coded bits */
+#define FJ_CODED_LUMA_DC   (1u << 24) /* Intra16x16 DC block present                        */
+#define FJ_CODED_CHROMA_DC (1u << 25) /* chroma DC block (Cb[0..3], Cr[4..7]) present        */
+
+typedef struct FjHeader {
+    uint32_t magic;
+    uint32_t total_bytes;     /* whole blob                                                   */
+    uint16_t width_mbs;
+    uint16_t height_mbs;
+    uint32_t n_mbs;
+    uint8_t  cur_slot;        /* DPB slot that receives this picture                          */
+    uint8_t  is_idr;
+    uint8_t  n_slots;         /* DPB slots of the owning decoder (dpbSize+1)                  */
+    uint8_t  any_deblock;     /* 0: no MB of the picture is filtered (idc==1 everywhere)      */
+    uint32_t rec_off;         /* FjMbRec[n_mbs]                                               */
+    uint32_t mv_off;          /* int16 mv[n_mbs][16][2]  (x,y) quarter-pel, raster 4x4 order  */
+    uint32_t lvl_off;         /* uint32 lvl_start[n_intra_levels+1]  (indices into intra_idx) */
+    uint32_t idx_off;         /* uint16 intra_idx[n_intra]  MB addresses sorted by level      */
+    uint32_t coef_off;        /* int16 coef[n_coef_blocks][16]                                */
+    uint32_t n_intra;
+    uint32_t n_intra_levels;
+    uint32_t n_coef_blocks;
+    uint32_t n_inter;         /* statistics for the byte accounting of the bench              */
+    uint32_t pic_seq;         /* running picture number of the stream                         */
+    uint32_t reserved[1];
+} FjHeader;                   /* 64 bytes */
+
+typedef struct FjMbRec {
+    uint8_t  kind;
+    uint8_t  qp_y;
+    uint8_t  qp_c;            /* QPc of THIS macroblock (chroma dequant)                      */
+    uint8_t  avail;
+    uint8_t  pred;            /* bits0-1 Intra16x16 mode (0 V,1 H,2 DC,3 plane);
+                                 bits2-3 intra chroma mode (0 DC,1 H,2 V,3 plane)             */
+    uint8_t  dbk;
+    int8_t   alpha_off;       /* FilterOffsetA = 2*slice_alpha_c0_offset_div2                 */
+    int8_t   beta_off;
+    uint32_t coded;           /* bit r (0..15): luma 4x4 block r has coefficients;
+                                 16..19 Cb AC, 20..23 Cr AC; 24 luma DC; 25 chroma DC         */
+    uint32_t coef_idx;        /* first coefficient block of this MB (16 x int16 each)         */
+    uint8_t  ref_slot[4];     /* reference DPB slot per 8x8 quadrant (raster)                 */
+    int8_t   cqp_off;         /* chroma_qp_index_offset of the MB's PPS (deblock QPc)         */
+    uint8_t  reserved;
+    uint16_t intra_level;     /* dependency level among intra MBs of the picture              */
+    uint8_t  i4mode[8];       /* 16 nibbles: Intra4x4PredMode of raster block r               */
+} FjMbRec;                    /* 32 bytes */
+
+/* Order of a macroblock's coefficient blocks starting at coef_idx:
+ *   [luma DC 4x4 (raster c[i][j])]            if FJ_CODED_LUMA_DC
+ *   luma raster blocks r with bit r set, ascending r; each block is RASTER 4x4 (row-major),
+ *        un-dequantised levels, position 0 forced to 0 for Intra16x16 AC blocks
+ *   [chroma DC: Cb c[0..3] raster 2x2, Cr c[4..7], 8 pad]   if FJ_CODED_CHROMA_DC
+ *   chroma AC blocks 16..23 with bit set, ascending (position 0 = 0)
+ * I_PCM: 12 blocks = 384 raw samples as bytes: Y[256] raster, Cb[64], Cr[64].
+ */
+
+static inline uint32_t fj_align32(uint32_t x) { return (x + 31u) & ~31u; }
+
+/* Byte size of one decoded frame (I420, uncropped, 16-aligned) */
+static inline uint32_t fj_frame_bytes(uint32_t width_mbs, uint32_t height_mbs)
+{
+    return width_mbs * height_mbs * 384u;
+}
+
+#endif

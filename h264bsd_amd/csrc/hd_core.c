@@ -1,0 +1,449 @@
+/*
+ * hd_core.c — decoder instance life cycle, the per-NAL control flow of h264bsdDecode and the
+ * assembly of one frame job per picture.
+ *
+ * The return-code protocol is the reference's (src/h264bsd_decoder.c:152-515):
+ *   - one NAL unit per call, *read_bytes = bytes to advance;
+ *   - first slice after a new SPS activation returns HDRS_RDY with read_bytes == 0 and expects to
+ *     be called again with the same pointer (:343-389, two-phase activation storage.c:297-419);
+ *   - PIC_RDY when the last macroblock of a picture has been parsed (:457-462, :473-510).
+ * What is different by design: at PIC_RDY no pixel exists yet.  The picture has been turned into a
+ * frame job and queued on the JobSink; pixels materialise when the application pulls the picture.
+ * Error concealment (reference src/h264bsd_conceal.c) is not implemented: an access-unit boundary
+ * in the middle of a picture, or a corrupt slice, is reported as HD_ERROR and the picture is
+ * dropped.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "hostdec.h"
+
+HostDec *hd_create(int no_output_reordering);
+void hd_destroy(HostDec *d);
+int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes);
+
+HostDec *hd_create(int no_output_reordering)
+{
+    HostDec *d = (HostDec *)calloc(1, sizeof(HostDec));
+    if (!d) return NULL;
+    hd_cavlc_init();
+    d->active_sps_id = d->active_pps_id = d->old_sps_id = -1;
+    d->no_reordering_app = (uint8_t)(no_output_reordering != 0);
+    d->aub_first_call = 1;
+    d->dpb.cur = -1;
+    return d;
+}
+
+void hd_destroy(HostDec *d)
+{
+    if (!d) return;
+    if (d->sink.close) d->sink.close(d->sink.user);
+    for (int i = 0; i < HD_MAX_SPS; i++) free(d->sps[i]);
+    for (int i = 0; i < HD_MAX_PPS; i++) { hd_free_pps(d->pps[i]); free(d->pps[i]); }
+    free(d->mb);
+    free(d->slice_group_map);
+    free(d->nal_buf);
+    free(d->job);
+    free(d->conv_buf);
+    free(d);
+}
+
+/* ---------------------------------------------------------------- frame job */
+static uint32_t job_capacity(uint32_t n_mbs)
+{
+    return 64u + n_mbs * (32u + 64u) + (n_mbs * 27u + 2u) * 32u /* coefficients, worst case */
+           + (n_mbs + 2u) * 4u /* level starts */ + fj_align32(n_mbs * 2u) + 256u;
+}
+
+int hd_job_begin(HostDec *d)
+{
+    const uint32_t n = d->pic_size_mbs, cap = job_capacity(n);
+    if (d->job_cap < cap) {
+        free(d->job);
+        d->job = (uint8_t *)malloc(cap);
+        if (!d->job) { d->job_cap = 0; return -1; }
+        d->job_cap = cap;
+    }
+    FjHeader *h = (FjHeader *)d->job;
+    memset(h, 0, sizeof(*h));
+    h->magic = FJ_MAGIC;
+    h->width_mbs = (uint16_t)d->width_mbs;
+    h->height_mbs = (uint16_t)d->height_mbs;
+    h->n_mbs = n;
+    h->rec_off = 64;
+    h->mv_off = h->rec_off + n * 32u;
+    h->coef_off = h->mv_off + n * 64u;
+    FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
+    memset(recs, 0, (size_t)n * 32u);
+    for (uint32_t i = 0; i < n; i++) recs[i].kind = FJ_MB_ABSENT;
+    memset(d->job + h->mv_off, 0, (size_t)n * 64u);
+    d->coef_blocks = 0;
+    d->n_inter = d->n_intra = 0;
+    d->job_open = 1;
+    return 0;
+}
+
+/* Dependency level of every intra macroblock: 0 when no intra neighbour among A, B, C, D precedes it,
+ * else 1 + the deepest of them.  Intra MBs of one level are mutually independent, so the device can
+ * reconstruct level by level (all inter MBs first). */
+int hd_job_finish(HostDec *d, int is_idr)
+{
+    FjHeader *h = (FjHeader *)d->job;
+    const uint32_t n = h->n_mbs, w = h->width_mbs;
+    FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
+    uint32_t max_level = 0, n_intra = 0;
+    uint8_t any_dbk = 0;
+    for (uint32_t a = 0; a < n; a++) {
+        FjMbRec *r = &recs[a];
+        any_dbk |= r->dbk;
+        if (r->kind == FJ_MB_INTER || r->kind == FJ_MB_ABSENT) continue;
+        const uint32_t x = a % w, y = a / w;
+        int lvl = -1;
+#define DEP(cond, idx) do { if (cond) { const FjMbRec *q = &recs[idx]; \
+            if (q->kind != FJ_MB_INTER && q->kind != FJ_MB_ABSENT && (int)q->intra_level > lvl) lvl = q->intra_level; } } while (0)
+        DEP(x > 0, a - 1);
+        DEP(y > 0, a - w);
+        DEP(y > 0 && x + 1 < w, a - w + 1);
+        DEP(y > 0 && x > 0, a - w - 1);
+#undef DEP
+        r->intra_level = (uint16_t)(lvl + 1);
+        if ((uint32_t)(lvl + 1) > max_level) max_level = (uint32_t)(lvl + 1);
+        n_intra++;
+    }
+    const uint32_t n_levels = n_intra ? max_level + 1 : 0;
+    h->n_coef_blocks = d->coef_blocks;
+    h->lvl_off = fj_align32(h->coef_off + d->coef_blocks * 32u);
+    h->idx_off = fj_align32(h->lvl_off + (n_levels + 1) * 4u);
+    h->total_bytes = fj_align32(h->idx_off + n_intra * 2u);
+    if (h->total_bytes > d->job_cap) return -1;
+    uint32_t *lvl_start = (uint32_t *)(d->job + h->lvl_off);
+    uint16_t *idx = (uint16_t *)(d->job + h->idx_off);
+    memset(lvl_start, 0, (n_levels + 1) * 4u);
+    /* counting sort by level */
+    for (uint32_t a = 0; a < n; a++)
+        if (recs[a].kind != FJ_MB_INTER && recs[a].kind != FJ_MB_ABSENT) lvl_start[recs[a].intra_level + 1]++;
+    for (uint32_t l = 0; l < n_levels; l++) lvl_start[l + 1] += lvl_start[l];
+    {
+        /* fill using a moving cursor per level, kept in the tail of the blob's slack */
+        uint32_t *cursor = (uint32_t *)malloc((n_levels + 1) * 4u);
+        if (!cursor) return -1;
+        memcpy(cursor, lvl_start, (n_levels + 1) * 4u);
+        for (uint32_t a = 0; a < n; a++)
+            if (recs[a].kind != FJ_MB_INTER && recs[a].kind != FJ_MB_ABSENT) idx[cursor[recs[a].intra_level]++] = (uint16_t)a;
+        free(cursor);
+    }
+    h->n_intra = n_intra;
+    h->n_intra_levels = n_levels;
+    h->n_inter = d->n_inter;
+    h->cur_slot = (uint8_t)d->dpb.cur;
+    h->n_slots = (uint8_t)d->dpb.n_slots;
+    h->is_idr = (uint8_t)is_idr;
+    h->any_deblock = any_dbk ? 1 : 0;
+    h->pic_seq = d->pic_seq++;
+    d->job_open = 0;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- parameter-set activation */
+static int check_pps_against_sps(const Pps *p, const Sps *s)
+{
+    const uint32_t n = s->width_mbs * s->height_mbs;
+    if (p->num_slice_groups > 1) {
+        if (p->slice_group_map_type == 0) {
+            for (uint32_t i = 0; i < p->num_slice_groups; i++) if (p->run_length[i] > n) return -1;
+        } else if (p->slice_group_map_type == 2) {
+            for (uint32_t i = 0; i + 1 < p->num_slice_groups; i++)
+                if (p->top_left[i] > p->bottom_right[i] || p->bottom_right[i] >= n ||
+                    (p->top_left[i] % s->width_mbs) > (p->bottom_right[i] % s->width_mbs)) return -1;
+        } else if (p->slice_group_map_type >= 3 && p->slice_group_map_type <= 5) {
+            if (p->slice_group_change_rate > n) return -1;
+        } else if (p->slice_group_map_type == 6 && p->pic_size_in_map_units < n) return -1;
+    }
+    return 0;
+}
+
+static void select_sps(HostDec *d, int pps_id)
+{
+    d->active_pps_id = pps_id;
+    d->active_pps = d->pps[pps_id];
+    d->active_sps_id = d->active_pps->sps_id;
+    d->active_sps = d->sps[d->active_sps_id];
+    d->width_mbs = d->active_sps->width_mbs;
+    d->height_mbs = d->active_sps->height_mbs;
+    d->pic_size_mbs = d->width_mbs * d->height_mbs;
+    d->pending_activation = 1;
+}
+
+/* returns 0, -1 (bad parameter sets) or -2 (out of memory / engine failure) */
+static int activate_param_sets(HostDec *d, uint32_t pps_id, int is_idr)
+{
+    Pps *p = d->pps[pps_id];
+    if (!p || !d->sps[p->sps_id]) return -1;
+    if (check_pps_against_sps(p, d->sps[p->sps_id])) return -1;
+
+    if (d->active_pps_id < 0) {
+        /* nothing active yet: phase 1 */
+        select_sps(d, (int)pps_id);
+    } else if (d->pending_activation) {
+        /* phase 2: the caller has seen HDRS_RDY; allocate per-sequence state */
+        d->pending_activation = 0;
+        free(d->mb);
+        free(d->slice_group_map);
+        d->mb = (MbInfo *)calloc(d->pic_size_mbs, sizeof(MbInfo));
+        d->slice_group_map = (uint32_t *)calloc(d->pic_size_mbs, sizeof(uint32_t));
+        if (!d->mb || !d->slice_group_map) return -2;
+        for (uint32_t i = 0; i < d->pic_size_mbs; i++) d->mb[i].kind = FJ_MB_ABSENT;
+        const Sps *s = d->active_sps;
+        int no_reorder = d->no_reordering_app || s->poc_type == 2 ||
+                         (s->vui_present && s->bitstream_restriction && s->num_reorder_frames == 0);
+        if (hd_dpb_reset(&d->dpb, s->max_dpb_size, s->num_ref_frames, s->max_frame_num, no_reorder)) return -1;
+        if (d->sink.configure &&
+            d->sink.configure(d->sink.user, d->width_mbs, d->height_mbs, d->dpb.n_slots)) return -2;
+        d->sink_configured = 1;
+    } else if ((int)pps_id != d->active_pps_id) {
+        if (p->sps_id != d->active_sps_id) {
+            if (!is_idr) return -1;          /* the SPS may only change at an IDR picture */
+            select_sps(d, (int)pps_id);
+        } else {
+            d->active_pps_id = (int)pps_id;
+            d->active_pps = p;
+        }
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- access-unit boundary, 7.4.1.2.4 */
+static int check_access_unit_boundary(HostDec *d, const BitReader *br0, int nal_type, int nal_ref_idc, int *boundary)
+{
+    *boundary = 0;
+    if ((nal_type > 5 && nal_type < 12) || (nal_type > 12 && nal_type <= 18)) { *boundary = 1; return 0; }
+    if (nal_type != 1 && nal_type != 5) return 0;
+    if (d->aub_first_call) { *boundary = 1; d->aub_first_call = 0; }
+
+    uint32_t pps_id;
+    if (hd_peek_pps_id(br0, &pps_id)) return -1;
+    const Pps *p = d->pps[pps_id];
+    if (!p || !d->sps[p->sps_id] ||
+        (d->active_sps_id >= 0 && p->sps_id != d->active_sps_id && nal_type != 5))
+        return -2;
+    const Sps *s = d->sps[p->sps_id];
+
+    if (d->prev_nal_ref_idc != nal_ref_idc && (d->prev_nal_ref_idc == 0 || nal_ref_idc == 0)) *boundary = 1;
+    if ((d->prev_nal_type == 5) != (nal_type == 5)) *boundary = 1;
+
+    /* re-read the leading slice-header fields with the candidate SPS/PPS */
+    BitReader br = *br0;
+    br_ue(&br); br_ue(&br); br_ue(&br);
+    uint32_t nb = 0;
+    while ((1u << nb) < s->max_frame_num) nb++;
+    uint32_t frame_num = br_get(&br, nb);
+    if (br_overrun(&br)) return -1;
+    if (d->aub_prev_frame_num != frame_num) { d->aub_prev_frame_num = frame_num; *boundary = 1; }
+    if (nal_type == 5) {
+        uint32_t idr_pic_id = br_ue(&br);
+        if (br_overrun(&br)) return -1;
+        if (d->prev_nal_type == 5 && d->aub_prev_idr_pic_id != idr_pic_id) *boundary = 1;
+        d->aub_prev_idr_pic_id = idr_pic_id;
+    }
+    if (s->poc_type == 0) {
+        nb = 0;
+        while ((1u << nb) < s->max_poc_lsb) nb++;
+        uint32_t lsb = br_get(&br, nb);
+        if (br_overrun(&br)) return -1;
+        if (d->aub_prev_poc_lsb != lsb) { d->aub_prev_poc_lsb = lsb; *boundary = 1; }
+        if (p->pic_order_present) {
+            int32_t db = br_se(&br);
+            if (br_overrun(&br)) return -1;
+            if (d->aub_prev_delta_poc_bottom != db) { d->aub_prev_delta_poc_bottom = db; *boundary = 1; }
+        }
+    } else if (s->poc_type == 1 && !s->delta_pic_order_always_zero) {
+        int32_t d0 = br_se(&br), d1 = 0;
+        if (p->pic_order_present) d1 = br_se(&br);
+        if (br_overrun(&br)) return -1;
+        if (d->aub_prev_delta_poc[0] != d0) { d->aub_prev_delta_poc[0] = d0; *boundary = 1; }
+        if (p->pic_order_present && d->aub_prev_delta_poc[1] != d1) { d->aub_prev_delta_poc[1] = d1; *boundary = 1; }
+    }
+    d->prev_nal_type = (uint8_t)nal_type;
+    d->prev_nal_ref_idc = (uint8_t)nal_ref_idc;
+    return 0;
+}
+
+static int end_of_picture(const HostDec *d)
+{
+    if (!d->slice.redundant_pic_cnt) return d->num_decoded_mbs == d->pic_size_mbs;
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < d->pic_size_mbs; i++) n += d->mb[i].decoded != 0;
+    return n == d->pic_size_mbs;
+}
+
+static void reset_picture_state(HostDec *d)
+{
+    d->num_decoded_mbs = 0;
+    d->slice_id = 0;
+    for (uint32_t i = 0; i < d->pic_size_mbs; i++) { d->mb[i].slice_id = 0; d->mb[i].decoded = 0; }
+}
+
+/* ---------------------------------------------------------------- parameter set storage */
+static int store_sps(HostDec *d, const Sps *s)
+{
+    const int id = s->sps_id;
+    if (!d->sps[id]) {
+        d->sps[id] = (Sps *)malloc(sizeof(Sps));
+        if (!d->sps[id]) return -2;
+    } else if (id == d->active_sps_id) {
+        if (hd_sps_equal(s, d->active_sps)) return 0;      /* identical re-send: keep everything */
+        d->active_sps_id = HD_MAX_SPS + 1;                  /* changed: force re-activation      */
+        d->active_pps_id = HD_MAX_PPS + 1;
+        d->active_sps = NULL;
+        d->active_pps = NULL;
+    }
+    *d->sps[id] = *s;
+    return 0;
+}
+static int store_pps(HostDec *d, Pps *p)
+{
+    const int id = p->pps_id;
+    if (!d->pps[id]) {
+        d->pps[id] = (Pps *)calloc(1, sizeof(Pps));
+        if (!d->pps[id]) { hd_free_pps(p); return -2; }
+    } else {
+        if (id == d->active_pps_id && p->sps_id != d->active_sps_id) d->active_pps_id = HD_MAX_PPS + 1;
+        hd_free_pps(d->pps[id]);
+    }
+    *d->pps[id] = *p;          /* takes ownership of slice_group_id */
+    if (id == d->active_pps_id) d->active_pps = d->pps[id];
+    return 0;
+}
+
+/* ---------------------------------------------------------------- one NAL unit */
+int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes)
+{
+    int rc;
+    if (d->prev_buf_not_finished && stream == d->prev_buf_ptr) {
+        *read_bytes = d->prev_bytes_consumed;      /* staged payload is still in nal_buf */
+    } else {
+        rc = hd_extract_nal(d, stream, len, read_bytes);
+        if (rc == -2) return HD_MEMALLOC_ERROR;
+        if (rc) return HD_ERROR;
+        d->prev_bytes_consumed = *read_bytes;
+        d->prev_buf_ptr = stream;
+    }
+    d->prev_buf_not_finished = 0;
+
+    BitReader br = { d->nal_buf, d->nal_size * 8u, 0 };
+    if (d->nal_size == 0) return HD_ERROR;
+    br_get1(&br);                                                   /* forbidden_zero_bit: not enforced (reference nal_unit.c:77) */
+    const int nal_ref_idc = (int)br_get(&br, 2);
+    const int nal_type = (int)br_get(&br, 5);
+    if (nal_type == 2 || nal_type == 3 || nal_type == 4) return HD_ERROR;   /* data partitioning */
+    if ((nal_type == 5 || nal_type == 7 || nal_type == 8) && nal_ref_idc == 0) return HD_ERROR;
+    if ((nal_type == 6 || (nal_type >= 9 && nal_type <= 12)) && nal_ref_idc != 0) return HD_ERROR;
+    if (nal_type == 0 || nal_type >= 13) return HD_RDY;
+
+    int boundary = 0;
+    rc = check_access_unit_boundary(d, &br, nal_type, nal_ref_idc, &boundary);
+    if (rc == -2) return HD_PARAM_SET_ERROR;
+    if (rc) return HD_ERROR;
+
+    if (boundary) {
+        if (d->pic_started && d->active_sps) {
+            /* a picture was left unfinished: the reference conceals it here (decoder.c:226-266).
+             * Concealment is out of scope: drop the partial picture and report the damage. */
+            if (d->pending_activation) return HD_ERROR;
+            d->pic_started = 0;
+            d->valid_slice_in_au = 0;
+            d->skip_redundant = 0;
+            d->job_open = 0;
+            d->dpb.cur = -1;
+            if (d->mb) reset_picture_state(d);
+            fprintf(stderr, "h264bsd-mi355x: incomplete picture dropped (error concealment not implemented)\n");
+            *read_bytes = 0;
+            d->prev_buf_not_finished = 1;
+            return HD_ERROR;
+        }
+        d->valid_slice_in_au = 0;
+        d->skip_redundant = 0;
+    }
+
+    int pic_ready = 0;
+    switch (nal_type) {
+    case 7: {
+        Sps s;
+        if (hd_parse_sps(&br, &s)) return HD_ERROR;
+        if (store_sps(d, &s)) return HD_MEMALLOC_ERROR;
+        break;
+    }
+    case 8: {
+        Pps p;
+        rc = hd_parse_pps(&br, &p);
+        if (rc == -2) return HD_MEMALLOC_ERROR;
+        if (rc) return HD_ERROR;
+        if (store_pps(d, &p)) return HD_MEMALLOC_ERROR;
+        break;
+    }
+    case 1:
+    case 5: {
+        if (d->skip_redundant) return HD_RDY;
+        d->pic_started = 1;
+        const int start_of_picture = !d->valid_slice_in_au;
+        if (start_of_picture) {
+            uint32_t pps_id;
+            d->current_pic_id = pic_id;
+            if (hd_peek_pps_id(&br, &pps_id)) return HD_ERROR;
+            const int old_sps = d->active_sps_id;
+            rc = activate_param_sets(d, pps_id, nal_type == 5);
+            if (rc) {
+                d->active_pps_id = -1; d->active_pps = NULL;
+                d->active_sps_id = -1; d->active_sps = NULL;
+                d->pending_activation = 0;
+                return rc == -2 ? HD_MEMALLOC_ERROR : HD_PARAM_SET_ERROR;
+            }
+            if (old_sps != d->active_sps_id) {
+                /* new sequence: tell the application, expect the same NAL again (decoder.c:343-389) */
+                *read_bytes = 0;
+                d->prev_buf_not_finished = 1;
+                d->old_sps_id = d->active_sps_id;
+                return HD_HDRS_RDY;
+            }
+        }
+        if (d->pending_activation) return HD_ERROR;
+        SliceHdr sh;
+        if (hd_parse_slice_header(&br, &sh, d->active_sps, d->active_pps, nal_type, nal_ref_idc)) return HD_ERROR;
+        if (start_of_picture) {
+            if (nal_type != 5) {
+                if (hd_dpb_check_gaps(&d->dpb, sh.frame_num, nal_ref_idc != 0, d->active_sps->gaps_in_frame_num_allowed))
+                    return HD_ERROR;
+            }
+            if (hd_dpb_alloc_current(&d->dpb) < 0) return HD_ERROR;
+            if (hd_job_begin(d)) return HD_MEMALLOC_ERROR;
+        }
+        d->slice = sh;
+        d->valid_slice_in_au = 1;
+        d->cur_nal_type = (uint8_t)nal_type;
+        d->cur_nal_ref_idc = (uint8_t)nal_ref_idc;
+        hd_slice_group_map(d->slice_group_map, d->active_pps, sh.slice_group_change_cycle, d->width_mbs, d->height_mbs);
+        if (hd_dpb_reorder_ref_list(&d->dpb, &d->slice)) return HD_ERROR;
+        if (hd_decode_slice_data(d, &br, &d->slice, nal_ref_idc)) return HD_ERROR;
+        if (end_of_picture(d)) { pic_ready = 1; d->skip_redundant = 1; }
+        break;
+    }
+    default: break;             /* SEI, AUD, end of sequence/stream, filler: ignored */
+    }
+
+    if (!pic_ready) return HD_RDY;
+
+    /* picture complete: queue the frame job, then do the bookkeeping the reference does after
+     * deblocking (decoder.c:473-510) */
+    const int is_idr = d->cur_nal_type == 5;
+    if (hd_job_finish(d, is_idr)) return HD_ERROR;
+    if (d->sink.submit && d->sink.submit(d->sink.user, d->job, ((FjHeader *)d->job)->total_bytes)) {
+        fprintf(stderr, "h264bsd-mi355x: frame job submission failed\n");
+        return HD_ERROR;
+    }
+    reset_picture_state(d);
+    int32_t poc = hd_decode_poc(&d->poc, d->active_sps, &d->slice, d->cur_nal_type, d->cur_nal_ref_idc);
+    hd_dpb_mark_current(&d->dpb, &d->slice, d->cur_nal_ref_idc != 0, is_idr, poc, d->current_pic_id, 0);
+    d->pic_started = 0;
+    d->valid_slice_in_au = 0;
+    return HD_PIC_RDY;
+}

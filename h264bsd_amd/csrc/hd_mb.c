@@ -1,0 +1,495 @@
+/*
+ * hd_mb.c — slice_data() and macroblock_layer() parsing (H.264 7.3.4, 7.3.5), motion-vector
+ * prediction (8.4.1), Intra4x4PredMode derivation (8.3.1.1), CAVLC nC derivation (9.2.1) and the
+ * packing of every macroblock into its FjMbRec + motion vectors + coefficient blocks.
+ *
+ * This is the host half of seam A in SURVEY.md §1: everything h264bsdDecodeMacroblockLayer
+ * (reference src/h264bsd_macroblock_layer.c:134) and the metadata half of h264bsdDecodeMacroblock
+ * (:965-1131: QP carry, totalCoeff bookkeeping), h264bsdInterPrediction's MvPrediction*
+ * (src/h264bsd_inter_prediction.c:494-1026) and DetermineIntra4x4PredMode
+ * (src/h264bsd_intra_prediction.c:1886) decide — without producing a single pixel.
+ *
+ * Reference-specific behaviour kept on purpose (differs from a literal reading of the standard):
+ *  - an I_PCM macroblock stores QP 0 for deblocking but does NOT reset the running slice QP
+ *    (macroblock_layer.c:989-1022 never writes *qpY);
+ *  - motion vectors outside [-8192,8191] x [-2048,2047] quarter-pels are a decode error
+ *    (inter_prediction.c:538-544).
+ */
+#include <string.h>
+#include "hostdec.h"
+
+/* H.264 4x4 block order (z-order) <-> position inside the macroblock */
+static const uint8_t Z_X[16] = { 0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3 };
+static const uint8_t Z_Y[16] = { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 };
+static inline int z_of(int x, int y) { return ((y >> 1) << 3) | ((x >> 1) << 2) | ((y & 1) << 1) | (x & 1); }
+
+/* Table 9-4: coded_block_pattern from codeNum, for Intra4x4 and Inter macroblocks */
+static const uint8_t cbp_intra[48] = {
+    47, 31, 15, 0, 23, 27, 29, 30, 7, 11, 13, 14, 39, 43, 45, 46, 16, 3, 5, 10, 12, 19, 21, 26,
+    28, 35, 37, 42, 44, 1, 2, 4, 8, 17, 18, 20, 24, 6, 9, 22, 25, 32, 33, 34, 36, 40, 38, 41 };
+static const uint8_t cbp_inter[48] = {
+    0, 16, 1, 2, 4, 8, 32, 3, 5, 10, 12, 15, 47, 7, 11, 13, 14, 6, 9, 31, 35, 37, 42, 44,
+    33, 34, 36, 40, 39, 43, 45, 46, 17, 18, 20, 24, 19, 21, 26, 28, 23, 27, 29, 30, 22, 25, 38, 41 };
+/* Table 8-15: QPc as a function of qPi */
+static const uint8_t qpc_table[52] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25,
+    26, 27, 28, 29, 29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39 };
+
+typedef struct MbCtx {
+    HostDec *d;
+    BitReader *br;
+    const SliceHdr *sh;
+    const Pps *pps;
+    uint32_t addr, mbx, mby;
+    MbInfo *cur, *A, *B, *C, *D;   /* NULL when outside the picture or another slice */
+    uint16_t done;                 /* raster bit per 4x4 block of cur whose mv/ref is final */
+} MbCtx;
+
+static inline MbInfo *usable(MbInfo *m, uint32_t slice_id) { return (m && m->slice_id == slice_id) ? m : NULL; }
+static inline int is_inter(const MbInfo *m) { return m->kind == FJ_MB_INTER; }
+
+/* ---------------------------------------------------------------- nC, 9.2.1 */
+static int nc_luma(const MbCtx *c, int z)
+{
+    const int x = Z_X[z], y = Z_Y[z];
+    int na = -1, nb = -1;
+    if (x > 0) na = c->cur->tc[z_of(x - 1, y)]; else if (c->A) na = c->A->tc[z_of(3, y)];
+    if (y > 0) nb = c->cur->tc[z_of(x, y - 1)]; else if (c->B) nb = c->B->tc[z_of(x, 3)];
+    if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
+    return na >= 0 ? na : nb >= 0 ? nb : 0;
+}
+static int nc_chroma(const MbCtx *c, int plane, int k) /* k = 2*cy+cx */
+{
+    const int base = 16 + 4 * plane, x = k & 1, y = k >> 1;
+    int na = -1, nb = -1;
+    if (x > 0) na = c->cur->tc[base + k - 1]; else if (c->A) na = c->A->tc[base + 2 * y + 1];
+    if (y > 0) nb = c->cur->tc[base + k - 2]; else if (c->B) nb = c->B->tc[base + 2 + x];
+    if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
+    return na >= 0 ? na : nb >= 0 ? nb : 0;
+}
+
+/* ---------------------------------------------------------------- motion vector prediction */
+typedef struct Nb { int avail, ref; int16_t mx, my; } Nb;
+
+static Nb nb_from(const MbInfo *m, int x, int y)
+{
+    Nb n = { 0, -1, 0, 0 };
+    if (!m) return n;
+    n.avail = 1;
+    if (is_inter(m)) {
+        const int z = z_of(x, y);
+        n.ref = m->ref_idx[z >> 2];
+        n.mx = m->mv[z][0];
+        n.my = m->mv[z][1];
+    }
+    return n;
+}
+/* neighbouring 4x4 block at (x,y) relative to the current MB, 6.4.11.7 + decoding-order rule */
+static Nb nb_at(const MbCtx *c, int x, int y)
+{
+    if (y < 0) {
+        if (x < 0) return nb_from(c->D, 3, 3);
+        if (x < 4) return nb_from(c->B, x, 3);
+        return nb_from(c->C, 0, 3);
+    }
+    if (x < 0) return nb_from(c->A, 3, y);
+    Nb n = { 0, -1, 0, 0 };
+    if (x >= 4 || !(c->done & (1u << (4 * y + x)))) return n;   /* right MB / later partition */
+    return nb_from(c->cur, x, y);
+}
+static inline int16_t median3(int a, int b, int cc)
+{
+    int mn = a < b ? a : b, mx = a < b ? b : a;
+    return (int16_t)(cc < mn ? mn : cc > mx ? mx : cc);
+}
+/* shape: 0 generic, 1 = upper 16x8, 2 = lower 16x8, 3 = left 8x16, 4 = right 8x16 (8.4.1.3) */
+static void predict_mv(const MbCtx *c, int x, int y, int w, int ref, int shape, int16_t out[2])
+{
+    Nb a = nb_at(c, x - 1, y), b = nb_at(c, x, y - 1), cc = nb_at(c, x + w, y - 1);
+    if (!cc.avail) cc = nb_at(c, x - 1, y - 1);
+    if (shape == 1 && b.ref == ref) { out[0] = b.mx; out[1] = b.my; return; }
+    if (shape == 2 && a.ref == ref) { out[0] = a.mx; out[1] = a.my; return; }
+    if (shape == 3 && a.ref == ref) { out[0] = a.mx; out[1] = a.my; return; }
+    if (shape == 4 && cc.ref == ref) { out[0] = cc.mx; out[1] = cc.my; return; }
+    if (!b.avail && !cc.avail && a.avail) { out[0] = a.mx; out[1] = a.my; return; }
+    const int ma = a.ref == ref, mb = b.ref == ref, mc = cc.ref == ref;
+    if (ma + mb + mc == 1) {
+        const Nb *s = ma ? &a : mb ? &b : &cc;
+        out[0] = s->mx; out[1] = s->my;
+        return;
+    }
+    out[0] = median3(a.mx, b.mx, cc.mx);
+    out[1] = median3(a.my, b.my, cc.my);
+}
+
+static int set_partition(MbCtx *c, int x, int y, int w, int h, int ref, const int16_t mv[2])
+{
+    /* horizontal [-2048, 2047.75], vertical [-512, 511.75] luma samples */
+    if ((uint32_t)(mv[0] + 8192) >= 16384u || (uint32_t)(mv[1] + 2048) >= 4096u) return -1;
+    for (int yy = y; yy < y + h; yy++)
+        for (int xx = x; xx < x + w; xx++) {
+            const int z = z_of(xx, yy);
+            c->cur->mv[z][0] = mv[0];
+            c->cur->mv[z][1] = mv[1];
+            c->done |= (uint16_t)(1u << (4 * yy + xx));
+        }
+    (void)ref;
+    return 0;
+}
+
+static int resolve_ref(MbCtx *c, int quadrant, int ref_idx)
+{
+    const Dpb *dpb = &c->d->dpb;
+    if (ref_idx < 0 || ref_idx > 32) return -1;
+    int slot = dpb->list[ref_idx];
+    if (slot < 0 || dpb->pic[slot].status == DPB_NON_EXISTING || dpb->pic[slot].status == DPB_UNUSED) return -1;
+    c->cur->ref_idx[quadrant] = (int8_t)ref_idx;
+    c->cur->ref_slot[quadrant] = (uint8_t)slot;
+    return 0;
+}
+
+static uint32_t read_te(BitReader *br, uint32_t n_active)
+{
+    if (n_active > 2) return br_ue(br);
+    return br_get1(br) ^ 1u;
+}
+
+/* P macroblock prediction syntax + mv reconstruction. p_type: 0 16x16, 1 16x8, 2 8x16, 3 8x8, 4 8x8ref0 */
+static int parse_inter(MbCtx *c, int p_type)
+{
+    BitReader *br = c->br;
+    const uint32_t n_active = c->sh->num_ref_idx_active;
+    int16_t mvd[16][2], mvp[2], mv[2];
+    c->done = 0;
+
+    if (p_type <= 2) {
+        const int nparts = p_type == 0 ? 1 : 2;
+        uint32_t ref[2] = { 0, 0 };
+        if (n_active > 1)
+            for (int i = 0; i < nparts; i++) {
+                ref[i] = read_te(br, n_active);
+                if (br_overrun(br) || ref[i] >= n_active) return -1;
+            }
+        for (int i = 0; i < nparts; i++) { mvd[i][0] = (int16_t)br_se(br); mvd[i][1] = (int16_t)br_se(br); }
+        if (br_overrun(br)) return -1;
+        for (int i = 0; i < nparts; i++) {
+            int x = 0, y = 0, w = 4, h = 4, shape = 0;
+            if (p_type == 1) { y = 2 * i; h = 2; shape = 1 + i; }
+            if (p_type == 2) { x = 2 * i; w = 2; shape = 3 + i; }
+            /* reference of the quadrants covered by this partition must be known before prediction
+             * of the next partition looks at it */
+            if (p_type == 0) { for (int q = 0; q < 4; q++) if (resolve_ref(c, q, (int)ref[0])) return -1; }
+            else if (p_type == 1) { if (resolve_ref(c, 2 * i, (int)ref[i]) || resolve_ref(c, 2 * i + 1, (int)ref[i])) return -1; }
+            else { if (resolve_ref(c, i, (int)ref[i]) || resolve_ref(c, i + 2, (int)ref[i])) return -1; }
+            predict_mv(c, x, y, w, (int)ref[i], shape, mvp);
+            mv[0] = (int16_t)(mvp[0] + mvd[i][0]);
+            mv[1] = (int16_t)(mvp[1] + mvd[i][1]);
+            if (set_partition(c, x, y, w, h, (int)ref[i], mv)) return -1;
+        }
+        return 0;
+    }
+
+    /* P_8x8 / P_8x8ref0 */
+    uint32_t sub[4], ref[4] = { 0, 0, 0, 0 };
+    for (int i = 0; i < 4; i++) {
+        sub[i] = br_ue(br);
+        if (br_overrun(br) || sub[i] > 3) return -1;
+    }
+    if (n_active > 1 && p_type != 4)
+        for (int i = 0; i < 4; i++) {
+            ref[i] = read_te(br, n_active);
+            if (br_overrun(br) || ref[i] >= n_active) return -1;
+        }
+    static const uint8_t nsub[4] = { 1, 2, 2, 4 };
+    int k = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < nsub[sub[i]]; j++, k++) { mvd[k][0] = (int16_t)br_se(br); mvd[k][1] = (int16_t)br_se(br); }
+    if (br_overrun(br)) return -1;
+    k = 0;
+    for (int i = 0; i < 4; i++) {
+        if (resolve_ref(c, i, (int)ref[i])) return -1;
+        const int bx = (i & 1) * 2, by = (i >> 1) * 2;
+        const int sw = (sub[i] == 0 || sub[i] == 1) ? 2 : 1;   /* 8x8, 8x4 are 2 blocks wide */
+        const int shh = (sub[i] == 0 || sub[i] == 2) ? 2 : 1;  /* 8x8, 4x8 are 2 blocks high */
+        for (int j = 0; j < nsub[sub[i]]; j++, k++) {
+            int x = bx, y = by;
+            if (sub[i] == 1) y += j;
+            else if (sub[i] == 2) x += j;
+            else if (sub[i] == 3) { x += j & 1; y += j >> 1; }
+            predict_mv(c, x, y, sw, (int)ref[i], 0, mvp);
+            mv[0] = (int16_t)(mvp[0] + mvd[k][0]);
+            mv[1] = (int16_t)(mvp[1] + mvd[k][1]);
+            if (set_partition(c, x, y, sw, shh, (int)ref[i], mv)) return -1;
+        }
+    }
+    return 0;
+}
+
+static int infer_skip(MbCtx *c)
+{
+    int16_t mv[2] = { 0, 0 };
+    c->done = 0;
+    for (int q = 0; q < 4; q++) if (resolve_ref(c, q, 0)) return -1;
+    Nb a = nb_at(c, -1, 0), b = nb_at(c, 0, -1);
+    if (a.avail && b.avail && !(a.ref == 0 && a.mx == 0 && a.my == 0) && !(b.ref == 0 && b.mx == 0 && b.my == 0))
+        predict_mv(c, 0, 0, 4, 0, 0, mv);
+    return set_partition(c, 0, 0, 4, 4, 0, mv);
+}
+
+/* ---------------------------------------------------------------- Intra4x4PredMode, 8.3.1.1 */
+static int i4_neighbour_mode(const MbCtx *c, const MbInfo *m, int z)
+{
+    /* -1: "not available" (forces DC prediction of the mode), else the neighbour's mode, 2 if not I4x4 */
+    if (!m) return -1;
+    if (c->pps->constrained_intra_pred && is_inter(m)) return -1;
+    return m->kind == FJ_MB_I4x4 ? m->i4mode[z] : 2;
+}
+static int parse_i4_modes(MbCtx *c)
+{
+    BitReader *br = c->br;
+    for (int z = 0; z < 16; z++) {
+        const int x = Z_X[z], y = Z_Y[z];
+        int ma = x > 0 ? c->cur->i4mode[z_of(x - 1, y)] : i4_neighbour_mode(c, c->A, z_of(3, y));
+        int mb = y > 0 ? c->cur->i4mode[z_of(x, y - 1)] : i4_neighbour_mode(c, c->B, z_of(x, 3));
+        int pred = (ma < 0 || mb < 0) ? 2 : (ma < mb ? ma : mb);
+        if (!br_get1(br)) {
+            int rem = (int)br_get(br, 3);
+            pred = rem < pred ? rem : rem + 1;
+        }
+        c->cur->i4mode[z] = (int8_t)pred;
+    }
+    return br_overrun(br) ? -1 : 0;
+}
+
+/* ---------------------------------------------------------------- residual, 7.3.5.3 */
+static inline int16_t *next_block(HostDec *d, int16_t *coefs)
+{
+    int16_t *p = coefs + 16u * d->coef_blocks;
+    memset(p, 0, 32);
+    return p;
+}
+
+static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, uint32_t *coded_out)
+{
+    HostDec *d = c->d;
+    BitReader *br = c->br;
+    MbInfo *m = c->cur;
+    uint32_t coded = 0;
+    int n;
+
+    if (is_i16) {
+        int16_t *blk = next_block(d, coefs);
+        n = hd_cavlc_block(br, nc_luma(c, 0), 16, blk);
+        if (n < 0) return -1;
+        if (n) { coded |= FJ_CODED_LUMA_DC; d->coef_blocks++; }
+    }
+    for (int z = 0; z < 16; z++) {
+        if (!(cbp & (1u << (z >> 2)))) { m->tc[z] = 0; continue; }
+        int16_t *blk = next_block(d, coefs);
+        n = hd_cavlc_block(br, nc_luma(c, z), is_i16 ? 15 : 16, blk);
+        if (n < 0) return -1;
+        m->tc[z] = (uint8_t)n;
+        if (n) { coded |= 1u << z; d->coef_blocks++; }
+    }
+    memset(m->tc + 16, 0, 8);
+    if (cbp & 0x30) {
+        int16_t *blk = next_block(d, coefs);
+        int n0 = hd_cavlc_block(br, -1, 4, blk);
+        if (n0 < 0) return -1;
+        int n1 = hd_cavlc_block(br, -1, 4, blk + 4);
+        if (n1 < 0) return -1;
+        if (n0 || n1) { coded |= FJ_CODED_CHROMA_DC; d->coef_blocks++; }
+    }
+    if (cbp & 0x20) {
+        for (int k = 0; k < 8; k++) {
+            int16_t *blk = next_block(d, coefs);
+            n = hd_cavlc_block(br, nc_chroma(c, k >> 2, k & 3), 15, blk);
+            if (n < 0) return -1;
+            m->tc[16 + k] = (uint8_t)n;
+            if (n) { coded |= 1u << (16 + k); d->coef_blocks++; }
+        }
+    }
+    *coded_out = coded;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- one macroblock */
+static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *pps, uint32_t addr,
+                     int skipped, int *qp)
+{
+    FjHeader *hdr = (FjHeader *)d->job;
+    FjMbRec *recs = (FjMbRec *)(d->job + hdr->rec_off);
+    int16_t (*mvs)[16][2] = (int16_t (*)[16][2])(d->job + hdr->mv_off);
+    int16_t *coefs = (int16_t *)(d->job + hdr->coef_off);
+
+    MbCtx c;
+    memset(&c, 0, sizeof(c));
+    c.d = d; c.br = br; c.sh = sh; c.pps = pps;
+    c.addr = addr; c.mbx = addr % d->width_mbs; c.mby = addr / d->width_mbs;
+    MbInfo *m = c.cur = &d->mb[addr];
+    const uint32_t sid = d->slice_id;
+    c.A = c.mbx ? usable(m - 1, sid) : NULL;
+    c.B = c.mby ? usable(m - d->width_mbs, sid) : NULL;
+    c.C = (c.mby && c.mbx + 1 < d->width_mbs) ? usable(m - d->width_mbs + 1, sid) : NULL;
+    c.D = (c.mby && c.mbx) ? usable(m - d->width_mbs - 1, sid) : NULL;
+
+    const int first_decode = m->decoded == 0;
+    const uint32_t coef_start = d->coef_blocks;
+    FjMbRec rec;
+    memset(&rec, 0, sizeof(rec));
+    rec.coef_idx = coef_start;
+    rec.cqp_off = (int8_t)pps->chroma_qp_index_offset;
+    rec.alpha_off = (int8_t)sh->alpha_off;
+    rec.beta_off = (int8_t)sh->beta_off;
+    if (sh->disable_deblocking_filter_idc != 1) {
+        rec.dbk = FJ_DBK_INNER;
+        if (c.mbx && (sh->disable_deblocking_filter_idc != 2 || c.A)) rec.dbk |= FJ_DBK_LEFT;
+        if (c.mby && (sh->disable_deblocking_filter_idc != 2 || c.B)) rec.dbk |= FJ_DBK_TOP;
+    }
+
+    if (skipped) {
+        m->mb_type = 0;
+        m->kind = FJ_MB_INTER;
+        if (infer_skip(&c)) return -1;
+        memset(m->tc, 0, sizeof(m->tc));
+        m->qp = (uint8_t)*qp;
+        rec.kind = FJ_MB_INTER;
+    } else {
+        uint32_t t = br_ue(br);
+        if (br_overrun(br)) return -1;
+        int itype = -1, ptype = -1;
+        if (sh->is_p) { if (t < 5) ptype = (int)t; else itype = (int)t - 5; }
+        else itype = (int)t;
+        if (itype > 25) return -1;
+        m->mb_type = (uint8_t)(ptype >= 0 ? ptype + 1 : itype + 6);
+
+        if (itype == 25) {                                   /* I_PCM */
+            while (br->pos & 7) if (br_get1(br)) return -1;
+            uint8_t *dst = (uint8_t *)(coefs + 16u * d->coef_blocks);
+            for (int i = 0; i < 384; i++) dst[i] = (uint8_t)br_get(br, 8);
+            if (br_overrun(br)) return -1;
+            d->coef_blocks += 12;
+            m->kind = FJ_MB_IPCM;
+            m->qp = 0;
+            memset(m->tc, 16, sizeof(m->tc));
+            rec.kind = FJ_MB_IPCM;
+        } else {
+            uint32_t cbp;
+            int is_i16 = 0;
+            if (ptype >= 0) {
+                m->kind = FJ_MB_INTER;
+                if (parse_inter(&c, ptype)) return -1;
+                rec.kind = FJ_MB_INTER;
+            } else {
+                /* intra: availability of the four neighbours for prediction */
+                const int cip = pps->constrained_intra_pred;
+                if (c.A && !(cip && is_inter(c.A))) rec.avail |= FJ_AVAIL_A;
+                if (c.B && !(cip && is_inter(c.B))) rec.avail |= FJ_AVAIL_B;
+                if (c.C && !(cip && is_inter(c.C))) rec.avail |= FJ_AVAIL_C;
+                if (c.D && !(cip && is_inter(c.D))) rec.avail |= FJ_AVAIL_D;
+                if (itype == 0) {
+                    /* the mode derivation must see the neighbours' kinds but the current MB's own
+                     * previous kind must not leak in: set kind after the modes are known */
+                    if (parse_i4_modes(&c)) return -1;
+                    m->kind = FJ_MB_I4x4;
+                    rec.kind = FJ_MB_I4x4;
+                    for (int z = 0; z < 16; z++) rec.i4mode[z >> 1] |= (uint8_t)(m->i4mode[z] << ((z & 1) * 4));
+                } else {
+                    is_i16 = 1;
+                    m->kind = FJ_MB_I16x16;
+                    rec.kind = FJ_MB_I16x16;
+                    rec.pred = (uint8_t)((itype - 1) & 3);
+                }
+                uint32_t cm = br_ue(br);
+                if (br_overrun(br) || cm > 3) return -1;
+                rec.pred |= (uint8_t)(cm << 2);
+            }
+            if (is_i16) {
+                cbp = (((uint32_t)(itype - 1) >> 2) % 3) << 4;
+                if (itype >= 13) cbp |= 15;
+            } else {
+                uint32_t code = br_ue(br);
+                if (br_overrun(br) || code > 47) return -1;
+                cbp = ptype >= 0 ? cbp_inter[code] : cbp_intra[code];
+            }
+            memset(m->tc, 0, sizeof(m->tc));
+            if (cbp || is_i16) {
+                int32_t dq = br_se(br);
+                if (br_overrun(br) || dq < -26 || dq > 25) return -1;
+                if (parse_residual(&c, is_i16, cbp, coefs, &rec.coded)) return -1;
+                *qp += dq;
+                if (*qp < 0) *qp += 52; else if (*qp >= 52) *qp -= 52;
+            }
+            m->qp = (uint8_t)*qp;
+        }
+    }
+    m->decoded++;
+
+    if (!first_decode) {          /* redundant re-decode: keep the primary's record and pixels */
+        d->coef_blocks = coef_start;
+        return 0;
+    }
+    rec.qp_y = m->qp;
+    {
+        int qi = (int)m->qp + pps->chroma_qp_index_offset;
+        qi = qi < 0 ? 0 : qi > 51 ? 51 : qi;
+        rec.qp_c = qpc_table[qi];
+    }
+    if (rec.kind == FJ_MB_INTER) {
+        memcpy(rec.ref_slot, m->ref_slot, 4);
+        int16_t (*dst)[2] = mvs[addr];
+        for (int z = 0; z < 16; z++) {
+            const int r = 4 * Z_Y[z] + Z_X[z];
+            dst[r][0] = m->mv[z][0];
+            dst[r][1] = m->mv[z][1];
+        }
+        d->n_inter++;
+    } else {
+        d->n_intra++;
+    }
+    recs[addr] = rec;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- slice_data(), 7.3.4 */
+static uint32_t next_mb_in_group(const uint32_t *map, uint32_t n, uint32_t addr)
+{
+    const uint32_t g = map[addr];
+    for (uint32_t i = addr + 1; i < n; i++) if (map[i] == g) return i;
+    return 0;
+}
+
+int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_ref_idc)
+{
+    (void)nal_ref_idc;
+    const Pps *pps = d->active_pps;
+    uint32_t addr = sh->first_mb, skip_run = 0, count = 0;
+    int prev_skipped = 0, more;
+    int qp = pps->pic_init_qp + sh->slice_qp_delta;
+    d->slice_id++;
+    d->last_mb_addr = 0;
+
+    do {
+        MbInfo *m = &d->mb[addr];
+        if (!sh->redundant_pic_cnt && m->decoded) return -1;
+        m->slice_id = d->slice_id;
+        if (sh->is_p && !prev_skipped) {
+            skip_run = br_ue(br);
+            if (br_overrun(br) || skip_run > d->pic_size_mbs - addr) return -1;
+            if (skip_run) prev_skipped = 1;
+        }
+        int skipped = 0;
+        if (skip_run) { skip_run--; skipped = 1; }
+        else prev_skipped = 0;
+        if (decode_mb(d, br, sh, pps, addr, skipped, &qp)) return -1;
+        if (m->decoded == 1) count++;
+        more = br_more_rbsp_data(br) || skip_run;
+        if (!sh->is_p) d->last_mb_addr = addr;
+        addr = next_mb_in_group(d->slice_group_map, d->pic_size_mbs, addr);
+        if (more && !addr) return -1;
+    } while (more);
+
+    if (d->num_decoded_mbs + count > d->pic_size_mbs) return -1;
+    d->num_decoded_mbs += count;
+    return 0;
+}

@@ -1,0 +1,316 @@
+/*
+ * hostdec.h — internal declarations of the host-side H.264 baseline parser.
+ *
+ * The host keeps everything that is bit-serial or control-plane (SURVEY.md §2 rows marked "host"):
+ * Annex-B/NAL extraction, SPS/PPS/VUI, slice headers, CAVLC, macroblock-layer syntax, motion-vector
+ * and intra-mode prediction, DPB bookkeeping.  It never touches a pixel; its product is the packed
+ * frame job of framejob.h, handed to a JobSink (the HIP engine, or a capture callback).
+ *
+ * Written from the H.264 specification (clause numbers cited inline); behaviour that is specific to
+ * the reference decoder (return-code protocol, output timing) cites /root/reference file:line.
+ */
+#ifndef H264BSD_AMD_HOSTDEC_H
+#define H264BSD_AMD_HOSTDEC_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "framejob.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- bit reader */
+typedef struct BitReader {
+    const uint8_t *buf;   /* RBSP bytes; at least 8 readable zero bytes follow buf[size-1] */
+    uint32_t size_bits;
+    uint32_t pos;         /* bits consumed; may run past size_bits, callers test br_overrun() */
+} BitReader;
+
+static inline uint32_t br_peek32(const BitReader *b)
+{
+    const uint8_t *p = b->buf + (b->pos >> 3);
+    uint64_t v = ((uint64_t)p[0] << 56) | ((uint64_t)p[1] << 48) | ((uint64_t)p[2] << 40) |
+                 ((uint64_t)p[3] << 32) | ((uint64_t)p[4] << 24) | ((uint64_t)p[5] << 16) |
+                 ((uint64_t)p[6] << 8) | (uint64_t)p[7];
+    return (uint32_t)((v << (b->pos & 7)) >> 32);
+}
+static inline int br_overrun(const BitReader *b) { return b->pos > b->size_bits; }
+static inline uint32_t br_left(const BitReader *b) { return b->pos >= b->size_bits ? 0 : b->size_bits - b->pos; }
+static inline void br_skip(BitReader *b, uint32_t n)
+{
+    /* saturate well past the end so an overrun stays an overrun and peeks stay in the pad */
+    if (b->pos <= b->size_bits) b->pos += n;
+    if (b->pos > b->size_bits) b->pos = b->size_bits + 1;
+}
+static inline uint32_t br_get(BitReader *b, uint32_t n) /* 0 <= n <= 32 */
+{
+    if (n == 0) return 0;
+    uint32_t v = br_peek32(b) >> (32 - n);
+    br_skip(b, n);
+    return v;
+}
+static inline uint32_t br_get1(BitReader *b) { return br_get(b, 1); }
+/* Exp-Golomb ue(v), clause 9.1; code numbers up to 2^32-2, anything longer flags an overrun */
+static inline uint32_t br_ue(BitReader *b)
+{
+    uint32_t w = br_peek32(b);
+    if (w & 0x80000000u) { br_skip(b, 1); return 0; }
+    if (w == 0) {
+        /* 32 or more leading zeros: only the 33-bit/65-bit forms are legal, treat as corrupt */
+        b->pos = b->size_bits + 1;
+        return 0xFFFFFFFFu;
+    }
+    uint32_t lz = (uint32_t)__builtin_clz(w);
+    if (lz <= 15) {
+        uint32_t v = (w >> (31 - 2 * lz)) - 1;
+        br_skip(b, 2 * lz + 1);
+        return v;
+    }
+    br_skip(b, lz + 1);
+    uint32_t suffix = br_get(b, lz);
+    return ((1u << lz) - 1) + suffix;
+}
+static inline int32_t br_se(BitReader *b)
+{
+    uint32_t k = br_ue(b);
+    return (k & 1) ? (int32_t)((k + 1) >> 1) : -(int32_t)(k >> 1);
+}
+/* more_rbsp_data(), clause 7.2: false when only the stop bit and alignment zeros remain */
+static inline int br_more_rbsp_data(const BitReader *b)
+{
+    uint32_t left = br_left(b);
+    if (left == 0) return 0;
+    if (left > 8) return 1;
+    return (br_peek32(b) >> (32 - left)) != (1u << (left - 1));
+}
+
+/* ---------------------------------------------------------------- parameter sets */
+#define HD_MAX_SPS 32
+#define HD_MAX_PPS 256
+
+typedef struct Sps {
+    uint8_t  valid;
+    uint8_t  profile_idc, level_idc, constraint_flags;
+    uint8_t  sps_id;
+    uint32_t max_frame_num;           /* 1 << log2_max_frame_num                     */
+    uint8_t  poc_type;
+    uint32_t max_poc_lsb;
+    uint8_t  delta_pic_order_always_zero;
+    int32_t  offset_for_non_ref_pic, offset_for_top_to_bottom_field;
+    uint32_t num_ref_frames_in_poc_cycle;
+    int32_t  offset_for_ref_frame[255];
+    uint32_t num_ref_frames;
+    uint8_t  gaps_in_frame_num_allowed;
+    uint32_t width_mbs, height_mbs;
+    uint8_t  cropping;
+    uint32_t crop_left, crop_right, crop_top, crop_bottom;
+    uint32_t max_dpb_size;
+    /* VUI subset */
+    uint8_t  vui_present;
+    uint8_t  aspect_ratio_present, aspect_ratio_idc;
+    uint32_t sar_width, sar_height;
+    uint8_t  video_signal_type_present, video_full_range, colour_description_present;
+    uint8_t  matrix_coefficients;
+    uint8_t  bitstream_restriction;
+    uint32_t num_reorder_frames, max_dec_frame_buffering;
+} Sps;
+
+typedef struct Pps {
+    uint8_t  valid;
+    uint8_t  pps_id, sps_id;
+    uint8_t  pic_order_present;
+    uint32_t num_slice_groups;
+    uint8_t  slice_group_map_type;
+    uint32_t run_length[8];
+    uint32_t top_left[8], bottom_right[8];
+    uint8_t  slice_group_change_direction;
+    uint32_t slice_group_change_rate;
+    uint32_t pic_size_in_map_units;
+    uint8_t *slice_group_id;          /* type 6 */
+    uint32_t num_ref_idx_l0_active;
+    int32_t  pic_init_qp;             /* 26 + pic_init_qp_minus26                    */
+    int32_t  chroma_qp_index_offset;
+    uint8_t  deblocking_filter_control_present;
+    uint8_t  constrained_intra_pred;
+    uint8_t  redundant_pic_cnt_present;
+} Pps;
+
+/* ---------------------------------------------------------------- slice header */
+typedef struct ReorderCmd { uint8_t idc; uint32_t val; } ReorderCmd;
+typedef struct MmcoCmd { uint8_t op; uint32_t a, b; } MmcoCmd;
+
+typedef struct SliceHdr {
+    uint32_t first_mb;
+    uint8_t  is_p;                    /* slice_type%5 == 0 (P) else I                */
+    uint32_t pps_id;
+    uint32_t frame_num;
+    uint32_t idr_pic_id;
+    uint32_t poc_lsb;
+    int32_t  delta_poc_bottom;
+    int32_t  delta_poc[2];
+    uint32_t redundant_pic_cnt;
+    uint32_t num_ref_idx_active;
+    uint8_t  reorder_flag;
+    uint32_t n_reorder;
+    ReorderCmd reorder[18];
+    /* dec_ref_pic_marking */
+    uint8_t  no_output_of_prior_pics, long_term_reference_flag;
+    uint8_t  adaptive_marking;
+    uint32_t n_mmco;
+    MmcoCmd  mmco[36];
+    int32_t  slice_qp_delta;
+    uint8_t  disable_deblocking_filter_idc;
+    int32_t  alpha_off, beta_off;     /* already x2                                  */
+    uint32_t slice_group_change_cycle;
+} SliceHdr;
+
+/* ---------------------------------------------------------------- per-MB persistent metadata */
+typedef struct MbInfo {
+    uint8_t  kind;          /* FJ_MB_* of the last decode of this MB                             */
+    uint8_t  mb_type;       /* reference numbering: 0 P_Skip, 1..5 P, 6 I4x4, 7..30 I16x16, 31 PCM */
+    uint8_t  qp;
+    uint8_t  decoded;       /* times decoded in the current picture                              */
+    uint32_t slice_id;      /* 0 = not part of the current picture yet                           */
+    uint8_t  tc[24];        /* total_coeff per 4x4 block, H.264 block order (luma 0-15, Cb, Cr)   */
+    int8_t   i4mode[16];    /* Intra4x4PredMode, H.264 block order                                */
+    int8_t   ref_idx[4];
+    uint8_t  ref_slot[4];
+    int16_t  mv[16][2];     /* H.264 block order                                                  */
+} MbInfo;
+
+/* ---------------------------------------------------------------- DPB bookkeeping */
+enum { DPB_UNUSED = 0, DPB_NON_EXISTING, DPB_SHORT, DPB_LONG };
+
+typedef struct DpbPic {
+    uint8_t  status;
+    uint8_t  to_be_displayed;
+    uint8_t  is_idr;
+    uint32_t frame_num;
+    int32_t  pic_num;       /* FrameNumWrap-derived PicNum, or LongTermPicNum for long-term */
+    int32_t  poc;
+    uint32_t pic_id, num_err_mbs;
+} DpbPic;
+
+typedef struct OutPic { uint8_t slot; uint8_t is_idr; uint32_t pic_id, num_err_mbs; } OutPic;
+
+typedef struct Dpb {
+    uint32_t n_slots;       /* dpb_size + 1 */
+    uint32_t dpb_size;
+    uint32_t max_ref_frames, max_frame_num;
+    uint32_t max_long_term_idx; /* 0xFFFF = no long-term indices */
+    uint8_t  no_reordering;
+    uint32_t num_ref_frames, fullness;
+    uint32_t prev_ref_frame_num;
+    uint8_t  last_contains_mmco5;
+    int32_t  cur;           /* slot of the picture being decoded, -1 none */
+    DpbPic   pic[FJ_MAX_SLOTS];
+    int8_t   list[33];          /* RefPicList0: index -> slot, -1 = none */
+    OutPic   out[FJ_MAX_SLOTS + 1];
+    uint32_t n_out, out_idx;
+} Dpb;
+
+/* ---------------------------------------------------------------- job sink (device boundary) */
+typedef struct JobSink {
+    void *user;
+    /* (re)configure for a sequence: n_slots frames of frame_bytes each. 0 = ok */
+    int  (*configure)(void *user, uint32_t width_mbs, uint32_t height_mbs, uint32_t n_slots);
+    /* one finished picture; blob is only valid during the call. 0 = ok */
+    int  (*submit)(void *user, const uint8_t *blob, uint32_t bytes);
+    /* make slot's pixels available at host address; returns pointer or NULL */
+    uint8_t *(*fetch)(void *user, uint32_t slot);
+    /* colour conversion of a slot into a host buffer of width*height u32; fmt 0 RGBA 1 BGRA 2 YCbCrA */
+    uint32_t *(*fetch_converted)(void *user, uint32_t slot, int fmt);
+    void (*close)(void *user);
+} JobSink;
+
+/* ---------------------------------------------------------------- decoder instance */
+typedef struct PocState {
+    uint32_t prev_poc_lsb; int32_t prev_poc_msb;
+    uint32_t prev_frame_num, prev_frame_num_offset;
+    uint8_t  contains_mmco5;
+} PocState;
+
+typedef struct HostDec {
+    Sps *sps[HD_MAX_SPS];
+    Pps *pps[HD_MAX_PPS];
+    int  active_sps_id, active_pps_id, old_sps_id;   /* -1 = none */
+    Sps *active_sps; Pps *active_pps;
+    uint8_t pending_activation;
+    uint8_t no_reordering_app;
+
+    uint32_t pic_size_mbs, width_mbs, height_mbs;
+    MbInfo  *mb;
+    uint32_t *slice_group_map;
+    uint32_t num_decoded_mbs, slice_id;
+    uint32_t last_mb_addr;
+
+    /* access-unit tracking, clause 7.4.1.2.4 */
+    uint8_t  aub_first_call;
+    uint8_t  prev_nal_type, prev_nal_ref_idc;
+    uint32_t aub_prev_frame_num, aub_prev_idr_pic_id, aub_prev_poc_lsb;
+    int32_t  aub_prev_delta_poc_bottom, aub_prev_delta_poc[2];
+    uint8_t  pic_started, valid_slice_in_au, skip_redundant;
+    uint8_t  cur_nal_type, cur_nal_ref_idc;   /* of the last stored slice */
+    uint32_t current_pic_id;
+    uint32_t pic_seq;
+
+    SliceHdr slice;        /* last successfully decoded slice header */
+    PocState poc;
+    Dpb      dpb;
+
+    /* NAL staging: unescaped payload with 16 bytes of zero padding */
+    uint8_t *nal_buf; uint32_t nal_cap, nal_size;
+    const uint8_t *prev_buf_ptr; uint32_t prev_bytes_consumed; uint8_t prev_buf_not_finished;
+
+    /* frame job under construction */
+    uint8_t *job; uint32_t job_cap;
+    uint32_t coef_blocks;  /* blocks written so far */
+    uint32_t n_inter, n_intra;
+    uint8_t  job_open;
+
+    JobSink sink;
+    uint8_t  sink_configured;
+    uint32_t *conv_buf; size_t conv_cap;
+} HostDec;
+
+/* return codes shared with the public API (reference src/h264bsd_decoder.h:45-52) */
+enum { HD_RDY = 0, HD_PIC_RDY = 1, HD_HDRS_RDY = 2, HD_ERROR = 3, HD_PARAM_SET_ERROR = 4, HD_MEMALLOC_ERROR = 5 };
+
+/* hd_nal.c */
+int hd_extract_nal(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t *read_bytes);
+/* hd_params.c */
+int hd_parse_sps(BitReader *br, Sps *sps);
+int hd_parse_pps(BitReader *br, Pps *pps);
+void hd_free_pps(Pps *pps);
+int hd_sps_equal(const Sps *a, const Sps *b);
+/* hd_slice.c */
+int hd_parse_slice_header(BitReader *br, SliceHdr *sh, const Sps *sps, const Pps *pps, int nal_type, int nal_ref_idc);
+int hd_peek_pps_id(const BitReader *br, uint32_t *pps_id);
+int32_t hd_decode_poc(PocState *st, const Sps *sps, const SliceHdr *sh, int nal_type, int nal_ref_idc);
+void hd_slice_group_map(uint32_t *map, const Pps *pps, uint32_t change_cycle, uint32_t w, uint32_t h);
+/* hd_dpb.c */
+int  hd_dpb_reset(Dpb *dpb, uint32_t dpb_size, uint32_t max_ref_frames, uint32_t max_frame_num, int no_reordering);
+int  hd_dpb_alloc_current(Dpb *dpb);
+void hd_dpb_init_ref_list(Dpb *dpb);
+int  hd_dpb_reorder_ref_list(Dpb *dpb, const SliceHdr *sh);
+int  hd_dpb_check_gaps(Dpb *dpb, uint32_t frame_num, int is_ref, int gaps_allowed);
+int  hd_dpb_mark_current(Dpb *dpb, const SliceHdr *sh, int is_ref, int is_idr, int32_t poc, uint32_t pic_id, uint32_t err_mbs);
+void hd_dpb_flush(Dpb *dpb);
+const OutPic *hd_dpb_next_output(Dpb *dpb);
+/* hd_cavlc.c */
+void hd_cavlc_init(void);
+/* Decodes one residual block.  coef[] (raster 4x4 via zig-zag, or plain order for chroma DC) must
+ * be zeroed by the caller; returns total_coeff or -1 on a bitstream error.
+ * max_coeff: 16, 15 (AC: scan positions 1..15) or 4 (chroma DC, nc == -1). */
+int hd_cavlc_block(BitReader *br, int nc, int max_coeff, int16_t *coef);
+/* hd_mb.c */
+int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_ref_idc);
+/* hd_api.c helpers used across files */
+int  hd_job_begin(HostDec *d);
+int  hd_job_finish(HostDec *d, int is_idr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,65 @@
+/*
+ * h264bsd_mi355x.h — extensions of the drop-in API that only exist because the pixel path runs on
+ * an MI355X: frame-job capture, explicit batching and the HBM-resident replay used for throughput
+ * measurement.  Plain C ABI: pointers and sizes only.
+ *
+ * None of these has a counterpart in the reference (it has no device, no batching: SURVEY.md §2);
+ * the seams they expose are the reference's internal ones:
+ *   frame job  = input of h264bsdDecodeMacroblock (src/h264bsd_macroblock_layer.c:965) for every
+ *                macroblock of a picture + input of h264bsdFilterPicture (src/h264bsd_deblocking.c:575)
+ */
+#ifndef H264BSD_MI355X_EXT_H
+#define H264BSD_MI355X_EXT_H
+
+#include "h264bsd_decoder.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- capture: run only the host parser, hand every finished picture's packed frame job to cb ----
+ * No GPU is touched.  h264bsdDecode()'s return codes are unchanged; h264bsdNextOutputPicture*()
+ * return NULL (there are no pixels).  cb's blob pointer is valid only during the call. */
+typedef void (*h264bsdmi_job_cb)(void *user, const u8 *blob, u32 bytes);
+u32 h264bsdmiInitCapture(storage_t *pStorage, u32 noOutputReordering, h264bsdmi_job_cb cb, void *user);
+
+/* ---- device engine ---- */
+/* Number of usable GPUs (0 when the HIP runtime finds none); selects the device for this process. */
+int  h264bsdmiDeviceCount(void);
+int  h264bsdmiSetDevice(int device);
+/* Run every queued frame job of every decoder instance of this process now (they are otherwise run
+ * lazily, when the first picture is pulled).  Returns 0 on success. */
+int  h264bsdmiFlush(void);
+
+/* ---- HBM-resident replay (bench / parity tests): kernels only, no host parsing in the loop ----
+ * A replay set holds n_streams independent copies of one captured stream: every copy owns private
+ * frame jobs and a private DPB in HBM.  One "tick" reconstructs + deblocks picture k of all streams
+ * in batched launches. */
+typedef struct h264bsdmi_replay h264bsdmi_replay;
+/* blobs[i]/bytes[i]: the n_pics frame jobs of ONE stream in decode order (from h264bsdmiInitCapture). */
+h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams);
+void h264bsdmiReplayDestroy(h264bsdmi_replay *r);
+/* Enqueue ticks [first, first+count) on the engine stream; asynchronous.  0 = ok. */
+int  h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count);
+/* Wait for everything enqueued. */
+int  h264bsdmiReplaySync(h264bsdmi_replay *r);
+/* Copy the current content of DPB slot `slot` of stream `stream` to host memory (frame_bytes). */
+int  h264bsdmiReplayFetch(h264bsdmi_replay *r, u32 stream, u32 slot, u8 *dst);
+/* 64-bit checksum (computed on the device) of slot `slot` of every stream into sums[n_streams]. */
+int  h264bsdmiReplayChecksums(h264bsdmi_replay *r, u32 slot, unsigned long long *sums);
+/* On-device colour conversion of slot `slot` of every stream (fmt 0 RGBA, 1 BGRA, 2 YCbCrA) into the
+ * set's ARGB planes; fetch one with ...FetchConverted. */
+int  h264bsdmiReplayConvert(h264bsdmi_replay *r, u32 slot, int fmt);
+int  h264bsdmiReplayFetchConverted(h264bsdmi_replay *r, u32 stream, u32 *dst);
+/* HIP-event timing of the kernels of the last h264bsdmiReplayRun(): ms per kernel class
+ * out[0]=inter reconstruction, out[1]=intra reconstruction, out[2]=deblocking, out[3]=whole run;
+ * launches[0..2] = number of launches per class. */
+int  h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[4], u32 launches[3]);
+/* Bytes of packed syntax (frame jobs) per stream and of one frame, for the byte accounting. */
+unsigned long long h264bsdmiReplayJobBytes(h264bsdmi_replay *r);
+u32  h264bsdmiReplayFrameBytes(h264bsdmi_replay *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
