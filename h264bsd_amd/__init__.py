@@ -1,0 +1,10 @@
+"""h264bsd_amd — MI355X-native macroblock-reconstruction back end behind the h264bsd C API.
+
+The product is the C-ABI shared library h264bsd_amd/lib/libh264bsd_mi355x.so (host parser in C,
+HIP kernels for gfx950).  This package is a thin ctypes mirror of that ABI, named after the reference's
+own entry points so tests read like /root/reference/posix/test_h264bsd.c.
+"""
+from .capi import (  # noqa: F401
+    H264BSD_RDY, H264BSD_PIC_RDY, H264BSD_HDRS_RDY, H264BSD_ERROR, H264BSD_PARAM_SET_ERROR, H264BSD_MEMALLOC_ERROR,
+    EXPORTED_SYMBOLS, LIB_PATH, Decoder, Replay, build, capture_stream, convert, device_count, lib,
+)

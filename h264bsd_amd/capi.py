@@ -1,0 +1,297 @@
+"""ctypes mirror of include/h264bsd_decoder.h + include/h264bsd_mi355x.h.
+
+No pixel is ever produced in Python or on the CPU here: every call goes through the C ABI of
+libh264bsd_mi355x.so, and anything that needs pixels fails loudly when the HIP engine is unavailable.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "lib", "libh264bsd_mi355x.so")
+
+(H264BSD_RDY, H264BSD_PIC_RDY, H264BSD_HDRS_RDY, H264BSD_ERROR, H264BSD_PARAM_SET_ERROR,
+ H264BSD_MEMALLOC_ERROR) = range(6)
+
+# every symbol include/*.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = [
+    "h264bsdInit", "h264bsdDecode", "h264bsdShutdown", "h264bsdNextOutputPicture",
+    "h264bsdNextOutputPictureRGBA", "h264bsdNextOutputPictureBGRA", "h264bsdNextOutputPictureYCbCrA",
+    "h264bsdPicWidth", "h264bsdPicHeight", "h264bsdVideoRange", "h264bsdMatrixCoefficients",
+    "h264bsdCroppingParams", "h264bsdSampleAspectRatio", "h264bsdCheckValidParamSets", "h264bsdFlushBuffer",
+    "h264bsdProfile", "h264bsdAlloc", "h264bsdFree", "h264bsdConvertToRGBA", "h264bsdConvertToBGRA",
+    "h264bsdConvertToYCbCrA",
+    "h264bsdmiInitCapture", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush",
+    "h264bsdmiReplayCreate", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
+    "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
+    "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
+]
+
+JOB_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint32)
+P32 = ctypes.POINTER(ctypes.c_uint32)
+
+
+def build(force=False):
+    """Compile the library in-tree for gfx950 (hipcc cross-compiles; no GPU needed)."""
+    if force:
+        subprocess.run(["make", "-s", "-C", CSRC, "clean"], check=True)
+    subprocess.run(["make", "-s", "-C", CSRC], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u32, u8p = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p
+    L.h264bsdAlloc.restype = vp
+    L.h264bsdFree.argtypes = [vp]
+    L.h264bsdInit.argtypes = [vp, u32]
+    L.h264bsdInit.restype = u32
+    L.h264bsdmiInitCapture.argtypes = [vp, u32, JOB_CB, vp]
+    L.h264bsdmiInitCapture.restype = u32
+    L.h264bsdDecode.argtypes = [vp, u8p, u32, u32, P32]
+    L.h264bsdDecode.restype = u32
+    L.h264bsdShutdown.argtypes = [vp]
+    for n in ("h264bsdNextOutputPicture", "h264bsdNextOutputPictureRGBA", "h264bsdNextOutputPictureBGRA",
+              "h264bsdNextOutputPictureYCbCrA"):
+        getattr(L, n).argtypes = [vp, P32, P32, P32]
+        getattr(L, n).restype = vp
+    for n in ("h264bsdPicWidth", "h264bsdPicHeight", "h264bsdVideoRange", "h264bsdMatrixCoefficients",
+              "h264bsdCheckValidParamSets", "h264bsdProfile"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = u32
+    L.h264bsdFlushBuffer.argtypes = [vp]
+    L.h264bsdCroppingParams.argtypes = [vp, P32, P32, P32, P32, P32]
+    L.h264bsdSampleAspectRatio.argtypes = [vp, P32, P32]
+    for n in ("h264bsdConvertToRGBA", "h264bsdConvertToBGRA", "h264bsdConvertToYCbCrA"):
+        getattr(L, n).argtypes = [u32, u32, vp, vp]
+        getattr(L, n).restype = None
+    L.h264bsdmiSetDevice.argtypes = [ctypes.c_int]
+    L.h264bsdmiReplayCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32]
+    L.h264bsdmiReplayCreate.restype = vp
+    L.h264bsdmiReplayDestroy.argtypes = [vp]
+    L.h264bsdmiReplayDestroy.restype = None
+    L.h264bsdmiReplayRun.argtypes = [vp, u32, u32]
+    L.h264bsdmiReplaySync.argtypes = [vp]
+    L.h264bsdmiReplayFetch.argtypes = [vp, u32, u32, vp]
+    L.h264bsdmiReplayChecksums.argtypes = [vp, u32, vp]
+    L.h264bsdmiReplayConvert.argtypes = [vp, u32, ctypes.c_int]
+    L.h264bsdmiReplayFetchConverted.argtypes = [vp, u32, vp]
+    L.h264bsdmiReplayTimings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), P32]
+    L.h264bsdmiReplaySetStages.argtypes = [vp, ctypes.c_uint]
+    L.h264bsdmiReplayJobBytes.argtypes = [vp]
+    L.h264bsdmiReplayJobBytes.restype = ctypes.c_ulonglong
+    L.h264bsdmiReplayFrameBytes.argtypes = [vp]
+    L.h264bsdmiReplayFrameBytes.restype = u32
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(lib().h264bsdmiDeviceCount())
+
+
+class Decoder:
+    """One decoder instance.  Method names follow the reference API (h264bsd_decoder.h)."""
+
+    def __init__(self, no_output_reordering=0, capture=None):
+        """capture: None -> pixels on the GPU (h264bsdInit; raises when there is no device);
+        a callable(bytes) -> parser only, every picture's frame job is handed to it."""
+        L = lib()
+        self._L = L
+        self._st = L.h264bsdAlloc()
+        self._cb = None
+        if capture is None:
+            rc = L.h264bsdInit(self._st, no_output_reordering)
+        else:
+            self._cb = JOB_CB(lambda user, p, n: capture(ctypes.string_at(p, n)))
+            rc = L.h264bsdmiInitCapture(self._st, no_output_reordering, self._cb, None)
+        if rc != 0:
+            L.h264bsdFree(self._st)
+            self._st = None
+            raise RuntimeError("h264bsdInit failed: the HIP engine is not available (no CPU pixel path exists)")
+
+    def close(self):
+        if self._st:
+            self._L.h264bsdShutdown(self._st)
+            self._L.h264bsdFree(self._st)
+            self._st = None
+
+    __del__ = close
+
+    def decode(self, buf_addr, length, pic_id=0):
+        """h264bsdDecode on raw memory: returns (status, readBytes)."""
+        rb = ctypes.c_uint32(0)
+        r = self._L.h264bsdDecode(self._st, buf_addr, length, pic_id, ctypes.byref(rb))
+        return int(r), int(rb.value)
+
+    def _next(self, fn, nbytes, dtype):
+        a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        p = fn(self._st, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        if not p:
+            return None
+        arr = np.frombuffer(ctypes.string_at(p, nbytes), dtype=dtype)
+        return arr, int(a.value), int(b.value), int(c.value)
+
+    def frame_bytes(self):
+        return self.pic_width() * self.pic_height() * 384
+
+    def next_output_picture(self):
+        """(uint8 I420 frame copy, picId, isIdr, numErrMbs) or None"""
+        return self._next(self._L.h264bsdNextOutputPicture, self.frame_bytes(), np.uint8)
+
+    def next_output_picture_converted(self, fmt):
+        fn = (self._L.h264bsdNextOutputPictureRGBA, self._L.h264bsdNextOutputPictureBGRA,
+              self._L.h264bsdNextOutputPictureYCbCrA)[fmt]
+        return self._next(fn, self.pic_width() * self.pic_height() * 256 * 4, np.uint32)
+
+    def pic_width(self):
+        return int(self._L.h264bsdPicWidth(self._st))
+
+    def pic_height(self):
+        return int(self._L.h264bsdPicHeight(self._st))
+
+    def video_range(self):
+        return int(self._L.h264bsdVideoRange(self._st))
+
+    def matrix_coefficients(self):
+        return int(self._L.h264bsdMatrixCoefficients(self._st))
+
+    def profile(self):
+        return int(self._L.h264bsdProfile(self._st))
+
+    def check_valid_param_sets(self):
+        return int(self._L.h264bsdCheckValidParamSets(self._st))
+
+    def flush_buffer(self):
+        self._L.h264bsdFlushBuffer(self._st)
+
+    def cropping_params(self):
+        v = [ctypes.c_uint32() for _ in range(5)]
+        self._L.h264bsdCroppingParams(self._st, *[ctypes.byref(x) for x in v])
+        return tuple(int(x.value) for x in v)   # flag, left, width, top, height
+
+    def sample_aspect_ratio(self):
+        w, h = ctypes.c_uint32(), ctypes.c_uint32()
+        self._L.h264bsdSampleAspectRatio(self._st, ctypes.byref(w), ctypes.byref(h))
+        return int(w.value), int(h.value)
+
+    def decode_stream(self, data, on_picture=None, drain=True):
+        """The reference harness loop (posix/test_h264bsd.c:146-177) over a whole byte stream.
+        Returns the call trace [(status, readBytes)]."""
+        buf = ctypes.create_string_buffer(data, len(data))
+        base, off, trace = ctypes.addressof(buf), 0, []
+        while off < len(data):
+            r, rb = self.decode(base + off, len(data) - off)
+            trace.append((r, rb))
+            off += rb
+            if r == H264BSD_PIC_RDY and drain:
+                while True:
+                    pic = self.next_output_picture() if on_picture is not None else None
+                    if pic is None:
+                        break
+                    on_picture(*pic)
+            elif r >= H264BSD_ERROR:
+                break
+        return trace
+
+
+def capture_stream(data):
+    """Parse a byte stream on the host only.  Returns (jobs, trace, info): the packed frame job of every
+    picture in decode order, the h264bsdDecode call trace, and stream geometry."""
+    jobs = []
+    dec = Decoder(capture=jobs.append)
+    trace = dec.decode_stream(data, drain=False)
+    info = dict(width_mbs=dec.pic_width(), height_mbs=dec.pic_height(), cropping=dec.cropping_params(),
+                video_range=dec.video_range(), matrix_coefficients=dec.matrix_coefficients(),
+                profile=dec.profile(), sar=dec.sample_aspect_ratio())
+    dec.close()
+    return jobs, trace, info
+
+
+def convert(fmt, width, height, yuv):
+    """h264bsdConvertToRGBA/BGRA/YCbCrA (fmt 0/1/2) of one host I420 frame, computed on the GPU."""
+    if device_count() <= 0:
+        raise RuntimeError("h264bsdConvertTo*: no HIP device (no CPU pixel path exists)")
+    L = lib()
+    fn = (L.h264bsdConvertToRGBA, L.h264bsdConvertToBGRA, L.h264bsdConvertToYCbCrA)[fmt]
+    src = np.ascontiguousarray(yuv, dtype=np.uint8)
+    out = np.zeros(width * height, dtype=np.uint32)
+    fn(width, height, src.ctypes.data, out.ctypes.data)
+    return out
+
+
+class Replay:
+    """HBM-resident replay set: n_streams private copies of one captured stream (kernels only)."""
+
+    def __init__(self, jobs, n_streams):
+        L = lib()
+        self._L = L
+        self._keep = [ctypes.create_string_buffer(j, len(j)) for j in jobs]
+        ptrs = (ctypes.c_void_p * len(jobs))(*[ctypes.addressof(b) for b in self._keep])
+        sizes = (ctypes.c_uint32 * len(jobs))(*[len(j) for j in jobs])
+        self.n_pics, self.n_streams = len(jobs), n_streams
+        self._h = L.h264bsdmiReplayCreate(ptrs, sizes, len(jobs), n_streams)
+        if not self._h:
+            raise RuntimeError("h264bsdmiReplayCreate failed (no HIP device or out of memory)")
+        self.frame_bytes = int(L.h264bsdmiReplayFrameBytes(self._h))
+        self.job_bytes = int(L.h264bsdmiReplayJobBytes(self._h))
+
+    def close(self):
+        if self._h:
+            self._L.h264bsdmiReplayDestroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def run(self, first=0, count=None):
+        count = self.n_pics - first if count is None else count
+        if self._L.h264bsdmiReplayRun(self._h, first, count) != 0:
+            raise RuntimeError("h264bsdmiReplayRun failed")
+
+    def sync(self):
+        if self._L.h264bsdmiReplaySync(self._h) != 0:
+            raise RuntimeError("h264bsdmiReplaySync failed")
+
+    def fetch(self, stream, slot):
+        out = np.empty(self.frame_bytes, dtype=np.uint8)
+        if self._L.h264bsdmiReplayFetch(self._h, stream, slot, out.ctypes.data) != 0:
+            raise RuntimeError("h264bsdmiReplayFetch failed")
+        return out
+
+    def checksums(self, slot):
+        out = np.empty(self.n_streams, dtype=np.uint64)
+        if self._L.h264bsdmiReplayChecksums(self._h, slot, out.ctypes.data) != 0:
+            raise RuntimeError("h264bsdmiReplayChecksums failed")
+        return out
+
+    def convert(self, slot, fmt):
+        if self._L.h264bsdmiReplayConvert(self._h, slot, fmt) != 0:
+            raise RuntimeError("h264bsdmiReplayConvert failed")
+
+    def fetch_converted(self, stream, n_pixels):
+        out = np.empty(n_pixels, dtype=np.uint32)
+        if self._L.h264bsdmiReplayFetchConverted(self._h, stream, out.ctypes.data) != 0:
+            raise RuntimeError("h264bsdmiReplayFetchConverted failed")
+        return out
+
+    def set_stages(self, mask):
+        self._L.h264bsdmiReplaySetStages(self._h, mask)
+
+    def timings(self):
+        ms = (ctypes.c_float * 4)()
+        n = (ctypes.c_uint32 * 3)()
+        if self._L.h264bsdmiReplayTimings(self._h, ms, n) != 0:
+            raise RuntimeError("h264bsdmiReplayTimings failed")
+        return dict(inter_ms=ms[0], intra_ms=ms[1], deblock_ms=ms[2], total_ms=ms[3],
+                    launches=dict(inter=int(n[0]), intra=int(n[1]), deblock=int(n[2])))

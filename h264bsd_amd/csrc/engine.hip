@@ -1,0 +1,532 @@
+/*
+ * engine.hip — host side of the HIP engine: device context, per-decoder DPB in HBM, lazy batched
+ * execution of queued frame jobs ("ticks"), and the HBM-resident replay sets used by bench.py and the
+ * parity tests.
+ *
+ * Execution model.  A tick holds at most one picture per stream (pictures of one stream depend on
+ * each other through the DPB; pictures of different streams never do).  For a tick of N pictures:
+ *     1 launch  k_recon_inter   grid (max MBs, N)            — every inter MB of every picture
+ *     L launches k_recon_intra  grid (level population, N)   — intra MBs, dependency level by level
+ *     D launches k_deblock      grid (MBs on diagonal, N)    — D = (W-1) + 2(H-1) + 1 anti-diagonals
+ * all on one HIP stream, so launch order is execution order and no inter-workgroup synchronisation
+ * is needed inside a launch.  Occupancy comes from batching streams: at 256 x 1080p a deblocking
+ * step has up to 256 x 60 wavefronts.
+ *
+ * This replaces, for the pixels, what the reference does synchronously inside h264bsdDecode
+ * (src/h264bsd_slice_data.c:185 -> h264bsdDecodeMacroblock, src/h264bsd_decoder.c:475 ->
+ * h264bsdFilterPicture) and the malloc'ed frame buffers of src/h264bsd_dpb.c:1014-1031.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <deque>
+#include <mutex>
+#include <vector>
+#include <algorithm>
+#include "kernels.hip.h"
+#include "engine.h"
+#include "../../include/h264bsd_mi355x.h"
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "h264bsd-mi355x: HIP error %s at %s:%d (%s)\n", hipGetErrorString(e_), \
+                    __FILE__, __LINE__, #expr);                                                    \
+            return -1;                                                                             \
+        }                                                                                          \
+    } while (0)
+
+namespace {
+
+struct PendingJob { uint8_t *host; uint32_t bytes; };
+
+struct StreamCtx {
+    uint32_t wmb = 0, hmb = 0, n_slots = 0, frame_bytes = 0;
+    uint8_t *d_frames = nullptr;
+    uint8_t *h_frame[FJ_MAX_SLOTS] = {};
+    uint32_t *h_conv = nullptr, *d_conv = nullptr;
+    std::deque<PendingJob> pending;
+};
+
+struct Engine {
+    std::mutex mu;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<StreamCtx *> streams;
+    uint8_t *d_arena = nullptr; size_t arena_cap = 0;      /* device copies of the blobs of one tick */
+    FrameDesc *d_desc = nullptr; size_t desc_cap = 0;
+    uint8_t *conv_in = nullptr; uint32_t *conv_out = nullptr; size_t conv_cap = 0; /* eng_convert_host scratch */
+};
+
+Engine *g_engine = nullptr;
+std::mutex g_engine_mu;
+int g_device_request = -1;
+
+Engine *engine_get()
+{
+    std::lock_guard<std::mutex> lk(g_engine_mu);
+    if (g_engine) return g_engine;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return nullptr;
+    Engine *e = new Engine();
+    if (g_device_request >= 0) e->device = g_device_request;
+    else if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
+    if (hipSetDevice(e->device) != hipSuccess) { delete e; return nullptr; }
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return nullptr; }
+    g_engine = e;
+    return e;
+}
+
+/* ---- launch of one tick ---- */
+struct TickShape {
+    uint32_t n_frames = 0, max_mbs = 0, max_w = 0, max_h = 0;
+    bool any_inter = false, any_deblock = false;
+    std::vector<uint32_t> level_pop;     /* max population per intra level over the frames of the tick */
+};
+
+void shape_add(TickShape &s, const uint8_t *host_blob)
+{
+    const FjHeader *h = reinterpret_cast<const FjHeader *>(host_blob);
+    s.n_frames++;
+    s.max_mbs = std::max(s.max_mbs, h->n_mbs);
+    s.max_w = std::max<uint32_t>(s.max_w, h->width_mbs);
+    s.max_h = std::max<uint32_t>(s.max_h, h->height_mbs);
+    s.any_inter |= h->n_inter != 0;
+    s.any_deblock |= h->any_deblock != 0;
+    const uint32_t *lvl = reinterpret_cast<const uint32_t *>(host_blob + h->lvl_off);
+    if (s.level_pop.size() < h->n_intra_levels) s.level_pop.resize(h->n_intra_levels, 0);
+    for (uint32_t l = 0; l < h->n_intra_levels; l++) s.level_pop[l] = std::max(s.level_pop[l], lvl[l + 1] - lvl[l]);
+}
+
+struct TickTimers { hipEvent_t ev[4]; bool on = false; };
+
+int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[3],
+                unsigned stages = 7u)
+{
+    if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[0], st));
+    if (s.any_inter && (stages & 1u)) {
+        hipLaunchKernelGGL(h264k::k_recon_inter, dim3(s.max_mbs, s.n_frames), dim3(64), 0, st, d_desc);
+        if (launches) launches[0]++;
+    }
+    if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[1], st));
+    for (uint32_t l = 0; (stages & 2u) && l < s.level_pop.size(); l++) {
+        hipLaunchKernelGGL(h264k::k_recon_intra, dim3(s.level_pop[l], s.n_frames), dim3(64), 0, st, d_desc, l);
+        if (launches) launches[1]++;
+    }
+    if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[2], st));
+    if (s.any_deblock && (stages & 4u)) {
+        const int w = (int)s.max_w, h = (int)s.max_h;
+        for (int d = 0; d <= (w - 1) + 2 * (h - 1); d++) {
+            const int ylo = std::max(0, (d - (w - 1) + 1) >> 1), yhi = std::min(h - 1, d >> 1);
+            if (yhi < ylo) continue;
+            hipLaunchKernelGGL(h264k::k_deblock, dim3((uint32_t)(yhi - ylo + 1), s.n_frames), dim3(64), 0, st, d_desc, d);
+            if (launches) launches[2]++;
+        }
+    }
+    if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[3], st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* ---- lazy execution of the queued jobs of all decoder instances ---- */
+int flush_locked(Engine *e)
+{
+    HIP_TRY(hipSetDevice(e->device));
+    for (;;) {
+        std::vector<StreamCtx *> part;
+        size_t bytes = 0;
+        for (StreamCtx *s : e->streams)
+            if (!s->pending.empty()) { part.push_back(s); bytes += (s->pending.front().bytes + 255u) & ~255u; }
+        if (part.empty()) return 0;
+        if (bytes > e->arena_cap) {
+            if (e->d_arena) HIP_TRY(hipFree(e->d_arena));
+            e->arena_cap = bytes + bytes / 4;
+            HIP_TRY(hipMalloc((void **)&e->d_arena, e->arena_cap));
+        }
+        if (part.size() > e->desc_cap) {
+            if (e->d_desc) HIP_TRY(hipFree(e->d_desc));
+            e->desc_cap = part.size() * 2;
+            HIP_TRY(hipMalloc((void **)&e->d_desc, e->desc_cap * sizeof(FrameDesc)));
+        }
+        std::vector<FrameDesc> descs(part.size());
+        TickShape shape;
+        size_t off = 0;
+        for (size_t i = 0; i < part.size(); i++) {
+            StreamCtx *s = part[i];
+            PendingJob &j = s->pending.front();
+            HIP_TRY(hipMemcpyAsync(e->d_arena + off, j.host, j.bytes, hipMemcpyHostToDevice, e->stream));
+            shape_add(shape, j.host);
+            descs[i].blob = e->d_arena + off;
+            for (uint32_t k = 0; k < FJ_MAX_SLOTS; k++)
+                descs[i].slot[k] = k < s->n_slots ? s->d_frames + (size_t)k * s->frame_bytes : nullptr;
+            off += (j.bytes + 255u) & ~255u;
+        }
+        HIP_TRY(hipMemcpyAsync(e->d_desc, descs.data(), descs.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream));
+        if (launch_tick(e->stream, e->d_desc, shape, nullptr, nullptr)) return -1;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (StreamCtx *s : part) {
+            hipHostFree(s->pending.front().host);
+            s->pending.pop_front();
+        }
+    }
+}
+
+/* ---- JobSink implementation ---- */
+struct SinkUser { Engine *e; StreamCtx *s; };
+
+void stream_release(StreamCtx *s)
+{
+    for (auto &j : s->pending) hipHostFree(j.host);
+    s->pending.clear();
+    if (s->d_frames) hipFree(s->d_frames);
+    for (auto &p : s->h_frame) if (p) { hipHostFree(p); p = nullptr; }
+    if (s->h_conv) hipHostFree(s->h_conv);
+    if (s->d_conv) hipFree(s->d_conv);
+    s->d_frames = nullptr; s->h_conv = nullptr; s->d_conv = nullptr;
+}
+
+int sink_configure(void *user, uint32_t wmb, uint32_t hmb, uint32_t n_slots)
+{
+    SinkUser *u = static_cast<SinkUser *>(user);
+    std::lock_guard<std::mutex> lk(u->e->mu);
+    if (flush_locked(u->e)) return -1;
+    HIP_TRY(hipSetDevice(u->e->device));
+    stream_release(u->s);
+    u->s->wmb = wmb; u->s->hmb = hmb; u->s->n_slots = n_slots;
+    u->s->frame_bytes = fj_frame_bytes(wmb, hmb);
+    const size_t total = (size_t)n_slots * u->s->frame_bytes + 256;
+    HIP_TRY(hipMalloc((void **)&u->s->d_frames, total));
+    HIP_TRY(hipMemsetAsync(u->s->d_frames, 0, total, u->e->stream));
+    return 0;
+}
+
+int sink_submit(void *user, const uint8_t *blob, uint32_t bytes)
+{
+    SinkUser *u = static_cast<SinkUser *>(user);
+    std::lock_guard<std::mutex> lk(u->e->mu);
+    PendingJob j;
+    j.bytes = bytes;
+    HIP_TRY(hipSetDevice(u->e->device));
+    HIP_TRY(hipHostMalloc((void **)&j.host, bytes, hipHostMallocDefault));
+    memcpy(j.host, blob, bytes);
+    u->s->pending.push_back(j);
+    return 0;
+}
+
+uint8_t *sink_fetch(void *user, uint32_t slot)
+{
+    SinkUser *u = static_cast<SinkUser *>(user);
+    std::lock_guard<std::mutex> lk(u->e->mu);
+    StreamCtx *s = u->s;
+    if (slot >= s->n_slots || flush_locked(u->e)) return nullptr;
+    if (!s->h_frame[slot] && hipHostMalloc((void **)&s->h_frame[slot], s->frame_bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipMemcpyAsync(s->h_frame[slot], s->d_frames + (size_t)slot * s->frame_bytes, s->frame_bytes,
+                       hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(u->e->stream) != hipSuccess) return nullptr;
+    return s->h_frame[slot];
+}
+
+uint32_t *sink_fetch_converted(void *user, uint32_t slot, int fmt)
+{
+    SinkUser *u = static_cast<SinkUser *>(user);
+    std::lock_guard<std::mutex> lk(u->e->mu);
+    StreamCtx *s = u->s;
+    if (slot >= s->n_slots || flush_locked(u->e)) return nullptr;
+    const uint32_t w = s->wmb * 16, h = s->hmb * 16;
+    const size_t bytes = (size_t)w * h * 4;
+    if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
+    if (!s->h_conv && hipHostMalloc((void **)&s->h_conv, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(h264k::k_convert, dim3(1024, 1), dim3(256), 0, u->e->stream,
+                       s->d_frames + (size_t)slot * s->frame_bytes, s->d_conv, w, h, fmt, (size_t)0, (size_t)0);
+    if (hipMemcpyAsync(s->h_conv, s->d_conv, bytes, hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(u->e->stream) != hipSuccess) return nullptr;
+    return s->h_conv;
+}
+
+void sink_close(void *user)
+{
+    SinkUser *u = static_cast<SinkUser *>(user);
+    {
+        std::lock_guard<std::mutex> lk(u->e->mu);
+        hipSetDevice(u->e->device);
+        hipStreamSynchronize(u->e->stream);
+        stream_release(u->s);
+        auto &v = u->e->streams;
+        v.erase(std::remove(v.begin(), v.end(), u->s), v.end());
+    }
+    delete u->s;
+    delete u;
+}
+
+} // namespace
+
+/* ================================================================== C interface */
+extern "C" {
+
+int eng_attach(JobSink *sink)
+{
+    Engine *e = engine_get();
+    if (!e) return -1;
+    SinkUser *u = new SinkUser{ e, new StreamCtx() };
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->streams.push_back(u->s);
+    }
+    sink->user = u;
+    sink->configure = sink_configure;
+    sink->submit = sink_submit;
+    sink->fetch = sink_fetch;
+    sink->fetch_converted = sink_fetch_converted;
+    sink->close = sink_close;
+    return 0;
+}
+
+void eng_convert_host(int fmt, uint32_t width, uint32_t height, const uint8_t *data, uint32_t *out)
+{
+    Engine *e = engine_get();
+    if (!e) {
+        fprintf(stderr, "h264bsd-mi355x: h264bsdConvertTo*: no usable HIP device (this library has no CPU pixel path)\n");
+        return;
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    const size_t in_b = (size_t)width * height * 3 / 2, out_b = (size_t)width * height * 4;
+    if (hipSetDevice(e->device) != hipSuccess) return;
+    if (out_b > e->conv_cap) {
+        if (e->conv_in) hipFree(e->conv_in);
+        if (e->conv_out) hipFree(e->conv_out);
+        e->conv_in = nullptr; e->conv_out = nullptr; e->conv_cap = 0;
+        if (hipMalloc((void **)&e->conv_in, in_b + 64) != hipSuccess || hipMalloc((void **)&e->conv_out, out_b) != hipSuccess) return;
+        e->conv_cap = out_b;
+    }
+    if (hipMemcpyAsync(e->conv_in, data, in_b, hipMemcpyHostToDevice, e->stream) != hipSuccess) return;
+    hipLaunchKernelGGL(h264k::k_convert, dim3(1024, 1), dim3(256), 0, e->stream, e->conv_in, e->conv_out, width, height, fmt,
+                       (size_t)0, (size_t)0);
+    if (hipMemcpyAsync(out, e->conv_out, out_b, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return;
+    hipStreamSynchronize(e->stream);
+}
+
+int h264bsdmiDeviceCount(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int h264bsdmiSetDevice(int device)
+{
+    std::lock_guard<std::mutex> lk(g_engine_mu);
+    if (g_engine) return g_engine->device == device ? 0 : -1;   /* engine already bound */
+    g_device_request = device;
+    return 0;
+}
+
+int h264bsdmiFlush(void)
+{
+    Engine *e = engine_get();
+    if (!e) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return flush_locked(e);
+}
+
+/* ------------------------------------------------------------------ replay sets */
+struct h264bsdmi_replay {
+    Engine *e;
+    uint32_t n_pics, n_streams, n_slots, wmb, hmb, frame_bytes;
+    size_t blob_stride;               /* bytes of all blobs of one stream (256-aligned) */
+    unsigned long long job_bytes;     /* sum of the blob sizes of one stream */
+    uint8_t *d_blobs;                 /* n_streams * blob_stride */
+    uint8_t *d_frames;                /* n_streams * n_slots * frame_bytes */
+    FrameDesc *d_desc;                /* n_pics * n_streams */
+    uint32_t *d_conv;                 /* n_streams * w*h (lazy) */
+    unsigned long long *d_sums;
+    std::vector<TickShape> shapes;
+    std::vector<uint8_t> cur_slot;
+    std::vector<TickTimers> timers;
+    uint32_t timed_first, timed_count;
+    hipEvent_t ev_begin, ev_end;
+    uint32_t launches[3];
+    unsigned stages;
+};
+
+h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams)
+{
+    Engine *e = engine_get();
+    if (!e || !n_pics || !n_streams) {
+        if (!e) fprintf(stderr, "h264bsd-mi355x: h264bsdmiReplayCreate: no usable HIP device\n");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (hipSetDevice(e->device) != hipSuccess) return nullptr;
+    h264bsdmi_replay *r = new h264bsdmi_replay();
+    r->e = e; r->n_pics = n_pics; r->n_streams = n_streams;
+    const FjHeader *h0 = reinterpret_cast<const FjHeader *>(blobs[0]);
+    r->wmb = h0->width_mbs; r->hmb = h0->height_mbs; r->n_slots = h0->n_slots;
+    r->frame_bytes = fj_frame_bytes(r->wmb, r->hmb);
+    std::vector<size_t> offs(n_pics);
+    size_t total = 0;
+    r->job_bytes = 0;
+    for (u32 i = 0; i < n_pics; i++) { offs[i] = total; total += ((size_t)bytes[i] + 255u) & ~(size_t)255u; r->job_bytes += bytes[i]; }
+    r->blob_stride = total;
+    r->d_blobs = nullptr; r->d_frames = nullptr; r->d_desc = nullptr; r->d_conv = nullptr; r->d_sums = nullptr;
+    const size_t frames_per_stream = (size_t)r->n_slots * r->frame_bytes;
+    bool ok = hipMalloc((void **)&r->d_blobs, total * n_streams) == hipSuccess &&
+              hipMalloc((void **)&r->d_frames, frames_per_stream * n_streams + 256) == hipSuccess &&
+              hipMalloc((void **)&r->d_desc, sizeof(FrameDesc) * (size_t)n_pics * n_streams) == hipSuccess &&
+              hipMalloc((void **)&r->d_sums, sizeof(unsigned long long) * n_streams) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(r->d_frames, 0, frames_per_stream * n_streams + 256, e->stream) == hipSuccess;
+    /* stream 0 from the host, the other copies device-to-device: every stream owns private jobs */
+    for (u32 i = 0; ok && i < n_pics; i++) {
+        ok = hipMemcpyAsync(r->d_blobs + offs[i], blobs[i], bytes[i], hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[i]);
+        if (h->width_mbs != r->wmb || h->height_mbs != r->hmb || h->n_slots != r->n_slots) ok = false;
+        TickShape s;
+        shape_add(s, blobs[i]);
+        s.n_frames = n_streams;
+        r->shapes.push_back(s);
+        r->cur_slot.push_back(h->cur_slot);
+    }
+    if (ok) ok = hipStreamSynchronize(e->stream) == hipSuccess;
+    for (u32 s = 1; ok && s < n_streams; s++)
+        ok = hipMemcpyAsync(r->d_blobs + (size_t)s * total, r->d_blobs, total, hipMemcpyDeviceToDevice, e->stream) == hipSuccess;
+    if (ok) {
+        std::vector<FrameDesc> descs((size_t)n_pics * n_streams);
+        for (u32 i = 0; i < n_pics; i++)
+            for (u32 s = 0; s < n_streams; s++) {
+                FrameDesc &d = descs[(size_t)i * n_streams + s];
+                d.blob = r->d_blobs + (size_t)s * total + offs[i];
+                for (u32 k = 0; k < FJ_MAX_SLOTS; k++)
+                    d.slot[k] = k < r->n_slots ? r->d_frames + (size_t)s * frames_per_stream + (size_t)k * r->frame_bytes : nullptr;
+            }
+        ok = hipMemcpyAsync(r->d_desc, descs.data(), descs.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream) == hipSuccess &&
+             hipStreamSynchronize(e->stream) == hipSuccess;
+    }
+    r->timers.resize(n_pics);
+    for (auto &t : r->timers) for (auto &ev : t.ev) if (ok) ok = hipEventCreate(&ev) == hipSuccess;
+    if (ok) ok = hipEventCreate(&r->ev_begin) == hipSuccess && hipEventCreate(&r->ev_end) == hipSuccess;
+    r->timed_first = r->timed_count = 0;
+    r->stages = 7u;
+    if (!ok) {
+        fprintf(stderr, "h264bsd-mi355x: h264bsdmiReplayCreate failed (%s)\n", hipGetErrorString(hipGetLastError()));
+        if (r->d_blobs) hipFree(r->d_blobs);
+        if (r->d_frames) hipFree(r->d_frames);
+        if (r->d_desc) hipFree(r->d_desc);
+        if (r->d_sums) hipFree(r->d_sums);
+        delete r;
+        return nullptr;
+    }
+    return r;
+}
+
+void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
+{
+    if (!r) return;
+    std::lock_guard<std::mutex> lk(r->e->mu);
+    hipSetDevice(r->e->device);
+    hipStreamSynchronize(r->e->stream);
+    hipFree(r->d_blobs); hipFree(r->d_frames); hipFree(r->d_desc); hipFree(r->d_sums);
+    if (r->d_conv) hipFree(r->d_conv);
+    for (auto &t : r->timers) for (auto &ev : t.ev) hipEventDestroy(ev);
+    hipEventDestroy(r->ev_begin); hipEventDestroy(r->ev_end);
+    delete r;
+}
+
+int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
+{
+    if (!r || first + count > r->n_pics) return -1;
+    std::lock_guard<std::mutex> lk(r->e->mu);
+    HIP_TRY(hipSetDevice(r->e->device));
+    r->timed_first = first; r->timed_count = count;
+    r->launches[0] = r->launches[1] = r->launches[2] = 0;
+    HIP_TRY(hipEventRecord(r->ev_begin, r->e->stream));
+    for (u32 i = first; i < first + count; i++) {
+        r->timers[i].on = true;
+        if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages)) return -1;
+    }
+    HIP_TRY(hipEventRecord(r->ev_end, r->e->stream));
+    return 0;
+}
+
+int h264bsdmiReplaySync(h264bsdmi_replay *r)
+{
+    if (!r) return -1;
+    HIP_TRY(hipSetDevice(r->e->device));
+    HIP_TRY(hipStreamSynchronize(r->e->stream));
+    return 0;
+}
+
+int h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[4], u32 launches[3])
+{
+    if (!r) return -1;
+    HIP_TRY(hipSetDevice(r->e->device));
+    HIP_TRY(hipStreamSynchronize(r->e->stream));
+    out_ms[0] = out_ms[1] = out_ms[2] = out_ms[3] = 0.f;
+    for (u32 i = r->timed_first; i < r->timed_first + r->timed_count; i++) {
+        float ms;
+        for (int k = 0; k < 3; k++) {
+            HIP_TRY(hipEventElapsedTime(&ms, r->timers[i].ev[k], r->timers[i].ev[k + 1]));
+            out_ms[k] += ms;
+        }
+    }
+    if (r->timed_count) HIP_TRY(hipEventElapsedTime(&out_ms[3], r->ev_begin, r->ev_end));
+    if (launches) { launches[0] = r->launches[0]; launches[1] = r->launches[1]; launches[2] = r->launches[2]; }
+    return 0;
+}
+
+int h264bsdmiReplayFetch(h264bsdmi_replay *r, u32 stream, u32 slot, u8 *dst)
+{
+    if (!r || stream >= r->n_streams || slot >= r->n_slots) return -1;
+    HIP_TRY(hipSetDevice(r->e->device));
+    HIP_TRY(hipStreamSynchronize(r->e->stream));
+    HIP_TRY(hipMemcpy(dst, r->d_frames + ((size_t)stream * r->n_slots + slot) * r->frame_bytes, r->frame_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int h264bsdmiReplayChecksums(h264bsdmi_replay *r, u32 slot, unsigned long long *sums)
+{
+    if (!r || slot >= r->n_slots) return -1;
+    std::lock_guard<std::mutex> lk(r->e->mu);
+    HIP_TRY(hipSetDevice(r->e->device));
+    hipLaunchKernelGGL(h264k::k_checksum, dim3(r->n_streams), dim3(256), 0, r->e->stream,
+                       r->d_frames + (size_t)slot * r->frame_bytes, (size_t)r->n_slots * r->frame_bytes, r->frame_bytes / 4, r->d_sums);
+    HIP_TRY(hipMemcpyAsync(sums, r->d_sums, sizeof(unsigned long long) * r->n_streams, hipMemcpyDeviceToHost, r->e->stream));
+    HIP_TRY(hipStreamSynchronize(r->e->stream));
+    return 0;
+}
+
+int h264bsdmiReplayConvert(h264bsdmi_replay *r, u32 slot, int fmt)
+{
+    if (!r || slot >= r->n_slots || fmt < 0 || fmt > 2) return -1;
+    std::lock_guard<std::mutex> lk(r->e->mu);
+    HIP_TRY(hipSetDevice(r->e->device));
+    const uint32_t w = r->wmb * 16, h = r->hmb * 16;
+    if (!r->d_conv) HIP_TRY(hipMalloc((void **)&r->d_conv, (size_t)w * h * 4 * r->n_streams));
+    hipLaunchKernelGGL(h264k::k_convert, dim3(256, r->n_streams), dim3(256), 0, r->e->stream,
+                       r->d_frames + (size_t)slot * r->frame_bytes, r->d_conv, w, h, fmt,
+                       (size_t)r->n_slots * r->frame_bytes, (size_t)w * h);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int h264bsdmiReplayFetchConverted(h264bsdmi_replay *r, u32 stream, u32 *dst)
+{
+    if (!r || stream >= r->n_streams || !r->d_conv) return -1;
+    HIP_TRY(hipSetDevice(r->e->device));
+    HIP_TRY(hipStreamSynchronize(r->e->stream));
+    const size_t n = (size_t)r->wmb * 16 * r->hmb * 16;
+    HIP_TRY(hipMemcpy(dst, r->d_conv + (size_t)stream * n, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int h264bsdmiReplaySetStages(h264bsdmi_replay *r, unsigned mask)
+{
+    if (!r) return -1;
+    r->stages = mask & 7u;
+    return 0;
+}
+
+unsigned long long h264bsdmiReplayJobBytes(h264bsdmi_replay *r) { return r ? r->job_bytes : 0; }
+u32 h264bsdmiReplayFrameBytes(h264bsdmi_replay *r) { return r ? r->frame_bytes : 0; }
+
+} // extern "C"

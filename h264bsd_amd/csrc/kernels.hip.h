@@ -1,0 +1,822 @@
+/*
+ * kernels.hip.h — hand-written gfx950 (CDNA4, wave64) kernels of the macroblock reconstruction path.
+ *
+ *   k_recon_inter : one wavefront per inter macroblock, all inter MBs of all pictures of a tick in ONE
+ *                   launch.  6-tap luma / bilinear chroma motion compensation straight from the
+ *                   reference frames (register windows, unaligned dword loads, clamp-to-edge slow
+ *                   path), dequant + 4x4 inverse transform with quad-wide DPP/shuffle transposes,
+ *                   residual add, packed u32 stores.       reference: src/h264bsd_reconstruct.c,
+ *                   src/h264bsd_inter_prediction.c:361-482, src/h264bsd_transform.c, src/h264bsd_image.c:172
+ *   k_recon_intra : one wavefront per intra macroblock of one dependency level (host-computed), the
+ *                   16x16 block + its neighbour row/column staged in LDS; Intra4x4 runs its 16 blocks in
+ *                   order inside the wave.                 reference: src/h264bsd_intra_prediction.c
+ *   k_deblock     : one wavefront per macroblock of one anti-diagonal x+2y=d of the picture (the
+ *                   in-loop filter's true dependency front), 20x20 luma + 2x(10x12) chroma tile in LDS,
+ *                   lanes own rows for the vertical edges, then columns for the horizontal edges.
+ *                                                          reference: src/h264bsd_deblocking.c:575-1745
+ *   k_convert     : YUV420 -> RGBA / BGRA / YCbCrA, 4 pixels per lane, 16-byte stores.
+ *                                                          reference: src/h264bsd_decoder.c:1163-1370
+ *   k_checksum    : position-weighted 64-bit checksum of a frame (on-device verification).
+ *
+ * Everything is integer arithmetic on u8 samples / i16 levels / i32 intermediates: there is no dense
+ * contraction on this path, hence no MFMA.  All kernels are HBM/latency bound by design.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "framejob.h"
+
+struct FrameDesc {
+    const uint8_t *blob;
+    uint8_t *slot[FJ_MAX_SLOTS];
+};
+
+namespace h264k {
+
+__constant__ int c_level_scale[6][3] = {
+    { 10, 13, 16 }, { 11, 14, 18 }, { 13, 16, 20 }, { 14, 18, 23 }, { 16, 20, 25 }, { 18, 23, 29 } };
+__constant__ uint8_t c_alpha[52] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13,
+    15, 17, 20, 22, 25, 28, 32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255 };
+__constant__ uint8_t c_beta[52] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6,
+    7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18 };
+__constant__ uint8_t c_tc0[52][4] = {
+    { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 },
+    { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 },
+    { 0, 0, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 1, 0 }, { 0, 0, 1, 0 }, { 0, 0, 1, 0 }, { 0, 1, 1, 0 }, { 0, 1, 1, 0 }, { 1, 1, 1, 0 },
+    { 1, 1, 1, 0 }, { 1, 1, 1, 0 }, { 1, 1, 1, 0 }, { 1, 1, 2, 0 }, { 1, 1, 2, 0 }, { 1, 1, 2, 0 }, { 1, 1, 2, 0 }, { 1, 2, 3, 0 },
+    { 1, 2, 3, 0 }, { 2, 2, 3, 0 }, { 2, 2, 4, 0 }, { 2, 3, 4, 0 }, { 2, 3, 4, 0 }, { 3, 3, 5, 0 }, { 3, 4, 6, 0 }, { 3, 4, 6, 0 },
+    { 4, 5, 7, 0 }, { 4, 5, 8, 0 }, { 4, 6, 9, 0 }, { 5, 7, 10, 0 }, { 6, 8, 11, 0 }, { 6, 8, 13, 0 }, { 7, 10, 14, 0 }, { 8, 11, 16, 0 },
+    { 9, 12, 18, 0 }, { 10, 13, 20, 0 }, { 11, 15, 23, 0 }, { 13, 17, 25, 0 } };
+__constant__ uint8_t c_qpc[52] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23,
+    24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39 };
+
+__device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+__device__ __forceinline__ int z_of(int x, int y) { return ((y >> 1) << 3) | ((x >> 1) << 2) | ((y & 1) << 1) | (x & 1); }
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
+{
+    return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+}
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+/* 4x4 transpose across the 4 lanes of a quad: lane q holds row q in v[0..3] -> holds column q */
+__device__ __forceinline__ void quad_transpose(int v[4], int q)
+{
+    const bool o1 = q & 1, o2 = q & 2;
+    int t0 = __shfl_xor(o1 ? v[0] : v[1], 1);
+    int t1 = __shfl_xor(o1 ? v[2] : v[3], 1);
+    if (o1) { v[0] = t0; v[2] = t1; } else { v[1] = t0; v[3] = t1; }
+    t0 = __shfl_xor(o2 ? v[0] : v[2], 2);
+    t1 = __shfl_xor(o2 ? v[1] : v[3], 2);
+    if (o2) { v[0] = t0; v[1] = t1; } else { v[2] = t0; v[3] = t1; }
+}
+
+/* Dequantise + inverse-transform one 4x4 block held one ROW per lane of a quad (H.264 8.5.12):
+ * in: c[0..3] = raster row q of the level block (zeros when the block is not coded); dc_override
+ * replaces element (0,0) after scaling (Intra16x16 / chroma DC paths).  out: residual row q. */
+__device__ __forceinline__ void idct_quad(int c[4], int q, int qp, bool use_dc, int dc)
+{
+    const int m = qp % 6, sh = qp / 6;
+    const int lsa = c_level_scale[m][(q & 1) ? 1 : 0], lsb = c_level_scale[m][(q & 1) ? 2 : 1];
+    int d0 = (c[0] * lsa) << sh, d1 = (c[1] * lsb) << sh, d2 = (c[2] * lsa) << sh, d3 = (c[3] * lsb) << sh;
+    if (use_dc && q == 0) d0 = dc;
+    int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
+    int f[4] = { e0 + e3, e1 + e2, e1 - e2, e0 - e3 };
+    quad_transpose(f, q);                    /* lane q: column q, f[k] = row k */
+    e0 = f[0] + f[2]; e1 = f[0] - f[2]; e2 = (f[1] >> 1) - f[3]; e3 = f[1] + (f[3] >> 1);
+    int r[4] = { (e0 + e3 + 32) >> 6, (e1 + e2 + 32) >> 6, (e1 - e2 + 32) >> 6, (e0 - e3 + 32) >> 6 };
+    quad_transpose(r, q);                    /* back to row q */
+    c[0] = r[0]; c[1] = r[1]; c[2] = r[2]; c[3] = r[3];
+}
+
+__device__ __forceinline__ void load_row4(const int16_t *p, bool valid, int c[4])
+{
+    int2 w = valid ? *reinterpret_cast<const int2 *>(p) : make_int2(0, 0);
+    c[0] = (int16_t)(w.x & 0xFFFF); c[1] = w.x >> 16; c[2] = (int16_t)(w.y & 0xFFFF); c[3] = w.y >> 16;
+}
+
+/* Residual of the macroblock, distributed over the wave:
+ *   ry[0..3]: luma, lane = 4*blk + row (blk raster 0..15): samples (row, 0..3) of block blk
+ *   rc[0..3]: chroma, lanes 0..31: lane = 4*k + row, k = 4*plane + 2*by + bx
+ * Must be called by all 64 lanes (quad shuffles).  coef = first coefficient block of the MB. */
+__device__ __forceinline__ void mb_residual(const FjMbRec &rec, const int16_t *coef, int lane, int ry[4], int rc[4])
+{
+    const uint32_t coded = rec.coded;
+    const int q = lane & 3;
+    const int has_ldc = (coded >> 24) & 1, has_cdc = (coded >> 25) & 1;
+    ry[0] = ry[1] = ry[2] = ry[3] = 0;
+    rc[0] = rc[1] = rc[2] = rc[3] = 0;
+    if (coded & 0x0100FFFFu) {                                   /* wave-uniform */
+        const int blk = lane >> 2, bx = blk & 3, by = blk >> 2, z = z_of(bx, by);
+        int dc = 0;
+        if (has_ldc) {
+            /* 4x4 Hadamard element (by,bx) of the DC block, then the 8.5.10 scaling */
+            const uint32_t neg = 0xA6C0u;                        /* sign rows: 0000 1100 0110 1010 (bit k of row i) */
+            const uint32_t nr = (neg >> (4 * by)) & 15, ncl = (neg >> (4 * bx)) & 15;
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    const int v = coef[4 * k + l];
+                    acc += (((nr >> k) ^ (ncl >> l)) & 1) ? -v : v;
+                }
+            const int ls = c_level_scale[rec.qp_y % 6][0], q6 = rec.qp_y / 6;
+            dc = q6 >= 2 ? (acc * ls) << (q6 - 2) : (acc * ls + (1 << (1 - q6))) >> (2 - q6);
+        }
+        const bool has_ac = (coded >> z) & 1;
+        const int off = has_ldc + __popc(coded & ((1u << z) - 1u));
+        load_row4(coef + 16 * off + 4 * q, has_ac, ry);
+        idct_quad(ry, q, rec.qp_y, rec.kind == FJ_MB_I16x16, dc);
+    }
+    if (coded & 0x02FF0000u) {                                   /* wave-uniform */
+        const int k = (lane >> 2) & 7;
+        const int base = has_ldc + __popc(coded & 0xFFFFu);
+        int dc = 0;
+        if (has_cdc) {
+            const int16_t *c = coef + 16 * base + 4 * (k >> 2);
+            const int i = k & 3;
+            const int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+            const int f = c0 + ((i & 1) ? -c1 : c1) + ((i & 2) ? -c2 : c2) + ((i == 1 || i == 2) ? -c3 : c3);
+            const int ls = c_level_scale[rec.qp_c % 6][0], q6 = rec.qp_c / 6;
+            dc = q6 >= 1 ? (f * ls) << (q6 - 1) : (f * ls) >> 1;
+        }
+        const bool has_ac = (coded >> (16 + k)) & 1;
+        const int off = base + has_cdc + __popc((coded >> 16) & ((1u << k) - 1u));
+        load_row4(coef + 16 * off + 4 * q, has_ac, rc);
+        idct_quad(rc, q, rec.qp_c, true, dc);
+    }
+}
+
+/* ------------------------------------------------------------------ inter prediction */
+__device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * (b + e) + 20 * (c + d) + f; }
+
+/* 4 luma samples (x..x+3, y) of the prediction at quarter-sample fraction (fx,fy) from plane p (w x h) */
+__device__ __forceinline__ void luma_pred4(const uint8_t *__restrict__ p, int w, int h, int x, int y, int fx, int fy, int out[4])
+{
+    if ((fx | fy) == 0) {
+        if (x >= 0 && x + 3 < w && y >= 0 && y < h) {
+            const uint32_t v = load_u32_unaligned(p + (size_t)y * w + x);
+            out[0] = v & 255; out[1] = (v >> 8) & 255; out[2] = (v >> 16) & 255; out[3] = v >> 24;
+        } else {
+            const int yy = clip3(0, h - 1, y);
+#pragma unroll
+            for (int i = 0; i < 4; i++) out[i] = p[(size_t)yy * w + clip3(0, w - 1, x + i)];
+        }
+        return;
+    }
+    /* window: rows y-2..y+3, columns x-2..x+6 (9 used, 12 loaded) */
+    uint32_t rw[6][3];
+    if (x >= 2 && x + 9 < w && y >= 2 && y + 3 < h) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const uint8_t *s = p + (size_t)(y - 2 + r) * w + (x - 2);
+            rw[r][0] = load_u32_unaligned(s); rw[r][1] = load_u32_unaligned(s + 4); rw[r][2] = load_u32_unaligned(s + 8);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const uint8_t *s = p + (size_t)clip3(0, h - 1, y - 2 + r) * w;
+            uint32_t a = 0, b = 0, c = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                a |= (uint32_t)s[clip3(0, w - 1, x - 2 + i)] << (8 * i);
+                b |= (uint32_t)s[clip3(0, w - 1, x + 2 + i)] << (8 * i);
+            }
+            c = (uint32_t)s[clip3(0, w - 1, x + 6)];
+            rw[r][0] = a; rw[r][1] = b; rw[r][2] = c;
+        }
+    }
+#define GW(r, c) ((int)((rw[(r)][(c) >> 2] >> (8 * ((c) & 3))) & 255u))
+    if (fy == 0) {                                   /* a, b, c: horizontal only (window row 2) */
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int b = clip255((tap6(GW(2, i), GW(2, i + 1), GW(2, i + 2), GW(2, i + 3), GW(2, i + 4), GW(2, i + 5)) + 16) >> 5);
+            out[i] = fx == 2 ? b : (b + (fx == 1 ? GW(2, i + 2) : GW(2, i + 3)) + 1) >> 1;
+        }
+        return;
+    }
+    if (fx == 0) {                                   /* d, h, n: vertical only */
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = i + 2;
+            const int hh = clip255((tap6(GW(0, c), GW(1, c), GW(2, c), GW(3, c), GW(4, c), GW(5, c)) + 16) >> 5);
+            out[i] = fy == 2 ? hh : (hh + (fy == 1 ? GW(2, c) : GW(3, c)) + 1) >> 1;
+        }
+        return;
+    }
+    /* vertical 6-tap sums at window columns 2..6 (sample columns x .. x+4): h and m candidates */
+#define VH1(c) tap6(GW(0, c), GW(1, c), GW(2, c), GW(3, c), GW(4, c), GW(5, c))
+#define HB1(r, i) tap6(GW(r, i), GW(r, (i) + 1), GW(r, (i) + 2), GW(r, (i) + 3), GW(r, (i) + 4), GW(r, (i) + 5))
+    if (fx == 2 || fy == 2) {                        /* j, f, q, i, k */
+        int h1c[5] = { 0, 0, 0, 0, 0 };
+        if (fx != 2) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) h1c[c] = VH1(c + 2);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int b1[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) b1[r] = HB1(r, i);
+            const int j = clip255((tap6(b1[0], b1[1], b1[2], b1[3], b1[4], b1[5]) + 512) >> 10);
+            int v = j;
+            if (fy != 2) {                           /* f / q: with b (row y) or s (row y+1) */
+                const int b = clip255(((fy == 1 ? b1[2] : b1[3]) + 16) >> 5);
+                v = (j + b + 1) >> 1;
+            } else if (fx != 2) {                    /* i / k: with h (col x) or m (col x+1) */
+                const int hh = clip255(((fx == 1 ? h1c[i] : h1c[i + 1]) + 16) >> 5);
+                v = (j + hh + 1) >> 1;
+            }
+            out[i] = v;
+        }
+        return;
+    }
+    /* e, g, p, r: average of the nearest horizontal and vertical half samples */
+    {
+        int h1c[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) h1c[c] = VH1(c + 2);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int b = clip255(((fy == 1 ? HB1(2, i) : HB1(3, i)) + 16) >> 5);
+            const int hh = clip255(((fx == 1 ? h1c[i] : h1c[i + 1]) + 16) >> 5);
+            out[i] = (b + hh + 1) >> 1;
+        }
+    }
+#undef VH1
+#undef HB1
+#undef GW
+}
+
+/* 2 chroma samples (x, x+1 ; y) at eighth-sample fraction (fx,fy) */
+__device__ __forceinline__ void chroma_pred2(const uint8_t *__restrict__ p, int w, int h, int x, int y, int fx, int fy, int out[2])
+{
+    int a[3], b[3];
+    if (x >= 0 && x + 3 < w && y >= 0 && y + 1 < h) {
+        const uint32_t r0 = load_u32_unaligned(p + (size_t)y * w + x), r1 = load_u32_unaligned(p + (size_t)(y + 1) * w + x);
+        a[0] = r0 & 255; a[1] = (r0 >> 8) & 255; a[2] = (r0 >> 16) & 255;
+        b[0] = r1 & 255; b[1] = (r1 >> 8) & 255; b[2] = (r1 >> 16) & 255;
+    } else {
+        const uint8_t *s0 = p + (size_t)clip3(0, h - 1, y) * w, *s1 = p + (size_t)clip3(0, h - 1, y + 1) * w;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { const int xx = clip3(0, w - 1, x + i); a[i] = s0[xx]; b[i] = s1[xx]; }
+    }
+    const int w00 = (8 - fx) * (8 - fy), w10 = fx * (8 - fy), w01 = (8 - fx) * fy, w11 = fx * fy;
+    out[0] = (w00 * a[0] + w10 * a[1] + w01 * b[0] + w11 * b[1] + 32) >> 6;
+    out[1] = (w00 * a[1] + w10 * a[2] + w01 * b[1] + w11 * b[2] + 32) >> 6;
+}
+
+__global__ __launch_bounds__(64) void k_recon_inter(const FrameDesc *__restrict__ frames)
+{
+    const FrameDesc &fd = frames[blockIdx.y];
+    const FjHeader *hdr = reinterpret_cast<const FjHeader *>(fd.blob);
+    const uint32_t mb = blockIdx.x;
+    if (mb >= hdr->n_mbs) return;
+    const FjMbRec rec = reinterpret_cast<const FjMbRec *>(fd.blob + hdr->rec_off)[mb];
+    if (rec.kind != FJ_MB_INTER) return;
+    const int lane = threadIdx.x;
+    const int wmb = hdr->width_mbs, W = wmb * 16, H = hdr->height_mbs * 16, CW = W >> 1, CH = H >> 1;
+    const int mbx = mb % wmb, mby = mb / wmb;
+    const int16_t *mvs = reinterpret_cast<const int16_t *>(fd.blob + hdr->mv_off) + 32 * (size_t)mb;
+    const int16_t *coef = reinterpret_cast<const int16_t *>(fd.blob + hdr->coef_off) + 16 * (size_t)rec.coef_idx;
+    uint8_t *cur = fd.slot[hdr->cur_slot];
+    const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
+
+    int ry[4], rc[4];
+    mb_residual(rec, coef, lane, ry, rc);
+    uint32_t refs;
+    __builtin_memcpy(&refs, rec.ref_slot, 4);
+
+    /* luma: lane = 4*blk + row */
+    {
+        const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
+        const int mvx = mvs[2 * blk], mvy = mvs[2 * blk + 1];
+        const uint8_t *ref = fd.slot[(refs >> (8 * ((by >> 1) * 2 + (bx >> 1)))) & 255u];
+        int pr[4];
+        luma_pred4(ref, W, H, mbx * 16 + bx * 4 + (mvx >> 2), mby * 16 + by * 4 + row + (mvy >> 2), mvx & 3, mvy & 3, pr);
+        const uint32_t v = pack4(clip255(pr[0] + ry[0]), clip255(pr[1] + ry[1]), clip255(pr[2] + ry[2]), clip255(pr[3] + ry[3]));
+        *reinterpret_cast<uint32_t *>(cur + (size_t)(mby * 16 + by * 4 + row) * W + mbx * 16 + bx * 4) = v;
+    }
+    /* chroma: lanes 0..31, lane = 4*k + row, k = 4*plane + 2*cby + cbx: 4 samples of one row */
+    if (lane < 32) {
+        const int k = lane >> 2, row = lane & 3, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
+        const int cy = cby * 4 + row, cx0 = cbx * 4;
+        int pr[4];
+#pragma unroll
+        for (int pair = 0; pair < 2; pair++) {
+            const int cx = cx0 + 2 * pair;
+            const int lb = (cy >> 1) * 4 + (cx >> 1);             /* owning 4x4 luma block */
+            const int mvx = mvs[2 * lb], mvy = mvs[2 * lb + 1];
+            const uint8_t *ref = fd.slot[(refs >> (8 * ((cy >> 2) * 2 + (cx >> 2)))) & 255u] + ysz + (plane ? csz : 0);
+            chroma_pred2(ref, CW, CH, mbx * 8 + cx + (mvx >> 3), mby * 8 + cy + (mvy >> 3), mvx & 7, mvy & 7, pr + 2 * pair);
+        }
+        const uint32_t v = pack4(clip255(pr[0] + rc[0]), clip255(pr[1] + rc[1]), clip255(pr[2] + rc[2]), clip255(pr[3] + rc[3]));
+        *reinterpret_cast<uint32_t *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + cy) * CW + mbx * 8 + cx0) = v;
+    }
+}
+
+/* ------------------------------------------------------------------ intra prediction */
+/* Intra4x4 sample (x,y) of mode `mode`; T(k) k=-1..7 and L(k) k=-1..3 read the LDS tile */
+#define I4_T(k) ((int)tile[(by4) * TS + 1 + (bx4) + ((k) > 3 && !has_tr ? 3 : (k))])
+#define I4_L(k) ((int)tile[((by4) + 1 + (k)) * TS + (bx4)])
+
+__global__ __launch_bounds__(64) void k_recon_intra(const FrameDesc *__restrict__ frames, uint32_t level)
+{
+    constexpr int TS = 32;                              /* luma tile stride; row 0 = above, col 0 = left */
+    __shared__ __attribute__((aligned(16))) uint8_t tile[17 * TS];
+    __shared__ __attribute__((aligned(16))) uint8_t ctile[2][9 * 16];
+
+    const FrameDesc &fd = frames[blockIdx.y];
+    const FjHeader *hdr = reinterpret_cast<const FjHeader *>(fd.blob);
+    if (level >= hdr->n_intra_levels) return;
+    const uint32_t *lvl = reinterpret_cast<const uint32_t *>(fd.blob + hdr->lvl_off);
+    const uint32_t first = lvl[level], count = lvl[level + 1] - first;
+    if (blockIdx.x >= count) return;
+    const uint32_t mb = reinterpret_cast<const uint16_t *>(fd.blob + hdr->idx_off)[first + blockIdx.x];
+    const FjMbRec rec = reinterpret_cast<const FjMbRec *>(fd.blob + hdr->rec_off)[mb];
+    const int lane = threadIdx.x;
+    const int wmb = hdr->width_mbs, W = wmb * 16, H = hdr->height_mbs * 16, CW = W >> 1, CH = H >> 1;
+    const int mbx = mb % wmb, mby = mb / wmb;
+    const int16_t *coef = reinterpret_cast<const int16_t *>(fd.blob + hdr->coef_off) + 16 * (size_t)rec.coef_idx;
+    uint8_t *cur = fd.slot[hdr->cur_slot];
+    const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
+    uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
+    const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
+
+    if (rec.kind == FJ_MB_IPCM) {
+        const uint8_t *s = reinterpret_cast<const uint8_t *>(coef);
+        *reinterpret_cast<uint32_t *>(Y + (size_t)(lane >> 2) * W + (lane & 3) * 4) = *reinterpret_cast<const uint32_t *>(s + 4 * lane);
+        if (lane < 32) {
+            const int plane = lane >> 4, r = (lane >> 1) & 7, half = lane & 1;
+            *reinterpret_cast<uint32_t *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + r) * CW + mbx * 8 + half * 4) =
+                *reinterpret_cast<const uint32_t *>(s + 256 + 64 * plane + 8 * r + 4 * half);
+        }
+        return;
+    }
+
+    int ry[4], rc[4];
+    mb_residual(rec, coef, lane, ry, rc);
+
+    const bool av_a = rec.avail & FJ_AVAIL_A, av_b = rec.avail & FJ_AVAIL_B, av_c = rec.avail & FJ_AVAIL_C, av_d = rec.avail & FJ_AVAIL_D;
+    /* neighbour samples into the tiles (un-deblocked current picture) */
+    if (lane < 21) {
+        const int c = lane;                               /* tile row 0: corner, 16 above, 4 above-right */
+        const bool ok = c == 0 ? av_d : c <= 16 ? av_b : av_c;
+        tile[c] = ok ? Y[-(ptrdiff_t)W + (c - 1)] : 128;
+    } else if (lane >= 32 && lane < 48) {
+        const int r = lane - 32;
+        tile[(r + 1) * TS] = av_a ? Y[(size_t)r * W - 1] : 128;
+    }
+    if (lane < 18) {
+        const int plane = lane / 9, c = lane % 9;
+        const uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+        const bool ok = c == 0 ? av_d : av_b;
+        ctile[plane][c] = ok ? P[-(ptrdiff_t)CW + (c - 1)] : 128;
+    } else if (lane >= 32 && lane < 48) {
+        const int plane = (lane - 32) >> 3, r = (lane - 32) & 7;
+        const uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+        ctile[plane][(r + 1) * 16] = av_a ? P[(size_t)r * CW - 1] : 128;
+    }
+    __syncthreads();
+
+    if (rec.kind == FJ_MB_I16x16) {
+        const int mode = rec.pred & 3;
+        const int y = by * 4 + row, x0 = bx * 4;
+        int pr[4];
+        if (mode == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) pr[i] = tile[1 + x0 + i];
+        } else if (mode == 1) {
+            pr[0] = pr[1] = pr[2] = pr[3] = tile[(y + 1) * TS];
+        } else if (mode == 2) {
+            int st = 0, sl = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { st += tile[1 + i]; sl += tile[(i + 1) * TS]; }
+            const int dc = (av_a && av_b) ? (st + sl + 16) >> 5 : av_a ? (sl + 8) >> 4 : av_b ? (st + 8) >> 4 : 128;
+            pr[0] = pr[1] = pr[2] = pr[3] = dc;
+        } else {
+            int Hh = 0, Vv = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                Hh += (k + 1) * ((int)tile[1 + 8 + k] - (int)tile[1 + 6 - k]);
+                Vv += (k + 1) * ((int)tile[(1 + 8 + k) * TS] - (int)(k == 7 ? tile[0] : tile[(1 + 6 - k) * TS]));
+            }
+            const int a = 16 * ((int)tile[16 * TS] + (int)tile[16]), b = (5 * Hh + 32) >> 6, c = (5 * Vv + 32) >> 6;
+#pragma unroll
+            for (int i = 0; i < 4; i++) pr[i] = clip255((a + b * (x0 + i - 7) + c * (y - 7) + 16) >> 5);
+        }
+        *reinterpret_cast<uint32_t *>(Y + (size_t)y * W + x0) =
+            pack4(clip255(pr[0] + ry[0]), clip255(pr[1] + ry[1]), clip255(pr[2] + ry[2]), clip255(pr[3] + ry[3]));
+    } else {
+        /* Intra4x4: blocks in decoding (z) order; the 4 lanes that own the block's rows do the work */
+        uint64_t i4modes;
+        __builtin_memcpy(&i4modes, rec.i4mode, 8);
+        for (int z = 0; z < 16; z++) {
+            const int zx = ((z >> 2) & 1) * 2 + (z & 1), zy = (z >> 3) * 2 + ((z >> 1) & 1);
+            if (bx == zx && by == zy) {
+                const int mode = (int)((i4modes >> (4 * z)) & 15u);
+                const int bx4 = zx * 4, by4 = zy * 4, y = row;
+                const bool has_left = zx > 0 || av_a, has_top = zy > 0 || av_b;
+                bool has_tr;
+                if (zy == 0) has_tr = zx < 3 ? av_b : av_c;
+                else has_tr = zx < 3 && z_of(zx + 1, zy - 1) < z;
+                int pr[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    int v;
+                    switch (mode) {
+                    case 0: v = I4_T(x); break;
+                    case 1: v = I4_L(y); break;
+                    case 2:
+                        if (has_top && has_left) v = (I4_T(0) + I4_T(1) + I4_T(2) + I4_T(3) + I4_L(0) + I4_L(1) + I4_L(2) + I4_L(3) + 4) >> 3;
+                        else if (has_left) v = (I4_L(0) + I4_L(1) + I4_L(2) + I4_L(3) + 2) >> 2;
+                        else if (has_top) v = (I4_T(0) + I4_T(1) + I4_T(2) + I4_T(3) + 2) >> 2;
+                        else v = 128;
+                        break;
+                    case 3:
+                        v = (x == 3 && y == 3) ? (I4_T(6) + 3 * I4_T(7) + 2) >> 2 : (I4_T(x + y) + 2 * I4_T(x + y + 1) + I4_T(x + y + 2) + 2) >> 2;
+                        break;
+                    case 4:
+                        if (x > y) v = (I4_T(x - y - 2) + 2 * I4_T(x - y - 1) + I4_T(x - y) + 2) >> 2;
+                        else if (x < y) v = (I4_L(y - x - 2) + 2 * I4_L(y - x - 1) + I4_L(y - x) + 2) >> 2;
+                        else v = (I4_T(0) + 2 * I4_T(-1) + I4_L(0) + 2) >> 2;
+                        break;
+                    case 5: {
+                        const int zz = 2 * x - y;
+                        if (zz >= 0 && !(zz & 1)) v = (I4_T(x - (y >> 1) - 1) + I4_T(x - (y >> 1)) + 1) >> 1;
+                        else if (zz >= 0) v = (I4_T(x - (y >> 1) - 2) + 2 * I4_T(x - (y >> 1) - 1) + I4_T(x - (y >> 1)) + 2) >> 2;
+                        else if (zz == -1) v = (I4_L(0) + 2 * I4_T(-1) + I4_T(0) + 2) >> 2;
+                        else v = (I4_L(y - 1) + 2 * I4_L(y - 2) + I4_L(y - 3) + 2) >> 2;
+                        break;
+                    }
+                    case 6: {
+                        const int zz = 2 * y - x;
+                        if (zz >= 0 && !(zz & 1)) v = (I4_L(y - (x >> 1) - 1) + I4_L(y - (x >> 1)) + 1) >> 1;
+                        else if (zz >= 0) v = (I4_L(y - (x >> 1) - 2) + 2 * I4_L(y - (x >> 1) - 1) + I4_L(y - (x >> 1)) + 2) >> 2;
+                        else if (zz == -1) v = (I4_L(0) + 2 * I4_T(-1) + I4_T(0) + 2) >> 2;
+                        else v = (I4_T(x - 1) + 2 * I4_T(x - 2) + I4_T(x - 3) + 2) >> 2;
+                        break;
+                    }
+                    case 7:
+                        v = !(y & 1) ? (I4_T(x + (y >> 1)) + I4_T(x + (y >> 1) + 1) + 1) >> 1
+                                     : (I4_T(x + (y >> 1)) + 2 * I4_T(x + (y >> 1) + 1) + I4_T(x + (y >> 1) + 2) + 2) >> 2;
+                        break;
+                    default: {
+                        const int zz = x + 2 * y;
+                        if (zz > 5) v = I4_L(3);
+                        else if (zz == 5) v = (I4_L(2) + 3 * I4_L(3) + 2) >> 2;
+                        else if (!(zz & 1)) v = (I4_L(y + (x >> 1)) + I4_L(y + (x >> 1) + 1) + 1) >> 1;
+                        else v = (I4_L(y + (x >> 1)) + 2 * I4_L(y + (x >> 1) + 1) + I4_L(y + (x >> 1) + 2) + 2) >> 2;
+                        break;
+                    }
+                    }
+                    pr[x] = clip255(v + ry[x]);
+                }
+                /* all four rows must have read their neighbours before anyone overwrites the tile:
+                 * the block's own samples are not inputs of its own prediction, so writing is safe */
+                uint8_t *d = &tile[(by4 + 1 + y) * TS + 1 + bx4];
+                d[0] = (uint8_t)pr[0]; d[1] = (uint8_t)pr[1]; d[2] = (uint8_t)pr[2]; d[3] = (uint8_t)pr[3];
+                *reinterpret_cast<uint32_t *>(Y + (size_t)(by4 + y) * W + bx4) = pack4(pr[0], pr[1], pr[2], pr[3]);
+            }
+            __syncthreads();
+        }
+    }
+
+    /* chroma: lanes 0..31, lane = 4*k + row */
+    if (lane < 32) {
+        const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
+        const int y = cby * 4 + row, x0 = cbx * 4;
+        const uint8_t *t = ctile[plane];
+        const int mode = (rec.pred >> 2) & 3;
+        int pr[4];
+        if (mode == 0) {
+            int st = 0, sl = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { st += t[1 + x0 + i]; sl += t[(1 + cby * 4 + i) * 16]; }
+            int dc = 128;
+            const int kk = cby * 2 + cbx;
+            if (kk == 0 || kk == 3) {
+                if (av_a && av_b) dc = (st + sl + 4) >> 3; else if (av_b) dc = (st + 2) >> 2; else if (av_a) dc = (sl + 2) >> 2;
+            } else if (kk == 1) {
+                if (av_b) dc = (st + 2) >> 2; else if (av_a) dc = (sl + 2) >> 2;
+            } else {
+                if (av_a) dc = (sl + 2) >> 2; else if (av_b) dc = (st + 2) >> 2;
+            }
+            pr[0] = pr[1] = pr[2] = pr[3] = dc;
+        } else if (mode == 1) {
+            pr[0] = pr[1] = pr[2] = pr[3] = t[(y + 1) * 16];
+        } else if (mode == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) pr[i] = t[1 + x0 + i];
+        } else {
+            int Hh = 0, Vv = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Hh += (i + 1) * ((int)t[1 + 4 + i] - (int)t[1 + 2 - i]);
+                Vv += (i + 1) * ((int)t[(1 + 4 + i) * 16] - (int)(i == 3 ? t[0] : t[(1 + 2 - i) * 16]));
+            }
+            const int a = 16 * ((int)t[8 * 16] + (int)t[8]), b = (34 * Hh + 32) >> 6, c = (34 * Vv + 32) >> 6;
+#pragma unroll
+            for (int i = 0; i < 4; i++) pr[i] = clip255((a + b * (x0 + i - 3) + c * (y - 3) + 16) >> 5);
+        }
+        *reinterpret_cast<uint32_t *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + y) * CW + mbx * 8 + x0) =
+            pack4(clip255(pr[0] + rc[0]), clip255(pr[1] + rc[1]), clip255(pr[2] + rc[2]), clip255(pr[3] + rc[3]));
+    }
+}
+#undef I4_T
+#undef I4_L
+
+/* ------------------------------------------------------------------ deblocking */
+__device__ __forceinline__ bool is_intra_kind(int k) { return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM; }
+
+/* v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 */
+__device__ __forceinline__ void filter_luma8(int v[8], int bs, int alpha, int beta, int tc0)
+{
+    const int p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6];
+    if (bs == 0 || !(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
+    const bool ap = abs(p2 - p0) < beta, aq = abs(q2 - q0) < beta;
+    if (bs < 4) {
+        const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+        const int d = clip3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
+        if (ap) v[2] = p1 + clip3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - 2 * p1) >> 1);
+        if (aq) v[5] = q1 + clip3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - 2 * q1) >> 1);
+        v[3] = clip255(p0 + d);
+        v[4] = clip255(q0 - d);
+    } else {
+        const int p3 = v[0], q3 = v[7];
+        const bool strong = abs(p0 - q0) < ((alpha >> 2) + 2);
+        if (strong && ap) {
+            v[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
+            v[2] = (p2 + p1 + p0 + q0 + 2) >> 2;
+            v[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+        } else v[3] = (2 * p1 + p0 + q1 + 2) >> 2;
+        if (strong && aq) {
+            v[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
+            v[5] = (p0 + q0 + q1 + q2 + 2) >> 2;
+            v[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+        } else v[4] = (2 * q1 + q0 + p1 + 2) >> 2;
+    }
+}
+/* v[0..3] = p1 p0 q0 q1 */
+__device__ __forceinline__ void filter_chroma4(int v[4], int bs, int alpha, int beta, int tc0)
+{
+    const int p1 = v[0], p0 = v[1], q0 = v[2], q1 = v[3];
+    if (bs == 0 || !(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
+    if (bs < 4) {
+        const int tc = tc0 + 1;
+        const int d = clip3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
+        v[1] = clip255(p0 + d);
+        v[2] = clip255(q0 - d);
+    } else {
+        v[1] = (2 * p1 + p0 + q1 + 2) >> 2;
+        v[2] = (2 * q1 + q0 + p1 + 2) >> 2;
+    }
+}
+
+struct EdgeThr { int alpha, beta, ia; };
+__device__ __forceinline__ EdgeThr edge_thr(int qp_av, int aoff, int boff)
+{
+    EdgeThr t;
+    t.ia = clip3(0, 51, qp_av + aoff);
+    t.alpha = c_alpha[t.ia];
+    t.beta = c_beta[clip3(0, 51, qp_av + boff)];
+    return t;
+}
+
+__global__ __launch_bounds__(64) void k_deblock(const FrameDesc *__restrict__ frames, int diag)
+{
+    constexpr int LS = 32;                               /* luma tile: 20 rows x 20 cols, stride 32 */
+    constexpr int CS = 16;                               /* chroma tiles: 10 rows x 12 cols, stride 16 */
+    __shared__ __attribute__((aligned(16))) uint8_t lt[20 * LS];
+    __shared__ __attribute__((aligned(16))) uint8_t ct[2][10 * CS];
+    __shared__ uint8_t bs_s[2][4][4];
+
+    const FrameDesc &fd = frames[blockIdx.y];
+    const FjHeader *hdr = reinterpret_cast<const FjHeader *>(fd.blob);
+    if (!hdr->any_deblock) return;
+    const int wmb = hdr->width_mbs, hmb = hdr->height_mbs;
+    /* macroblocks with x + 2y == diag */
+    const int ylo = max(0, (diag - (wmb - 1) + 1) >> 1), yhi = min(hmb - 1, diag >> 1);
+    const int mby = ylo + (int)blockIdx.x;
+    if (mby > yhi) return;
+    const int mbx = diag - 2 * mby;
+    if (mbx < 0 || mbx >= wmb) return;
+    const uint32_t mb = (uint32_t)(mby * wmb + mbx);
+    const FjMbRec *recs = reinterpret_cast<const FjMbRec *>(fd.blob + hdr->rec_off);
+    const FjMbRec q = recs[mb];
+    if (q.kind == FJ_MB_ABSENT || !q.dbk) return;
+    const int lane = threadIdx.x;
+    const bool f_left = q.dbk & FJ_DBK_LEFT, f_top = q.dbk & FJ_DBK_TOP;
+    const int16_t *mvbase = reinterpret_cast<const int16_t *>(fd.blob + hdr->mv_off);
+
+    /* boundary strengths: lanes 0..31, lane = 16*dir + 4*e + k */
+    int my_bs = 0;
+    if (lane < 32) {
+        const int dir = lane >> 4, e = (lane >> 2) & 3, k = lane & 3;
+        const bool edge_on = e ? true : (dir ? f_top : f_left);
+        if (edge_on) {
+            const uint32_t pmb = e ? mb : (dir ? mb - wmb : mb - 1);
+            const FjMbRec p = recs[pmb];
+            uint32_t qrefs, prefs;
+            __builtin_memcpy(&qrefs, q.ref_slot, 4);
+            __builtin_memcpy(&prefs, p.ref_slot, 4);
+            const int qx = dir ? k : e, qy = dir ? e : k;
+            const int px = dir ? k : (e ? e - 1 : 3), py = dir ? (e ? e - 1 : 3) : k;
+            if (is_intra_kind(q.kind) || is_intra_kind(p.kind)) my_bs = e ? 3 : 4;
+            else if (((q.coded >> z_of(qx, qy)) & 1) || ((p.coded >> z_of(px, py)) & 1)) my_bs = 2;
+            else if (((qrefs >> (8 * ((qy >> 1) * 2 + (qx >> 1)))) & 255u) != ((prefs >> (8 * ((py >> 1) * 2 + (px >> 1)))) & 255u)) my_bs = 1;
+            else {
+                const int16_t *a = mvbase + 32 * (size_t)mb + 2 * (4 * qy + qx), *b = mvbase + 32 * (size_t)pmb + 2 * (4 * py + px);
+                my_bs = (abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4) ? 1 : 0;
+            }
+        }
+        bs_s[dir][e][k] = (uint8_t)my_bs;
+    }
+    if (!__any(my_bs != 0)) return;                      /* nothing to filter in this macroblock */
+
+    const int W = wmb * 16, H = hmb * 16, CW = W >> 1, CH = H >> 1;
+    uint8_t *cur = fd.slot[hdr->cur_slot];
+    const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
+    uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
+
+    /* ---- load tiles (u32 granules; neighbours only where they exist) ---- */
+    for (int wd = lane; wd < 100; wd += 64) {
+        const int r = wd / 5, cw = wd % 5;
+        if ((r >= 4 || mby > 0) && (cw >= 1 || mbx > 0))
+            *reinterpret_cast<uint32_t *>(&lt[r * LS + 4 * cw]) =
+                *reinterpret_cast<const uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * (cw - 1));
+    }
+    if (lane < 60) {
+        const int plane = lane / 30, wd = lane % 30, r = wd / 3, cw = wd % 3;
+        const uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+        if ((r >= 2 || mby > 0) && (cw >= 1 || mbx > 0))
+            *reinterpret_cast<uint32_t *>(&ct[plane][r * CS + 4 * cw]) =
+                *reinterpret_cast<const uint32_t *>(P + (ptrdiff_t)(r - 2) * CW + 4 * (cw - 1));
+    }
+
+    /* ---- thresholds (wave-uniform) ---- */
+    const int qcq = c_qpc[clip3(0, 51, (int)q.qp_y + q.cqp_off)];
+    int qp_l = q.qp_y, qp_t = q.qp_y, qc_l = qcq, qc_t = qcq;
+    if (f_left) { const int pq = recs[mb - 1].qp_y; qp_l = (q.qp_y + pq + 1) >> 1; qc_l = (qcq + c_qpc[clip3(0, 51, pq + q.cqp_off)] + 1) >> 1; }
+    if (f_top) { const int pq = recs[mb - wmb].qp_y; qp_t = (q.qp_y + pq + 1) >> 1; qc_t = (qcq + c_qpc[clip3(0, 51, pq + q.cqp_off)] + 1) >> 1; }
+    const EdgeThr tl_in = edge_thr(q.qp_y, q.alpha_off, q.beta_off), tc_in = edge_thr(qcq, q.alpha_off, q.beta_off);
+    const EdgeThr tl_l = edge_thr(qp_l, q.alpha_off, q.beta_off), tc_l = edge_thr(qc_l, q.alpha_off, q.beta_off);
+    const EdgeThr tl_t = edge_thr(qp_t, q.alpha_off, q.beta_off), tc_t = edge_thr(qc_t, q.alpha_off, q.beta_off);
+    __syncthreads();
+
+    /* ---- vertical edges: a lane owns one sample row across all four edges ---- */
+    if (lane < 16) {
+        uint8_t *rowp = &lt[(4 + lane) * LS];
+        int px[20];
+#pragma unroll
+        for (int w4 = 0; w4 < 5; w4++) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(rowp + 4 * w4);
+            px[4 * w4] = v & 255; px[4 * w4 + 1] = (v >> 8) & 255; px[4 * w4 + 2] = (v >> 16) & 255; px[4 * w4 + 3] = v >> 24;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int bs = bs_s[0][e][lane >> 2];
+            const EdgeThr t = e ? tl_in : tl_l;
+            filter_luma8(px + 4 * e, bs, t.alpha, t.beta, bs > 0 && bs < 4 ? c_tc0[t.ia][bs - 1] : 0);
+        }
+#pragma unroll
+        for (int w4 = 0; w4 < 5; w4++)
+            *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = pack4(px[4 * w4], px[4 * w4 + 1], px[4 * w4 + 2], px[4 * w4 + 3]);
+    } else if (lane < 32) {
+        const int plane = (lane - 16) >> 3, r = (lane - 16) & 7;
+        uint8_t *rowp = &ct[plane][(2 + r) * CS];
+        int px[12];
+#pragma unroll
+        for (int w4 = 0; w4 < 3; w4++) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(rowp + 4 * w4);
+            px[4 * w4] = v & 255; px[4 * w4 + 1] = (v >> 8) & 255; px[4 * w4 + 2] = (v >> 16) & 255; px[4 * w4 + 3] = v >> 24;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            const int bs = bs_s[0][e][r >> 1];
+            const EdgeThr t = e ? tc_in : tc_l;
+            filter_chroma4(px + 2 + 2 * e, bs, t.alpha, t.beta, bs > 0 && bs < 4 ? c_tc0[t.ia][bs - 1] : 0);
+        }
+#pragma unroll
+        for (int w4 = 0; w4 < 3; w4++)
+            *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = pack4(px[4 * w4], px[4 * w4 + 1], px[4 * w4 + 2], px[4 * w4 + 3]);
+    }
+    __syncthreads();
+
+    /* ---- horizontal edges: a lane owns one sample column ---- */
+    if (lane < 16) {
+        uint8_t *colp = &lt[4 + lane];
+        int px[20];
+#pragma unroll
+        for (int r = 0; r < 20; r++) px[r] = colp[r * LS];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int bs = bs_s[1][e][lane >> 2];
+            const EdgeThr t = e ? tl_in : tl_t;
+            filter_luma8(px + 4 * e, bs, t.alpha, t.beta, bs > 0 && bs < 4 ? c_tc0[t.ia][bs - 1] : 0);
+        }
+#pragma unroll
+        for (int r = 1; r < 20; r++) colp[r * LS] = (uint8_t)px[r];
+    } else if (lane < 32) {
+        const int plane = (lane - 16) >> 3, c = (lane - 16) & 7;
+        uint8_t *colp = &ct[plane][4 + c];
+        int px[10];
+#pragma unroll
+        for (int r = 0; r < 10; r++) px[r] = colp[r * CS];
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            const int bs = bs_s[1][e][c >> 1];
+            const EdgeThr t = e ? tc_in : tc_t;
+            filter_chroma4(px + 2 * e, bs, t.alpha, t.beta, bs > 0 && bs < 4 ? c_tc0[t.ia][bs - 1] : 0);
+        }
+#pragma unroll
+        for (int r = 1; r < 10; r++) colp[r * CS] = (uint8_t)px[r];
+    }
+    __syncthreads();
+
+    /* ---- store: own macroblock, the 3 (1) columns of the left and rows of the upper neighbour ---- */
+    {
+        const int r = lane >> 2, cw = lane & 3;              /* 16 rows x 4 words */
+        *reinterpret_cast<uint32_t *>(Y + (size_t)r * W + 4 * cw) = *reinterpret_cast<const uint32_t *>(&lt[(4 + r) * LS + 4 + 4 * cw]);
+    }
+    if (lane < 16 && f_left)
+        *reinterpret_cast<uint32_t *>(Y + (size_t)lane * W - 4) = *reinterpret_cast<const uint32_t *>(&lt[(4 + lane) * LS]);
+    if (lane >= 16 && lane < 28 && f_top) {
+        const int i = lane - 16, r = 1 + i / 4, cw = i % 4;  /* tile rows 1..3 */
+        *reinterpret_cast<uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * cw) = *reinterpret_cast<const uint32_t *>(&lt[r * LS + 4 + 4 * cw]);
+    }
+    if (lane >= 32) {
+        const int i = lane - 32, plane = i >> 4, r = (i >> 1) & 7, cw = i & 1;
+        uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+        *reinterpret_cast<uint32_t *>(P + (size_t)r * CW + 4 * cw) = *reinterpret_cast<const uint32_t *>(&ct[plane][(2 + r) * CS + 4 + 4 * cw]);
+    }
+    if (lane < 16 && f_left) {
+        const int plane = lane >> 3, r = lane & 7;
+        uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+        *reinterpret_cast<uint32_t *>(P + (size_t)r * CW - 4) = *reinterpret_cast<const uint32_t *>(&ct[plane][(2 + r) * CS]);
+    }
+    if (lane >= 16 && lane < 20 && f_top) {
+        const int i = lane - 16, plane = i >> 1, cw = i & 1;
+        uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+        *reinterpret_cast<uint32_t *>(P - (ptrdiff_t)CW + 4 * cw) = *reinterpret_cast<const uint32_t *>(&ct[plane][1 * CS + 4 + 4 * cw]);
+    }
+}
+
+/* ------------------------------------------------------------------ colour conversion */
+/* 4 horizontally adjacent pixels per thread; fmt 0 RGBA, 1 BGRA, 2 YCbCrA (bytes in memory order) */
+__global__ __launch_bounds__(256) void k_convert(const uint8_t *__restrict__ yuv, uint32_t *__restrict__ out,
+                                                 uint32_t width, uint32_t height, int fmt, size_t in_stride, size_t out_stride)
+{
+    const uint8_t *src = yuv + blockIdx.y * in_stride;
+    uint32_t *dst = out + blockIdx.y * out_stride;
+    const uint32_t quads_per_row = width >> 2;
+    const uint32_t total = quads_per_row * height;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t y = i / quads_per_row, x = (i % quads_per_row) * 4;
+        const uint32_t yy = *reinterpret_cast<const uint32_t *>(src + (size_t)y * width + x);
+        const uint8_t *cbp = src + (size_t)width * height + (size_t)(y >> 1) * (width >> 1) + (x >> 1);
+        const uint8_t *crp = cbp + (size_t)(width >> 1) * (height >> 1);
+        const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(cbp), cr2 = *reinterpret_cast<const uint16_t *>(crp);
+        uint32_t px[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int Yv = (yy >> (8 * k)) & 255, cb = (cb2 >> (8 * (k >> 1))) & 255, cr = (cr2 >> (8 * (k >> 1))) & 255;
+            if (fmt == 2) px[k] = 0xFF000000u | ((uint32_t)cr << 16) | ((uint32_t)cb << 8) | (uint32_t)Yv;
+            else {
+                const int c = Yv - 16, d = cb - 128, e = cr - 128;
+                const uint32_t r = clip255((298 * c + 409 * e + 128) >> 8);
+                const uint32_t g = clip255((298 * c - 100 * d - 208 * e + 128) >> 8);
+                const uint32_t b = clip255((298 * c + 516 * d + 128) >> 8);
+                px[k] = fmt == 0 ? 0xFF000000u | (b << 16) | (g << 8) | r : 0xFF000000u | (r << 16) | (g << 8) | b;
+            }
+        }
+        *reinterpret_cast<uint4 *>(dst + (size_t)y * width + x) = make_uint4(px[0], px[1], px[2], px[3]);
+    }
+}
+
+/* ------------------------------------------------------------------ on-device verification */
+/* sum over 32-bit words w[i] of (w[i] ^ i*0x9E3779B1) * (2i+1)  (mod 2^64); one block per frame */
+__global__ __launch_bounds__(256) void k_checksum(const uint8_t *__restrict__ base, size_t stride, uint32_t words,
+                                                  unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long part[256];
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(base + blockIdx.x * stride);
+    unsigned long long acc = 0;
+    for (uint32_t i = threadIdx.x; i < words; i += 256)
+        acc += (unsigned long long)(w[i] ^ (i * 0x9E3779B1u)) * (unsigned long long)(2u * i + 1u);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+
+} // namespace h264k

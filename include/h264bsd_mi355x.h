@@ -55,6 +55,9 @@ int  h264bsdmiReplayFetchConverted(h264bsdmi_replay *r, u32 stream, u32 *dst);
  * out[0]=inter reconstruction, out[1]=intra reconstruction, out[2]=deblocking, out[3]=whole run;
  * launches[0..2] = number of launches per class. */
 int  h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[4], u32 launches[3]);
+/* Test hook: which stages h264bsdmiReplayRun() launches: bit0 inter reconstruction, bit1 intra
+ * reconstruction, bit2 deblocking (default 7 = all). */
+int  h264bsdmiReplaySetStages(h264bsdmi_replay *r, unsigned mask);
 /* Bytes of packed syntax (frame jobs) per stream and of one frame, for the byte accounting. */
 unsigned long long h264bsdmiReplayJobBytes(h264bsdmi_replay *r);
 u32  h264bsdmiReplayFrameBytes(h264bsdmi_replay *r);
