@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the macroblock-reconstruction hot path on MI355X.
+
+Workload (BASELINE.json configs[3] / [4]): 256 concurrent, private copies of tests/golden/test_1920x1080.h264
+per GPU.  The stream is parsed ONCE on the host into packed frame jobs (capture mode), the jobs are
+replicated into HBM (every stream owns its jobs and its DPB), and a "step" is one pass of the hot path
+over the whole batch: 73 pictures x 256 streams = 18,688 pictures = 152.5 M macroblocks per GPU,
+reconstructed (inter + intra) and deblocked by the HIP kernels.  Inputs are resident in HBM when the
+timed region starts; outputs stay in HBM and are verified on the device against the reference's golden
+checksums (every picture of every stream, in an untimed verification pass, and the final picture after
+the timed region).  A run that is not bit-exact aborts.
+
+One process per GPU: `python bench.py` (N=1) or
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.  Streams are independent,
+so ranks share nothing on the data path (weak scaling: 256 streams per GPU); torch.distributed (RCCL)
+is used only for the barriers and the MAX-over-ranks of the elapsed time.
+
+Output: ONE JSON line on rank 0 (see the driver contract), with `roofline` (dominant kernel, HBM bound)
+and `cpu_baseline` (the compiled reference, oracle/_ref, timed on this host; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
+STREAM = "test_1920x1080"
+
+
+def cpu_baseline(data, seconds=12.0):
+    """Reference decoder (oracle/_ref) on ONE host core, decode-only loop, fresh input copy per pass."""
+    from oracle import pyoracle
+    try:
+        ref = pyoracle.RefDecoder()
+        kind = "reference"
+        run = lambda: ref.decode_stream(data)[1]
+    except (FileNotFoundError, OSError):
+        import h264bsd_amd
+        kind = "port"
+
+        def run():
+            jobs, _, _ = h264bsd_amd.capture_stream(data)
+            dpb = pyoracle.OracleDpb(jobs[0])
+            for j in jobs:
+                dpb.decode(j)
+            return len(jobs)
+    n_pics, t0, passes = 0, time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        n_pics += run()
+        passes += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n_pics * 8160 / dt, unit="macroblocks/s", fps=n_pics / dt, cores=1, kind=kind,
+                sample=f"{passes} full passes of {STREAM}.h264 ({n_pics} pictures, {dt:.1f} s) on 1 of {os.cpu_count()} host cores")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=256, help="concurrent streams per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import h264bsd_amd
+    from oracle import pyoracle
+
+    if not torch.cuda.is_available() or h264bsd_amd.device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU pixel path")
+    torch.cuda.set_device(local_rank)
+    h264bsd_amd.lib().h264bsdmiSetDevice(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    golden = json.load(open(os.path.join(gdir, "golden.json")))[STREAM]
+    data = open(os.path.join(gdir, STREAM + ".h264"), "rb").read()
+    jobs, _, info = h264bsd_amd.capture_stream(data)                 # host parse, once
+    heads = [pyoracle.blob_header(j) for j in jobs]
+    n_pics, n_mbs = len(jobs), heads[0]["n_mbs"]
+    rep = h264bsd_amd.Replay(jobs, n_streams=args.streams)          # jobs + DPBs resident in HBM
+
+    # ---- untimed verification pass: every picture of every stream against the reference ----
+    for i in range(n_pics):
+        rep.run(i, 1)
+        sums = rep.checksums(heads[i]["cur_slot"])
+        if not (sums == golden["frame_checksum64"][i]).all():
+            raise SystemExit(f"rank {rank}: picture {i} is not bit-exact on {(sums != golden['frame_checksum64'][i]).sum()} streams")
+
+    for _ in range(args.warmup):
+        rep.run()
+    barrier()
+    t0 = time.perf_counter()
+    agg = dict(inter_ms=0.0, intra_ms=0.0, deblock_ms=0.0, total_ms=0.0, inter=0, intra=0, deblock=0)
+    for _ in range(args.steps):
+        rep.run()
+        t = rep.timings()        # waits for the step; HIP events recorded on the engine's own stream
+        for k in ("inter_ms", "intra_ms", "deblock_ms", "total_ms"):
+            agg[k] += t[k]
+        for k in ("inter", "intra", "deblock"):
+            agg[k] += t["launches"][k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    sums = rep.checksums(heads[-1]["cur_slot"])
+    if not (sums == golden["frame_checksum64"][-1]).all():
+        raise SystemExit(f"rank {rank}: final picture is not bit-exact")
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        pics_per_step = n_pics * args.streams * world
+        mbs = pics_per_step * n_mbs * args.steps
+        # algorithmic bytes: 384 B written per MB + 384 B of reference read per inter MB +
+        # the packed syntax actually consumed (the frame jobs)
+        n_inter = sum(h["n_inter"] for h in heads)
+        alg_bytes_stream = 384 * n_mbs * n_pics + 384 * n_inter + rep.job_bytes
+        alg_per_mb = alg_bytes_stream / (n_mbs * n_pics)
+        # dominant kernel: the one with the largest share of device time in the timed region
+        shares = {"k_recon_inter": agg["inter_ms"], "k_recon_intra": agg["intra_ms"], "k_deblock": agg["deblock_ms"]}
+        dom = max(shares, key=shares.get)
+        dom_key = {"k_recon_inter": "inter", "k_recon_intra": "intra", "k_deblock": "deblock"}[dom]
+        launches = max(agg[dom_key], 1)
+        avg_launch_us = shares[dom] * 1e3 / launches
+        units_per_launch = n_mbs * n_pics * args.streams * args.steps / launches       # macroblocks per launch
+        achieved = alg_per_mb * units_per_launch / (avg_launch_us * 1e-6) / 1e9       # GB/s
+        path_gbs = alg_bytes_stream * args.streams * args.steps / (agg["total_ms"] * 1e-3) / 1e9
+        out = {
+            "metric": "1080p macroblocks/s", "value": mbs / elapsed, "unit": "macroblocks/s",
+            "fps": pics_per_step * args.steps / elapsed,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.streams} concurrent copies of {STREAM}.h264 per GPU "
+                                   f"({n_pics} pictures x {n_mbs} MB), kernel-only replay from HBM-resident frame jobs, "
+                                   "inter+intra reconstruction + in-loop deblocking, bit-exact vs reference verified on device",
+                       "streams_per_gpu": args.streams, "pictures_per_step": pics_per_step, "parallelism": f"streams/{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_mb": alg_per_mb, "mbs_per_launch": units_per_launch,
+                         "avg_launch_us": avg_launch_us, "launches": launches,
+                         "whole_path_GBs": path_gbs, "whole_path_frac": path_gbs / HBM_PEAK_GBS,
+                         "device_ms": {k: agg[k] / args.steps for k in ("inter_ms", "intra_ms", "deblock_ms", "total_ms")}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data)
+        print(json.dumps(out), flush=True)
+    rep.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
