@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdmiInitCapture", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush",
     "h264bsdmiReplayCreate", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
-    "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
+    "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
 ]
 
 JOB_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint32)
@@ -89,6 +89,7 @@ def lib():
     L.h264bsdmiReplayFetchConverted.argtypes = [vp, u32, vp]
     L.h264bsdmiReplayTimings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), P32]
     L.h264bsdmiReplaySetStages.argtypes = [vp, ctypes.c_uint]
+    L.h264bsdmiReplaySetGroups.argtypes = [vp, u32]
     L.h264bsdmiReplayJobBytes.argtypes = [vp]
     L.h264bsdmiReplayJobBytes.restype = ctypes.c_ulonglong
     L.h264bsdmiReplayFrameBytes.argtypes = [vp]
@@ -285,6 +286,10 @@ class Replay:
             raise RuntimeError("h264bsdmiReplayFetchConverted failed")
         return out
 
+    def set_groups(self, n):
+        if self._L.h264bsdmiReplaySetGroups(self._h, n) != 0:
+            raise RuntimeError('h264bsdmiReplaySetGroups failed')
+
     def set_stages(self, mask):
         self._L.h264bsdmiReplaySetStages(self._h, mask)
 
@@ -293,5 +298,6 @@ class Replay:
         n = (ctypes.c_uint32 * 3)()
         if self._L.h264bsdmiReplayTimings(self._h, ms, n) != 0:
             raise RuntimeError("h264bsdmiReplayTimings failed")
+        # ms[0] k_recon_inter, ms[2] k_frame_tail (intra levels + deblocking), ms[3] whole run
         return dict(inter_ms=ms[0], intra_ms=ms[1], deblock_ms=ms[2], total_ms=ms[3],
                     launches=dict(inter=int(n[0]), intra=int(n[1]), deblock=int(n[2])))

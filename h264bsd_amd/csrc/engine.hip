@@ -4,13 +4,13 @@
  * parity tests.
  *
  * Execution model.  A tick holds at most one picture per stream (pictures of one stream depend on
- * each other through the DPB; pictures of different streams never do).  For a tick of N pictures:
- *     1 launch  k_recon_inter   grid (max MBs, N)            — every inter MB of every picture
- *     L launches k_recon_intra  grid (level population, N)   — intra MBs, dependency level by level
- *     D launches k_deblock      grid (MBs on diagonal, N)    — D = (W-1) + 2(H-1) + 1 anti-diagonals
- * all on one HIP stream, so launch order is execution order and no inter-workgroup synchronisation
- * is needed inside a launch.  Occupancy comes from batching streams: at 256 x 1080p a deblocking
- * step has up to 256 x 60 wavefronts.
+ * each other through the DPB; pictures of different streams never do).  A tick of N pictures is TWO
+ * launches on one HIP stream:
+ *     k_recon_inter  grid (ceil(MBs/4), N) x 256 threads — every inter MB of every picture, one wave each
+ *     k_frame_tail   grid (N) x 1024 threads             — one workgroup per picture: intra levels, then
+ *                                                          the deblocking wavefront, synchronised by
+ *                                                          __syncthreads() only
+ * Occupancy of the second launch comes from batching streams: 256 pictures = one workgroup per CU.
  *
  * This replaces, for the pixels, what the reference does synchronously inside h264bsdDecode
  * (src/h264bsd_slice_data.c:185 -> h264bsdDecodeMacroblock, src/h264bsd_decoder.c:475 ->
@@ -45,6 +45,7 @@ struct PendingJob { uint8_t *host; uint32_t bytes; };
 struct StreamCtx {
     uint32_t wmb = 0, hmb = 0, n_slots = 0, frame_bytes = 0;
     uint8_t *d_frames = nullptr;
+    uint8_t *d_dbk = nullptr;
     uint8_t *h_frame[FJ_MAX_SLOTS] = {};
     uint32_t *h_conv = nullptr, *d_conv = nullptr;
     std::deque<PendingJob> pending;
@@ -60,6 +61,7 @@ struct Engine {
     uint8_t *conv_in = nullptr; uint32_t *conv_out = nullptr; size_t conv_cap = 0; /* eng_convert_host scratch */
 };
 
+unsigned long long *g_tail_prof = nullptr;   /* debug: per-wave cycle accounting of k_frame_tail (block 0) */
 Engine *g_engine = nullptr;
 std::mutex g_engine_mu;
 int g_device_request = -1;
@@ -81,51 +83,77 @@ Engine *engine_get()
 
 /* ---- launch of one tick ---- */
 struct TickShape {
-    uint32_t n_frames = 0, max_mbs = 0, max_w = 0, max_h = 0;
-    bool any_inter = false, any_deblock = false;
-    std::vector<uint32_t> level_pop;     /* max population per intra level over the frames of the tick */
+    uint32_t n_frames = 0, max_mbs = 0;
+    uint32_t max_copy = 0, max_gen = 0, max_levels = 0, max_w = 0, max_h = 0;
+    bool any_tail = false, any_deblock = false;
 };
 
-void shape_add(TickShape &s, const uint8_t *host_blob)
+/* descriptor of one picture: device addresses of the sections of its (device-resident) frame job */
+void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, uint8_t *dev_frames, uint32_t frame_bytes,
+               uint8_t *dev_dbk, TickShape *shape)
 {
     const FjHeader *h = reinterpret_cast<const FjHeader *>(host_blob);
-    s.n_frames++;
-    s.max_mbs = std::max(s.max_mbs, h->n_mbs);
-    s.max_w = std::max<uint32_t>(s.max_w, h->width_mbs);
-    s.max_h = std::max<uint32_t>(s.max_h, h->height_mbs);
-    s.any_inter |= h->n_inter != 0;
-    s.any_deblock |= h->any_deblock != 0;
-    const uint32_t *lvl = reinterpret_cast<const uint32_t *>(host_blob + h->lvl_off);
-    if (s.level_pop.size() < h->n_intra_levels) s.level_pop.resize(h->n_intra_levels, 0);
-    for (uint32_t l = 0; l < h->n_intra_levels; l++) s.level_pop[l] = std::max(s.level_pop[l], lvl[l + 1] - lvl[l]);
+    d.recs = reinterpret_cast<const FjMbRec *>(dev_blob + h->rec_off);
+    d.mvs = reinterpret_cast<const int16_t *>(dev_blob + h->mv_off);
+    d.coefs = reinterpret_cast<const int16_t *>(dev_blob + h->coef_off);
+    d.lvl = reinterpret_cast<const uint32_t *>(dev_blob + h->lvl_off);
+    d.idx = reinterpret_cast<const uint16_t *>(dev_blob + h->idx_off);
+    d.copy = reinterpret_cast<const FjCopy *>(dev_blob + h->copy_off);
+    d.gen = reinterpret_cast<const uint16_t *>(dev_blob + h->gen_off);
+    d.n_copy = h->n_copy;
+    d.n_gen = h->n_gen;
+    d.dbk = dev_dbk;
+    d.cur = dev_frames + (size_t)h->cur_slot * frame_bytes;
+    d.n_mbs = h->n_mbs;
+    d.n_levels = h->n_intra_levels;
+    d.wmb = h->width_mbs;
+    d.hmb = h->height_mbs;
+    d.any_deblock = h->any_deblock;
+    for (uint32_t k = 0; k < FJ_MAX_SLOTS; k++) d.slot[k] = k < h->n_slots ? dev_frames + (size_t)k * frame_bytes : nullptr;
+    if (shape) {
+        shape->n_frames++;
+        shape->max_mbs = std::max(shape->max_mbs, h->n_mbs);
+        shape->max_copy = std::max(shape->max_copy, h->n_copy);
+        shape->max_gen = std::max(shape->max_gen, h->n_gen);
+        shape->any_deblock |= h->any_deblock != 0;
+        shape->max_levels = std::max(shape->max_levels, h->n_intra_levels);
+        shape->max_w = std::max<uint32_t>(shape->max_w, h->width_mbs);
+        shape->max_h = std::max<uint32_t>(shape->max_h, h->height_mbs);
+        shape->any_tail |= h->n_intra_levels != 0 || h->any_deblock != 0;
+    }
 }
 
-struct TickTimers { hipEvent_t ev[4]; bool on = false; };
+struct TickTimers { hipEvent_t ev[3]; bool on = false; };
 
 int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[3],
                 unsigned stages = 7u)
 {
     if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[0], st));
-    if (s.any_inter && (stages & 1u)) {
-        hipLaunchKernelGGL(h264k::k_recon_inter, dim3(s.max_mbs, s.n_frames), dim3(64), 0, st, d_desc);
-        if (launches) launches[0]++;
+    if (stages & 1u) {
+        if (s.max_copy) hipLaunchKernelGGL(h264k::k_copy, dim3((s.max_copy + 15) / 16, s.n_frames), dim3(256), 0, st, d_desc);
+        if (s.max_gen) hipLaunchKernelGGL(h264k::k_recon_inter, dim3((s.max_gen + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
+        if (launches) launches[0] += (s.max_copy ? 1 : 0) + (s.max_gen ? 1 : 0);
+    }
+    if ((stages & 4u) && s.any_deblock) {
+        hipLaunchKernelGGL(h264k::k_dbk, dim3((s.max_mbs + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
     }
     if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[1], st));
-    for (uint32_t l = 0; (stages & 2u) && l < s.level_pop.size(); l++) {
-        hipLaunchKernelGGL(h264k::k_recon_intra, dim3(s.level_pop[l], s.n_frames), dim3(64), 0, st, d_desc, l);
+    if (s.max_levels && (stages & 2u)) {
+        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * h264k::TAIL_WAVES), 0, st, d_desc);
         if (launches) launches[1]++;
     }
-    if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[2], st));
     if (s.any_deblock && (stages & 4u)) {
-        const int w = (int)s.max_w, h = (int)s.max_h;
-        for (int d = 0; d <= (w - 1) + 2 * (h - 1); d++) {
-            const int ylo = std::max(0, (d - (w - 1) + 1) >> 1), yhi = std::min(h - 1, d >> 1);
-            if (yhi < ylo) continue;
-            hipLaunchKernelGGL(h264k::k_deblock, dim3((uint32_t)(yhi - ylo + 1), s.n_frames), dim3(64), 0, st, d_desc, d);
-            if (launches) launches[2]++;
+        const uint32_t nl = s.max_w + 2 * s.max_h, n = s.max_mbs;
+        const size_t lds = (size_t)h264k::TAIL_WORKERS * h264k::WORKER_LDS + ((n + 15) & ~15u) + 2 * 2 * (size_t)((n + 7) & ~7u) + 2 * 4 * (size_t)(nl + 2);
+        static size_t lds_enabled = 0;
+        if (lds > lds_enabled) {
+            HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_dbk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_enabled = lds;
         }
+        hipLaunchKernelGGL(h264k::k_frame_dbk, dim3(s.n_frames), dim3(64 * h264k::TAIL_WAVES), lds, st, d_desc, g_tail_prof);
+        if (launches) launches[2]++;
     }
-    if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[3], st));
+    if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[2], st));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -157,10 +185,7 @@ int flush_locked(Engine *e)
             StreamCtx *s = part[i];
             PendingJob &j = s->pending.front();
             HIP_TRY(hipMemcpyAsync(e->d_arena + off, j.host, j.bytes, hipMemcpyHostToDevice, e->stream));
-            shape_add(shape, j.host);
-            descs[i].blob = e->d_arena + off;
-            for (uint32_t k = 0; k < FJ_MAX_SLOTS; k++)
-                descs[i].slot[k] = k < s->n_slots ? s->d_frames + (size_t)k * s->frame_bytes : nullptr;
+            make_desc(descs[i], j.host, e->d_arena + off, s->d_frames, s->frame_bytes, s->d_dbk, &shape);
             off += (j.bytes + 255u) & ~255u;
         }
         HIP_TRY(hipMemcpyAsync(e->d_desc, descs.data(), descs.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream));
@@ -181,6 +206,8 @@ void stream_release(StreamCtx *s)
     for (auto &j : s->pending) hipHostFree(j.host);
     s->pending.clear();
     if (s->d_frames) hipFree(s->d_frames);
+    if (s->d_dbk) hipFree(s->d_dbk);
+    s->d_dbk = nullptr;
     for (auto &p : s->h_frame) if (p) { hipHostFree(p); p = nullptr; }
     if (s->h_conv) hipHostFree(s->h_conv);
     if (s->d_conv) hipFree(s->d_conv);
@@ -199,6 +226,8 @@ int sink_configure(void *user, uint32_t wmb, uint32_t hmb, uint32_t n_slots)
     const size_t total = (size_t)n_slots * u->s->frame_bytes + 256;
     HIP_TRY(hipMalloc((void **)&u->s->d_frames, total));
     HIP_TRY(hipMemsetAsync(u->s->d_frames, 0, total, u->e->stream));
+    HIP_TRY(hipMalloc((void **)&u->s->d_dbk, (size_t)wmb * hmb * (DBK_REC_BYTES + 1) + 64));
+    HIP_TRY(hipMemsetAsync(u->s->d_dbk, 0, (size_t)wmb * hmb * (DBK_REC_BYTES + 1) + 64, u->e->stream));
     return 0;
 }
 
@@ -338,6 +367,7 @@ struct h264bsdmi_replay {
     unsigned long long job_bytes;     /* sum of the blob sizes of one stream */
     uint8_t *d_blobs;                 /* n_streams * blob_stride */
     uint8_t *d_frames;                /* n_streams * n_slots * frame_bytes */
+    uint8_t *d_dbk;                   /* n_streams * n_mbs * 32 */
     FrameDesc *d_desc;                /* n_pics * n_streams */
     uint32_t *d_conv;                 /* n_streams * w*h (lazy) */
     unsigned long long *d_sums;
@@ -348,6 +378,9 @@ struct h264bsdmi_replay {
     hipEvent_t ev_begin, ev_end;
     uint32_t launches[3];
     unsigned stages;
+    uint32_t n_groups;
+    hipStream_t gstream[8];
+    hipEvent_t gdone[8];
 };
 
 h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams)
@@ -369,12 +402,15 @@ h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes
     r->job_bytes = 0;
     for (u32 i = 0; i < n_pics; i++) { offs[i] = total; total += ((size_t)bytes[i] + 255u) & ~(size_t)255u; r->job_bytes += bytes[i]; }
     r->blob_stride = total;
-    r->d_blobs = nullptr; r->d_frames = nullptr; r->d_desc = nullptr; r->d_conv = nullptr; r->d_sums = nullptr;
+    r->d_blobs = nullptr; r->d_frames = nullptr; r->d_desc = nullptr; r->d_conv = nullptr; r->d_sums = nullptr; r->d_dbk = nullptr;
     const size_t frames_per_stream = (size_t)r->n_slots * r->frame_bytes;
+    const size_t dbk_stride = (((size_t)h0->n_mbs * (DBK_REC_BYTES + 1) + 64) + 255) & ~(size_t)255;
     bool ok = hipMalloc((void **)&r->d_blobs, total * n_streams) == hipSuccess &&
               hipMalloc((void **)&r->d_frames, frames_per_stream * n_streams + 256) == hipSuccess &&
               hipMalloc((void **)&r->d_desc, sizeof(FrameDesc) * (size_t)n_pics * n_streams) == hipSuccess &&
-              hipMalloc((void **)&r->d_sums, sizeof(unsigned long long) * n_streams) == hipSuccess;
+              hipMalloc((void **)&r->d_sums, sizeof(unsigned long long) * n_streams) == hipSuccess &&
+              hipMalloc((void **)&r->d_dbk, (size_t)n_streams * dbk_stride) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(r->d_dbk, 0, (size_t)n_streams * dbk_stride, e->stream) == hipSuccess;
     if (ok) ok = hipMemsetAsync(r->d_frames, 0, frames_per_stream * n_streams + 256, e->stream) == hipSuccess;
     /* stream 0 from the host, the other copies device-to-device: every stream owns private jobs */
     for (u32 i = 0; ok && i < n_pics; i++) {
@@ -382,7 +418,8 @@ h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes
         const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[i]);
         if (h->width_mbs != r->wmb || h->height_mbs != r->hmb || h->n_slots != r->n_slots) ok = false;
         TickShape s;
-        shape_add(s, blobs[i]);
+        FrameDesc tmp;
+        make_desc(tmp, blobs[i], nullptr, nullptr, 0, nullptr, &s);
         s.n_frames = n_streams;
         r->shapes.push_back(s);
         r->cur_slot.push_back(h->cur_slot);
@@ -394,10 +431,9 @@ h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes
         std::vector<FrameDesc> descs((size_t)n_pics * n_streams);
         for (u32 i = 0; i < n_pics; i++)
             for (u32 s = 0; s < n_streams; s++) {
-                FrameDesc &d = descs[(size_t)i * n_streams + s];
-                d.blob = r->d_blobs + (size_t)s * total + offs[i];
-                for (u32 k = 0; k < FJ_MAX_SLOTS; k++)
-                    d.slot[k] = k < r->n_slots ? r->d_frames + (size_t)s * frames_per_stream + (size_t)k * r->frame_bytes : nullptr;
+                make_desc(descs[(size_t)i * n_streams + s], blobs[i], r->d_blobs + (size_t)s * total + offs[i],
+                          r->d_frames + (size_t)s * frames_per_stream, r->frame_bytes,
+                          r->d_dbk + (size_t)s * dbk_stride, nullptr);
             }
         ok = hipMemcpyAsync(r->d_desc, descs.data(), descs.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream) == hipSuccess &&
              hipStreamSynchronize(e->stream) == hipSuccess;
@@ -407,12 +443,15 @@ h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes
     if (ok) ok = hipEventCreate(&r->ev_begin) == hipSuccess && hipEventCreate(&r->ev_end) == hipSuccess;
     r->timed_first = r->timed_count = 0;
     r->stages = 7u;
+    r->n_groups = 1;
+    for (int g = 0; g < 8; g++) { r->gstream[g] = nullptr; r->gdone[g] = nullptr; }
     if (!ok) {
         fprintf(stderr, "h264bsd-mi355x: h264bsdmiReplayCreate failed (%s)\n", hipGetErrorString(hipGetLastError()));
         if (r->d_blobs) hipFree(r->d_blobs);
         if (r->d_frames) hipFree(r->d_frames);
         if (r->d_desc) hipFree(r->d_desc);
         if (r->d_sums) hipFree(r->d_sums);
+        if (r->d_dbk) hipFree(r->d_dbk);
         delete r;
         return nullptr;
     }
@@ -425,10 +464,11 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     std::lock_guard<std::mutex> lk(r->e->mu);
     hipSetDevice(r->e->device);
     hipStreamSynchronize(r->e->stream);
-    hipFree(r->d_blobs); hipFree(r->d_frames); hipFree(r->d_desc); hipFree(r->d_sums);
+    hipFree(r->d_blobs); hipFree(r->d_frames); hipFree(r->d_desc); hipFree(r->d_sums); hipFree(r->d_dbk);
     if (r->d_conv) hipFree(r->d_conv);
     for (auto &t : r->timers) for (auto &ev : t.ev) hipEventDestroy(ev);
     hipEventDestroy(r->ev_begin); hipEventDestroy(r->ev_end);
+    for (int g = 0; g < 8; g++) { if (r->gstream[g]) hipStreamDestroy(r->gstream[g]); if (r->gdone[g]) hipEventDestroy(r->gdone[g]); }
     delete r;
 }
 
@@ -440,11 +480,54 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
     r->timed_first = first; r->timed_count = count;
     r->launches[0] = r->launches[1] = r->launches[2] = 0;
     HIP_TRY(hipEventRecord(r->ev_begin, r->e->stream));
-    for (u32 i = first; i < first + count; i++) {
-        r->timers[i].on = true;
-        if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages)) return -1;
+    if (r->n_groups <= 1) {
+        for (u32 i = first; i < first + count; i++) {
+            r->timers[i].on = true;
+            if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages)) return -1;
+        }
+    } else {
+        /* stream groups on separate HIP streams: the latency-bound per-picture tail of one group overlaps
+         * with the throughput-bound inter reconstruction of another (pictures of different streams are
+         * independent; every group still runs its own pictures strictly in order) */
+        const u32 G = r->n_groups, per = (r->n_streams + G - 1) / G;
+        for (u32 g = 0; g < G; g++) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->ev_begin, 0));
+        for (u32 i = first; i < first + count; i++) {
+            for (u32 g = 0; g < G; g++) {
+                const u32 s0 = g * per, s1 = std::min(r->n_streams, s0 + per);
+                if (s0 >= s1) continue;
+                TickShape sh = r->shapes[i];
+                sh.n_frames = s1 - s0;
+                TickTimers &tt = r->timers[(size_t)g * r->n_pics + i];
+                tt.on = true;
+                /* de-phase the groups once: group g starts when group g-1 has entered its first tail */
+                if (i == first && g > 0) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->timers[(size_t)(g - 1) * r->n_pics + i].ev[1], 0));
+                if (launch_tick(r->gstream[g], r->d_desc + (size_t)i * r->n_streams + s0, sh, &tt, r->launches, r->stages)) return -1;
+            }
+        }
+        for (u32 g = 0; g < G; g++) {
+            HIP_TRY(hipEventRecord(r->gdone[g], r->gstream[g]));
+            HIP_TRY(hipStreamWaitEvent(r->e->stream, r->gdone[g], 0));
+        }
     }
     HIP_TRY(hipEventRecord(r->ev_end, r->e->stream));
+    return 0;
+}
+
+int h264bsdmiReplaySetGroups(h264bsdmi_replay *r, u32 n_groups)
+{
+    if (!r || n_groups < 1 || n_groups > 8) return -1;
+    std::lock_guard<std::mutex> lk(r->e->mu);
+    HIP_TRY(hipSetDevice(r->e->device));
+    while (r->timers.size() < (size_t)n_groups * r->n_pics) {
+        TickTimers t;
+        for (auto &ev : t.ev) HIP_TRY(hipEventCreate(&ev));
+        r->timers.push_back(t);
+    }
+    for (u32 g = 0; g < n_groups; g++) {
+        if (!r->gstream[g]) HIP_TRY(hipStreamCreateWithFlags(&r->gstream[g], hipStreamNonBlocking));
+        if (!r->gdone[g]) HIP_TRY(hipEventCreateWithFlags(&r->gdone[g], hipEventDisableTiming));
+    }
+    r->n_groups = n_groups;
     return 0;
 }
 
@@ -462,12 +545,14 @@ int h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[4], u32 launches[3]
     HIP_TRY(hipSetDevice(r->e->device));
     HIP_TRY(hipStreamSynchronize(r->e->stream));
     out_ms[0] = out_ms[1] = out_ms[2] = out_ms[3] = 0.f;
-    for (u32 i = r->timed_first; i < r->timed_first + r->timed_count; i++) {
+    for (u32 g = 0; g < r->n_groups; g++)
+    for (u32 i0 = r->timed_first; i0 < r->timed_first + r->timed_count; i0++) {
+        const size_t i = (size_t)g * r->n_pics + i0;
         float ms;
-        for (int k = 0; k < 3; k++) {
-            HIP_TRY(hipEventElapsedTime(&ms, r->timers[i].ev[k], r->timers[i].ev[k + 1]));
-            out_ms[k] += ms;
-        }
+        HIP_TRY(hipEventElapsedTime(&ms, r->timers[i].ev[0], r->timers[i].ev[1]));
+        out_ms[0] += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, r->timers[i].ev[1], r->timers[i].ev[2]));
+        out_ms[2] += ms;
     }
     if (r->timed_count) HIP_TRY(hipEventElapsedTime(&out_ms[3], r->ev_begin, r->ev_end));
     if (launches) { launches[0] = r->launches[0]; launches[1] = r->launches[1]; launches[2] = r->launches[2]; }
@@ -523,6 +608,25 @@ int h264bsdmiReplaySetStages(h264bsdmi_replay *r, unsigned mask)
 {
     if (!r) return -1;
     r->stages = mask & 7u;
+    return 0;
+}
+
+/* Debug hook: cycle accounting of k_frame_tail's deblocking loop (workgroup 0 of the next launches).
+ * out[16][8]: per wave {pick, filter, extra rounds, own-memory wait, filtered count, barrier wait}. */
+int h264bsdmiDebugTailProfile(int enable, unsigned long long *out)
+{
+    Engine *e = engine_get();
+    if (!e) return -1;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (enable) {
+        if (!g_tail_prof) HIP_TRY(hipMalloc((void **)&g_tail_prof, 16 * 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(g_tail_prof, 0, 16 * 8 * sizeof(unsigned long long)));
+    } else if (g_tail_prof) {
+        if (out) HIP_TRY(hipMemcpy(out, g_tail_prof, 16 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(g_tail_prof));
+        g_tail_prof = nullptr;
+    }
     return 0;
 }
 

@@ -15,6 +15,8 @@
  * (blk = 4*by + bx), not the H.264 zig-zag block order the reference uses.
  *
  * All integers little-endian; every section starts 32-byte aligned.
+ * Section order in the blob: header | records | motion vectors | coefficients | level starts |
+ * intra index | copy list | general-inter index.
  */
 #ifndef H264BSD_AMD_FRAMEJOB_H
 #define H264BSD_AMD_FRAMEJOB_H
@@ -68,8 +70,22 @@ typedef struct FjHeader {
     uint32_t n_coef_blocks;
     uint32_t n_inter;         /* statistics for the byte accounting of the bench              */
     uint32_t pic_seq;         /* running picture number of the stream                         */
-    uint32_t reserved[1];
-} FjHeader;                   /* 64 bytes */
+    uint32_t copy_off;        /* FjCopy[n_copy]: inter MBs that are pure whole-sample copies   */
+    uint32_t n_copy;
+    uint32_t gen_off;         /* uint16 gen_idx[n_gen]: all other inter MBs                    */
+    uint32_t n_gen;
+    uint32_t reserved[13];
+} FjHeader;                   /* 128 bytes */
+
+/* An inter macroblock with no coefficients whose 16 motion vectors are equal and whole-sample for
+ * luma AND chroma (mv multiple of 8 quarter-samples; 66 % of the inter MBs of the bundled 1080p
+ * stream, almost all of them P_Skip with mv 0): reconstruction is a 384-byte copy. */
+typedef struct FjCopy {
+    uint16_t mb;              /* macroblock address                                           */
+    uint8_t  slot;            /* reference DPB slot                                           */
+    uint8_t  reserved;
+    int16_t  dx, dy;          /* displacement in luma samples (even)                          */
+} FjCopy;                     /* 8 bytes */
 
 typedef struct FjMbRec {
     uint8_t  kind;

@@ -51,8 +51,9 @@ void hd_destroy(HostDec *d)
 /* ---------------------------------------------------------------- frame job */
 static uint32_t job_capacity(uint32_t n_mbs)
 {
-    return 64u + n_mbs * (32u + 64u) + (n_mbs * 27u + 2u) * 32u /* coefficients, worst case */
-           + (n_mbs + 2u) * 4u /* level starts */ + fj_align32(n_mbs * 2u) + 256u;
+    return 128u + n_mbs * (32u + 64u) + (n_mbs * 27u + 2u) * 32u /* coefficients, worst case */
+           + (n_mbs + 2u) * 4u /* level starts */ + fj_align32(n_mbs * 2u) /* intra index */
+           + n_mbs * 8u /* copy list or general index */ + 512u;
 }
 
 int hd_job_begin(HostDec *d)
@@ -70,7 +71,7 @@ int hd_job_begin(HostDec *d)
     h->width_mbs = (uint16_t)d->width_mbs;
     h->height_mbs = (uint16_t)d->height_mbs;
     h->n_mbs = n;
-    h->rec_off = 64;
+    h->rec_off = 128;
     h->mv_off = h->rec_off + n * 32u;
     h->coef_off = h->mv_off + n * 64u;
     FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
@@ -114,8 +115,41 @@ int hd_job_finish(HostDec *d, int is_idr)
     h->n_coef_blocks = d->coef_blocks;
     h->lvl_off = fj_align32(h->coef_off + d->coef_blocks * 32u);
     h->idx_off = fj_align32(h->lvl_off + (n_levels + 1) * 4u);
-    h->total_bytes = fj_align32(h->idx_off + n_intra * 2u);
-    if (h->total_bytes > d->job_cap) return -1;
+    h->copy_off = fj_align32(h->idx_off + n_intra * 2u);
+    {
+        /* split the inter macroblocks: whole-sample uniform copies vs everything else */
+        const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(d->job + h->mv_off);
+        uint32_t n_copy = 0, n_gen = 0;
+        for (uint32_t a = 0; a < n; a++) {
+            if (recs[a].kind != FJ_MB_INTER) continue;
+            const int16_t *m0 = mvs[a][0];
+            int copy = recs[a].coded == 0 && ((m0[0] | m0[1]) & 7) == 0 &&
+                       recs[a].ref_slot[0] == recs[a].ref_slot[1] && recs[a].ref_slot[0] == recs[a].ref_slot[2] &&
+                       recs[a].ref_slot[0] == recs[a].ref_slot[3];
+            for (int k = 1; copy && k < 16; k++) copy = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
+            if (copy) n_copy++; else n_gen++;
+        }
+        h->n_copy = n_copy;
+        h->n_gen = n_gen;
+        h->gen_off = fj_align32(h->copy_off + n_copy * 8u);
+        h->total_bytes = fj_align32(h->gen_off + n_gen * 2u);
+        if (h->total_bytes > d->job_cap) return -1;
+        FjCopy *cp = (FjCopy *)(d->job + h->copy_off);
+        uint16_t *gi = (uint16_t *)(d->job + h->gen_off);
+        for (uint32_t a = 0; a < n; a++) {
+            if (recs[a].kind != FJ_MB_INTER) continue;
+            const int16_t *m0 = mvs[a][0];
+            int copy = recs[a].coded == 0 && ((m0[0] | m0[1]) & 7) == 0 &&
+                       recs[a].ref_slot[0] == recs[a].ref_slot[1] && recs[a].ref_slot[0] == recs[a].ref_slot[2] &&
+                       recs[a].ref_slot[0] == recs[a].ref_slot[3];
+            for (int k = 1; copy && k < 16; k++) copy = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
+            if (copy) {
+                cp->mb = (uint16_t)a; cp->slot = recs[a].ref_slot[0]; cp->reserved = 0;
+                cp->dx = (int16_t)(m0[0] >> 2); cp->dy = (int16_t)(m0[1] >> 2);
+                cp++;
+            } else *gi++ = (uint16_t)a;
+        }
+    }
     uint32_t *lvl_start = (uint32_t *)(d->job + h->lvl_off);
     uint16_t *idx = (uint16_t *)(d->job + h->idx_off);
     memset(lvl_start, 0, (n_levels + 1) * 4u);

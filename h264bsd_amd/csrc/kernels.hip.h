@@ -1,35 +1,63 @@
 /*
  * kernels.hip.h — hand-written gfx950 (CDNA4, wave64) kernels of the macroblock reconstruction path.
  *
- *   k_recon_inter : one wavefront per inter macroblock, all inter MBs of all pictures of a tick in ONE
- *                   launch.  6-tap luma / bilinear chroma motion compensation straight from the
- *                   reference frames (register windows, unaligned dword loads, clamp-to-edge slow
- *                   path), dequant + 4x4 inverse transform with quad-wide DPP/shuffle transposes,
- *                   residual add, packed u32 stores.       reference: src/h264bsd_reconstruct.c,
- *                   src/h264bsd_inter_prediction.c:361-482, src/h264bsd_transform.c, src/h264bsd_image.c:172
- *   k_recon_intra : one wavefront per intra macroblock of one dependency level (host-computed), the
- *                   16x16 block + its neighbour row/column staged in LDS; Intra4x4 runs its 16 blocks in
- *                   order inside the wave.                 reference: src/h264bsd_intra_prediction.c
- *   k_deblock     : one wavefront per macroblock of one anti-diagonal x+2y=d of the picture (the
- *                   in-loop filter's true dependency front), 20x20 luma + 2x(10x12) chroma tile in LDS,
- *                   lanes own rows for the vertical edges, then columns for the horizontal edges.
- *                                                          reference: src/h264bsd_deblocking.c:575-1745
+ *   k_copy        : inter macroblocks that are whole-sample copies without residual (host-built list,
+ *                   66 % of the inter MBs of the 1080p stream): 4 macroblocks per wavefront, 8 loads in
+ *                   flight per lane, nothing but data movement.
+ *                       reference: the P_Skip / integer-mv path of src/h264bsd_inter_prediction.c:361-482,
+ *                                  h264bsdFillBlock src/h264bsd_reconstruct.c:2244, src/h264bsd_image.c:81
+ *   k_recon_inter : every other inter macroblock, one wavefront each (4 per 256-thread workgroup),
+ *                   list-driven.  6-tap luma / bilinear chroma motion compensation straight from the
+ *                   reference frames (register windows, unaligned dword loads, clamp-to-edge slow path),
+ *                   dequant + 4x4 inverse transform with quad-wide shuffles, residual add, u32 stores.
+ *                       reference: src/h264bsd_reconstruct.c, src/h264bsd_inter_prediction.c:361-482,
+ *                                  src/h264bsd_transform.c, src/h264bsd_image.c:172
+ *   k_dbk         : boundary strengths + threshold indices of every macroblock (metadata only, two MBs
+ *                   per wavefront) -> 32-byte deblocking records + one "needs filtering" byte per MB.
+ *                       reference: src/h264bsd_deblocking.c:1187-1541
+ *   k_frame_tail  : ONE 1024-thread workgroup per picture (a picture never leaves its CU): first the
+ *                   intra macroblocks, dependency level by level, then the in-loop deblocking filter,
+ *                   anti-diagonal (x+2y=d) by anti-diagonal.  Waves of the workgroup take the MBs of a
+ *                   level/diagonal; the only synchronisation is __syncthreads() between levels — no
+ *                   kernel boundary, no inter-workgroup traffic.  Per-wave LDS tiles: 16x16 block +
+ *                   neighbour row/column for intra, 20x20 luma + 2x(10x12) chroma for deblocking.
+ *                       reference: src/h264bsd_intra_prediction.c, src/h264bsd_deblocking.c:575-1745
  *   k_convert     : YUV420 -> RGBA / BGRA / YCbCrA, 4 pixels per lane, 16-byte stores.
- *                                                          reference: src/h264bsd_decoder.c:1163-1370
+ *                       reference: src/h264bsd_decoder.c:1163-1370
  *   k_checksum    : position-weighted 64-bit checksum of a frame (on-device verification).
  *
  * Everything is integer arithmetic on u8 samples / i16 levels / i32 intermediates: there is no dense
- * contraction on this path, hence no MFMA.  All kernels are HBM/latency bound by design.
+ * contraction on this path, hence no MFMA.
  */
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "framejob.h"
 
+/* Per-picture launch descriptor, built on the host from the frame-job header (saves the kernels one
+ * dependent load: blob header -> section pointers). */
 struct FrameDesc {
-    const uint8_t *blob;
-    uint8_t *slot[FJ_MAX_SLOTS];
+    const FjMbRec  *recs;
+    const int16_t  *mvs;
+    const int16_t  *coefs;
+    const uint32_t *lvl;          /* lvl_start[n_levels+1] */
+    const uint16_t *idx;          /* intra MB addresses sorted by level */
+    const FjCopy   *copy;         /* whole-sample copy macroblocks */
+    const uint16_t *gen;          /* all other inter macroblocks */
+    uint8_t        *dbk;          /* per-stream scratch: n_mbs x 32-byte deblocking records, then n_mbs "any" bytes */
+    uint8_t        *cur;          /* slot that receives the picture */
+    uint32_t        n_mbs, n_levels, n_copy, n_gen;
+    uint16_t        wmb, hmb;
+    uint32_t        any_deblock;
+    uint8_t        *slot[FJ_MAX_SLOTS];
 };
+
+/* Deblocking record of one macroblock (32 bytes), written by the reconstruction of that MB:
+ *   bytes 0..15  boundary strengths, one nibble per (dir, edge e, segment k): n = 16*dir + 4*e + k
+ *   bytes 16..21 indexA, bytes 22..27 indexB for the classes luma{left,top,inner}, chroma{left,top,inner}
+ *   byte 28 FJ_DBK_* flags, byte 29 "any strength non-zero"
+ * followed (at dbk + 32*n_mbs) by one byte per MB: 1 = at least one non-zero strength.           */
+#define DBK_REC_BYTES 32
 
 namespace h264k {
 
@@ -272,20 +300,150 @@ __device__ __forceinline__ void chroma_pred2(const uint8_t *__restrict__ p, int 
     out[1] = (w00 * a[1] + w10 * a[2] + w01 * b[1] + w11 * b[2] + 32) >> 6;
 }
 
-__global__ __launch_bounds__(64) void k_recon_inter(const FrameDesc *__restrict__ frames)
+/* ------------------------------------------------------------------ deblocking records */
+__device__ __forceinline__ bool is_intra_kind(int k) { return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM; }
+
+__device__ __forceinline__ void wave_sync()
+{
+    /* LDS operations of one wavefront execute in issue order; only the compiler has to be told */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* Boundary strengths (8.7.2.1) + threshold indices from metadata only; one macroblock per 32 lanes.
+ * reference: GetBoundaryStrengths / GetLumaEdgeThresholds / GetChromaEdgeThresholds,
+ * src/h264bsd_deblocking.c:1187-1541 */
+__global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frames)
 {
     const FrameDesc &fd = frames[blockIdx.y];
-    const FjHeader *hdr = reinterpret_cast<const FjHeader *>(fd.blob);
-    const uint32_t mb = blockIdx.x;
-    if (mb >= hdr->n_mbs) return;
-    const FjMbRec rec = reinterpret_cast<const FjMbRec *>(fd.blob + hdr->rec_off)[mb];
-    if (rec.kind != FJ_MB_INTER) return;
-    const int lane = threadIdx.x;
-    const int wmb = hdr->width_mbs, W = wmb * 16, H = hdr->height_mbs * 16, CW = W >> 1, CH = H >> 1;
+    const uint32_t mb = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (mb >= fd.n_mbs) return;
+    const int n = threadIdx.x & 31;
+    const FjMbRec q = fd.recs[mb];
+    uint8_t *out = fd.dbk + (size_t)mb * DBK_REC_BYTES;
+    uint8_t *any_out = fd.dbk + (size_t)fd.n_mbs * DBK_REC_BYTES + mb;
+    if (!q.dbk || q.kind == FJ_MB_ABSENT) {
+        if (n == 0) { *reinterpret_cast<uint32_t *>(out + 28) = 0; *any_out = 0; }
+        return;
+    }
+    const int wmb = fd.wmb;
+    const bool f_left = q.dbk & FJ_DBK_LEFT, f_top = q.dbk & FJ_DBK_TOP;
+    const FjMbRec pl = fd.recs[f_left ? mb - 1 : mb], pt = fd.recs[f_top ? mb - wmb : mb];
+    int my_bs = 0;
+    {
+        const int dir = n >> 4, e = (n >> 2) & 3, k = n & 3;
+        const bool edge_on = e ? true : (dir ? f_top : f_left);
+        if (edge_on) {
+            const uint32_t pmb = e ? mb : (dir ? mb - wmb : mb - 1);
+            const int p_kind = e ? q.kind : (dir ? pt.kind : pl.kind);
+            const uint32_t p_coded = e ? q.coded : (dir ? pt.coded : pl.coded);
+            uint32_t qrefs, prefs, t0, t1;
+            __builtin_memcpy(&qrefs, q.ref_slot, 4);
+            __builtin_memcpy(&t0, pl.ref_slot, 4);
+            __builtin_memcpy(&t1, pt.ref_slot, 4);
+            prefs = e ? qrefs : (dir ? t1 : t0);
+            const int qx = dir ? k : e, qy = dir ? e : k;
+            const int px = dir ? k : (e ? e - 1 : 3), py = dir ? (e ? e - 1 : 3) : k;
+            if (is_intra_kind(q.kind) || is_intra_kind(p_kind)) my_bs = e ? 3 : 4;
+            else if (((q.coded >> z_of(qx, qy)) & 1) || ((p_coded >> z_of(px, py)) & 1)) my_bs = 2;
+            else if (((qrefs >> (8 * ((qy >> 1) * 2 + (qx >> 1)))) & 255u) != ((prefs >> (8 * ((py >> 1) * 2 + (px >> 1)))) & 255u)) my_bs = 1;
+            else {
+                const int16_t *a = fd.mvs + 32 * (size_t)mb + 2 * (4 * qy + qx), *b = fd.mvs + 32 * (size_t)pmb + 2 * (4 * py + px);
+                my_bs = (abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4) ? 1 : 0;
+            }
+        }
+    }
+    /* pack 32 nibbles: lanes n = 0,8,16,24 of the half-wave end up with one dword each */
+    uint32_t v = (uint32_t)my_bs;
+    v |= (uint32_t)__shfl_down((int)v, 1) << 4;
+    v |= (uint32_t)__shfl_down((int)v, 2) << 8;
+    v |= (uint32_t)__shfl_down((int)v, 4) << 16;
+    const unsigned long long bal = __ballot(my_bs != 0);
+    const bool any = ((threadIdx.x & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal) != 0u;
+    if ((n & 7) == 0) *reinterpret_cast<uint32_t *>(out + (n >> 3) * 4) = v;
+    if (n == 1) {
+        const int qcq = c_qpc[clip3(0, 51, (int)q.qp_y + q.cqp_off)];
+        const int ql = (q.qp_y + pl.qp_y + 1) >> 1, qt = (q.qp_y + pt.qp_y + 1) >> 1;
+        const int cl = (qcq + c_qpc[clip3(0, 51, (int)pl.qp_y + q.cqp_off)] + 1) >> 1;   /* current MB's offset: deblocking.c:1501,1523 */
+        const int ct = (qcq + c_qpc[clip3(0, 51, (int)pt.qp_y + q.cqp_off)] + 1) >> 1;
+        const int qp6[6] = { ql, qt, (int)q.qp_y, cl, ct, qcq };
+        uint32_t w[3] = { 0, 0, 0 };
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const uint32_t ia = (uint32_t)clip3(0, 51, qp6[i] + q.alpha_off), ib = (uint32_t)clip3(0, 51, qp6[i] + q.beta_off);
+            w[i >> 2] |= ia << (8 * (i & 3));                    /* bytes 16..21 */
+            w[(6 + i) >> 2] |= ib << (8 * ((6 + i) & 3));        /* bytes 22..27 */
+        }
+        *reinterpret_cast<uint32_t *>(out + 16) = w[0];
+        *reinterpret_cast<uint32_t *>(out + 20) = w[1];
+        *reinterpret_cast<uint32_t *>(out + 24) = w[2];
+        *reinterpret_cast<uint32_t *>(out + 28) = (uint32_t)q.dbk | (any ? 0x100u : 0u);
+        *any_out = any ? 1 : 0;
+    }
+}
+
+/* ------------------------------------------------------------------ whole-sample copy macroblocks */
+/* 4 list entries per wavefront, all loads issued before the first store.  Luma: lane = 4*row + word
+ * (16 rows x 16 bytes); chroma: lanes 0..31 = 16*plane + 2*row + word (2 planes x 8 rows x 8 bytes). */
+__global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ frames)
+{
+    const FrameDesc &fd = frames[blockIdx.y];
+    const uint32_t first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (first >= fd.n_copy) return;
+    const int lane = threadIdx.x & 63;
+    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
+    const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
+    const int lrow = lane >> 2, lcol = (lane & 3) * 4;
+    const int plane = (lane >> 4) & 1, crow = (lane >> 1) & 7, ccol = (lane & 1) * 4;
+    uint32_t vy[4], vc[4];
+    int mbx[4], mby[4];
+    bool on[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        on[j] = first + j < fd.n_copy;
+        const FjCopy e = fd.copy[on[j] ? first + j : first];
+        mbx[j] = e.mb % wmb; mby[j] = e.mb / wmb;
+        const uint8_t *ref = fd.slot[e.slot];
+        const int x = mbx[j] * 16 + e.dx, y = mby[j] * 16 + e.dy;
+        if (x >= 0 && x + 16 <= W && y >= 0 && y + 16 <= H) {
+            vy[j] = load_u32_unaligned(ref + (size_t)(y + lrow) * W + x + lcol);
+            vc[j] = load_u32_unaligned(ref + ysz + (plane ? csz : 0) + (size_t)((y >> 1) + crow) * CW + (x >> 1) + ccol);
+        } else {                                               /* clamp-to-edge, sample by sample */
+            const uint8_t *s = ref + (size_t)clip3(0, H - 1, y + lrow) * W;
+            const uint8_t *c = ref + ysz + (plane ? csz : 0) + (size_t)clip3(0, CH - 1, (y >> 1) + crow) * CW;
+            uint32_t a = 0, b = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                a |= (uint32_t)s[clip3(0, W - 1, x + lcol + i)] << (8 * i);
+                b |= (uint32_t)c[clip3(0, CW - 1, (x >> 1) + ccol + i)] << (8 * i);
+            }
+            vy[j] = a; vc[j] = b;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!on[j]) continue;
+        *reinterpret_cast<uint32_t *>(fd.cur + (size_t)(mby[j] * 16 + lrow) * W + mbx[j] * 16 + lcol) = vy[j];
+        if (lane < 32)
+            *reinterpret_cast<uint32_t *>(fd.cur + ysz + (plane ? csz : 0) + (size_t)(mby[j] * 8 + crow) * CW + mbx[j] * 8 + ccol) = vc[j];
+    }
+}
+
+/* ------------------------------------------------------------------ inter macroblocks */
+__global__ __launch_bounds__(256) void k_recon_inter(const FrameDesc *__restrict__ frames)
+{
+    const FrameDesc &fd = frames[blockIdx.y];
+    const uint32_t gi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gi >= fd.n_gen) return;
+    const uint32_t mb = fd.gen[gi];
+    const FjMbRec rec = fd.recs[mb];
+    const int lane = threadIdx.x & 63;
+    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mbx = mb % wmb, mby = mb / wmb;
-    const int16_t *mvs = reinterpret_cast<const int16_t *>(fd.blob + hdr->mv_off) + 32 * (size_t)mb;
-    const int16_t *coef = reinterpret_cast<const int16_t *>(fd.blob + hdr->coef_off) + 16 * (size_t)rec.coef_idx;
-    uint8_t *cur = fd.slot[hdr->cur_slot];
+    const int16_t *mvs = fd.mvs + 32 * (size_t)mb;
+    const int16_t *coef = fd.coefs + 16 * (size_t)rec.coef_idx;
+    uint8_t *cur = fd.cur;
     const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
 
     int ry[4], rc[4];
@@ -321,30 +479,21 @@ __global__ __launch_bounds__(64) void k_recon_inter(const FrameDesc *__restrict_
     }
 }
 
-/* ------------------------------------------------------------------ intra prediction */
+/* ------------------------------------------------------------------ intra macroblocks */
 /* Intra4x4 sample (x,y) of mode `mode`; T(k) k=-1..7 and L(k) k=-1..3 read the LDS tile */
 #define I4_T(k) ((int)tile[(by4) * TS + 1 + (bx4) + ((k) > 3 && !has_tr ? 3 : (k))])
 #define I4_L(k) ((int)tile[((by4) + 1 + (k)) * TS + (bx4)])
 
-__global__ __launch_bounds__(64) void k_recon_intra(const FrameDesc *__restrict__ frames, uint32_t level)
-{
-    constexpr int TS = 32;                              /* luma tile stride; row 0 = above, col 0 = left */
-    __shared__ __attribute__((aligned(16))) uint8_t tile[17 * TS];
-    __shared__ __attribute__((aligned(16))) uint8_t ctile[2][9 * 16];
+constexpr int TS = 32;                                  /* intra luma tile stride; row 0 = above, col 0 = left */
 
-    const FrameDesc &fd = frames[blockIdx.y];
-    const FjHeader *hdr = reinterpret_cast<const FjHeader *>(fd.blob);
-    if (level >= hdr->n_intra_levels) return;
-    const uint32_t *lvl = reinterpret_cast<const uint32_t *>(fd.blob + hdr->lvl_off);
-    const uint32_t first = lvl[level], count = lvl[level + 1] - first;
-    if (blockIdx.x >= count) return;
-    const uint32_t mb = reinterpret_cast<const uint16_t *>(fd.blob + hdr->idx_off)[first + blockIdx.x];
-    const FjMbRec rec = reinterpret_cast<const FjMbRec *>(fd.blob + hdr->rec_off)[mb];
-    const int lane = threadIdx.x;
-    const int wmb = hdr->width_mbs, W = wmb * 16, H = hdr->height_mbs * 16, CW = W >> 1, CH = H >> 1;
+/* one intra macroblock by one wavefront; tile = 17*TS bytes, ctile = 2 x 9*16 bytes (wave-private LDS) */
+__device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0)
+{
+    const FjMbRec rec = fd.recs[mb];
+    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mbx = mb % wmb, mby = mb / wmb;
-    const int16_t *coef = reinterpret_cast<const int16_t *>(fd.blob + hdr->coef_off) + 16 * (size_t)rec.coef_idx;
-    uint8_t *cur = fd.slot[hdr->cur_slot];
+    const int16_t *coef = fd.coefs + 16 * (size_t)rec.coef_idx;
+    uint8_t *cur = fd.cur;
     const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
     uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
@@ -377,13 +526,13 @@ __global__ __launch_bounds__(64) void k_recon_intra(const FrameDesc *__restrict_
         const int plane = lane / 9, c = lane % 9;
         const uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
         const bool ok = c == 0 ? av_d : av_b;
-        ctile[plane][c] = ok ? P[-(ptrdiff_t)CW + (c - 1)] : 128;
+        ctile0[plane * 144 + c] = ok ? P[-(ptrdiff_t)CW + (c - 1)] : 128;
     } else if (lane >= 32 && lane < 48) {
         const int plane = (lane - 32) >> 3, r = (lane - 32) & 7;
         const uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
-        ctile[plane][(r + 1) * 16] = av_a ? P[(size_t)r * CW - 1] : 128;
+        ctile0[plane * 144 + (r + 1) * 16] = av_a ? P[(size_t)r * CW - 1] : 128;
     }
-    __syncthreads();
+    wave_sync();
 
     if (rec.kind == FJ_MB_I16x16) {
         const int mode = rec.pred & 3;
@@ -405,7 +554,7 @@ __global__ __launch_bounds__(64) void k_recon_intra(const FrameDesc *__restrict_
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 Hh += (k + 1) * ((int)tile[1 + 8 + k] - (int)tile[1 + 6 - k]);
-                Vv += (k + 1) * ((int)tile[(1 + 8 + k) * TS] - (int)(k == 7 ? tile[0] : tile[(1 + 6 - k) * TS]));
+                Vv += (k + 1) * ((int)tile[(1 + 8 + k) * TS] - (int)tile[(1 + 6 - k) * TS]);
             }
             const int a = 16 * ((int)tile[16 * TS] + (int)tile[16]), b = (5 * Hh + 32) >> 6, c = (5 * Vv + 32) >> 6;
 #pragma unroll
@@ -478,13 +627,12 @@ __global__ __launch_bounds__(64) void k_recon_intra(const FrameDesc *__restrict_
                     }
                     pr[x] = clip255(v + ry[x]);
                 }
-                /* all four rows must have read their neighbours before anyone overwrites the tile:
-                 * the block's own samples are not inputs of its own prediction, so writing is safe */
+                /* the block's own samples are not inputs of its own prediction: writing is safe */
                 uint8_t *d = &tile[(by4 + 1 + y) * TS + 1 + bx4];
                 d[0] = (uint8_t)pr[0]; d[1] = (uint8_t)pr[1]; d[2] = (uint8_t)pr[2]; d[3] = (uint8_t)pr[3];
                 *reinterpret_cast<uint32_t *>(Y + (size_t)(by4 + y) * W + bx4) = pack4(pr[0], pr[1], pr[2], pr[3]);
             }
-            __syncthreads();
+            wave_sync();
         }
     }
 
@@ -492,7 +640,7 @@ __global__ __launch_bounds__(64) void k_recon_intra(const FrameDesc *__restrict_
     if (lane < 32) {
         const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
         const int y = cby * 4 + row, x0 = cbx * 4;
-        const uint8_t *t = ctile[plane];
+        const uint8_t *t = ctile0 + plane * 144;
         const int mode = (rec.pred >> 2) & 3;
         int pr[4];
         if (mode == 0) {
@@ -519,7 +667,7 @@ __global__ __launch_bounds__(64) void k_recon_intra(const FrameDesc *__restrict_
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 Hh += (i + 1) * ((int)t[1 + 4 + i] - (int)t[1 + 2 - i]);
-                Vv += (i + 1) * ((int)t[(1 + 4 + i) * 16] - (int)(i == 3 ? t[0] : t[(1 + 2 - i) * 16]));
+                Vv += (i + 1) * ((int)t[(1 + 4 + i) * 16] - (int)t[(1 + 2 - i) * 16]);
             }
             const int a = 16 * ((int)t[8 * 16] + (int)t[8]), b = (34 * Hh + 32) >> 6, c = (34 * Vv + 32) >> 6;
 #pragma unroll
@@ -528,244 +676,392 @@ __global__ __launch_bounds__(64) void k_recon_intra(const FrameDesc *__restrict_
         *reinterpret_cast<uint32_t *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + y) * CW + mbx * 8 + x0) =
             pack4(clip255(pr[0] + rc[0]), clip255(pr[1] + rc[1]), clip255(pr[2] + rc[2]), clip255(pr[3] + rc[3]));
     }
+    wave_sync();          /* the tiles are reused by this wave's next macroblock */
 }
 #undef I4_T
 #undef I4_L
 
 /* ------------------------------------------------------------------ deblocking */
-__device__ __forceinline__ bool is_intra_kind(int k) { return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM; }
-
-/* v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 */
+/* Edge filters, branch-free (every lane computes both the bS<4 and the bS=4 result and selects): the
+ * caller skips whole edges whose strengths are zero in every lane of the wavefront.
+ * v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3   (8.7.2.3 / 8.7.2.4) */
 __device__ __forceinline__ void filter_luma8(int v[8], int bs, int alpha, int beta, int tc0)
 {
-    const int p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6];
-    if (bs == 0 || !(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
+    const int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
+    const bool fs = bs != 0 && abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta;
     const bool ap = abs(p2 - p0) < beta, aq = abs(q2 - q0) < beta;
-    if (bs < 4) {
-        const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
-        const int d = clip3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
-        if (ap) v[2] = p1 + clip3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - 2 * p1) >> 1);
-        if (aq) v[5] = q1 + clip3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - 2 * q1) >> 1);
-        v[3] = clip255(p0 + d);
-        v[4] = clip255(q0 - d);
-    } else {
-        const int p3 = v[0], q3 = v[7];
-        const bool strong = abs(p0 - q0) < ((alpha >> 2) + 2);
-        if (strong && ap) {
-            v[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
-            v[2] = (p2 + p1 + p0 + q0 + 2) >> 2;
-            v[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-        } else v[3] = (2 * p1 + p0 + q1 + 2) >> 2;
-        if (strong && aq) {
-            v[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
-            v[5] = (p0 + q0 + q1 + q2 + 2) >> 2;
-            v[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-        } else v[4] = (2 * q1 + q0 + p1 + 2) >> 2;
-    }
+    const bool strong = bs == 4;
+    /* bS < 4 */
+    const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+    const int d = clip3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
+    const int avg = (p0 + q0 + 1) >> 1;
+    const int n_p0 = clip255(p0 + d), n_q0 = clip255(q0 - d);
+    const int n_p1 = p1 + clip3(-tc0, tc0, (p2 + avg - 2 * p1) >> 1);
+    const int n_q1 = q1 + clip3(-tc0, tc0, (q2 + avg - 2 * q1) >> 1);
+    /* bS == 4 */
+    const bool sm = abs(p0 - q0) < ((alpha >> 2) + 2);
+    const bool sp = sm && ap, sq = sm && aq;
+    const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
+    const int s_p1 = (p2 + p1 + p0 + q0 + 2) >> 2;
+    const int s_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+    const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
+    const int s_q1 = (p0 + q0 + q1 + q2 + 2) >> 2;
+    const int s_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+    v[3] = fs ? (strong ? s_p0 : n_p0) : p0;
+    v[4] = fs ? (strong ? s_q0 : n_q0) : q0;
+    v[2] = fs && (strong ? sp : ap) ? (strong ? s_p1 : n_p1) : p1;
+    v[5] = fs && (strong ? sq : aq) ? (strong ? s_q1 : n_q1) : q1;
+    v[1] = fs && strong && sp ? s_p2 : p2;
+    v[6] = fs && strong && sq ? s_q2 : q2;
 }
 /* v[0..3] = p1 p0 q0 q1 */
 __device__ __forceinline__ void filter_chroma4(int v[4], int bs, int alpha, int beta, int tc0)
 {
     const int p1 = v[0], p0 = v[1], q0 = v[2], q1 = v[3];
-    if (bs == 0 || !(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
-    if (bs < 4) {
-        const int tc = tc0 + 1;
-        const int d = clip3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
-        v[1] = clip255(p0 + d);
-        v[2] = clip255(q0 - d);
-    } else {
-        v[1] = (2 * p1 + p0 + q1 + 2) >> 2;
-        v[2] = (2 * q1 + q0 + p1 + 2) >> 2;
-    }
+    const bool fs = bs != 0 && abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta;
+    const int tc = tc0 + 1;
+    const int d = clip3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
+    const int n_p0 = bs == 4 ? (2 * p1 + p0 + q1 + 2) >> 2 : clip255(p0 + d);
+    const int n_q0 = bs == 4 ? (2 * q1 + q0 + p1 + 2) >> 2 : clip255(q0 - d);
+    v[1] = fs ? n_p0 : p0;
+    v[2] = fs ? n_q0 : q0;
 }
 
 struct EdgeThr { int alpha, beta, ia; };
-__device__ __forceinline__ EdgeThr edge_thr(int qp_av, int aoff, int boff)
+__device__ __forceinline__ EdgeThr thr_of(uint32_t ia, uint32_t ib)
 {
     EdgeThr t;
-    t.ia = clip3(0, 51, qp_av + aoff);
-    t.alpha = c_alpha[t.ia];
-    t.beta = c_beta[clip3(0, 51, qp_av + boff)];
+    t.ia = (int)ia; t.alpha = c_alpha[ia]; t.beta = c_beta[ib];
     return t;
 }
 
-__global__ __launch_bounds__(64) void k_deblock(const FrameDesc *__restrict__ frames, int diag)
+constexpr int LS = 32;                               /* deblock luma tile: 20 rows x 20 cols, stride 32 */
+constexpr int CS = 16;                               /* deblock chroma tiles: 10 rows x 12 cols, stride 16 */
+constexpr int WORKER_LDS = 1024;                     /* LDS per deblocking worker (= half a wavefront)   */
+
+/* Everything a worker can fetch about a macroblock BEFORE its neighbours are final: the deblocking
+ * record and the macroblock's own (still un-filtered) samples.  Issued one diagonal ahead. */
+struct DbkPrefetch { uint32_t y0, y1, c, bsb; uint4 thr; };
+
+__device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int hl, DbkPrefetch &p)
 {
-    constexpr int LS = 32;                               /* luma tile: 20 rows x 20 cols, stride 32 */
-    constexpr int CS = 16;                               /* chroma tiles: 10 rows x 12 cols, stride 16 */
-    __shared__ __attribute__((aligned(16))) uint8_t lt[20 * LS];
-    __shared__ __attribute__((aligned(16))) uint8_t ct[2][10 * CS];
-    __shared__ uint8_t bs_s[2][4][4];
+    if (mb < 0) return;
+    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
+    const int mbx = mb % wmb, mby = mb / wmb;
+    const uint8_t *Y = fd.cur + (size_t)(mby * 16) * W + mbx * 16;
+    const int row = hl >> 2, cw = hl & 3;
+    p.y0 = *reinterpret_cast<const uint32_t *>(Y + (size_t)row * W + 4 * cw);
+    p.y1 = *reinterpret_cast<const uint32_t *>(Y + (size_t)(row + 8) * W + 4 * cw);
+    const int plane = hl >> 4, r = (hl >> 1) & 7, ccw = hl & 1;
+    const uint8_t *P = fd.cur + (size_t)W * H + (plane ? (size_t)CW * CH : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+    p.c = *reinterpret_cast<const uint32_t *>(P + (size_t)r * CW + 4 * ccw);
+    const uint8_t *rec = fd.dbk + (size_t)mb * DBK_REC_BYTES;
+    p.bsb = rec[hl >> 1];
+    p.thr = *reinterpret_cast<const uint4 *>(rec + 16);
+}
 
-    const FrameDesc &fd = frames[blockIdx.y];
-    const FjHeader *hdr = reinterpret_cast<const FjHeader *>(fd.blob);
-    if (!hdr->any_deblock) return;
-    const int wmb = hdr->width_mbs, hmb = hdr->height_mbs;
-    /* macroblocks with x + 2y == diag */
-    const int ylo = max(0, (diag - (wmb - 1) + 1) >> 1), yhi = min(hmb - 1, diag >> 1);
-    const int mby = ylo + (int)blockIdx.x;
-    if (mby > yhi) return;
-    const int mbx = diag - 2 * mby;
-    if (mbx < 0 || mbx >= wmb) return;
-    const uint32_t mb = (uint32_t)(mby * wmb + mbx);
-    const FjMbRec *recs = reinterpret_cast<const FjMbRec *>(fd.blob + hdr->rec_off);
-    const FjMbRec q = recs[mb];
-    if (q.kind == FJ_MB_ABSENT || !q.dbk) return;
-    const int lane = threadIdx.x;
-    const bool f_left = q.dbk & FJ_DBK_LEFT, f_top = q.dbk & FJ_DBK_TOP;
-    const int16_t *mvbase = reinterpret_cast<const int16_t *>(fd.blob + hdr->mv_off);
-
-    /* boundary strengths: lanes 0..31, lane = 16*dir + 4*e + k */
-    int my_bs = 0;
-    if (lane < 32) {
-        const int dir = lane >> 4, e = (lane >> 2) & 3, k = lane & 3;
-        const bool edge_on = e ? true : (dir ? f_top : f_left);
-        if (edge_on) {
-            const uint32_t pmb = e ? mb : (dir ? mb - wmb : mb - 1);
-            const FjMbRec p = recs[pmb];
-            uint32_t qrefs, prefs;
-            __builtin_memcpy(&qrefs, q.ref_slot, 4);
-            __builtin_memcpy(&prefs, p.ref_slot, 4);
-            const int qx = dir ? k : e, qy = dir ? e : k;
-            const int px = dir ? k : (e ? e - 1 : 3), py = dir ? (e ? e - 1 : 3) : k;
-            if (is_intra_kind(q.kind) || is_intra_kind(p.kind)) my_bs = e ? 3 : 4;
-            else if (((q.coded >> z_of(qx, qy)) & 1) || ((p.coded >> z_of(px, py)) & 1)) my_bs = 2;
-            else if (((qrefs >> (8 * ((qy >> 1) * 2 + (qx >> 1)))) & 255u) != ((prefs >> (8 * ((py >> 1) * 2 + (px >> 1)))) & 255u)) my_bs = 1;
-            else {
-                const int16_t *a = mvbase + 32 * (size_t)mb + 2 * (4 * qy + qx), *b = mvbase + 32 * (size_t)pmb + 2 * (4 * py + px);
-                my_bs = (abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4) ? 1 : 0;
-            }
-        }
-        bs_s[dir][e][k] = (uint8_t)my_bs;
-    }
-    if (!__any(my_bs != 0)) return;                      /* nothing to filter in this macroblock */
-
-    const int W = wmb * 16, H = hmb * 16, CW = W >> 1, CH = H >> 1;
-    uint8_t *cur = fd.slot[hdr->cur_slot];
+/* In-loop filter of one macroblock by one worker = 32 lanes (hl = lane & 31): vertical edges, then
+ * horizontal edges (8.7).  mb < 0: this half of the wavefront idles.  w = worker-private LDS. */
+__device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, const DbkPrefetch &p, uint8_t *w,
+                                           int nxt, DbkPrefetch &nxt_pf)
+{
+    uint8_t *lt = w, *ct0 = w + 20 * LS, *bs_s = w + 20 * LS + 2 * 10 * CS;
+    const bool act = mb >= 0;
+    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
+    const int mbx = act ? mb % wmb : 0, mby = act ? mb / wmb : 0;
+    uint8_t *cur = fd.cur;
     const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
     uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
+    uint8_t *PC = cur + ysz + (size_t)(mby * 8) * CW + mbx * 8;
+    const bool f_left = p.thr.w & FJ_DBK_LEFT, f_top = p.thr.w & FJ_DBK_TOP;
 
-    /* ---- load tiles (u32 granules; neighbours only where they exist) ---- */
-    for (int wd = lane; wd < 100; wd += 64) {
-        const int r = wd / 5, cw = wd % 5;
-        if ((r >= 4 || mby > 0) && (cw >= 1 || mbx > 0))
-            *reinterpret_cast<uint32_t *>(&lt[r * LS + 4 * cw]) =
-                *reinterpret_cast<const uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * (cw - 1));
+    /* neighbour strips (the only samples that depend on the previous diagonals): 56 words, issued
+     * first; then the NEXT diagonal's prefetch goes out behind them so that it flies during the filter */
+    uint32_t strip[2] = { 0, 0 };
+    if (act) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int s = hl + 32 * it;
+            if (s < 16) {
+                if (mbx > 0) strip[it] = *reinterpret_cast<const uint32_t *>(Y + (size_t)s * W - 4);
+            } else if (s < 32) {
+                const int r = (s - 16) >> 2, cw = (s - 16) & 3;
+                if (mby > 0) strip[it] = *reinterpret_cast<const uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * cw);
+            } else if (s < 48) {
+                const int plane = (s - 32) >> 3, r = (s - 32) & 7;
+                if (mbx > 0) strip[it] = *reinterpret_cast<const uint32_t *>(PC + (plane ? csz : 0) + (size_t)r * CW - 4);
+            } else if (s < 56) {
+                const int plane = (s - 48) >> 2, r = ((s - 48) >> 1) & 1, cw = (s - 48) & 1;
+                if (mby > 0) strip[it] = *reinterpret_cast<const uint32_t *>(PC + (plane ? csz : 0) + (ptrdiff_t)(r - 2) * CW + 4 * cw);
+            }
+        }
     }
-    if (lane < 60) {
-        const int plane = lane / 30, wd = lane % 30, r = wd / 3, cw = wd % 3;
-        const uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
-        if ((r >= 2 || mby > 0) && (cw >= 1 || mbx > 0))
-            *reinterpret_cast<uint32_t *>(&ct[plane][r * CS + 4 * cw]) =
-                *reinterpret_cast<const uint32_t *>(P + (ptrdiff_t)(r - 2) * CW + 4 * (cw - 1));
+    dbk_prefetch(fd, nxt, hl, nxt_pf);
+    if (act) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int s = hl + 32 * it;
+            if (s < 16) *reinterpret_cast<uint32_t *>(&lt[(4 + s) * LS]) = strip[it];
+            else if (s < 32) *reinterpret_cast<uint32_t *>(&lt[((s - 16) >> 2) * LS + 4 + 4 * ((s - 16) & 3)]) = strip[it];
+            else if (s < 48) *reinterpret_cast<uint32_t *>(&ct0[((s - 32) >> 3) * 10 * CS + (2 + ((s - 32) & 7)) * CS]) = strip[it];
+            else if (s < 56) *reinterpret_cast<uint32_t *>(&ct0[((s - 48) >> 2) * 10 * CS + (((s - 48) >> 1) & 1) * CS + 4 + 4 * ((s - 48) & 1)]) = strip[it];
+        }
+        /* own samples (prefetched) and boundary strengths */
+        {
+            const int row = hl >> 2, cw = hl & 3;
+            *reinterpret_cast<uint32_t *>(&lt[(4 + row) * LS + 4 + 4 * cw]) = p.y0;
+            *reinterpret_cast<uint32_t *>(&lt[(12 + row) * LS + 4 + 4 * cw]) = p.y1;
+            const int plane = hl >> 4, r = (hl >> 1) & 7, ccw = hl & 1;
+            *reinterpret_cast<uint32_t *>(&ct0[plane * 10 * CS + (2 + r) * CS + 4 + 4 * ccw]) = p.c;
+            bs_s[hl] = (uint8_t)((p.bsb >> (4 * (hl & 1))) & 15u);
+        }
     }
-
-    /* ---- thresholds (wave-uniform) ---- */
-    const int qcq = c_qpc[clip3(0, 51, (int)q.qp_y + q.cqp_off)];
-    int qp_l = q.qp_y, qp_t = q.qp_y, qc_l = qcq, qc_t = qcq;
-    if (f_left) { const int pq = recs[mb - 1].qp_y; qp_l = (q.qp_y + pq + 1) >> 1; qc_l = (qcq + c_qpc[clip3(0, 51, pq + q.cqp_off)] + 1) >> 1; }
-    if (f_top) { const int pq = recs[mb - wmb].qp_y; qp_t = (q.qp_y + pq + 1) >> 1; qc_t = (qcq + c_qpc[clip3(0, 51, pq + q.cqp_off)] + 1) >> 1; }
-    const EdgeThr tl_in = edge_thr(q.qp_y, q.alpha_off, q.beta_off), tc_in = edge_thr(qcq, q.alpha_off, q.beta_off);
-    const EdgeThr tl_l = edge_thr(qp_l, q.alpha_off, q.beta_off), tc_l = edge_thr(qc_l, q.alpha_off, q.beta_off);
-    const EdgeThr tl_t = edge_thr(qp_t, q.alpha_off, q.beta_off), tc_t = edge_thr(qc_t, q.alpha_off, q.beta_off);
-    __syncthreads();
+    /* thresholds: classes luma left/top/inner = 0,1,2 ; chroma left/top/inner = 3,4,5 */
+    const uint4 r1 = p.thr;
+    const bool chroma = hl >= 16;
+    const uint32_t ia_in = chroma ? (r1.y >> 8) & 255u : (r1.x >> 16) & 255u, ib_in = chroma ? (r1.z >> 24) & 255u : r1.z & 255u;
+    const uint32_t ia_l = chroma ? (r1.x >> 24) & 255u : r1.x & 255u, ib_l = chroma ? (r1.z >> 8) & 255u : (r1.y >> 16) & 255u;
+    const uint32_t ia_t = chroma ? r1.y & 255u : (r1.x >> 8) & 255u, ib_t = chroma ? (r1.z >> 16) & 255u : (r1.y >> 24) & 255u;
+    const int al_in = c_alpha[ia_in & 63u], be_in = c_beta[ib_in & 63u];
+    const int al_l = c_alpha[ia_l & 63u], be_l = c_beta[ib_l & 63u];
+    const int al_t = c_alpha[ia_t & 63u], be_t = c_beta[ib_t & 63u];
+    wave_sync();
 
     /* ---- vertical edges: a lane owns one sample row across all four edges ---- */
-    if (lane < 16) {
-        uint8_t *rowp = &lt[(4 + lane) * LS];
-        int px[20];
+    if (act) {
+        if (hl < 16) {
+            uint8_t *rowp = &lt[(4 + hl) * LS];
+            int px[20];
 #pragma unroll
-        for (int w4 = 0; w4 < 5; w4++) {
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(rowp + 4 * w4);
-            px[4 * w4] = v & 255; px[4 * w4 + 1] = (v >> 8) & 255; px[4 * w4 + 2] = (v >> 16) & 255; px[4 * w4 + 3] = v >> 24;
+            for (int w4 = 0; w4 < 5; w4++) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(rowp + 4 * w4);
+                px[4 * w4] = v & 255; px[4 * w4 + 1] = (v >> 8) & 255; px[4 * w4 + 2] = (v >> 16) & 255; px[4 * w4 + 3] = v >> 24;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int bs = bs_s[4 * e + (hl >> 2)];
+                const uint32_t ia = e ? ia_in : ia_l;
+                if (__ballot(bs != 0)) filter_luma8(px + 4 * e, bs, e ? al_in : al_l, e ? be_in : be_l, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0);
+            }
+#pragma unroll
+            for (int w4 = 0; w4 < 5; w4++)
+                *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = pack4(px[4 * w4], px[4 * w4 + 1], px[4 * w4 + 2], px[4 * w4 + 3]);
+        } else {
+            const int plane = (hl - 16) >> 3, r = (hl - 16) & 7;
+            uint8_t *rowp = &ct0[plane * 10 * CS + (2 + r) * CS];
+            int px[12];
+#pragma unroll
+            for (int w4 = 0; w4 < 3; w4++) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(rowp + 4 * w4);
+                px[4 * w4] = v & 255; px[4 * w4 + 1] = (v >> 8) & 255; px[4 * w4 + 2] = (v >> 16) & 255; px[4 * w4 + 3] = v >> 24;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const int bs = bs_s[4 * e + (r >> 1)];
+                const uint32_t ia = e ? ia_in : ia_l;
+                if (__ballot(bs != 0)) filter_chroma4(px + 2 + 2 * e, bs, e ? al_in : al_l, e ? be_in : be_l, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0);
+            }
+#pragma unroll
+            for (int w4 = 0; w4 < 3; w4++)
+                *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = pack4(px[4 * w4], px[4 * w4 + 1], px[4 * w4 + 2], px[4 * w4 + 3]);
         }
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int bs = bs_s[0][e][lane >> 2];
-            const EdgeThr t = e ? tl_in : tl_l;
-            filter_luma8(px + 4 * e, bs, t.alpha, t.beta, bs > 0 && bs < 4 ? c_tc0[t.ia][bs - 1] : 0);
-        }
-#pragma unroll
-        for (int w4 = 0; w4 < 5; w4++)
-            *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = pack4(px[4 * w4], px[4 * w4 + 1], px[4 * w4 + 2], px[4 * w4 + 3]);
-    } else if (lane < 32) {
-        const int plane = (lane - 16) >> 3, r = (lane - 16) & 7;
-        uint8_t *rowp = &ct[plane][(2 + r) * CS];
-        int px[12];
-#pragma unroll
-        for (int w4 = 0; w4 < 3; w4++) {
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(rowp + 4 * w4);
-            px[4 * w4] = v & 255; px[4 * w4 + 1] = (v >> 8) & 255; px[4 * w4 + 2] = (v >> 16) & 255; px[4 * w4 + 3] = v >> 24;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-            const int bs = bs_s[0][e][r >> 1];
-            const EdgeThr t = e ? tc_in : tc_l;
-            filter_chroma4(px + 2 + 2 * e, bs, t.alpha, t.beta, bs > 0 && bs < 4 ? c_tc0[t.ia][bs - 1] : 0);
-        }
-#pragma unroll
-        for (int w4 = 0; w4 < 3; w4++)
-            *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = pack4(px[4 * w4], px[4 * w4 + 1], px[4 * w4 + 2], px[4 * w4 + 3]);
     }
-    __syncthreads();
+    wave_sync();
 
     /* ---- horizontal edges: a lane owns one sample column ---- */
-    if (lane < 16) {
-        uint8_t *colp = &lt[4 + lane];
-        int px[20];
+    if (act) {
+        if (hl < 16) {
+            uint8_t *colp = &lt[4 + hl];
+            int px[20];
 #pragma unroll
-        for (int r = 0; r < 20; r++) px[r] = colp[r * LS];
+            for (int r = 0; r < 20; r++) px[r] = colp[r * LS];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int bs = bs_s[1][e][lane >> 2];
-            const EdgeThr t = e ? tl_in : tl_t;
-            filter_luma8(px + 4 * e, bs, t.alpha, t.beta, bs > 0 && bs < 4 ? c_tc0[t.ia][bs - 1] : 0);
+            for (int e = 0; e < 4; e++) {
+                const int bs = bs_s[16 + 4 * e + (hl >> 2)];
+                const uint32_t ia = e ? ia_in : ia_t;
+                if (__ballot(bs != 0)) filter_luma8(px + 4 * e, bs, e ? al_in : al_t, e ? be_in : be_t, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0);
+            }
+#pragma unroll
+            for (int r = 1; r < 20; r++) colp[r * LS] = (uint8_t)px[r];
+        } else {
+            const int plane = (hl - 16) >> 3, c = (hl - 16) & 7;
+            uint8_t *colp = &ct0[plane * 10 * CS + 4 + c];
+            int px[10];
+#pragma unroll
+            for (int r = 0; r < 10; r++) px[r] = colp[r * CS];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const int bs = bs_s[16 + 4 * e + (c >> 1)];
+                const uint32_t ia = e ? ia_in : ia_t;
+                if (__ballot(bs != 0)) filter_chroma4(px + 2 * e, bs, e ? al_in : al_t, e ? be_in : be_t, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0);
+            }
+#pragma unroll
+            for (int r = 1; r < 10; r++) colp[r * CS] = (uint8_t)px[r];
         }
-#pragma unroll
-        for (int r = 1; r < 20; r++) colp[r * LS] = (uint8_t)px[r];
-    } else if (lane < 32) {
-        const int plane = (lane - 16) >> 3, c = (lane - 16) & 7;
-        uint8_t *colp = &ct[plane][4 + c];
-        int px[10];
-#pragma unroll
-        for (int r = 0; r < 10; r++) px[r] = colp[r * CS];
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-            const int bs = bs_s[1][e][c >> 1];
-            const EdgeThr t = e ? tc_in : tc_t;
-            filter_chroma4(px + 2 * e, bs, t.alpha, t.beta, bs > 0 && bs < 4 ? c_tc0[t.ia][bs - 1] : 0);
-        }
-#pragma unroll
-        for (int r = 1; r < 10; r++) colp[r * CS] = (uint8_t)px[r];
     }
-    __syncthreads();
+    wave_sync();
 
     /* ---- store: own macroblock, the 3 (1) columns of the left and rows of the upper neighbour ---- */
+    if (act) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int r = (hl >> 2) + 8 * it, cw = hl & 3;       /* 16 rows x 4 words */
+            *reinterpret_cast<uint32_t *>(Y + (size_t)r * W + 4 * cw) = *reinterpret_cast<const uint32_t *>(&lt[(4 + r) * LS + 4 + 4 * cw]);
+        }
+        {
+            const int plane = hl >> 4, r = (hl >> 1) & 7, cw = hl & 1;
+            *reinterpret_cast<uint32_t *>(PC + (plane ? csz : 0) + (size_t)r * CW + 4 * cw) =
+                *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + (2 + r) * CS + 4 + 4 * cw]);
+        }
+        if (f_left) {
+            if (hl < 16) *reinterpret_cast<uint32_t *>(Y + (size_t)hl * W - 4) = *reinterpret_cast<const uint32_t *>(&lt[(4 + hl) * LS]);
+            else {
+                const int plane = (hl - 16) >> 3, r = (hl - 16) & 7;
+                *reinterpret_cast<uint32_t *>(PC + (plane ? csz : 0) + (size_t)r * CW - 4) = *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + (2 + r) * CS]);
+            }
+        }
+        if (f_top) {
+            if (hl < 12) {
+                const int r = 1 + hl / 4, cw = hl % 4;               /* tile rows 1..3 */
+                *reinterpret_cast<uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * cw) = *reinterpret_cast<const uint32_t *>(&lt[r * LS + 4 + 4 * cw]);
+            } else if (hl >= 16 && hl < 20) {
+                const int i = hl - 16, plane = i >> 1, cw = i & 1;
+                *reinterpret_cast<uint32_t *>(PC + (plane ? csz : 0) - (ptrdiff_t)CW + 4 * cw) = *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + 1 * CS + 4 + 4 * cw]);
+            }
+        }
+    }
+    wave_sync();          /* tiles are reused by this worker's next macroblock */
+}
+
+/* ------------------------------------------------------------------ per-picture persistent kernels */
+/* ONE 1024-thread workgroup per picture (a picture never leaves its CU); the waves of the workgroup take
+ * the macroblocks of a dependency level, __syncthreads() separates levels: no kernel boundary and no
+ * inter-workgroup traffic inside a picture.  Occupancy comes from batching streams (256 pictures = one
+ * workgroup per CU). */
+constexpr int TAIL_WAVES = 16;
+constexpr int TAIL_WORKERS = 2 * TAIL_WAVES;
+
+/* intra macroblocks, level by level (levels computed by the host parser, hd_core.c) */
+__global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[TAIL_WAVES * 1024];
+    const FrameDesc &fd = frames[blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t *my = lds + wave * 1024;
+    for (uint32_t l = 0; l < fd.n_levels; l++) {
+        const uint32_t first = fd.lvl[l], count = fd.lvl[l + 1] - first;
+        for (uint32_t i = wave; i < count; i += TAIL_WAVES)
+            intra_mb(fd, fd.idx[first + i], lane, my, my + 17 * TS);
+        __syncthreads();
+    }
+}
+
+/* In-loop deblocking of one picture.  The filter of macroblock (x,y) touches its own samples, the last
+ * 4 columns of (x-1,y) and the last 4 rows of (x,y-1); in the standard's raster order that makes it
+ * depend on exactly three earlier steps: (x-1,y), (x,y-1) and (x+1,y-1) — and only if those macroblocks
+ * are filtered at all (most P-picture macroblocks have all-zero strengths and are never touched).  So:
+ *   1. level[mb] = 1 + max(level of the filtered ones among those three), by a sweep over anti-diagonals;
+ *   2. counting sort of the filtered macroblocks by level (LDS);
+ *   3. level by level, 32 workers (half wavefronts) filter one macroblock each; the next level's
+ *      macroblock (record + own samples) is prefetched while the current one is filtered.
+ * Dynamic LDS: 32 x WORKER_LDS tiles | any[n_mbs] u8 | level[n_mbs] u16 | order[n_mbs] u16 |
+ *              start[NL+2] u32 | cursor[NL+2] u32,  NL = wmb + 2*hmb. */
+__global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const FrameDesc &fd = frames[blockIdx.x];
+    if (!fd.any_deblock) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, hl = lane & 31;
+    const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs, NL = wmb + 2 * hmb;
+    uint8_t *anyf = lds + TAIL_WORKERS * WORKER_LDS;
+    uint16_t *lvl = reinterpret_cast<uint16_t *>(anyf + ((n_mbs + 15) & ~15));
+    uint16_t *order = lvl + ((n_mbs + 7) & ~7);
+    uint32_t *start = reinterpret_cast<uint32_t *>(order + ((n_mbs + 7) & ~7));
+    uint32_t *cursor = start + NL + 2;
+    uint8_t *wlds = lds + (wave * 2 + half) * WORKER_LDS;
+
+    unsigned long long t_acc[4] = { 0, 0, 0, 0 };
+    const bool profiling = prof != nullptr && blockIdx.x == 0;
+#define TICK() (profiling ? __builtin_readcyclecounter() : 0ull)
+    const unsigned long long tA = TICK();
     {
-        const int r = lane >> 2, cw = lane & 3;              /* 16 rows x 4 words */
-        *reinterpret_cast<uint32_t *>(Y + (size_t)r * W + 4 * cw) = *reinterpret_cast<const uint32_t *>(&lt[(4 + r) * LS + 4 + 4 * cw]);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(fd.dbk + (size_t)n_mbs * DBK_REC_BYTES);
+        for (int i = tid; i < (n_mbs + 3) / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(anyf)[i] = src[i];
+        for (int i = tid; i < NL + 2; i += blockDim.x) { start[i] = 0; cursor[i] = 0; }
     }
-    if (lane < 16 && f_left)
-        *reinterpret_cast<uint32_t *>(Y + (size_t)lane * W - 4) = *reinterpret_cast<const uint32_t *>(&lt[(4 + lane) * LS]);
-    if (lane >= 16 && lane < 28 && f_top) {
-        const int i = lane - 16, r = 1 + i / 4, cw = i % 4;  /* tile rows 1..3 */
-        *reinterpret_cast<uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * cw) = *reinterpret_cast<const uint32_t *>(&lt[r * LS + 4 + 4 * cw]);
+    __syncthreads();
+    /* 1. dependency levels, anti-diagonal sweep (every dependency lies on an earlier diagonal) */
+    const int D = (wmb - 1) + 2 * (hmb - 1);
+    for (int d = 0; d <= D; d++) {
+        const int ylo = max(0, (d - (wmb - 1) + 1) >> 1), yhi = min(hmb - 1, d >> 1);
+        const int y = ylo + tid;
+        if (y <= yhi) {
+            const int x = d - 2 * y, mb = y * wmb + x;
+            int l = 0;
+            if (anyf[mb]) {
+                if (x > 0) l = max(l, (int)lvl[mb - 1]);
+                if (y > 0) l = max(l, (int)lvl[mb - wmb]);
+                if (y > 0 && x + 1 < wmb) l = max(l, (int)lvl[mb - wmb + 1]);
+                l += 1;
+                atomicAdd(&start[l + 1], 1u);            /* histogram, shifted by one for the prefix sum */
+            }
+            lvl[mb] = (uint16_t)l;
+        }
+        __syncthreads();
     }
-    if (lane >= 32) {
-        const int i = lane - 32, plane = i >> 4, r = (i >> 1) & 7, cw = i & 1;
-        uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
-        *reinterpret_cast<uint32_t *>(P + (size_t)r * CW + 4 * cw) = *reinterpret_cast<const uint32_t *>(&ct[plane][(2 + r) * CS + 4 + 4 * cw]);
+    /* 2. prefix sum (levels 1..NL) and fill */
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int l = 1; l <= NL + 1; l++) { acc += start[l]; start[l] = acc; }   /* start[l] = first index of level l+... see below */
     }
-    if (lane < 16 && f_left) {
-        const int plane = lane >> 3, r = lane & 7;
-        uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
-        *reinterpret_cast<uint32_t *>(P + (size_t)r * CW - 4) = *reinterpret_cast<const uint32_t *>(&ct[plane][(2 + r) * CS]);
+    __syncthreads();
+    /* after the scan start[l] = number of macroblocks with level < l  (start[1] = 0): level l occupies
+     * [start[l], start[l+1]) */
+    for (int mb = tid; mb < n_mbs; mb += blockDim.x) {
+        const int l = lvl[mb];
+        if (l) order[start[l] + atomicAdd(&cursor[l], 1u)] = (uint16_t)mb;
     }
-    if (lane >= 16 && lane < 20 && f_top) {
-        const int i = lane - 16, plane = i >> 1, cw = i & 1;
-        uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
-        *reinterpret_cast<uint32_t *>(P - (ptrdiff_t)CW + 4 * cw) = *reinterpret_cast<const uint32_t *>(&ct[plane][1 * CS + 4 + 4 * cw]);
+    __syncthreads();
+    const unsigned long long tB = TICK();
+    int maxl = 0;
+    for (int l = NL; l >= 1; l--) if (start[l + 1] != start[l]) { maxl = l; break; }
+
+    /* 3. filter, level by level */
+    auto item = [&](int l, int k) -> int {               /* k-th macroblock of level l or -1 */
+        if (l > maxl) return -1;
+        const uint32_t s0 = start[l], s1 = start[l + 1];
+        return s0 + (uint32_t)k < s1 ? (int)order[s0 + k] : -1;
+    };
+    const int wk = wave * 2 + half;
+    int nxt = item(1, wk);
+    DbkPrefetch pf = {};
+    dbk_prefetch(fd, nxt, hl, pf);
+    for (int l = 1; l <= maxl; l++) {
+        const unsigned long long t0 = TICK();
+        const int cur = nxt;
+        const DbkPrefetch cp = pf;
+        nxt = item(l + 1, wk);
+        if (__any(cur >= 0)) { deblock_mb(fd, cur, hl, cp, wlds, nxt, pf); t_acc[2] += 1; }
+        else dbk_prefetch(fd, nxt, hl, pf);
+        /* crowded levels (> 32 macroblocks): further rounds, fetched on the spot */
+        const int n_l = (int)(start[l + 1] - start[l]);
+        for (int k = wk + TAIL_WORKERS; k - half - (wk - half) < n_l && (k - half) < n_l + 1; k += TAIL_WORKERS) {
+            const int em = item(l, k);
+            if (!__any(em >= 0)) break;
+            DbkPrefetch ep = {}, dummy = {};
+            dbk_prefetch(fd, em, hl, ep);
+            deblock_mb(fd, em, hl, ep, wlds, -1, dummy);
+        }
+        const unsigned long long t1 = TICK();
+        __syncthreads();
+        const unsigned long long t2 = TICK();
+        t_acc[0] += t1 - t0; t_acc[1] += t2 - t1;
     }
+    if (profiling && lane == 0) {
+        prof[wave * 8 + 0] = tB - tA; prof[wave * 8 + 1] = t_acc[0]; prof[wave * 8 + 2] = t_acc[1];
+        prof[wave * 8 + 3] = t_acc[2]; prof[wave * 8 + 4] = (unsigned long long)maxl;
+    }
+#undef TICK
 }
 
 /* ------------------------------------------------------------------ colour conversion */

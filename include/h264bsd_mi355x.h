@@ -52,12 +52,21 @@ int  h264bsdmiReplayChecksums(h264bsdmi_replay *r, u32 slot, unsigned long long 
 int  h264bsdmiReplayConvert(h264bsdmi_replay *r, u32 slot, int fmt);
 int  h264bsdmiReplayFetchConverted(h264bsdmi_replay *r, u32 stream, u32 *dst);
 /* HIP-event timing of the kernels of the last h264bsdmiReplayRun(): ms per kernel class
- * out[0]=inter reconstruction, out[1]=intra reconstruction, out[2]=deblocking, out[3]=whole run;
+ * out[0]=k_recon_inter, out[1]=0 (reserved), out[2]=k_frame_tail (intra + deblocking), out[3]=whole run;
  * launches[0..2] = number of launches per class. */
 int  h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[4], u32 launches[3]);
+/* Split the streams of the set into n_groups (1..8) groups, each on its own HIP stream, so that the
+ * latency-bound per-picture kernel of one group overlaps the throughput-bound kernels of another.
+ * With more than one group the per-class times of h264bsdmiReplayTimings() are sums over concurrently
+ * running launches (they exceed out[3], the whole run). */
+int  h264bsdmiReplaySetGroups(h264bsdmi_replay *r, u32 n_groups);
 /* Test hook: which stages h264bsdmiReplayRun() launches: bit0 inter reconstruction, bit1 intra
  * reconstruction, bit2 deblocking (default 7 = all). */
 int  h264bsdmiReplaySetStages(h264bsdmi_replay *r, unsigned mask);
+/* Debug hook: cycle accounting of k_frame_tail's deblocking loop for workgroup 0 of every launch between
+ * enable=1 and enable=0 (which copies out[16 waves][8]: cycles in {choose MB, filter, extra rounds, wait for
+ * own memory traffic, #filtered, barrier wait}). */
+int  h264bsdmiDebugTailProfile(int enable, unsigned long long *out);
 /* Bytes of packed syntax (frame jobs) per stream and of one frame, for the byte accounting. */
 unsigned long long h264bsdmiReplayJobBytes(h264bsdmi_replay *r);
 u32  h264bsdmiReplayFrameBytes(h264bsdmi_replay *r);
