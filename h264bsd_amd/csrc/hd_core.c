@@ -166,6 +166,12 @@ int hd_job_finish(HostDec *d, int is_idr)
             if (recs[a].kind != FJ_MB_INTER && recs[a].kind != FJ_MB_ABSENT) idx[cursor[recs[a].intra_level]++] = (uint16_t)a;
         free(cursor);
     }
+    {   /* zero the alignment gaps so that a frame job is a pure function of the bitstream */
+        const uint32_t ends[5] = { h->coef_off + d->coef_blocks * 32u, h->lvl_off + (n_levels + 1) * 4u,
+                                   h->idx_off + n_intra * 2u, h->copy_off + h->n_copy * 8u, h->gen_off + h->n_gen * 2u };
+        const uint32_t nexts[5] = { h->lvl_off, h->idx_off, h->copy_off, h->gen_off, h->total_bytes };
+        for (int i = 0; i < 5; i++) if (nexts[i] > ends[i]) memset(d->job + ends[i], 0, nexts[i] - ends[i]);
+    }
     h->n_intra = n_intra;
     h->n_intra_levels = n_levels;
     h->n_inter = d->n_inter;

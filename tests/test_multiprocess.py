@@ -1,0 +1,55 @@
+"""N>1 plumbing on CPU: two ranks over gloo, each owning its own shard of independent streams (weak
+scaling, no data-path collective) — the same sharding + MAX-of-elapsed reduction bench.py uses over RCCL.
+Each rank runs the PRODUCT's host parser in capture mode on its streams; nothing here needs a GPU."""
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import os, sys, json, hashlib, time
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    import h264bsd_amd
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    streams_total, per_rank = 4, 2
+    mine = list(range(rank * per_rank, (rank + 1) * per_rank))          # stream s -> rank s // per_rank
+    data = open(os.path.join(%r, "tests", "golden", "test_640x360.h264"), "rb").read()
+    dist.barrier()
+    t0 = time.perf_counter()
+    pics = 0
+    digests = []
+    for s in mine:
+        jobs, trace, info = h264bsd_amd.capture_stream(data)
+        pics += len(jobs)
+        digests.append(hashlib.sha256(b"".join(jobs)).hexdigest())
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    total = torch.tensor([pics], dtype=torch.int64)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, digests)
+    if rank == 0:
+        print(json.dumps({"pics": int(total.item()), "elapsed": float(elapsed.item()),
+                          "distinct_job_streams": len({d for g in gathered for d in g}), "world": world}))
+    dist.destroy_process_group()
+""") % (ROOT, ROOT)
+
+
+def test_two_ranks_shard_streams_over_gloo(tmp_path, built):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["world"] == 2 and res["pics"] == 4 * 73          # every rank decoded its own 2 streams
+    assert res["distinct_job_streams"] == 1                        # identical copies -> identical frame jobs
