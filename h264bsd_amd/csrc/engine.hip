@@ -84,7 +84,7 @@ Engine *engine_get()
 /* ---- launch of one tick ---- */
 struct TickShape {
     uint32_t n_frames = 0, max_mbs = 0;
-    uint32_t max_copy = 0, max_gen = 0, max_levels = 0, max_w = 0, max_h = 0;
+    uint32_t max_copy = 0, max_gen = 0, max_dbk = 0, max_levels = 0, max_w = 0, max_h = 0;
     bool any_tail = false, any_deblock = false;
 };
 
@@ -102,6 +102,8 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     d.gen = reinterpret_cast<const uint16_t *>(dev_blob + h->gen_off);
     d.n_copy = h->n_copy;
     d.n_gen = h->n_gen;
+    d.dbki = reinterpret_cast<const uint16_t *>(dev_blob + h->dbk_off);
+    d.n_dbk = h->n_dbk;
     d.dbk = dev_dbk;
     d.cur = dev_frames + (size_t)h->cur_slot * frame_bytes;
     d.n_mbs = h->n_mbs;
@@ -115,6 +117,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
         shape->max_mbs = std::max(shape->max_mbs, h->n_mbs);
         shape->max_copy = std::max(shape->max_copy, h->n_copy);
         shape->max_gen = std::max(shape->max_gen, h->n_gen);
+        shape->max_dbk = std::max(shape->max_dbk, h->n_dbk);
         shape->any_deblock |= h->any_deblock != 0;
         shape->max_levels = std::max(shape->max_levels, h->n_intra_levels);
         shape->max_w = std::max<uint32_t>(shape->max_w, h->width_mbs);
@@ -130,12 +133,12 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
 {
     if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[0], st));
     if (stages & 1u) {
-        if (s.max_copy) hipLaunchKernelGGL(h264k::k_copy, dim3((s.max_copy + 15) / 16, s.n_frames), dim3(256), 0, st, d_desc);
+        if (s.max_copy) hipLaunchKernelGGL(h264k::k_copy, dim3((s.max_copy + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
         if (s.max_gen) hipLaunchKernelGGL(h264k::k_recon_inter, dim3((s.max_gen + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[0] += (s.max_copy ? 1 : 0) + (s.max_gen ? 1 : 0);
     }
-    if ((stages & 4u) && s.any_deblock) {
-        hipLaunchKernelGGL(h264k::k_dbk, dim3((s.max_mbs + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
+    if ((stages & 4u) && s.any_deblock && s.max_dbk) {
+        hipLaunchKernelGGL(h264k::k_dbk, dim3((s.max_dbk + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
     }
     if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[1], st));
     if (s.max_levels && (stages & 2u)) {

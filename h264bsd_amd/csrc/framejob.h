@@ -16,7 +16,7 @@
  *
  * All integers little-endian; every section starts 32-byte aligned.
  * Section order in the blob: header | records | motion vectors | coefficients | level starts |
- * intra index | copy list | general-inter index.
+ * intra index | copy list (runs of <= 4 MBs) | general-inter index | non-trivial deblocking index.
  */
 #ifndef H264BSD_AMD_FRAMEJOB_H
 #define H264BSD_AMD_FRAMEJOB_H
@@ -74,16 +74,18 @@ typedef struct FjHeader {
     uint32_t n_copy;
     uint32_t gen_off;         /* uint16 gen_idx[n_gen]: all other inter MBs                    */
     uint32_t n_gen;
-    uint32_t reserved[13];
+    uint32_t dbk_off;         /* uint16 dbk_idx[n_dbk]: MBs whose boundary strengths are not trivially all zero */
+    uint32_t n_dbk;
+    uint32_t reserved[11];
 } FjHeader;                   /* 128 bytes */
 
 /* An inter macroblock with no coefficients whose 16 motion vectors are equal and whole-sample for
  * luma AND chroma (mv multiple of 8 quarter-samples; 66 % of the inter MBs of the bundled 1080p
  * stream, almost all of them P_Skip with mv 0): reconstruction is a 384-byte copy. */
 typedef struct FjCopy {
-    uint16_t mb;              /* macroblock address                                           */
+    uint16_t mb;              /* address of the first macroblock of the run                   */
     uint8_t  slot;            /* reference DPB slot                                           */
-    uint8_t  reserved;
+    uint8_t  count;           /* 1..4 horizontally adjacent MBs with the same slot and mv     */
     int16_t  dx, dy;          /* displacement in luma samples (even)                          */
 } FjCopy;                     /* 8 bytes */
 
@@ -102,7 +104,7 @@ typedef struct FjMbRec {
     uint32_t coef_idx;        /* first coefficient block of this MB (16 x int16 each)         */
     uint8_t  ref_slot[4];     /* reference DPB slot per 8x8 quadrant (raster)                 */
     int8_t   cqp_off;         /* chroma_qp_index_offset of the MB's PPS (deblock QPc)         */
-    uint8_t  reserved;
+    uint8_t  dbk_trivial;     /* 1: every boundary strength of this MB is zero by construction (host-proved) */
     uint16_t intra_level;     /* dependency level among intra MBs of the picture              */
     uint8_t  i4mode[8];       /* 16 nibbles: Intra4x4PredMode of raster block r               */
 } FjMbRec;                    /* 32 bytes */

@@ -53,7 +53,7 @@ static uint32_t job_capacity(uint32_t n_mbs)
 {
     return 128u + n_mbs * (32u + 64u) + (n_mbs * 27u + 2u) * 32u /* coefficients, worst case */
            + (n_mbs + 2u) * 4u /* level starts */ + fj_align32(n_mbs * 2u) /* intra index */
-           + n_mbs * 8u /* copy list or general index */ + 512u;
+           + n_mbs * 8u /* copy list or general index */ + fj_align32(n_mbs * 2u) /* deblocking index */ + 512u;
 }
 
 int hd_job_begin(HostDec *d)
@@ -117,48 +117,78 @@ int hd_job_finish(HostDec *d, int is_idr)
     h->idx_off = fj_align32(h->lvl_off + (n_levels + 1) * 4u);
     h->copy_off = fj_align32(h->idx_off + n_intra * 2u);
     {
-        /* split the inter macroblocks: whole-sample uniform copies vs everything else */
+        /* Classify the inter macroblocks.  cls bit0: uniform (16 equal mvs, one reference, no coefficients);
+         * bit1: additionally whole-sample for luma and chroma -> pure copy. */
         const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(d->job + h->mv_off);
-        uint32_t n_copy = 0, n_gen = 0;
+        uint8_t *cls = (uint8_t *)calloc(n, 1);
+        if (!cls) return -1;
+        uint32_t n_gen = 0;
         for (uint32_t a = 0; a < n; a++) {
             if (recs[a].kind != FJ_MB_INTER) continue;
             const int16_t *m0 = mvs[a][0];
-            int copy = recs[a].coded == 0 && ((m0[0] | m0[1]) & 7) == 0 &&
-                       recs[a].ref_slot[0] == recs[a].ref_slot[1] && recs[a].ref_slot[0] == recs[a].ref_slot[2] &&
-                       recs[a].ref_slot[0] == recs[a].ref_slot[3];
-            for (int k = 1; copy && k < 16; k++) copy = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
-            if (copy) n_copy++; else n_gen++;
+            int uni = recs[a].coded == 0 && recs[a].ref_slot[0] == recs[a].ref_slot[1] &&
+                      recs[a].ref_slot[0] == recs[a].ref_slot[2] && recs[a].ref_slot[0] == recs[a].ref_slot[3];
+            for (int k = 1; uni && k < 16; k++) uni = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
+            cls[a] = (uint8_t)(uni ? (((m0[0] | m0[1]) & 7) == 0 ? 3 : 1) : 0);
+            if (!(cls[a] & 2)) n_gen++;
+        }
+        /* copy list: runs of up to 4 horizontally adjacent copy MBs with equal reference and mv */
+        FjCopy *cp = (FjCopy *)(d->job + h->copy_off);
+        uint32_t n_copy = 0;
+        for (uint32_t a = 0; a < n; a++) {
+            if (!(cls[a] & 2)) continue;
+            const int16_t *m0 = mvs[a][0];
+            FjCopy *last = n_copy ? &cp[n_copy - 1] : NULL;
+            if (last && last->count < 4 && (uint32_t)last->mb + last->count == a && a % w != 0 &&
+                last->slot == recs[a].ref_slot[0] && last->dx == (m0[0] >> 2) && last->dy == (m0[1] >> 2)) {
+                last->count++;
+            } else {
+                if ((uint8_t *)&cp[n_copy + 1] > d->job + d->job_cap) { free(cls); return -1; }
+                cp[n_copy].mb = (uint16_t)a; cp[n_copy].slot = recs[a].ref_slot[0]; cp[n_copy].count = 1;
+                cp[n_copy].dx = (int16_t)(m0[0] >> 2); cp[n_copy].dy = (int16_t)(m0[1] >> 2);
+                n_copy++;
+            }
         }
         h->n_copy = n_copy;
         h->n_gen = n_gen;
         h->gen_off = fj_align32(h->copy_off + n_copy * 8u);
-        h->total_bytes = fj_align32(h->gen_off + n_gen * 2u);
-        if (h->total_bytes > d->job_cap) return -1;
-        FjCopy *cp = (FjCopy *)(d->job + h->copy_off);
         uint16_t *gi = (uint16_t *)(d->job + h->gen_off);
+        for (uint32_t a = 0; a < n; a++)
+            if (recs[a].kind == FJ_MB_INTER && !(cls[a] & 2)) *gi++ = (uint16_t)a;
+        /* deblocking: a uniform MB whose filtered left/top neighbours are uniform too, with the same reference and
+         * mv components closer than 4 quarter samples, has all-zero strengths (8.7.2.1) — never visited again */
+        h->dbk_off = fj_align32(h->gen_off + n_gen * 2u);
+        uint16_t *di = (uint16_t *)(d->job + h->dbk_off);
+        uint32_t n_dbk = 0;
         for (uint32_t a = 0; a < n; a++) {
-            if (recs[a].kind != FJ_MB_INTER) continue;
-            const int16_t *m0 = mvs[a][0];
-            int copy = recs[a].coded == 0 && ((m0[0] | m0[1]) & 7) == 0 &&
-                       recs[a].ref_slot[0] == recs[a].ref_slot[1] && recs[a].ref_slot[0] == recs[a].ref_slot[2] &&
-                       recs[a].ref_slot[0] == recs[a].ref_slot[3];
-            for (int k = 1; copy && k < 16; k++) copy = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
-            if (copy) {
-                cp->mb = (uint16_t)a; cp->slot = recs[a].ref_slot[0]; cp->reserved = 0;
-                cp->dx = (int16_t)(m0[0] >> 2); cp->dy = (int16_t)(m0[1] >> 2);
-                cp++;
-            } else *gi++ = (uint16_t)a;
+            FjMbRec *r = &recs[a];
+            int trivial = r->kind == FJ_MB_ABSENT || r->dbk == 0;
+            if (!trivial && (cls[a] & 1)) {
+                trivial = 1;
+                const uint32_t nb[2] = { a - 1, a - w };
+                const uint8_t need[2] = { (uint8_t)(r->dbk & FJ_DBK_LEFT), (uint8_t)(r->dbk & FJ_DBK_TOP) };
+                for (int k = 0; k < 2 && trivial; k++) {
+                    if (!need[k]) continue;
+                    const uint32_t p = nb[k];
+                    int dx = mvs[a][0][0] - mvs[p][0][0], dy = mvs[a][0][1] - mvs[p][0][1];
+                    trivial = (cls[p] & 1) && recs[p].ref_slot[0] == r->ref_slot[0] && dx > -4 && dx < 4 && dy > -4 && dy < 4;
+                }
+            }
+            r->dbk_trivial = (uint8_t)trivial;
+            if (!trivial) di[n_dbk++] = (uint16_t)a;
         }
+        h->n_dbk = n_dbk;
+        h->total_bytes = fj_align32(h->dbk_off + n_dbk * 2u);
+        free(cls);
+        if (h->total_bytes > d->job_cap) return -1;
     }
-    uint32_t *lvl_start = (uint32_t *)(d->job + h->lvl_off);
-    uint16_t *idx = (uint16_t *)(d->job + h->idx_off);
-    memset(lvl_start, 0, (n_levels + 1) * 4u);
-    /* counting sort by level */
-    for (uint32_t a = 0; a < n; a++)
-        if (recs[a].kind != FJ_MB_INTER && recs[a].kind != FJ_MB_ABSENT) lvl_start[recs[a].intra_level + 1]++;
-    for (uint32_t l = 0; l < n_levels; l++) lvl_start[l + 1] += lvl_start[l];
-    {
-        /* fill using a moving cursor per level, kept in the tail of the blob's slack */
+    {   /* intra schedule: counting sort of the intra MB addresses by dependency level */
+        uint32_t *lvl_start = (uint32_t *)(d->job + h->lvl_off);
+        uint16_t *idx = (uint16_t *)(d->job + h->idx_off);
+        memset(lvl_start, 0, (n_levels + 1) * 4u);
+        for (uint32_t a = 0; a < n; a++)
+            if (recs[a].kind != FJ_MB_INTER && recs[a].kind != FJ_MB_ABSENT) lvl_start[recs[a].intra_level + 1]++;
+        for (uint32_t l = 0; l < n_levels; l++) lvl_start[l + 1] += lvl_start[l];
         uint32_t *cursor = (uint32_t *)malloc((n_levels + 1) * 4u);
         if (!cursor) return -1;
         memcpy(cursor, lvl_start, (n_levels + 1) * 4u);
@@ -167,10 +197,11 @@ int hd_job_finish(HostDec *d, int is_idr)
         free(cursor);
     }
     {   /* zero the alignment gaps so that a frame job is a pure function of the bitstream */
-        const uint32_t ends[5] = { h->coef_off + d->coef_blocks * 32u, h->lvl_off + (n_levels + 1) * 4u,
-                                   h->idx_off + n_intra * 2u, h->copy_off + h->n_copy * 8u, h->gen_off + h->n_gen * 2u };
-        const uint32_t nexts[5] = { h->lvl_off, h->idx_off, h->copy_off, h->gen_off, h->total_bytes };
-        for (int i = 0; i < 5; i++) if (nexts[i] > ends[i]) memset(d->job + ends[i], 0, nexts[i] - ends[i]);
+        const uint32_t ends[6] = { h->coef_off + d->coef_blocks * 32u, h->lvl_off + (n_levels + 1) * 4u,
+                                   h->idx_off + n_intra * 2u, h->copy_off + h->n_copy * 8u, h->gen_off + h->n_gen * 2u,
+                                   h->dbk_off + h->n_dbk * 2u };
+        const uint32_t nexts[6] = { h->lvl_off, h->idx_off, h->copy_off, h->gen_off, h->dbk_off, h->total_bytes };
+        for (int i = 0; i < 6; i++) if (nexts[i] > ends[i]) memset(d->job + ends[i], 0, nexts[i] - ends[i]);
     }
     h->n_intra = n_intra;
     h->n_intra_levels = n_levels;

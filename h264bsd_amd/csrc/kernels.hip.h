@@ -44,9 +44,10 @@ struct FrameDesc {
     const uint16_t *idx;          /* intra MB addresses sorted by level */
     const FjCopy   *copy;         /* whole-sample copy macroblocks */
     const uint16_t *gen;          /* all other inter macroblocks */
+    const uint16_t *dbki;         /* macroblocks whose boundary strengths are not trivially zero */
     uint8_t        *dbk;          /* per-stream scratch: n_mbs x 32-byte deblocking records, then n_mbs "any" bytes */
     uint8_t        *cur;          /* slot that receives the picture */
-    uint32_t        n_mbs, n_levels, n_copy, n_gen;
+    uint32_t        n_mbs, n_levels, n_copy, n_gen, n_dbk;
     uint16_t        wmb, hmb;
     uint32_t        any_deblock;
     uint8_t        *slot[FJ_MAX_SLOTS];
@@ -184,22 +185,11 @@ __device__ __forceinline__ void mb_residual(const FjMbRec &rec, const int16_t *c
 /* ------------------------------------------------------------------ inter prediction */
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * (b + e) + 20 * (c + d) + f; }
 
-/* 4 luma samples (x..x+3, y) of the prediction at quarter-sample fraction (fx,fy) from plane p (w x h) */
-__device__ __forceinline__ void luma_pred4(const uint8_t *__restrict__ p, int w, int h, int x, int y, int fx, int fy, int out[4])
+/* Register window of one lane: rows y-2..y+3, columns x-2..x+9 of the reference plane (9 columns used),
+ * rw[r][k] = dword k of window row r.  Filled either straight from global memory (clamp-to-edge on the
+ * slow path = h264bsdFillBlock, src/h264bsd_reconstruct.c:2244) or from the wave's LDS-staged window. */
+__device__ __forceinline__ void luma_window_global(const uint8_t *__restrict__ p, int w, int h, int x, int y, uint32_t rw[6][3])
 {
-    if ((fx | fy) == 0) {
-        if (x >= 0 && x + 3 < w && y >= 0 && y < h) {
-            const uint32_t v = load_u32_unaligned(p + (size_t)y * w + x);
-            out[0] = v & 255; out[1] = (v >> 8) & 255; out[2] = (v >> 16) & 255; out[3] = v >> 24;
-        } else {
-            const int yy = clip3(0, h - 1, y);
-#pragma unroll
-            for (int i = 0; i < 4; i++) out[i] = p[(size_t)yy * w + clip3(0, w - 1, x + i)];
-        }
-        return;
-    }
-    /* window: rows y-2..y+3, columns x-2..x+6 (9 used, 12 loaded) */
-    uint32_t rw[6][3];
     if (x >= 2 && x + 9 < w && y >= 2 && y + 3 < h) {
 #pragma unroll
         for (int r = 0; r < 6; r++) {
@@ -220,7 +210,17 @@ __device__ __forceinline__ void luma_pred4(const uint8_t *__restrict__ p, int w,
             rw[r][0] = a; rw[r][1] = b; rw[r][2] = c;
         }
     }
+}
+
+/* 4 luma samples (x..x+3, y) of the prediction at quarter-sample fraction (fx,fy) from the window (8.4.2.2.1) */
+__device__ __forceinline__ void luma_from_window(const uint32_t rw[6][3], int fx, int fy, int out[4])
+{
 #define GW(r, c) ((int)((rw[(r)][(c) >> 2] >> (8 * ((c) & 3))) & 255u))
+    if ((fx | fy) == 0) {                            /* G: whole-sample */
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = GW(2, i + 2);
+        return;
+    }
     if (fy == 0) {                                   /* a, b, c: horizontal only (window row 2) */
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -282,7 +282,14 @@ __device__ __forceinline__ void luma_pred4(const uint8_t *__restrict__ p, int w,
 #undef GW
 }
 
-/* 2 chroma samples (x, x+1 ; y) at eighth-sample fraction (fx,fy) */
+/* 2 chroma samples from the two rows a[0..2], b[0..2] at eighth-sample fraction (fx,fy), 8.4.2.2.2 */
+__device__ __forceinline__ void chroma_from_rows(const int a[3], const int b[3], int fx, int fy, int out[2])
+{
+    const int w00 = (8 - fx) * (8 - fy), w10 = fx * (8 - fy), w01 = (8 - fx) * fy, w11 = fx * fy;
+    out[0] = (w00 * a[0] + w10 * a[1] + w01 * b[0] + w11 * b[1] + 32) >> 6;
+    out[1] = (w00 * a[1] + w10 * a[2] + w01 * b[1] + w11 * b[2] + 32) >> 6;
+}
+/* 2 chroma samples (x, x+1 ; y) straight from global memory */
 __device__ __forceinline__ void chroma_pred2(const uint8_t *__restrict__ p, int w, int h, int x, int y, int fx, int fy, int out[2])
 {
     int a[3], b[3];
@@ -295,9 +302,7 @@ __device__ __forceinline__ void chroma_pred2(const uint8_t *__restrict__ p, int 
 #pragma unroll
         for (int i = 0; i < 3; i++) { const int xx = clip3(0, w - 1, x + i); a[i] = s0[xx]; b[i] = s1[xx]; }
     }
-    const int w00 = (8 - fx) * (8 - fy), w10 = fx * (8 - fy), w01 = (8 - fx) * fy, w11 = fx * fy;
-    out[0] = (w00 * a[0] + w10 * a[1] + w01 * b[0] + w11 * b[1] + 32) >> 6;
-    out[1] = (w00 * a[1] + w10 * a[2] + w01 * b[1] + w11 * b[2] + 32) >> 6;
+    chroma_from_rows(a, b, fx, fy, out);
 }
 
 /* ------------------------------------------------------------------ deblocking records */
@@ -317,8 +322,9 @@ __device__ __forceinline__ void wave_sync()
 __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frames)
 {
     const FrameDesc &fd = frames[blockIdx.y];
-    const uint32_t mb = blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (mb >= fd.n_mbs) return;
+    const uint32_t di = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (di >= fd.n_dbk) return;
+    const uint32_t mb = fd.dbki[di];
     const int n = threadIdx.x & 31;
     const FjMbRec q = fd.recs[mb];
     uint8_t *out = fd.dbk + (size_t)mb * DBK_REC_BYTES;
@@ -384,61 +390,82 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
 }
 
 /* ------------------------------------------------------------------ whole-sample copy macroblocks */
-/* 4 list entries per wavefront, all loads issued before the first store.  Luma: lane = 4*row + word
- * (16 rows x 16 bytes); chroma: lanes 0..31 = 16*plane + 2*row + word (2 planes x 8 rows x 8 bytes). */
+/* List entries are runs of up to 4 horizontally adjacent MBs with one displacement: a 64x16 luma block
+ * = 16 rows x 64 B (one cache line per row when aligned) and two 32x8 chroma blocks.  One wavefront
+ * moves 2 entries: 16 B per lane per access (luma lane = 4*row + 16-byte column; chroma lanes 0..31 =
+ * 16*plane + 2*row + column), every load issued before the first store. */
 __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ frames)
 {
     const FrameDesc &fd = frames[blockIdx.y];
-    const uint32_t first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    const uint32_t first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
     if (first >= fd.n_copy) return;
     const int lane = threadIdx.x & 63;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
-    const int lrow = lane >> 2, lcol = (lane & 3) * 4;
-    const int plane = (lane >> 4) & 1, crow = (lane >> 1) & 7, ccol = (lane & 1) * 4;
-    uint32_t vy[4], vc[4];
-    int mbx[4], mby[4];
-    bool on[4];
+    const int lrow = lane >> 2, lseg = lane & 3;                /* luma: MB lseg of the run, row lrow */
+    const int plane = (lane >> 4) & 1, crow = (lane >> 1) & 7, cseg = lane & 1;   /* chroma: 16 B = 2 MBs */
+    uint4 vy[2], vc[2];
+    int mbx[2], mby[2], cnt[2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        on[j] = first + j < fd.n_copy;
-        const FjCopy e = fd.copy[on[j] ? first + j : first];
+    for (int j = 0; j < 2; j++) {
+        const bool on = first + j < fd.n_copy;
+        const FjCopy e = fd.copy[on ? first + j : first];
+        cnt[j] = on ? e.count : 0;
         mbx[j] = e.mb % wmb; mby[j] = e.mb / wmb;
         const uint8_t *ref = fd.slot[e.slot];
         const int x = mbx[j] * 16 + e.dx, y = mby[j] * 16 + e.dy;
-        if (x >= 0 && x + 16 <= W && y >= 0 && y + 16 <= H) {
-            vy[j] = load_u32_unaligned(ref + (size_t)(y + lrow) * W + x + lcol);
-            vc[j] = load_u32_unaligned(ref + ysz + (plane ? csz : 0) + (size_t)((y >> 1) + crow) * CW + (x >> 1) + ccol);
+        if (x >= 0 && x + 64 <= W && y >= 0 && y + 16 <= H) {
+            __builtin_memcpy(&vy[j], ref + (size_t)(y + lrow) * W + x + 16 * lseg, 16);
+            __builtin_memcpy(&vc[j], ref + ysz + (plane ? csz : 0) + (size_t)((y >> 1) + crow) * CW + (x >> 1) + 16 * cseg, 16);
         } else {                                               /* clamp-to-edge, sample by sample */
             const uint8_t *s = ref + (size_t)clip3(0, H - 1, y + lrow) * W;
             const uint8_t *c = ref + ysz + (plane ? csz : 0) + (size_t)clip3(0, CH - 1, (y >> 1) + crow) * CW;
-            uint32_t a = 0, b = 0;
+            uint32_t a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                a |= (uint32_t)s[clip3(0, W - 1, x + lcol + i)] << (8 * i);
-                b |= (uint32_t)c[clip3(0, CW - 1, (x >> 1) + ccol + i)] << (8 * i);
+            for (int q = 0; q < 4; q++) {
+                a[q] = b[q] = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    a[q] |= (uint32_t)s[clip3(0, W - 1, x + 16 * lseg + 4 * q + i)] << (8 * i);
+                    b[q] |= (uint32_t)c[clip3(0, CW - 1, (x >> 1) + 16 * cseg + 4 * q + i)] << (8 * i);
+                }
             }
-            vy[j] = a; vc[j] = b;
+            vy[j] = make_uint4(a[0], a[1], a[2], a[3]);
+            vc[j] = make_uint4(b[0], b[1], b[2], b[3]);
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (!on[j]) continue;
-        *reinterpret_cast<uint32_t *>(fd.cur + (size_t)(mby[j] * 16 + lrow) * W + mbx[j] * 16 + lcol) = vy[j];
-        if (lane < 32)
-            *reinterpret_cast<uint32_t *>(fd.cur + ysz + (plane ? csz : 0) + (size_t)(mby[j] * 8 + crow) * CW + mbx[j] * 8 + ccol) = vc[j];
+    for (int j = 0; j < 2; j++) {
+        if (lseg < cnt[j])
+            *reinterpret_cast<uint4 *>(fd.cur + (size_t)(mby[j] * 16 + lrow) * W + mbx[j] * 16 + 16 * lseg) = vy[j];
+        if (lane < 32 && 2 * cseg < cnt[j]) {
+            uint8_t *dst = fd.cur + ysz + (plane ? csz : 0) + (size_t)(mby[j] * 8 + crow) * CW + mbx[j] * 8 + 16 * cseg;
+            if (2 * cseg + 1 < cnt[j]) *reinterpret_cast<uint4 *>(dst) = vc[j];
+            else *reinterpret_cast<uint2 *>(dst) = make_uint2(vc[j].x, vc[j].y);      /* odd run length: last MB only */
+        }
     }
 }
 
 /* ------------------------------------------------------------------ inter macroblocks */
+/* General inter macroblocks, one wavefront each.  When the 16 motion vectors and the four references of
+ * the macroblock agree (82 % of the general MBs, everything but sub-partitioned ones) the 21x21 luma and two
+ * 9x9 chroma reference windows are staged ONCE in LDS with row-wide coalesced dword loads and every lane
+ * cuts its 6x12-byte register window out of LDS; otherwise every lane fetches its own window from global
+ * memory.  Both feed the same textbook interpolation (luma_from_window / chroma_from_rows). */
+constexpr int IW_STRIDE = 32;                        /* luma window: 21 rows x 28 bytes */
+constexpr int IC_STRIDE = 16;                        /* chroma windows: 9 rows x 16 bytes, two planes */
+constexpr int INTER_WAVE_LDS = 21 * IW_STRIDE + 2 * 9 * IC_STRIDE;
+
 __global__ __launch_bounds__(256) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * INTER_WAVE_LDS];
     const FrameDesc &fd = frames[blockIdx.y];
     const uint32_t gi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gi >= fd.n_gen) return;
     const uint32_t mb = fd.gen[gi];
     const FjMbRec rec = fd.recs[mb];
     const int lane = threadIdx.x & 63;
+    uint8_t *lw = lds + (threadIdx.x >> 6) * INTER_WAVE_LDS, *lc = lw + 21 * IW_STRIDE;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mbx = mb % wmb, mby = mb / wmb;
     const int16_t *mvs = fd.mvs + 32 * (size_t)mb;
@@ -446,36 +473,120 @@ __global__ __launch_bounds__(256) void k_recon_inter(const FrameDesc *__restrict
     uint8_t *cur = fd.cur;
     const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
 
-    int ry[4], rc[4];
-    mb_residual(rec, coef, lane, ry, rc);
     uint32_t refs;
     __builtin_memcpy(&refs, rec.ref_slot, 4);
+    const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
+    const uint32_t mv_mine = *reinterpret_cast<const uint32_t *>(mvs + 2 * blk);
+    const uint32_t mv0 = __builtin_amdgcn_readfirstlane(mv_mine);
+    const bool uniform = __all(mv_mine == mv0) && refs == (refs & 255u) * 0x01010101u;
 
-    /* luma: lane = 4*blk + row */
-    {
-        const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
-        const int mvx = mvs[2 * blk], mvy = mvs[2 * blk + 1];
-        const uint8_t *ref = fd.slot[(refs >> (8 * ((by >> 1) * 2 + (bx >> 1)))) & 255u];
-        int pr[4];
-        luma_pred4(ref, W, H, mbx * 16 + bx * 4 + (mvx >> 2), mby * 16 + by * 4 + row + (mvy >> 2), mvx & 3, mvy & 3, pr);
-        const uint32_t v = pack4(clip255(pr[0] + ry[0]), clip255(pr[1] + ry[1]), clip255(pr[2] + ry[2]), clip255(pr[3] + ry[3]));
-        *reinterpret_cast<uint32_t *>(cur + (size_t)(mby * 16 + by * 4 + row) * W + mbx * 16 + bx * 4) = v;
-    }
-    /* chroma: lanes 0..31, lane = 4*k + row, k = 4*plane + 2*cby + cbx: 4 samples of one row */
-    if (lane < 32) {
-        const int k = lane >> 2, row = lane & 3, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
-        const int cy = cby * 4 + row, cx0 = cbx * 4;
-        int pr[4];
+    int ry[4], rc[4];
+    mb_residual(rec, coef, lane, ry, rc);
+
+    int pl[4], pc[4] = { 0, 0, 0, 0 };
+    if (uniform) {
+        const int mvx = (int16_t)(mv0 & 0xFFFFu), mvy = (int32_t)mv0 >> 16;
+        const uint8_t *ref = fd.slot[refs & 255u];
+        const int xi = mbx * 16 + (mvx >> 2) - 2, yi = mby * 16 + (mvy >> 2) - 2;
+        const int xs = xi - (xi & 3);
+        const int cxi = mbx * 8 + (mvx >> 3), cyi = mby * 8 + (mvy >> 3);
+        const int cxs = cxi - (cxi & 3);
+        /* ---- stage: luma rows yi..yi+20, bytes xs..xs+27; chroma rows cyi..cyi+8, bytes cxs..cxs+15 ---- */
+        if (xs >= 0 && xs + 28 <= W && yi >= 0 && yi + 21 <= H) {
 #pragma unroll
-        for (int pair = 0; pair < 2; pair++) {
-            const int cx = cx0 + 2 * pair;
-            const int lb = (cy >> 1) * 4 + (cx >> 1);             /* owning 4x4 luma block */
-            const int mvx = mvs[2 * lb], mvy = mvs[2 * lb + 1];
-            const uint8_t *ref = fd.slot[(refs >> (8 * ((cy >> 2) * 2 + (cx >> 2)))) & 255u] + ysz + (plane ? csz : 0);
-            chroma_pred2(ref, CW, CH, mbx * 8 + cx + (mvx >> 3), mby * 8 + cy + (mvy >> 3), mvx & 7, mvy & 7, pr + 2 * pair);
+            for (int it = 0; it < 3; it++) {
+                const int d = lane + 64 * it;
+                if (d < 147) {
+                    const int r = d / 7, c = d % 7;
+                    *reinterpret_cast<uint32_t *>(lw + r * IW_STRIDE + 4 * c) = *reinterpret_cast<const uint32_t *>(ref + (size_t)(yi + r) * W + xs + 4 * c);
+                }
+            }
+        } else {
+            for (int d = lane; d < 21 * 28; d += 64) {
+                const int r = d / 28, c = d % 28;
+                lw[r * IW_STRIDE + c] = ref[(size_t)clip3(0, H - 1, yi + r) * W + clip3(0, W - 1, xs + c)];
+            }
         }
-        const uint32_t v = pack4(clip255(pr[0] + rc[0]), clip255(pr[1] + rc[1]), clip255(pr[2] + rc[2]), clip255(pr[3] + rc[3]));
-        *reinterpret_cast<uint32_t *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + cy) * CW + mbx * 8 + cx0) = v;
+        if (cxs >= 0 && cxs + 16 <= CW && cyi >= 0 && cyi + 9 <= CH) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int d = lane + 64 * it;
+                if (d < 72) {
+                    const int p = d / 36, r = (d % 36) / 4, c = d % 4;
+                    *reinterpret_cast<uint32_t *>(lc + p * 9 * IC_STRIDE + r * IC_STRIDE + 4 * c) =
+                        *reinterpret_cast<const uint32_t *>(ref + ysz + (p ? csz : 0) + (size_t)(cyi + r) * CW + cxs + 4 * c);
+                }
+            }
+        } else {
+            for (int d = lane; d < 2 * 9 * 16; d += 64) {
+                const int p = d / 144, r = (d % 144) / 16, c = d % 16;
+                lc[p * 9 * IC_STRIDE + r * IC_STRIDE + c] =
+                    ref[ysz + (p ? csz : 0) + (size_t)clip3(0, CH - 1, cyi + r) * CW + clip3(0, CW - 1, cxs + c)];
+            }
+        }
+        wave_sync();
+        /* ---- luma: window rows (4*by+row)..+5, bytes o..o+11 with o = (xi-xs) + 4*bx ---- */
+        {
+            const int o = (xi - xs) + 4 * bx, sh = 8 * (o & 3);
+            const uint8_t *src = lw + (4 * by + row) * IW_STRIDE + (o & ~3);
+            uint32_t rw[6][3];
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(src + r * IW_STRIDE);   /* 4-byte aligned only */
+                const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                rw[r][0] = (uint32_t)(((unsigned long long)q1 << 32 | q0) >> sh);
+                rw[r][1] = (uint32_t)(((unsigned long long)q2 << 32 | q1) >> sh);
+                rw[r][2] = (uint32_t)(((unsigned long long)q3 << 32 | q2) >> sh);
+            }
+            luma_from_window(rw, mvx & 3, mvy & 3, pl);
+        }
+        /* ---- chroma: lanes 0..31, 4 samples of one row = two pairs ---- */
+        if (lane < 32) {
+            const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
+            const int cy = cby * 4 + row, cx0 = cbx * 4;
+            const uint8_t *s0 = lc + plane * 9 * IC_STRIDE + cy * IC_STRIDE + (cxi - cxs) + cx0, *s1 = s0 + IC_STRIDE;
+            int a[5], b[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) { a[i] = s0[i]; b[i] = s1[i]; }
+            chroma_from_rows(a, b, mvx & 7, mvy & 7, pc);
+            chroma_from_rows(a + 2, b + 2, mvx & 7, mvy & 7, pc + 2);
+        }
+    } else {
+        /* ---- per-lane windows straight from global memory ---- */
+        {
+            const int mvx = (int16_t)(mv_mine & 0xFFFFu), mvy = (int32_t)mv_mine >> 16;
+            const uint8_t *ref = fd.slot[(refs >> (8 * ((by >> 1) * 2 + (bx >> 1)))) & 255u];
+            const int x = mbx * 16 + bx * 4 + (mvx >> 2), y = mby * 16 + by * 4 + row + (mvy >> 2);
+            if (((mvx | mvy) & 3) == 0 && x >= 0 && x + 3 < W && y >= 0 && y < H) {
+                const uint32_t v = load_u32_unaligned(ref + (size_t)y * W + x);
+                pl[0] = v & 255; pl[1] = (v >> 8) & 255; pl[2] = (v >> 16) & 255; pl[3] = v >> 24;
+            } else {
+                uint32_t rw[6][3];
+                luma_window_global(ref, W, H, x, y, rw);
+                luma_from_window(rw, mvx & 3, mvy & 3, pl);
+            }
+        }
+        if (lane < 32) {
+            const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
+            const int cy = cby * 4 + row, cx0 = cbx * 4;
+#pragma unroll
+            for (int pair = 0; pair < 2; pair++) {
+                const int cx = cx0 + 2 * pair;
+                const int lb = (cy >> 1) * 4 + (cx >> 1);             /* owning 4x4 luma block */
+                const int mvx = mvs[2 * lb], mvy = mvs[2 * lb + 1];
+                const uint8_t *ref = fd.slot[(refs >> (8 * ((cy >> 2) * 2 + (cx >> 2)))) & 255u] + ysz + (plane ? csz : 0);
+                chroma_pred2(ref, CW, CH, mbx * 8 + cx + (mvx >> 3), mby * 8 + cy + (mvy >> 3), mvx & 7, mvy & 7, pc + 2 * pair);
+            }
+        }
+    }
+
+    /* ---- residual add, clip, packed stores: luma lane = 4*blk + row; chroma lanes 0..31 = 4*k + row ---- */
+    *reinterpret_cast<uint32_t *>(cur + (size_t)(mby * 16 + by * 4 + row) * W + mbx * 16 + bx * 4) =
+        pack4(clip255(pl[0] + ry[0]), clip255(pl[1] + ry[1]), clip255(pl[2] + ry[2]), clip255(pl[3] + ry[3]));
+    if (lane < 32) {
+        const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
+        *reinterpret_cast<uint32_t *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + cby * 4 + row) * CW + mbx * 8 + cbx * 4) =
+            pack4(clip255(pc[0] + rc[0]), clip255(pc[1] + rc[1]), clip255(pc[2] + rc[2]), clip255(pc[3] + rc[3]));
     }
 }
 
@@ -773,7 +884,13 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, 
     const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
     uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
     uint8_t *PC = cur + ysz + (size_t)(mby * 8) * CW + mbx * 8;
-    const bool f_left = p.thr.w & FJ_DBK_LEFT, f_top = p.thr.w & FJ_DBK_TOP;
+    /* the left / upper neighbour is touched only if that macroblock edge has a non-zero strength:
+     * lane hl holds byte hl>>1; left edge = nibbles 0..3 = bytes 0,1 (lanes 0..3), top edge = nibbles 16..19 =
+     * bytes 8,9 (lanes 16..19) */
+    const unsigned long long bl = __ballot(act && (hl >> 2) == 0 && p.bsb != 0), bt = __ballot(act && (hl >> 2) == 4 && p.bsb != 0);
+    const uint32_t hsel = (threadIdx.x & 32) ? 32 : 0;
+    const bool f_left = (p.thr.w & FJ_DBK_LEFT) && ((uint32_t)(bl >> hsel) != 0u);
+    const bool f_top = (p.thr.w & FJ_DBK_TOP) && ((uint32_t)(bt >> hsel) != 0u);
 
     /* neighbour strips (the only samples that depend on the previous diagonals): 56 words, issued
      * first; then the NEXT diagonal's prefetch goes out behind them so that it flies during the filter */
@@ -783,16 +900,16 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, 
         for (int it = 0; it < 2; it++) {
             const int s = hl + 32 * it;
             if (s < 16) {
-                if (mbx > 0) strip[it] = *reinterpret_cast<const uint32_t *>(Y + (size_t)s * W - 4);
+                if (f_left) strip[it] = *reinterpret_cast<const uint32_t *>(Y + (size_t)s * W - 4);
             } else if (s < 32) {
                 const int r = (s - 16) >> 2, cw = (s - 16) & 3;
-                if (mby > 0) strip[it] = *reinterpret_cast<const uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * cw);
+                if (f_top) strip[it] = *reinterpret_cast<const uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * cw);
             } else if (s < 48) {
                 const int plane = (s - 32) >> 3, r = (s - 32) & 7;
-                if (mbx > 0) strip[it] = *reinterpret_cast<const uint32_t *>(PC + (plane ? csz : 0) + (size_t)r * CW - 4);
+                if (f_left) strip[it] = *reinterpret_cast<const uint32_t *>(PC + (plane ? csz : 0) + (size_t)r * CW - 4);
             } else if (s < 56) {
                 const int plane = (s - 48) >> 2, r = ((s - 48) >> 1) & 1, cw = (s - 48) & 1;
-                if (mby > 0) strip[it] = *reinterpret_cast<const uint32_t *>(PC + (plane ? csz : 0) + (ptrdiff_t)(r - 2) * CW + 4 * cw);
+                if (f_top) strip[it] = *reinterpret_cast<const uint32_t *>(PC + (plane ? csz : 0) + (ptrdiff_t)(r - 2) * CW + 4 * cw);
             }
         }
     }
@@ -986,7 +1103,11 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *
     const unsigned long long tA = TICK();
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(fd.dbk + (size_t)n_mbs * DBK_REC_BYTES);
-        for (int i = tid; i < (n_mbs + 3) / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(anyf)[i] = src[i];
+        uint32_t *srcw = reinterpret_cast<uint32_t *>(fd.dbk + (size_t)n_mbs * DBK_REC_BYTES);
+        for (int i = tid; i < (n_mbs + 3) / 4; i += blockDim.x) {
+            reinterpret_cast<uint32_t *>(anyf)[i] = src[i];
+            srcw[i] = 0;                 /* k_dbk only visits non-trivial MBs: leave the flags clean for the next picture */
+        }
         for (int i = tid; i < NL + 2; i += blockDim.x) { start[i] = 0; cursor[i] = 0; }
     }
     __syncthreads();

@@ -62,3 +62,49 @@ def test_frame_job_statistics(captured):
     h1 = pyoracle.blob_header(jobs[1])
     assert h1["n_inter"] + h1["n_intra"] == 8160
     assert sum(pyoracle.blob_header(j)["n_inter"] for j in jobs) == 410704 + 151131
+
+
+def _sections(job):
+    import struct
+    import numpy as np
+    h = pyoracle.blob_header(job)
+    copy_off, n_copy, gen_off, n_gen, dbk_off, n_dbk = struct.unpack_from("<IIIIII", job, 60)
+    n = h["n_mbs"]
+    rec = np.frombuffer(job, dtype=np.uint8, count=n * 32, offset=h["rec_off"]).reshape(n, 32)
+    lvl = np.frombuffer(job, dtype="<u4", count=h["n_intra_levels"] + 1, offset=h["lvl_off"])
+    idx = np.frombuffer(job, dtype="<u2", count=h["n_intra"], offset=h["idx_off"])
+    copy = np.frombuffer(job, dtype=np.uint8, count=n_copy * 8, offset=copy_off).reshape(n_copy, 8)
+    gen = np.frombuffer(job, dtype="<u2", count=n_gen, offset=gen_off)
+    dbk = np.frombuffer(job, dtype="<u2", count=n_dbk, offset=dbk_off)
+    return h, rec, lvl, idx, copy, gen, dbk
+
+
+@pytest.mark.parametrize("pic", [0, 1, 20, 40, 72])
+def test_frame_job_schedules_are_consistent(pic, captured):
+    """host logic: the work lists the kernels are driven by partition the macroblocks correctly"""
+    import numpy as np
+    jobs, _, _ = captured("test_1920x1080")
+    h, rec, lvl, idx, copy, gen, dbk = _sections(jobs[pic])
+    n, w = h["n_mbs"], h["width_mbs"]
+    kind = rec[:, 0]
+    intra = np.nonzero((kind >= 1) & (kind <= 3))[0]
+    inter = np.nonzero(kind == 0)[0]
+    # intra schedule: every intra MB exactly once, level starts monotone, neighbours strictly earlier
+    assert lvl[0] == 0 and lvl[-1] == len(idx) == len(intra) and (np.diff(lvl.astype(np.int64)) >= 0).all()
+    assert sorted(idx.tolist()) == intra.tolist()
+    level_of = np.full(n, -1)
+    for l in range(len(lvl) - 1):
+        level_of[idx[lvl[l]:lvl[l + 1]]] = l
+    for a in intra[:: max(1, len(intra) // 500)]:
+        x, y = a % w, a // w
+        for ok, nb in ((x > 0, a - 1), (y > 0, a - w), (y > 0 and x + 1 < w, a - w + 1), (y > 0 and x > 0, a - w - 1)):
+            if ok and level_of[nb] >= 0:
+                assert level_of[nb] < level_of[a]
+    # inter MBs: copy runs + general index partition them
+    run_mb = copy[:, 0].astype(int) | (copy[:, 1].astype(int) << 8)
+    run_cnt = copy[:, 3].astype(int)
+    covered = np.concatenate([np.arange(m, m + c) for m, c in zip(run_mb, run_cnt)] + [gen.astype(int)]) if len(inter) else np.array([], int)
+    assert sorted(covered.tolist()) == inter.tolist()
+    assert ((run_cnt >= 1) & (run_cnt <= 4)).all() and ((run_mb % w) + run_cnt <= w).all()
+    # deblocking index: exactly the MBs not marked trivially strength-free
+    assert sorted(dbk.tolist()) == np.nonzero(rec[:, 21] == 0)[0].tolist()
