@@ -99,7 +99,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     d.lvl = reinterpret_cast<const uint32_t *>(dev_blob + h->lvl_off);
     d.idx = reinterpret_cast<const uint16_t *>(dev_blob + h->idx_off);
     d.copy = reinterpret_cast<const FjCopy *>(dev_blob + h->copy_off);
-    d.gen = reinterpret_cast<const uint16_t *>(dev_blob + h->gen_off);
+    d.gen = reinterpret_cast<const FjGen *>(dev_blob + h->gen_off);
     d.n_copy = h->n_copy;
     d.n_gen = h->n_gen;
     d.dbki = reinterpret_cast<const uint16_t *>(dev_blob + h->dbk_off);

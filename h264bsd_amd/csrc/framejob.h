@@ -16,7 +16,7 @@
  *
  * All integers little-endian; every section starts 32-byte aligned.
  * Section order in the blob: header | records | motion vectors | coefficients | level starts |
- * intra index | copy list (runs of <= 4 MBs) | general-inter index | non-trivial deblocking index.
+ * intra index | copy list (runs of <= 4 MBs) | general-inter list | non-trivial deblocking index.
  */
 #ifndef H264BSD_AMD_FRAMEJOB_H
 #define H264BSD_AMD_FRAMEJOB_H
@@ -72,7 +72,7 @@ typedef struct FjHeader {
     uint32_t pic_seq;         /* running picture number of the stream                         */
     uint32_t copy_off;        /* FjCopy[n_copy]: inter MBs that are pure whole-sample copies   */
     uint32_t n_copy;
-    uint32_t gen_off;         /* uint16 gen_idx[n_gen]: all other inter MBs                    */
+    uint32_t gen_off;         /* FjGen[n_gen]: all other inter MBs                             */
     uint32_t n_gen;
     uint32_t dbk_off;         /* uint16 dbk_idx[n_dbk]: MBs whose boundary strengths are not trivially all zero */
     uint32_t n_dbk;
@@ -88,6 +88,18 @@ typedef struct FjCopy {
     uint8_t  count;           /* 1..4 horizontally adjacent MBs with the same slot and mv     */
     int16_t  dx, dy;          /* displacement in luma samples (even)                          */
 } FjCopy;                     /* 8 bytes */
+
+/* Every other inter macroblock.  The entry repeats what the reconstruction needs first (reference,
+ * motion vector when all 16 agree, where the coefficients are) so that the reference-window loads
+ * can be issued one dependent load after the launch descriptor instead of three. */
+typedef struct FjGen {
+    uint16_t mb;
+    uint8_t  uniform;         /* 1: 16 equal motion vectors and one reference slot            */
+    uint8_t  slot;            /* reference slot when uniform                                  */
+    int16_t  mvx, mvy;        /* the motion vector when uniform (quarter samples)             */
+    uint32_t coef_idx;        /* = FjMbRec.coef_idx                                           */
+    uint32_t coded;           /* = FjMbRec.coded                                              */
+} FjGen;                      /* 16 bytes */
 
 typedef struct FjMbRec {
     uint8_t  kind;

@@ -53,7 +53,7 @@ static uint32_t job_capacity(uint32_t n_mbs)
 {
     return 128u + n_mbs * (32u + 64u) + (n_mbs * 27u + 2u) * 32u /* coefficients, worst case */
            + (n_mbs + 2u) * 4u /* level starts */ + fj_align32(n_mbs * 2u) /* intra index */
-           + n_mbs * 8u /* copy list or general index */ + fj_align32(n_mbs * 2u) /* deblocking index */ + 512u;
+           + n_mbs * 16u /* copy list + general list */ + fj_align32(n_mbs * 2u) /* deblocking index */ + 512u;
 }
 
 int hd_job_begin(HostDec *d)
@@ -152,12 +152,20 @@ int hd_job_finish(HostDec *d, int is_idr)
         h->n_copy = n_copy;
         h->n_gen = n_gen;
         h->gen_off = fj_align32(h->copy_off + n_copy * 8u);
-        uint16_t *gi = (uint16_t *)(d->job + h->gen_off);
-        for (uint32_t a = 0; a < n; a++)
-            if (recs[a].kind == FJ_MB_INTER && !(cls[a] & 2)) *gi++ = (uint16_t)a;
+        FjGen *gi = (FjGen *)(d->job + h->gen_off);
+        for (uint32_t a = 0; a < n; a++) {
+            if (recs[a].kind != FJ_MB_INTER || (cls[a] & 2)) continue;
+            const int16_t *m0 = mvs[a][0];
+            int uni = recs[a].ref_slot[0] == recs[a].ref_slot[1] && recs[a].ref_slot[0] == recs[a].ref_slot[2] &&
+                      recs[a].ref_slot[0] == recs[a].ref_slot[3];
+            for (int k = 1; uni && k < 16; k++) uni = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
+            gi->mb = (uint16_t)a; gi->uniform = (uint8_t)uni; gi->slot = recs[a].ref_slot[0];
+            gi->mvx = m0[0]; gi->mvy = m0[1]; gi->coef_idx = recs[a].coef_idx; gi->coded = recs[a].coded;
+            gi++;
+        }
         /* deblocking: a uniform MB whose filtered left/top neighbours are uniform too, with the same reference and
          * mv components closer than 4 quarter samples, has all-zero strengths (8.7.2.1) — never visited again */
-        h->dbk_off = fj_align32(h->gen_off + n_gen * 2u);
+        h->dbk_off = fj_align32(h->gen_off + n_gen * 16u);
         uint16_t *di = (uint16_t *)(d->job + h->dbk_off);
         uint32_t n_dbk = 0;
         for (uint32_t a = 0; a < n; a++) {
@@ -198,7 +206,7 @@ int hd_job_finish(HostDec *d, int is_idr)
     }
     {   /* zero the alignment gaps so that a frame job is a pure function of the bitstream */
         const uint32_t ends[6] = { h->coef_off + d->coef_blocks * 32u, h->lvl_off + (n_levels + 1) * 4u,
-                                   h->idx_off + n_intra * 2u, h->copy_off + h->n_copy * 8u, h->gen_off + h->n_gen * 2u,
+                                   h->idx_off + n_intra * 2u, h->copy_off + h->n_copy * 8u, h->gen_off + h->n_gen * 16u,
                                    h->dbk_off + h->n_dbk * 2u };
         const uint32_t nexts[6] = { h->lvl_off, h->idx_off, h->copy_off, h->gen_off, h->dbk_off, h->total_bytes };
         for (int i = 0; i < 6; i++) if (nexts[i] > ends[i]) memset(d->job + ends[i], 0, nexts[i] - ends[i]);

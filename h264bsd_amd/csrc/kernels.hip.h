@@ -43,7 +43,7 @@ struct FrameDesc {
     const uint32_t *lvl;          /* lvl_start[n_levels+1] */
     const uint16_t *idx;          /* intra MB addresses sorted by level */
     const FjCopy   *copy;         /* whole-sample copy macroblocks */
-    const uint16_t *gen;          /* all other inter macroblocks */
+    const FjGen    *gen;          /* all other inter macroblocks */
     const uint16_t *dbki;         /* macroblocks whose boundary strengths are not trivially zero */
     uint8_t        *dbk;          /* per-stream scratch: n_mbs x 32-byte deblocking records, then n_mbs "any" bytes */
     uint8_t        *cur;          /* slot that receives the picture */
@@ -133,9 +133,8 @@ __device__ __forceinline__ void load_row4(const int16_t *p, bool valid, int c[4]
  *   ry[0..3]: luma, lane = 4*blk + row (blk raster 0..15): samples (row, 0..3) of block blk
  *   rc[0..3]: chroma, lanes 0..31: lane = 4*k + row, k = 4*plane + 2*by + bx
  * Must be called by all 64 lanes (quad shuffles).  coef = first coefficient block of the MB. */
-__device__ __forceinline__ void mb_residual(const FjMbRec &rec, const int16_t *coef, int lane, int ry[4], int rc[4])
+__device__ __forceinline__ void mb_residual(uint32_t coded, int qp_y, int qp_c, bool is_i16, const int16_t *coef, int lane, int ry[4], int rc[4])
 {
-    const uint32_t coded = rec.coded;
     const int q = lane & 3;
     const int has_ldc = (coded >> 24) & 1, has_cdc = (coded >> 25) & 1;
     ry[0] = ry[1] = ry[2] = ry[3] = 0;
@@ -155,13 +154,13 @@ __device__ __forceinline__ void mb_residual(const FjMbRec &rec, const int16_t *c
                     const int v = coef[4 * k + l];
                     acc += (((nr >> k) ^ (ncl >> l)) & 1) ? -v : v;
                 }
-            const int ls = c_level_scale[rec.qp_y % 6][0], q6 = rec.qp_y / 6;
+            const int ls = c_level_scale[qp_y % 6][0], q6 = qp_y / 6;
             dc = q6 >= 2 ? (acc * ls) << (q6 - 2) : (acc * ls + (1 << (1 - q6))) >> (2 - q6);
         }
         const bool has_ac = (coded >> z) & 1;
         const int off = has_ldc + __popc(coded & ((1u << z) - 1u));
         load_row4(coef + 16 * off + 4 * q, has_ac, ry);
-        idct_quad(ry, q, rec.qp_y, rec.kind == FJ_MB_I16x16, dc);
+        idct_quad(ry, q, qp_y, is_i16, dc);
     }
     if (coded & 0x02FF0000u) {                                   /* wave-uniform */
         const int k = (lane >> 2) & 7;
@@ -172,13 +171,13 @@ __device__ __forceinline__ void mb_residual(const FjMbRec &rec, const int16_t *c
             const int i = k & 3;
             const int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
             const int f = c0 + ((i & 1) ? -c1 : c1) + ((i & 2) ? -c2 : c2) + ((i == 1 || i == 2) ? -c3 : c3);
-            const int ls = c_level_scale[rec.qp_c % 6][0], q6 = rec.qp_c / 6;
+            const int ls = c_level_scale[qp_c % 6][0], q6 = qp_c / 6;
             dc = q6 >= 1 ? (f * ls) << (q6 - 1) : (f * ls) >> 1;
         }
         const bool has_ac = (coded >> (16 + k)) & 1;
         const int off = base + has_cdc + __popc((coded >> 16) & ((1u << k) - 1u));
         load_row4(coef + 16 * off + 4 * q, has_ac, rc);
-        idct_quad(rc, q, rec.qp_c, true, dc);
+        idct_quad(rc, q, qp_c, true, dc);
     }
 }
 
@@ -462,26 +461,25 @@ __global__ __launch_bounds__(256) void k_recon_inter(const FrameDesc *__restrict
     const FrameDesc &fd = frames[blockIdx.y];
     const uint32_t gi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gi >= fd.n_gen) return;
-    const uint32_t mb = fd.gen[gi];
-    const FjMbRec rec = fd.recs[mb];
+    const FjGen ge = fd.gen[gi];
+    const uint32_t mb = ge.mb;
+    const FjMbRec rec = fd.recs[mb];                  /* only the QPs are needed from it (in flight meanwhile) */
     const int lane = threadIdx.x & 63;
     uint8_t *lw = lds + (threadIdx.x >> 6) * INTER_WAVE_LDS, *lc = lw + 21 * IW_STRIDE;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mbx = mb % wmb, mby = mb / wmb;
     const int16_t *mvs = fd.mvs + 32 * (size_t)mb;
-    const int16_t *coef = fd.coefs + 16 * (size_t)rec.coef_idx;
+    const int16_t *coef = fd.coefs + 16 * (size_t)ge.coef_idx;
     uint8_t *cur = fd.cur;
     const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
-
-    uint32_t refs;
-    __builtin_memcpy(&refs, rec.ref_slot, 4);
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
-    const uint32_t mv_mine = *reinterpret_cast<const uint32_t *>(mvs + 2 * blk);
-    const uint32_t mv0 = __builtin_amdgcn_readfirstlane(mv_mine);
-    const bool uniform = __all(mv_mine == mv0) && refs == (refs & 255u) * 0x01010101u;
-
-    int ry[4], rc[4];
-    mb_residual(rec, coef, lane, ry, rc);
+    const bool uniform = ge.uniform != 0;
+    uint32_t refs = ge.slot * 0x01010101u, mv_mine = 0;
+    const uint32_t mv0 = (uint32_t)(uint16_t)ge.mvx | ((uint32_t)(uint16_t)ge.mvy << 16);
+    if (!uniform) {
+        __builtin_memcpy(&refs, rec.ref_slot, 4);
+        mv_mine = *reinterpret_cast<const uint32_t *>(mvs + 2 * blk);
+    }
 
     int pl[4], pc[4] = { 0, 0, 0, 0 };
     if (uniform) {
@@ -580,6 +578,8 @@ __global__ __launch_bounds__(256) void k_recon_inter(const FrameDesc *__restrict
         }
     }
 
+    int ry[4], rc[4];
+    mb_residual(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, ry, rc);
     /* ---- residual add, clip, packed stores: luma lane = 4*blk + row; chroma lanes 0..31 = 4*k + row ---- */
     *reinterpret_cast<uint32_t *>(cur + (size_t)(mby * 16 + by * 4 + row) * W + mbx * 16 + bx * 4) =
         pack4(clip255(pl[0] + ry[0]), clip255(pl[1] + ry[1]), clip255(pl[2] + ry[2]), clip255(pl[3] + ry[3]));
@@ -621,7 +621,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
     }
 
     int ry[4], rc[4];
-    mb_residual(rec, coef, lane, ry, rc);
+    mb_residual(rec.coded, rec.qp_y, rec.qp_c, rec.kind == FJ_MB_I16x16, coef, lane, ry, rc);
 
     const bool av_a = rec.avail & FJ_AVAIL_A, av_b = rec.avail & FJ_AVAIL_B, av_c = rec.avail & FJ_AVAIL_C, av_d = rec.avail & FJ_AVAIL_D;
     /* neighbour samples into the tiles (un-deblocked current picture) */

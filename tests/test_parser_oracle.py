@@ -74,7 +74,7 @@ def _sections(job):
     lvl = np.frombuffer(job, dtype="<u4", count=h["n_intra_levels"] + 1, offset=h["lvl_off"])
     idx = np.frombuffer(job, dtype="<u2", count=h["n_intra"], offset=h["idx_off"])
     copy = np.frombuffer(job, dtype=np.uint8, count=n_copy * 8, offset=copy_off).reshape(n_copy, 8)
-    gen = np.frombuffer(job, dtype="<u2", count=n_gen, offset=gen_off)
+    gen = np.frombuffer(job, dtype="<u2", count=n_gen * 8, offset=gen_off).reshape(n_gen, 8)[:, 0]   # FjGen.mb
     dbk = np.frombuffer(job, dtype="<u2", count=n_dbk, offset=dbk_off)
     return h, rec, lvl, idx, copy, gen, dbk
 
