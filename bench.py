@@ -112,14 +112,17 @@ def main():
         rep.run()
     barrier()
     t0 = time.perf_counter()
-    agg = dict(inter_ms=0.0, intra_ms=0.0, deblock_ms=0.0, total_ms=0.0, inter=0, intra=0, deblock=0)
+    kernels = h264bsd_amd.Replay.KERNELS
+    k_ms = {k: 0.0 for k in kernels}
+    k_n = {k: 0 for k in kernels}
+    dev_total_ms = 0.0
     for _ in range(args.steps):
         rep.run()
         t = rep.timings()        # waits for the step; HIP events recorded on the engine's own stream
-        for k in ("inter_ms", "intra_ms", "deblock_ms", "total_ms"):
-            agg[k] += t[k]
-        for k in ("inter", "intra", "deblock"):
-            agg[k] += t["launches"][k]
+        for k in kernels:
+            k_ms[k] += t[k][0]
+            k_n[k] += t[k][1]
+        dev_total_ms += t["total_ms"]
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -141,14 +144,14 @@ def main():
         alg_bytes_stream = 384 * n_mbs * n_pics + 384 * n_inter + rep.job_bytes
         alg_per_mb = alg_bytes_stream / (n_mbs * n_pics)
         # dominant kernel: the one with the largest share of device time in the timed region
-        shares = {"k_recon_inter": agg["inter_ms"], "k_frame_tail": agg["deblock_ms"]}
-        dom = max(shares, key=shares.get)
-        dom_key = {"k_recon_inter": "inter", "k_frame_tail": "deblock"}[dom]
-        launches = max(agg[dom_key], 1)
-        avg_launch_us = shares[dom] * 1e3 / launches
-        units_per_launch = n_mbs * n_pics * args.streams * args.steps / launches       # macroblocks per launch
+        dom = max(kernels, key=lambda k: k_ms[k])
+        launches = max(k_n[dom], 1)
+        avg_launch_us = k_ms[dom] * 1e3 / launches
+        # every launch of every kernel covers one picture of every stream: the units of one launch are the
+        # macroblocks of one tick (SURVEY.md §8d per-MB figure x MBs per launch)
+        units_per_launch = n_mbs * n_pics * args.streams * args.steps / launches
         achieved = alg_per_mb * units_per_launch / (avg_launch_us * 1e-6) / 1e9       # GB/s
-        path_gbs = alg_bytes_stream * args.streams * args.steps / (agg["total_ms"] * 1e-3) / 1e9
+        path_gbs = alg_bytes_stream * args.streams * args.steps / (dev_total_ms * 1e-3) / 1e9
         out = {
             "metric": "1080p macroblocks/s", "value": mbs / elapsed, "unit": "macroblocks/s",
             "fps": pics_per_step * args.steps / elapsed,
@@ -164,8 +167,8 @@ def main():
                          "alg_bytes_per_mb": alg_per_mb, "mbs_per_launch": units_per_launch,
                          "avg_launch_us": avg_launch_us, "launches": launches,
                          "whole_path_GBs": path_gbs, "whole_path_frac": path_gbs / HBM_PEAK_GBS,
-                         "device_ms_per_step": {"k_recon_inter": agg["inter_ms"] / args.steps, "k_frame_tail": agg["deblock_ms"] / args.steps,
-                                                "total": agg["total_ms"] / args.steps}},
+                         "device_ms_per_step": dict({k: k_ms[k] / args.steps for k in kernels}, total=dev_total_ms / args.steps),
+                         "launches_per_step": {k: k_n[k] // args.steps for k in kernels}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data)

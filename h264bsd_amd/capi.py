@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdCroppingParams", "h264bsdSampleAspectRatio", "h264bsdCheckValidParamSets", "h264bsdFlushBuffer",
     "h264bsdProfile", "h264bsdAlloc", "h264bsdFree", "h264bsdConvertToRGBA", "h264bsdConvertToBGRA",
     "h264bsdConvertToYCbCrA",
-    "h264bsdmiInitCapture", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush",
+    "h264bsdmiInitCapture", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush",
     "h264bsdmiReplayCreate", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
@@ -76,6 +76,7 @@ def lib():
     for n in ("h264bsdConvertToRGBA", "h264bsdConvertToBGRA", "h264bsdConvertToYCbCrA"):
         getattr(L, n).argtypes = [u32, u32, vp, vp]
         getattr(L, n).restype = None
+    L.h264bsdmiJobFinalize.argtypes = [ctypes.c_void_p, u32, u32]
     L.h264bsdmiSetDevice.argtypes = [ctypes.c_int]
     L.h264bsdmiReplayCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32]
     L.h264bsdmiReplayCreate.restype = vp
@@ -293,11 +294,14 @@ class Replay:
     def set_stages(self, mask):
         self._L.h264bsdmiReplaySetStages(self._h, mask)
 
+    KERNELS = ("k_copy", "k_recon_inter", "k_dbk", "k_frame_intra", "k_frame_dbk")
+
     def timings(self):
-        ms = (ctypes.c_float * 4)()
-        n = (ctypes.c_uint32 * 3)()
+        """HIP-event times of the last run(): {kernel: (ms, launches)} + total_ms"""
+        ms = (ctypes.c_float * 6)()
+        n = (ctypes.c_uint32 * 5)()
         if self._L.h264bsdmiReplayTimings(self._h, ms, n) != 0:
             raise RuntimeError("h264bsdmiReplayTimings failed")
-        # ms[0] k_recon_inter, ms[2] k_frame_tail (intra levels + deblocking), ms[3] whole run
-        return dict(inter_ms=ms[0], intra_ms=ms[1], deblock_ms=ms[2], total_ms=ms[3],
-                    launches=dict(inter=int(n[0]), intra=int(n[1]), deblock=int(n[2])))
+        out = {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.KERNELS)}
+        out["total_ms"] = float(ms[5])
+        return out

@@ -189,6 +189,9 @@ void h264bsdFlushBuffer(storage_t *s)
     if (a) hd_dpb_flush(&a->hd->dpb);
 }
 
+/* test/tooling hook: complete a hand-built frame job (see fj_finalize, hd_core.c) */
+int h264bsdmiJobFinalize(u8 *job, u32 capacity, u32 n_coef_blocks) { return fj_finalize(job, capacity, n_coef_blocks); }
+
 void h264bsdConvertToRGBA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(0, width, height, data, pOutput); }
 void h264bsdConvertToBGRA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(1, width, height, data, pOutput); }
 void h264bsdConvertToYCbCrA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(2, width, height, data, pOutput); }

@@ -126,25 +126,33 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     }
 }
 
-struct TickTimers { hipEvent_t ev[3]; bool on = false; };
+struct TickTimers { hipEvent_t ev[6]; bool on = false; };   /* boundaries of the 5 kernels of a tick */
 
-int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[3],
+int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5],
                 unsigned stages = 7u)
 {
-    if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[0], st));
-    if (stages & 1u) {
-        if (s.max_copy) hipLaunchKernelGGL(h264k::k_copy, dim3((s.max_copy + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
-        if (s.max_gen) hipLaunchKernelGGL(h264k::k_recon_inter, dim3((s.max_gen + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
-        if (launches) launches[0] += (s.max_copy ? 1 : 0) + (s.max_gen ? 1 : 0);
+    const bool timed = tt && tt->on;
+    if (timed) HIP_TRY(hipEventRecord(tt->ev[0], st));
+    if ((stages & 1u) && s.max_copy) {
+        hipLaunchKernelGGL(h264k::k_copy, dim3((s.max_copy + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
+        if (launches) launches[0]++;
     }
-    if ((stages & 4u) && s.any_deblock && s.max_dbk) {
-        hipLaunchKernelGGL(h264k::k_dbk, dim3((s.max_dbk + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
-    }
-    if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[1], st));
-    if (s.max_levels && (stages & 2u)) {
-        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * h264k::TAIL_WAVES), 0, st, d_desc);
+    if (timed) HIP_TRY(hipEventRecord(tt->ev[1], st));
+    if ((stages & 1u) && s.max_gen) {
+        hipLaunchKernelGGL(h264k::k_recon_inter, dim3((s.max_gen + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[1]++;
     }
+    if (timed) HIP_TRY(hipEventRecord(tt->ev[2], st));
+    if ((stages & 4u) && s.any_deblock && s.max_dbk) {
+        hipLaunchKernelGGL(h264k::k_dbk, dim3((s.max_dbk + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
+        if (launches) launches[2]++;
+    }
+    if (timed) HIP_TRY(hipEventRecord(tt->ev[3], st));
+    if (s.max_levels && (stages & 2u)) {
+        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * h264k::TAIL_WAVES), 0, st, d_desc);
+        if (launches) launches[3]++;
+    }
+    if (timed) HIP_TRY(hipEventRecord(tt->ev[4], st));
     if (s.any_deblock && (stages & 4u)) {
         const uint32_t nl = s.max_w + 2 * s.max_h, n = s.max_mbs;
         const size_t lds = (size_t)h264k::TAIL_WORKERS * h264k::WORKER_LDS + ((n + 15) & ~15u) + 2 * 2 * (size_t)((n + 7) & ~7u) + 2 * 4 * (size_t)(nl + 2);
@@ -154,9 +162,9 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
             lds_enabled = lds;
         }
         hipLaunchKernelGGL(h264k::k_frame_dbk, dim3(s.n_frames), dim3(64 * h264k::TAIL_WAVES), lds, st, d_desc, g_tail_prof);
-        if (launches) launches[2]++;
+        if (launches) launches[4]++;
     }
-    if (tt && tt->on) HIP_TRY(hipEventRecord(tt->ev[2], st));
+    if (timed) HIP_TRY(hipEventRecord(tt->ev[5], st));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -379,7 +387,7 @@ struct h264bsdmi_replay {
     std::vector<TickTimers> timers;
     uint32_t timed_first, timed_count;
     hipEvent_t ev_begin, ev_end;
-    uint32_t launches[3];
+    uint32_t launches[5];
     unsigned stages;
     uint32_t n_groups;
     hipStream_t gstream[8];
@@ -481,7 +489,7 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
     std::lock_guard<std::mutex> lk(r->e->mu);
     HIP_TRY(hipSetDevice(r->e->device));
     r->timed_first = first; r->timed_count = count;
-    r->launches[0] = r->launches[1] = r->launches[2] = 0;
+    for (auto &l : r->launches) l = 0;
     HIP_TRY(hipEventRecord(r->ev_begin, r->e->stream));
     if (r->n_groups <= 1) {
         for (u32 i = first; i < first + count; i++) {
@@ -503,7 +511,7 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
                 TickTimers &tt = r->timers[(size_t)g * r->n_pics + i];
                 tt.on = true;
                 /* de-phase the groups once: group g starts when group g-1 has entered its first tail */
-                if (i == first && g > 0) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->timers[(size_t)(g - 1) * r->n_pics + i].ev[1], 0));
+                if (i == first && g > 0) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->timers[(size_t)(g - 1) * r->n_pics + i].ev[3], 0));
                 if (launch_tick(r->gstream[g], r->d_desc + (size_t)i * r->n_streams + s0, sh, &tt, r->launches, r->stages)) return -1;
             }
         }
@@ -542,23 +550,23 @@ int h264bsdmiReplaySync(h264bsdmi_replay *r)
     return 0;
 }
 
-int h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[4], u32 launches[3])
+int h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[6], u32 launches[5])
 {
     if (!r) return -1;
     HIP_TRY(hipSetDevice(r->e->device));
     HIP_TRY(hipStreamSynchronize(r->e->stream));
-    out_ms[0] = out_ms[1] = out_ms[2] = out_ms[3] = 0.f;
+    for (int k = 0; k < 6; k++) out_ms[k] = 0.f;
     for (u32 g = 0; g < r->n_groups; g++)
-    for (u32 i0 = r->timed_first; i0 < r->timed_first + r->timed_count; i0++) {
-        const size_t i = (size_t)g * r->n_pics + i0;
-        float ms;
-        HIP_TRY(hipEventElapsedTime(&ms, r->timers[i].ev[0], r->timers[i].ev[1]));
-        out_ms[0] += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, r->timers[i].ev[1], r->timers[i].ev[2]));
-        out_ms[2] += ms;
-    }
-    if (r->timed_count) HIP_TRY(hipEventElapsedTime(&out_ms[3], r->ev_begin, r->ev_end));
-    if (launches) { launches[0] = r->launches[0]; launches[1] = r->launches[1]; launches[2] = r->launches[2]; }
+        for (u32 i0 = r->timed_first; i0 < r->timed_first + r->timed_count; i0++) {
+            const size_t i = (size_t)g * r->n_pics + i0;
+            for (int k = 0; k < 5; k++) {
+                float ms;
+                HIP_TRY(hipEventElapsedTime(&ms, r->timers[i].ev[k], r->timers[i].ev[k + 1]));
+                out_ms[k] += ms;
+            }
+        }
+    if (r->timed_count) HIP_TRY(hipEventElapsedTime(&out_ms[5], r->ev_begin, r->ev_end));
+    if (launches) for (int k = 0; k < 5; k++) launches[k] = r->launches[k];
     return 0;
 }
 

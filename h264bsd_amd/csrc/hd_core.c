@@ -84,19 +84,25 @@ int hd_job_begin(HostDec *d)
     return 0;
 }
 
-/* Dependency level of every intra macroblock: 0 when no intra neighbour among A, B, C, D precedes it,
+/* Derived sections of a frame job whose header (geometry, rec_off, mv_off, coef_off), records, motion vectors
+ * and coefficient blocks are filled in: intra dependency levels + schedule, copy runs, general-inter list,
+ * non-trivial deblocking index, statistics, total size.  Pure function of those inputs (also exported as
+ * h264bsdmiJobFinalize so that tests can hand-craft frame jobs).
+ *
+ * Dependency level of every intra macroblock: 0 when no intra neighbour among A, B, C, D precedes it,
  * else 1 + the deepest of them.  Intra MBs of one level are mutually independent, so the device can
  * reconstruct level by level (all inter MBs first). */
-int hd_job_finish(HostDec *d, int is_idr)
+int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
 {
-    FjHeader *h = (FjHeader *)d->job;
+    FjHeader *h = (FjHeader *)job;
     const uint32_t n = h->n_mbs, w = h->width_mbs;
-    FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
-    uint32_t max_level = 0, n_intra = 0;
+    FjMbRec *recs = (FjMbRec *)(job + h->rec_off);
+    uint32_t max_level = 0, n_intra = 0, n_absent = 0;
     uint8_t any_dbk = 0;
     for (uint32_t a = 0; a < n; a++) {
         FjMbRec *r = &recs[a];
         any_dbk |= r->dbk;
+        if (r->kind == FJ_MB_ABSENT) n_absent++;
         if (r->kind == FJ_MB_INTER || r->kind == FJ_MB_ABSENT) continue;
         const uint32_t x = a % w, y = a / w;
         int lvl = -1;
@@ -112,14 +118,14 @@ int hd_job_finish(HostDec *d, int is_idr)
         n_intra++;
     }
     const uint32_t n_levels = n_intra ? max_level + 1 : 0;
-    h->n_coef_blocks = d->coef_blocks;
-    h->lvl_off = fj_align32(h->coef_off + d->coef_blocks * 32u);
+    h->n_coef_blocks = coef_blocks;
+    h->lvl_off = fj_align32(h->coef_off + coef_blocks * 32u);
     h->idx_off = fj_align32(h->lvl_off + (n_levels + 1) * 4u);
     h->copy_off = fj_align32(h->idx_off + n_intra * 2u);
     {
         /* Classify the inter macroblocks.  cls bit0: uniform (16 equal mvs, one reference, no coefficients);
          * bit1: additionally whole-sample for luma and chroma -> pure copy. */
-        const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(d->job + h->mv_off);
+        const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(job + h->mv_off);
         uint8_t *cls = (uint8_t *)calloc(n, 1);
         if (!cls) return -1;
         uint32_t n_gen = 0;
@@ -133,7 +139,7 @@ int hd_job_finish(HostDec *d, int is_idr)
             if (!(cls[a] & 2)) n_gen++;
         }
         /* copy list: runs of up to 4 horizontally adjacent copy MBs with equal reference and mv */
-        FjCopy *cp = (FjCopy *)(d->job + h->copy_off);
+        FjCopy *cp = (FjCopy *)(job + h->copy_off);
         uint32_t n_copy = 0;
         for (uint32_t a = 0; a < n; a++) {
             if (!(cls[a] & 2)) continue;
@@ -143,7 +149,7 @@ int hd_job_finish(HostDec *d, int is_idr)
                 last->slot == recs[a].ref_slot[0] && last->dx == (m0[0] >> 2) && last->dy == (m0[1] >> 2)) {
                 last->count++;
             } else {
-                if ((uint8_t *)&cp[n_copy + 1] > d->job + d->job_cap) { free(cls); return -1; }
+                if ((uint8_t *)&cp[n_copy + 1] > job + cap) { free(cls); return -1; }
                 cp[n_copy].mb = (uint16_t)a; cp[n_copy].slot = recs[a].ref_slot[0]; cp[n_copy].count = 1;
                 cp[n_copy].dx = (int16_t)(m0[0] >> 2); cp[n_copy].dy = (int16_t)(m0[1] >> 2);
                 n_copy++;
@@ -152,7 +158,7 @@ int hd_job_finish(HostDec *d, int is_idr)
         h->n_copy = n_copy;
         h->n_gen = n_gen;
         h->gen_off = fj_align32(h->copy_off + n_copy * 8u);
-        FjGen *gi = (FjGen *)(d->job + h->gen_off);
+        FjGen *gi = (FjGen *)(job + h->gen_off);
         for (uint32_t a = 0; a < n; a++) {
             if (recs[a].kind != FJ_MB_INTER || (cls[a] & 2)) continue;
             const int16_t *m0 = mvs[a][0];
@@ -166,7 +172,7 @@ int hd_job_finish(HostDec *d, int is_idr)
         /* deblocking: a uniform MB whose filtered left/top neighbours are uniform too, with the same reference and
          * mv components closer than 4 quarter samples, has all-zero strengths (8.7.2.1) — never visited again */
         h->dbk_off = fj_align32(h->gen_off + n_gen * 16u);
-        uint16_t *di = (uint16_t *)(d->job + h->dbk_off);
+        uint16_t *di = (uint16_t *)(job + h->dbk_off);
         uint32_t n_dbk = 0;
         for (uint32_t a = 0; a < n; a++) {
             FjMbRec *r = &recs[a];
@@ -188,11 +194,11 @@ int hd_job_finish(HostDec *d, int is_idr)
         h->n_dbk = n_dbk;
         h->total_bytes = fj_align32(h->dbk_off + n_dbk * 2u);
         free(cls);
-        if (h->total_bytes > d->job_cap) return -1;
+        if (h->total_bytes > cap) return -1;
     }
     {   /* intra schedule: counting sort of the intra MB addresses by dependency level */
-        uint32_t *lvl_start = (uint32_t *)(d->job + h->lvl_off);
-        uint16_t *idx = (uint16_t *)(d->job + h->idx_off);
+        uint32_t *lvl_start = (uint32_t *)(job + h->lvl_off);
+        uint16_t *idx = (uint16_t *)(job + h->idx_off);
         memset(lvl_start, 0, (n_levels + 1) * 4u);
         for (uint32_t a = 0; a < n; a++)
             if (recs[a].kind != FJ_MB_INTER && recs[a].kind != FJ_MB_ABSENT) lvl_start[recs[a].intra_level + 1]++;
@@ -205,19 +211,26 @@ int hd_job_finish(HostDec *d, int is_idr)
         free(cursor);
     }
     {   /* zero the alignment gaps so that a frame job is a pure function of the bitstream */
-        const uint32_t ends[6] = { h->coef_off + d->coef_blocks * 32u, h->lvl_off + (n_levels + 1) * 4u,
+        const uint32_t ends[6] = { h->coef_off + coef_blocks * 32u, h->lvl_off + (n_levels + 1) * 4u,
                                    h->idx_off + n_intra * 2u, h->copy_off + h->n_copy * 8u, h->gen_off + h->n_gen * 16u,
                                    h->dbk_off + h->n_dbk * 2u };
         const uint32_t nexts[6] = { h->lvl_off, h->idx_off, h->copy_off, h->gen_off, h->dbk_off, h->total_bytes };
-        for (int i = 0; i < 6; i++) if (nexts[i] > ends[i]) memset(d->job + ends[i], 0, nexts[i] - ends[i]);
+        for (int i = 0; i < 6; i++) if (nexts[i] > ends[i]) memset(job + ends[i], 0, nexts[i] - ends[i]);
     }
     h->n_intra = n_intra;
     h->n_intra_levels = n_levels;
-    h->n_inter = d->n_inter;
+    h->n_inter = n - n_intra - n_absent;
+    h->any_deblock = any_dbk ? 1 : 0;
+    return 0;
+}
+
+int hd_job_finish(HostDec *d, int is_idr)
+{
+    FjHeader *h = (FjHeader *)d->job;
+    if (fj_finalize(d->job, d->job_cap, d->coef_blocks)) return -1;
     h->cur_slot = (uint8_t)d->dpb.cur;
     h->n_slots = (uint8_t)d->dpb.n_slots;
     h->is_idr = (uint8_t)is_idr;
-    h->any_deblock = any_dbk ? 1 : 0;
     h->pic_seq = d->pic_seq++;
     d->job_open = 0;
     return 0;

@@ -309,6 +309,7 @@ int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_
 /* hd_api.c helpers used across files */
 int  hd_job_begin(HostDec *d);
 int  hd_job_finish(HostDec *d, int is_idr);
+int  fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks);
 
 #ifdef __cplusplus
 }

@@ -455,7 +455,7 @@ constexpr int IW_STRIDE = 32;                        /* luma window: 21 rows x 2
 constexpr int IC_STRIDE = 16;                        /* chroma windows: 9 rows x 16 bytes, two planes */
 constexpr int INTER_WAVE_LDS = 21 * IW_STRIDE + 2 * 9 * IC_STRIDE;
 
-__global__ __launch_bounds__(256) void k_recon_inter(const FrameDesc *__restrict__ frames)
+__global__ __launch_bounds__(256, 6) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * INTER_WAVE_LDS];
     const FrameDesc &fd = frames[blockIdx.y];
@@ -846,9 +846,9 @@ __device__ __forceinline__ EdgeThr thr_of(uint32_t ia, uint32_t ib)
     return t;
 }
 
-constexpr int LS = 32;                               /* deblock luma tile: 20 rows x 20 cols, stride 32 */
-constexpr int CS = 16;                               /* deblock chroma tiles: 10 rows x 12 cols, stride 16 */
-constexpr int WORKER_LDS = 1024;                     /* LDS per deblocking worker (= half a wavefront)   */
+constexpr int LS = 36;                               /* deblock luma tile: 20 rows x 20 cols; 9-dword stride = no bank conflicts for row-per-lane reads */
+constexpr int CS = 20;                               /* deblock chroma tiles: 10 rows x 12 cols, 5-dword stride */
+constexpr int WORKER_LDS = 1280;                     /* LDS per deblocking worker (= half a wavefront)   */
 
 /* Everything a worker can fetch about a macroblock BEFORE its neighbours are final: the deblocking
  * record and the macroblock's own (still un-filtered) samples.  Issued one diagonal ahead. */

@@ -23,6 +23,12 @@ extern "C" {
 typedef void (*h264bsdmi_job_cb)(void *user, const u8 *blob, u32 bytes);
 u32 h264bsdmiInitCapture(storage_t *pStorage, u32 noOutputReordering, h264bsdmi_job_cb cb, void *user);
 
+/* Complete a frame job built outside the parser (tests, tools): given a buffer whose FjHeader geometry /
+ * rec_off / mv_off / coef_off, records, motion vectors and n_coef_blocks coefficient blocks are filled in,
+ * derive the schedules (intra levels, copy runs, general-inter list, deblocking index) and total_bytes exactly
+ * as the parser does.  cur_slot / n_slots / is_idr stay as the caller set them.  0 = ok. */
+int h264bsdmiJobFinalize(u8 *job, u32 capacity, u32 n_coef_blocks);
+
 /* ---- device engine ---- */
 /* Number of usable GPUs (0 when the HIP runtime finds none); selects the device for this process. */
 int  h264bsdmiDeviceCount(void);
@@ -51,10 +57,10 @@ int  h264bsdmiReplayChecksums(h264bsdmi_replay *r, u32 slot, unsigned long long 
  * set's ARGB planes; fetch one with ...FetchConverted. */
 int  h264bsdmiReplayConvert(h264bsdmi_replay *r, u32 slot, int fmt);
 int  h264bsdmiReplayFetchConverted(h264bsdmi_replay *r, u32 stream, u32 *dst);
-/* HIP-event timing of the kernels of the last h264bsdmiReplayRun(): ms per kernel class
- * out[0]=k_recon_inter, out[1]=0 (reserved), out[2]=k_frame_tail (intra + deblocking), out[3]=whole run;
- * launches[0..2] = number of launches per class. */
-int  h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[4], u32 launches[3]);
+/* HIP-event timing (events on the engine's own stream) of the last h264bsdmiReplayRun(), summed over its
+ * ticks: out_ms[0..4] = k_copy, k_recon_inter, k_dbk, k_frame_intra, k_frame_dbk; out_ms[5] = whole run;
+ * launches[0..4] = number of launches of each kernel. */
+int  h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[6], u32 launches[5]);
 /* Split the streams of the set into n_groups (1..8) groups, each on its own HIP stream, so that the
  * latency-bound per-picture kernel of one group overlaps the throughput-bound kernels of another.
  * With more than one group the per-class times of h264bsdmiReplayTimings() are sums over concurrently

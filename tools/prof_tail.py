@@ -10,7 +10,7 @@ for tick in (10, 20, 40):
     rep.run(tick,1); rep.sync()
     out=np.zeros((16,8),dtype=np.uint64)
     L.h264bsdmiDebugTailProfile(0, ctypes.c_void_p(out.ctypes.data))
-    print('tick',tick,'timings',rep.timings())
+    print('tick',tick,'timings',{k:v for k,v in rep.timings().items()})
     print(' cols: setup(levels+sort) filter barrier nfilt maxlevel (cycles, per wave)')
     for w in (0,1,7,15): print(' wave',w, out[w,:5])
     print(' mean', out[:,:5].mean(axis=0))
