@@ -152,6 +152,12 @@ def main():
         units_per_launch = n_mbs * n_pics * args.streams * args.steps / launches
         achieved = alg_per_mb * units_per_launch / (avg_launch_us * 1e-6) / 1e9       # GB/s
         path_gbs = alg_bytes_stream * args.streams * args.steps / (dev_total_ms * 1e-3) / 1e9
+        traffic = None
+        try:   # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes (profiles/)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"][dom]
+            traffic = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "1080p macroblocks/s", "value": mbs / elapsed, "unit": "macroblocks/s",
             "fps": pics_per_step * args.steps / elapsed,
@@ -163,7 +169,8 @@ def main():
                                    "inter+intra reconstruction + in-loop deblocking, bit-exact vs reference verified on device",
                        "streams_per_gpu": args.streams, "pictures_per_step": pics_per_step, "parallelism": f"streams/{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "alg_bytes_per_launch": alg_per_mb * units_per_launch,
                          "alg_bytes_per_mb": alg_per_mb, "mbs_per_launch": units_per_launch,
                          "avg_launch_us": avg_launch_us, "launches": launches,
                          "whole_path_GBs": path_gbs, "whole_path_frac": path_gbs / HBM_PEAK_GBS,
