@@ -155,7 +155,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     if (timed) HIP_TRY(hipEventRecord(tt->ev[4], st));
     if (s.any_deblock && (stages & 4u)) {
         const uint32_t nl = s.max_w + 2 * s.max_h, n = s.max_mbs;
-        const size_t lds = (size_t)h264k::TAIL_WORKERS * h264k::WORKER_LDS + ((n + 15) & ~15u) + 2 * 2 * (size_t)((n + 7) & ~7u) + 2 * 4 * (size_t)(nl + 2);
+        const size_t lds = (size_t)h264k::TAIL_WORKERS * h264k::WORKER_LDS + 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64;
+        (void)nl;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
             HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_dbk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -880,8 +880,10 @@ __device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int hl
 /* In-loop filter of one macroblock by one worker = 32 lanes (hl = lane & 31): vertical edges, then
  * horizontal edges (8.7).  mb < 0: this half of the wavefront idles.  w = worker-private LDS. */
 __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, const DbkPrefetch &p, uint8_t *w,
-                                           int nxt, DbkPrefetch &nxt_pf)
+                                           int nxt, DbkPrefetch &nxt_pf, unsigned long long *tp = nullptr)
 {
+#define DTICK() (tp ? __builtin_readcyclecounter() : 0ull)
+    const unsigned long long d0 = DTICK();
     uint8_t *lt = w, *ct0 = w + 20 * LS, *bs_s = w + 20 * LS + 2 * 10 * CS;
     const bool act = mb >= 0;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
@@ -895,6 +897,9 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, 
      * bytes 8,9 (lanes 16..19) */
     const unsigned long long bl = __ballot(act && (hl >> 2) == 0 && p.bsb != 0), bt = __ballot(act && (hl >> 2) == 4 && p.bsb != 0);
     const uint32_t hsel = (threadIdx.x & 32) ? 32 : 0;
+    /* whole phases are skipped when no lane of the wavefront has a non-zero strength in that direction:
+     * bytes 0..7 (lanes hl < 16) = vertical edges, bytes 8..15 (lanes hl >= 16) = horizontal edges */
+    const bool any_v = __ballot(act && hl < 16 && p.bsb != 0) != 0ull, any_h = __ballot(act && hl >= 16 && p.bsb != 0) != 0ull;
     const bool f_left = (p.thr.w & FJ_DBK_LEFT) && ((uint32_t)(bl >> hsel) != 0u);
     const bool f_top = (p.thr.w & FJ_DBK_TOP) && ((uint32_t)(bt >> hsel) != 0u);
 
@@ -949,9 +954,10 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, 
     const int al_l = c_alpha[ia_l & 63u], be_l = c_beta[ib_l & 63u];
     const int al_t = c_alpha[ia_t & 63u], be_t = c_beta[ib_t & 63u];
     wave_sync();
+    const unsigned long long d1 = DTICK();
 
     /* ---- vertical edges: a lane owns one sample row across all four edges ---- */
-    if (act) {
+    if (act && any_v) {
         if (hl < 16) {
             uint8_t *rowp = &lt[(4 + hl) * LS];
             int px[20];
@@ -990,9 +996,10 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, 
         }
     }
     wave_sync();
+    const unsigned long long d2 = DTICK();
 
     /* ---- horizontal edges: a lane owns one sample column ---- */
-    if (act) {
+    if (act && any_h) {
         if (hl < 16) {
             uint8_t *colp = &lt[4 + hl];
             int px[20];
@@ -1023,6 +1030,7 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, 
         }
     }
     wave_sync();
+    const unsigned long long d3 = DTICK();
 
     /* ---- store: own macroblock, the 3 (1) columns of the left and rows of the upper neighbour ---- */
     if (act) {
@@ -1054,6 +1062,8 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, 
         }
     }
     wave_sync();          /* tiles are reused by this worker's next macroblock */
+    if (tp) { const unsigned long long d4 = DTICK(); tp[0] += d1 - d0; tp[1] += d2 - d1; tp[2] += d3 - d2; tp[3] += d4 - d3; }
+#undef DTICK
 }
 
 /* ------------------------------------------------------------------ per-picture persistent kernels */
@@ -1082,31 +1092,30 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
 /* In-loop deblocking of one picture.  The filter of macroblock (x,y) touches its own samples, the last
  * 4 columns of (x-1,y) and the last 4 rows of (x,y-1); in the standard's raster order that makes it
  * depend on exactly three earlier steps: (x-1,y), (x,y-1) and (x+1,y-1) — and only if those macroblocks
- * are filtered at all (most P-picture macroblocks have all-zero strengths and are never touched).  So:
- *   1. level[mb] = 1 + max(level of the filtered ones among those three), by a sweep over anti-diagonals;
- *   2. counting sort of the filtered macroblocks by level (LDS);
- *   3. level by level, 32 workers (half wavefronts) filter one macroblock each; the next level's
- *      macroblock (record + own samples) is prefetched while the current one is filtered.
- * Dynamic LDS: 32 x WORKER_LDS tiles | any[n_mbs] u8 | level[n_mbs] u16 | order[n_mbs] u16 |
- *              start[NL+2] u32 | cursor[NL+2] u32,  NL = wmb + 2*hmb. */
+ * are filtered at all (most P-picture macroblocks have all-zero strengths and are never touched).
+ * Dataflow scheduling inside the workgroup, all state in LDS:
+ *   dep[mb]   number of filtered macroblocks among those three that are not finished yet
+ *   queue[]   ready list: every filtered macroblock is pushed exactly once, when its dep reaches 0
+ *   head/tail claim / publish cursors (LDS atomics)
+ * 32 workers (half wavefronts) claim queue slots in order, wait for the slot to be published, filter the
+ * macroblock (one slot ahead is prefetched: record + own samples), wait for their stores, then release the
+ * three dependants (x+1,y), (x,y+1), (x-1,y+1).  No level barriers: a worker never idles while a macroblock
+ * is ready.  Same-CU visibility of the stores needs only s_waitcnt vmcnt(0) before the LDS release.
+ * Dynamic LDS: 32 x WORKER_LDS tiles | any[n_mbs] u8 | dep[n_mbs] u8 | queue[n_mbs] u16 | counters. */
 __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const FrameDesc &fd = frames[blockIdx.x];
     if (!fd.any_deblock) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, hl = lane & 31;
-    const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs, NL = wmb + 2 * hmb;
+    const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
     uint8_t *anyf = lds + TAIL_WORKERS * WORKER_LDS;
-    uint16_t *lvl = reinterpret_cast<uint16_t *>(anyf + ((n_mbs + 15) & ~15));
-    uint16_t *order = lvl + ((n_mbs + 7) & ~7);
-    uint32_t *start = reinterpret_cast<uint32_t *>(order + ((n_mbs + 7) & ~7));
-    uint32_t *cursor = start + NL + 2;
+    uint8_t *dep = anyf + ((n_mbs + 15) & ~15);
+    uint16_t *queue = reinterpret_cast<uint16_t *>(dep + ((n_mbs + 15) & ~15));
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + ((n_mbs + 7) & ~7));   /* [0] head, [1] tail, [2] total */
     uint8_t *wlds = lds + (wave * 2 + half) * WORKER_LDS;
+    (void)prof; (void)hmb;
 
-    unsigned long long t_acc[4] = { 0, 0, 0, 0 };
-    const bool profiling = prof != nullptr && blockIdx.x == 0;
-#define TICK() (profiling ? __builtin_readcyclecounter() : 0ull)
-    const unsigned long long tA = TICK();
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(fd.dbk + (size_t)n_mbs * DBK_REC_BYTES);
         uint32_t *srcw = reinterpret_cast<uint32_t *>(fd.dbk + (size_t)n_mbs * DBK_REC_BYTES);
@@ -1114,81 +1123,71 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *
             reinterpret_cast<uint32_t *>(anyf)[i] = src[i];
             srcw[i] = 0;                 /* k_dbk only visits non-trivial MBs: leave the flags clean for the next picture */
         }
-        for (int i = tid; i < NL + 2; i += blockDim.x) { start[i] = 0; cursor[i] = 0; }
+        for (int i = tid; i < (n_mbs + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
+        if (tid < 4) ctr[tid] = 0;
     }
     __syncthreads();
-    /* 1. dependency levels, anti-diagonal sweep (every dependency lies on an earlier diagonal) */
-    const int D = (wmb - 1) + 2 * (hmb - 1);
-    for (int d = 0; d <= D; d++) {
-        const int ylo = max(0, (d - (wmb - 1) + 1) >> 1), yhi = min(hmb - 1, d >> 1);
-        const int y = ylo + tid;
-        if (y <= yhi) {
-            const int x = d - 2 * y, mb = y * wmb + x;
-            int l = 0;
-            if (anyf[mb]) {
-                if (x > 0) l = max(l, (int)lvl[mb - 1]);
-                if (y > 0) l = max(l, (int)lvl[mb - wmb]);
-                if (y > 0 && x + 1 < wmb) l = max(l, (int)lvl[mb - wmb + 1]);
-                l += 1;
-                atomicAdd(&start[l + 1], 1u);            /* histogram, shifted by one for the prefix sum */
-            }
-            lvl[mb] = (uint16_t)l;
-        }
-        __syncthreads();
-    }
-    /* 2. prefix sum (levels 1..NL) and fill */
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (int l = 1; l <= NL + 1; l++) { acc += start[l]; start[l] = acc; }   /* start[l] = first index of level l+... see below */
-    }
-    __syncthreads();
-    /* after the scan start[l] = number of macroblocks with level < l  (start[1] = 0): level l occupies
-     * [start[l], start[l+1]) */
     for (int mb = tid; mb < n_mbs; mb += blockDim.x) {
-        const int l = lvl[mb];
-        if (l) order[start[l] + atomicAdd(&cursor[l], 1u)] = (uint16_t)mb;
+        if (!anyf[mb]) continue;
+        const int x = mb % wmb, y = mb / wmb;
+        const int d = (x > 0 && anyf[mb - 1] ? 1 : 0) + (y > 0 && anyf[mb - wmb] ? 1 : 0) + (y > 0 && x + 1 < wmb && anyf[mb - wmb + 1] ? 1 : 0);
+        dep[mb] = (uint8_t)d;
+        atomicAdd(&ctr[2], 1u);
+        if (d == 0) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)mb;
     }
     __syncthreads();
-    const unsigned long long tB = TICK();
-    int maxl = 0;
-    for (int l = NL; l >= 1; l--) if (start[l + 1] != start[l]) { maxl = l; break; }
+    const uint32_t total = ctr[2];
+    volatile uint16_t *vq = queue;
 
-    /* 3. filter, level by level */
-    auto item = [&](int l, int k) -> int {               /* k-th macroblock of level l or -1 */
-        if (l > maxl) return -1;
-        const uint32_t s0 = start[l], s1 = start[l + 1];
-        return s0 + (uint32_t)k < s1 ? (int)order[s0 + k] : -1;
-    };
-    const int wk = wave * 2 + half;
-    int nxt = item(1, wk);
-    DbkPrefetch pf = {};
-    dbk_prefetch(fd, nxt, hl, pf);
-    for (int l = 1; l <= maxl; l++) {
-        const unsigned long long t0 = TICK();
-        const int cur = nxt;
-        const DbkPrefetch cp = pf;
-        nxt = item(l + 1, wk);
-        if (__any(cur >= 0)) { deblock_mb(fd, cur, hl, cp, wlds, nxt, pf); t_acc[2] += 1; }
-        else dbk_prefetch(fd, nxt, hl, pf);
-        /* crowded levels (> 32 macroblocks): further rounds, fetched on the spot */
-        const int n_l = (int)(start[l + 1] - start[l]);
-        for (int k = wk + TAIL_WORKERS; k - half - (wk - half) < n_l && (k - half) < n_l + 1; k += TAIL_WORKERS) {
-            const int em = item(l, k);
-            if (!__any(em >= 0)) break;
-            DbkPrefetch ep = {}, dummy = {};
-            dbk_prefetch(fd, em, hl, ep);
-            deblock_mb(fd, em, hl, ep, wlds, -1, dummy);
+    /* every worker owns two claimed slots: cur (being waited for / filtered) and nxt (prefetched when ready) */
+    uint32_t s_cur = 0, s_nxt = 0;
+    if (hl == 0) { s_cur = atomicAdd(&ctr[0], 1u); s_nxt = atomicAdd(&ctr[0], 1u); }
+    s_cur = __shfl(s_cur, half * 32); s_nxt = __shfl(s_nxt, half * 32);
+    int mb_cur = -1, mb_nxt = -1;
+    bool pf_valid = false;
+    uint32_t spins = 0;                  /* safety net: a scheduling bug must end in wrong pixels, never in a hung GPU */
+    DbkPrefetch pf_cur = {};
+    for (;;) {
+        /* look for published slots */
+        if (mb_cur < 0 && s_cur < total) { const int v = vq[s_cur]; if (v != 0xFFFF) mb_cur = v; }
+        if (mb_nxt < 0 && s_nxt < total) { const int v = vq[s_nxt]; if (v != 0xFFFF) mb_nxt = v; }
+        if (!__any(mb_cur >= 0)) {
+            if (__all(s_cur >= total) || ++spins > (1u << 24)) break;
+            __builtin_amdgcn_s_sleep(2);
+            continue;
         }
-        const unsigned long long t1 = TICK();
-        __syncthreads();
-        const unsigned long long t2 = TICK();
-        t_acc[0] += t1 - t0; t_acc[1] += t2 - t1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int run = mb_cur;                                  /* -1 in a half that has nothing ready */
+        DbkPrefetch cp = pf_cur;
+        if (run >= 0 && !pf_valid) dbk_prefetch(fd, run, hl, cp); /* not prefetched ahead: fetch now */
+        const bool want_pf = run >= 0 && mb_nxt >= 0;
+        DbkPrefetch np = {};
+        deblock_mb(fd, run, hl, cp, wlds, want_pf ? mb_nxt : -1, np);
+        if (run >= 0) {
+            /* release: stores done -> dependants */
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (hl < 3) {
+                const int x = run % wmb, y = run / wmb;
+                int dmb = -1;
+                if (hl == 0) { if (x + 1 < wmb) dmb = run + 1; }
+                else if (hl == 1) { if (y + 1 < hmb) dmb = run + wmb; }
+                else { if (y + 1 < hmb && x > 0) dmb = run + wmb - 1; }
+                if (dmb >= 0 && anyf[dmb]) {
+                    /* byte-wide counters: decrement through a 32-bit LDS atomic on the containing word */
+                    uint32_t *w = reinterpret_cast<uint32_t *>(dep + (dmb & ~3));
+                    const uint32_t sh = 8u * (dmb & 3);
+                    const uint32_t old = atomicSub(w, 1u << sh);
+                    if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)dmb;
+                }
+            }
+            /* advance: nxt becomes cur, claim a new nxt */
+            s_cur = s_nxt; mb_cur = mb_nxt; pf_cur = np; pf_valid = want_pf;
+            uint32_t c = 0;
+            if (hl == 0) c = atomicAdd(&ctr[0], 1u);
+            s_nxt = __shfl(c, half * 32); mb_nxt = -1;
+        }
     }
-    if (profiling && lane == 0) {
-        prof[wave * 8 + 0] = tB - tA; prof[wave * 8 + 1] = t_acc[0]; prof[wave * 8 + 2] = t_acc[1];
-        prof[wave * 8 + 3] = t_acc[2]; prof[wave * 8 + 4] = (unsigned long long)maxl;
-    }
-#undef TICK
 }
 
 /* ------------------------------------------------------------------ colour conversion */

@@ -11,8 +11,7 @@ for tick in (10, 20, 40):
     out=np.zeros((16,8),dtype=np.uint64)
     L.h264bsdmiDebugTailProfile(0, ctypes.c_void_p(out.ctypes.data))
     print('tick',tick,'timings',{k:v for k,v in rep.timings().items()})
-    print(' cols: setup(levels+sort) filter barrier nfilt maxlevel (cycles, per wave)')
-    for w in (0,1,7,15): print(' wave',w, out[w,:5])
-    print(' mean', out[:,:5].mean(axis=0))
+    print(' cols: setup filter barrier nfilt maxlevel | load V H store (cycles, per wave)')
+    for w in (0,7,15): print(' wave',w, out[w,:5], out[w,5], out[w,6], out[w,7]&0xffffffff, out[w,7]>>32)
     if tick==10: rep.run(11,9); rep.sync()
     if tick==20: rep.run(21,19); rep.sync()
