@@ -40,7 +40,7 @@
 
 namespace {
 
-struct PendingJob { uint8_t *host; uint32_t bytes; };
+struct PendingJob { uint8_t *host; uint32_t bytes, cap; };
 
 struct StreamCtx {
     uint32_t wmb = 0, hmb = 0, n_slots = 0, frame_bytes = 0;
@@ -48,7 +48,9 @@ struct StreamCtx {
     uint8_t *d_dbk = nullptr;
     uint8_t *h_frame[FJ_MAX_SLOTS] = {};
     uint32_t *h_conv = nullptr, *d_conv = nullptr;
+    std::mutex qmu;                         /* guards pending / free_bufs (submit runs on the caller's threads) */
     std::deque<PendingJob> pending;
+    std::vector<PendingJob> free_bufs;      /* recycled pinned staging buffers */
 };
 
 struct Engine {
@@ -177,8 +179,10 @@ int flush_locked(Engine *e)
     for (;;) {
         std::vector<StreamCtx *> part;
         size_t bytes = 0;
-        for (StreamCtx *s : e->streams)
+        for (StreamCtx *s : e->streams) {
+            std::lock_guard<std::mutex> ql(s->qmu);
             if (!s->pending.empty()) { part.push_back(s); bytes += (s->pending.front().bytes + 255u) & ~255u; }
+        }
         if (part.empty()) return 0;
         if (bytes > e->arena_cap) {
             if (e->d_arena) HIP_TRY(hipFree(e->d_arena));
@@ -195,7 +199,8 @@ int flush_locked(Engine *e)
         size_t off = 0;
         for (size_t i = 0; i < part.size(); i++) {
             StreamCtx *s = part[i];
-            PendingJob &j = s->pending.front();
+            PendingJob j;
+            { std::lock_guard<std::mutex> ql(s->qmu); j = s->pending.front(); }
             HIP_TRY(hipMemcpyAsync(e->d_arena + off, j.host, j.bytes, hipMemcpyHostToDevice, e->stream));
             make_desc(descs[i], j.host, e->d_arena + off, s->d_frames, s->frame_bytes, s->d_dbk, &shape);
             off += (j.bytes + 255u) & ~255u;
@@ -204,7 +209,8 @@ int flush_locked(Engine *e)
         if (launch_tick(e->stream, e->d_desc, shape, nullptr, nullptr)) return -1;
         HIP_TRY(hipStreamSynchronize(e->stream));
         for (StreamCtx *s : part) {
-            hipHostFree(s->pending.front().host);
+            std::lock_guard<std::mutex> ql(s->qmu);
+            s->free_bufs.push_back(s->pending.front());
             s->pending.pop_front();
         }
     }
@@ -217,6 +223,8 @@ void stream_release(StreamCtx *s)
 {
     for (auto &j : s->pending) hipHostFree(j.host);
     s->pending.clear();
+    for (auto &j : s->free_bufs) hipHostFree(j.host);
+    s->free_bufs.clear();
     if (s->d_frames) hipFree(s->d_frames);
     if (s->d_dbk) hipFree(s->d_dbk);
     s->d_dbk = nullptr;
@@ -245,13 +253,27 @@ int sink_configure(void *user, uint32_t wmb, uint32_t hmb, uint32_t n_slots)
 
 int sink_submit(void *user, const uint8_t *blob, uint32_t bytes)
 {
+    /* runs on the application's threads, concurrently for different decoder instances: only the stream's own
+     * queue lock is taken, and not while the job is copied into pinned memory */
     SinkUser *u = static_cast<SinkUser *>(user);
-    std::lock_guard<std::mutex> lk(u->e->mu);
-    PendingJob j;
+    PendingJob j = { nullptr, bytes, 0 };
+    {
+        std::lock_guard<std::mutex> ql(u->s->qmu);
+        for (size_t i = 0; i < u->s->free_bufs.size(); i++)
+            if (u->s->free_bufs[i].cap >= bytes) {
+                j = u->s->free_bufs[i];
+                u->s->free_bufs.erase(u->s->free_bufs.begin() + (long)i);
+                break;
+            }
+    }
+    if (!j.host) {
+        HIP_TRY(hipSetDevice(u->e->device));
+        j.cap = bytes + bytes / 2 + 65536;                  /* pinned: recycled across pictures */
+        HIP_TRY(hipHostMalloc((void **)&j.host, j.cap, hipHostMallocDefault));
+    }
     j.bytes = bytes;
-    HIP_TRY(hipSetDevice(u->e->device));
-    HIP_TRY(hipHostMalloc((void **)&j.host, bytes, hipHostMallocDefault));
     memcpy(j.host, blob, bytes);
+    std::lock_guard<std::mutex> ql(u->s->qmu);
     u->s->pending.push_back(j);
     return 0;
 }
