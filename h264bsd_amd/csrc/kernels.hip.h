@@ -451,8 +451,8 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
  * 9x9 chroma reference windows are staged ONCE in LDS with row-wide coalesced dword loads and every lane
  * cuts its 6x12-byte register window out of LDS; otherwise every lane fetches its own window from global
  * memory.  Both feed the same textbook interpolation (luma_from_window / chroma_from_rows). */
-constexpr int IW_STRIDE = 32;                        /* luma window: 21 rows x 28 bytes */
-constexpr int IC_STRIDE = 16;                        /* chroma windows: 9 rows x 16 bytes, two planes */
+constexpr int IW_STRIDE = 36;                        /* luma window: 21 rows x 28 bytes; 9-dword stride: no bank conflicts for row-per-lane reads */
+constexpr int IC_STRIDE = 20;                        /* chroma windows: 9 rows x 16 bytes, two planes */
 constexpr int INTER_WAVE_LDS = 21 * IW_STRIDE + 2 * 9 * IC_STRIDE;
 
 __global__ __launch_bounds__(256, 6) void k_recon_inter(const FrameDesc *__restrict__ frames)
