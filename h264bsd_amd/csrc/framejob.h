@@ -11,8 +11,10 @@
  * What the blob replaces in the reference: the per-MB hand-off at seam A/B of SURVEY.md §1 —
  * macroblockLayer_t + mbStorage_t (reference src/h264bsd_macroblock_layer.h:140-185) as consumed by
  * h264bsdDecodeMacroblock (src/h264bsd_macroblock_layer.c:965) and h264bsdFilterPicture
- * (src/h264bsd_deblocking.c:575).  All indices inside a record are RASTER 4x4-block indices
- * (blk = 4*by + bx), not the H.264 zig-zag block order the reference uses.
+ * (src/h264bsd_deblocking.c:575).  Motion vectors and the levels inside a coefficient block are in RASTER
+ * order (blk = 4*by + bx; c = 4*row + col); the per-block bit fields (`coded`, `i4mode`) keep the H.264
+ * block order (z-order: z = 8*(by>>1) + 4*(bx>>1) + 2*(by&1) + (bx&1)), which is also the order in which a
+ * macroblock's coefficient blocks are stored.
  *
  * All integers little-endian; every section starts 32-byte aligned.
  * Section order in the blob: header | records | motion vectors | coefficients | level starts |
@@ -111,20 +113,20 @@ typedef struct FjMbRec {
     uint8_t  dbk;
     int8_t   alpha_off;       /* FilterOffsetA = 2*slice_alpha_c0_offset_div2                 */
     int8_t   beta_off;
-    uint32_t coded;           /* bit r (0..15): luma 4x4 block r has coefficients;
-                                 16..19 Cb AC, 20..23 Cr AC; 24 luma DC; 25 chroma DC         */
+    uint32_t coded;           /* bit z (0..15): luma 4x4 block z (H.264 block order) has coefficients;
+                                 16..19 Cb AC, 20..23 Cr AC (raster 2x2); 24 luma DC; 25 chroma DC */
     uint32_t coef_idx;        /* first coefficient block of this MB (16 x int16 each)         */
     uint8_t  ref_slot[4];     /* reference DPB slot per 8x8 quadrant (raster)                 */
     int8_t   cqp_off;         /* chroma_qp_index_offset of the MB's PPS (deblock QPc)         */
     uint8_t  dbk_trivial;     /* 1: every boundary strength of this MB is zero by construction (host-proved) */
     uint16_t intra_level;     /* dependency level among intra MBs of the picture              */
-    uint8_t  i4mode[8];       /* 16 nibbles: Intra4x4PredMode of raster block r               */
+    uint8_t  i4mode[8];       /* 16 nibbles: Intra4x4PredMode of block z (H.264 block order)  */
 } FjMbRec;                    /* 32 bytes */
 
 /* Order of a macroblock's coefficient blocks starting at coef_idx:
  *   [luma DC 4x4 (raster c[i][j])]            if FJ_CODED_LUMA_DC
- *   luma raster blocks r with bit r set, ascending r; each block is RASTER 4x4 (row-major),
- *        un-dequantised levels, position 0 forced to 0 for Intra16x16 AC blocks
+ *   luma blocks z with bit z set, ascending z (H.264 block order); each block is RASTER 4x4
+ *        (row-major), un-dequantised levels, position 0 forced to 0 for Intra16x16 AC blocks
  *   [chroma DC: Cb c[0..3] raster 2x2, Cr c[4..7], 8 pad]   if FJ_CODED_CHROMA_DC
  *   chroma AC blocks 16..23 with bit set, ascending (position 0 = 0)
  * I_PCM: 12 blocks = 384 raw samples as bytes: Y[256] raster, Cb[64], Cr[64].
