@@ -799,49 +799,43 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
 #undef I4_L
 
 /* ------------------------------------------------------------------ deblocking */
-/* Edge filters, branch-free (every lane computes both the bS<4 and the bS=4 result and selects): the
- * caller skips whole edges whose strengths are zero in every lane of the wavefront.
- * v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3   (8.7.2.3 / 8.7.2.4) */
-__device__ __forceinline__ void filter_luma8(int v[8], int bs, int alpha, int beta, int tc0)
+/* Edge filter, branch-free per lane (8.7.2.3 / 8.7.2.4): every lane computes the bS<4 result and — only if
+ * some lane of the wavefront has bS = 4 — the bS=4 result, then selects.  Chroma lines run through the SAME
+ * instruction stream (chroma = true): only p0/q0 change, tc = tc0 + 1, and bS=4 uses the weak formula, which is
+ * exactly the luma filter with ap = aq = false.  v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 */
+__device__ __forceinline__ void filter_edge8(int v[8], int bs, int alpha, int beta, int tc0, bool chroma)
 {
     const int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
     const bool fs = bs != 0 && abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta;
-    const bool ap = abs(p2 - p0) < beta, aq = abs(q2 - q0) < beta;
+    const bool ap = !chroma && abs(p2 - p0) < beta, aq = !chroma && abs(q2 - q0) < beta;
     const bool strong = bs == 4;
     /* bS < 4 */
-    const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+    const int tc = tc0 + (chroma ? 1 : (ap ? 1 : 0) + (aq ? 1 : 0));
     const int d = clip3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
     const int avg = (p0 + q0 + 1) >> 1;
-    const int n_p0 = clip255(p0 + d), n_q0 = clip255(q0 - d);
-    const int n_p1 = p1 + clip3(-tc0, tc0, (p2 + avg - 2 * p1) >> 1);
-    const int n_q1 = q1 + clip3(-tc0, tc0, (q2 + avg - 2 * q1) >> 1);
-    /* bS == 4 */
-    const bool sm = abs(p0 - q0) < ((alpha >> 2) + 2);
-    const bool sp = sm && ap, sq = sm && aq;
-    const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
-    const int s_p1 = (p2 + p1 + p0 + q0 + 2) >> 2;
-    const int s_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-    const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
-    const int s_q1 = (p0 + q0 + q1 + q2 + 2) >> 2;
-    const int s_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-    v[3] = fs ? (strong ? s_p0 : n_p0) : p0;
-    v[4] = fs ? (strong ? s_q0 : n_q0) : q0;
-    v[2] = fs && (strong ? sp : ap) ? (strong ? s_p1 : n_p1) : p1;
-    v[5] = fs && (strong ? sq : aq) ? (strong ? s_q1 : n_q1) : q1;
-    v[1] = fs && strong && sp ? s_p2 : p2;
-    v[6] = fs && strong && sq ? s_q2 : q2;
-}
-/* v[0..3] = p1 p0 q0 q1 */
-__device__ __forceinline__ void filter_chroma4(int v[4], int bs, int alpha, int beta, int tc0)
-{
-    const int p1 = v[0], p0 = v[1], q0 = v[2], q1 = v[3];
-    const bool fs = bs != 0 && abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta;
-    const int tc = tc0 + 1;
-    const int d = clip3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
-    const int n_p0 = bs == 4 ? (2 * p1 + p0 + q1 + 2) >> 2 : clip255(p0 + d);
-    const int n_q0 = bs == 4 ? (2 * q1 + q0 + p1 + 2) >> 2 : clip255(q0 - d);
-    v[1] = fs ? n_p0 : p0;
-    v[2] = fs ? n_q0 : q0;
+    int r_p0 = clip255(p0 + d), r_q0 = clip255(q0 - d);
+    int r_p1 = p1 + clip3(-tc0, tc0, (p2 + avg - 2 * p1) >> 1);
+    int r_q1 = q1 + clip3(-tc0, tc0, (q2 + avg - 2 * q1) >> 1);
+    int r_p2 = p2, r_q2 = q2;
+    bool m_p1 = ap, m_q1 = aq, m_p2 = false, m_q2 = false;
+    if (__ballot(strong && fs)) {                       /* wave-uniform: intra edges only */
+        const bool sm = abs(p0 - q0) < ((alpha >> 2) + 2);
+        const bool sp = sm && ap, sq = sm && aq;
+        const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
+        const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
+        if (strong) {
+            r_p0 = s_p0; r_q0 = s_q0;
+            r_p1 = (p2 + p1 + p0 + q0 + 2) >> 2; r_q1 = (p0 + q0 + q1 + q2 + 2) >> 2;
+            r_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3; r_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+            m_p1 = sp; m_q1 = sq; m_p2 = sp; m_q2 = sq;
+        }
+    }
+    v[3] = fs ? r_p0 : p0;
+    v[4] = fs ? r_q0 : q0;
+    v[2] = fs && m_p1 ? r_p1 : p1;
+    v[5] = fs && m_q1 ? r_q1 : q1;
+    v[1] = fs && m_p2 ? r_p2 : p2;
+    v[6] = fs && m_q2 ? r_q2 : q2;
 }
 
 struct EdgeThr { int alpha, beta, ia; };
@@ -956,77 +950,55 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, 
     wave_sync();
     const unsigned long long d1 = DTICK();
 
-    /* ---- vertical edges: a lane owns one sample row across all four edges ---- */
+    /* ---- vertical edges: a lane owns one sample row across all edges.  Lanes 0..15 = luma rows (20 bytes, edges
+     * at byte 4,8,12,16), lanes 16..31 = chroma rows (12 bytes, edges at byte 4 and 8 = luma edges 0 and 2): one
+     * instruction stream for both ---- */
     if (act && any_v) {
-        if (hl < 16) {
-            uint8_t *rowp = &lt[(4 + hl) * LS];
-            int px[20];
+        const int cplane = (hl - 16) >> 3, crow_ = (hl - 16) & 7;
+        uint8_t *rowp = chroma ? &ct0[cplane * 10 * CS + (2 + crow_) * CS] : &lt[(4 + hl) * LS];
+        const int kseg = chroma ? (crow_ >> 1) : (hl >> 2);
+        int px[20];
 #pragma unroll
-            for (int w4 = 0; w4 < 5; w4++) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(rowp + 4 * w4);
-                px[4 * w4] = v & 255; px[4 * w4 + 1] = (v >> 8) & 255; px[4 * w4 + 2] = (v >> 16) & 255; px[4 * w4 + 3] = v >> 24;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int bs = bs_s[4 * e + (hl >> 2)];
-                const uint32_t ia = e ? ia_in : ia_l;
-                if (__ballot(bs != 0)) filter_luma8(px + 4 * e, bs, e ? al_in : al_l, e ? be_in : be_l, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0);
-            }
-#pragma unroll
-            for (int w4 = 0; w4 < 5; w4++)
-                *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = pack4(px[4 * w4], px[4 * w4 + 1], px[4 * w4 + 2], px[4 * w4 + 3]);
-        } else {
-            const int plane = (hl - 16) >> 3, r = (hl - 16) & 7;
-            uint8_t *rowp = &ct0[plane * 10 * CS + (2 + r) * CS];
-            int px[12];
-#pragma unroll
-            for (int w4 = 0; w4 < 3; w4++) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(rowp + 4 * w4);
-                px[4 * w4] = v & 255; px[4 * w4 + 1] = (v >> 8) & 255; px[4 * w4 + 2] = (v >> 16) & 255; px[4 * w4 + 3] = v >> 24;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const int bs = bs_s[4 * e + (r >> 1)];
-                const uint32_t ia = e ? ia_in : ia_l;
-                if (__ballot(bs != 0)) filter_chroma4(px + 2 + 2 * e, bs, e ? al_in : al_l, e ? be_in : be_l, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0);
-            }
-#pragma unroll
-            for (int w4 = 0; w4 < 3; w4++)
-                *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = pack4(px[4 * w4], px[4 * w4 + 1], px[4 * w4 + 2], px[4 * w4 + 3]);
+        for (int w4 = 0; w4 < 5; w4++) {
+            const uint32_t v = (w4 < 3 || !chroma) ? *reinterpret_cast<const uint32_t *>(rowp + 4 * w4) : 0u;
+            px[4 * w4] = v & 255; px[4 * w4 + 1] = (v >> 8) & 255; px[4 * w4 + 2] = (v >> 16) & 255; px[4 * w4 + 3] = v >> 24;
         }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int bs = chroma ? (e < 2 ? bs_s[8 * e + kseg] : 0) : bs_s[4 * e + kseg];
+            const uint32_t ia = e ? ia_in : ia_l;
+            if (__ballot(bs != 0)) filter_edge8(px + 4 * e, bs, e ? al_in : al_l, e ? be_in : be_l, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0, chroma);
+        }
+#pragma unroll
+        for (int w4 = 0; w4 < 5; w4++)
+            if (w4 < 3 || !chroma)
+                *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = pack4(px[4 * w4], px[4 * w4 + 1], px[4 * w4 + 2], px[4 * w4 + 3]);
     }
     wave_sync();
     const unsigned long long d2 = DTICK();
 
-    /* ---- horizontal edges: a lane owns one sample column ---- */
+    /* ---- horizontal edges: a lane owns one sample column; chroma columns (10 rows) sit at px[2..11] so that
+     * their edges (rows 2 and 6 of the tile) fall on px[4] and px[8] like the first two luma edges ---- */
     if (act && any_h) {
-        if (hl < 16) {
-            uint8_t *colp = &lt[4 + hl];
-            int px[20];
+        const int cplane = (hl - 16) >> 3, ccol_ = (hl - 16) & 7;
+        uint8_t *colp = chroma ? &ct0[cplane * 10 * CS + 4 + ccol_] : &lt[4 + hl];
+        const int kseg = chroma ? (ccol_ >> 1) : (hl >> 2);
+        int px[20];
 #pragma unroll
-            for (int r = 0; r < 20; r++) px[r] = colp[r * LS];
+        for (int r = 0; r < 20; r++) {
+            if (!chroma) px[r] = colp[r * LS];
+            else px[r] = (r >= 2 && r < 12) ? colp[(r - 2) * CS] : 0;
+        }
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int bs = bs_s[16 + 4 * e + (hl >> 2)];
-                const uint32_t ia = e ? ia_in : ia_t;
-                if (__ballot(bs != 0)) filter_luma8(px + 4 * e, bs, e ? al_in : al_t, e ? be_in : be_t, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0);
-            }
+        for (int e = 0; e < 4; e++) {
+            const int bs = chroma ? (e < 2 ? bs_s[16 + 8 * e + kseg] : 0) : bs_s[16 + 4 * e + kseg];
+            const uint32_t ia = e ? ia_in : ia_t;
+            if (__ballot(bs != 0)) filter_edge8(px + 4 * e, bs, e ? al_in : al_t, e ? be_in : be_t, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0, chroma);
+        }
 #pragma unroll
-            for (int r = 1; r < 20; r++) colp[r * LS] = (uint8_t)px[r];
-        } else {
-            const int plane = (hl - 16) >> 3, c = (hl - 16) & 7;
-            uint8_t *colp = &ct0[plane * 10 * CS + 4 + c];
-            int px[10];
-#pragma unroll
-            for (int r = 0; r < 10; r++) px[r] = colp[r * CS];
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const int bs = bs_s[16 + 4 * e + (c >> 1)];
-                const uint32_t ia = e ? ia_in : ia_t;
-                if (__ballot(bs != 0)) filter_chroma4(px + 2 * e, bs, e ? al_in : al_t, e ? be_in : be_t, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0);
-            }
-#pragma unroll
-            for (int r = 1; r < 10; r++) colp[r * CS] = (uint8_t)px[r];
+        for (int r = 1; r < 20; r++) {
+            if (!chroma) colp[r * LS] = (uint8_t)px[r];
+            else if (r >= 3 && r < 12) colp[(r - 2) * CS] = (uint8_t)px[r];
         }
     }
     wave_sync();
