@@ -89,8 +89,8 @@ int hd_job_begin(HostDec *d)
  * non-trivial deblocking index, statistics, total size.  Pure function of those inputs (also exported as
  * h264bsdmiJobFinalize so that tests can hand-craft frame jobs).
  *
- * Dependency level of every intra macroblock: 0 when no intra neighbour among A, B, C, D precedes it,
- * else 1 + the deepest of them.  Intra MBs of one level are mutually independent, so the device can
+ * Dependency level of every intra macroblock: 0 when none of the intra neighbours whose samples its
+ * prediction modes actually read (subset of A, B, C, D) precedes it, else 1 + the deepest of them.  Intra MBs of one level are mutually independent, so the device can
  * reconstruct level by level (all inter MBs first). */
 int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
 {
@@ -106,12 +106,36 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
         if (r->kind == FJ_MB_INTER || r->kind == FJ_MB_ABSENT) continue;
         const uint32_t x = a % w, y = a / w;
         int lvl = -1;
+        /* which neighbouring macroblocks does the prediction of this one actually read? (8.3.1.2, 8.3.3, 8.3.4) */
+        unsigned need = 0;
+        if (r->kind == FJ_MB_I16x16) {
+            const int m = r->pred & 3;
+            need |= m == 0 ? FJ_AVAIL_B : m == 1 ? FJ_AVAIL_A : m == 2 ? (FJ_AVAIL_A | FJ_AVAIL_B) : (FJ_AVAIL_A | FJ_AVAIL_B | FJ_AVAIL_D);
+        } else if (r->kind == FJ_MB_I4x4) {
+            for (int z = 0; z < 16; z++) {
+                const int bx = ((z >> 2) & 1) * 2 + (z & 1), by = (z >> 3) * 2 + ((z >> 1) & 1);
+                if (bx && by) continue;
+                const int m = (r->i4mode[z >> 1] >> ((z & 1) * 4)) & 15;
+                const int uses_left = m == 1 || m == 2 || m == 4 || m == 5 || m == 6 || m == 8;
+                const int uses_top = m == 0 || m == 2 || m == 3 || m == 4 || m == 5 || m == 6 || m == 7;
+                const int uses_corner = m == 4 || m == 5 || m == 6;
+                if (bx == 0 && (uses_left || uses_corner)) need |= FJ_AVAIL_A;
+                if (by == 0 && (uses_top || uses_corner)) need |= FJ_AVAIL_B;
+                if (bx == 0 && by == 0 && uses_corner) need |= FJ_AVAIL_D;
+                if (bx == 3 && by == 0 && (m == 3 || m == 7)) need |= FJ_AVAIL_C;
+            }
+        }
+        if (r->kind != FJ_MB_IPCM) {
+            const int m = (r->pred >> 2) & 3;
+            need |= m == 0 ? (FJ_AVAIL_A | FJ_AVAIL_B) : m == 1 ? FJ_AVAIL_A : m == 2 ? FJ_AVAIL_B : (FJ_AVAIL_A | FJ_AVAIL_B | FJ_AVAIL_D);
+        }
+        need &= r->avail;             /* an unavailable neighbour is never read (its samples are replaced by 128) */
 #define DEP(cond, idx) do { if (cond) { const FjMbRec *q = &recs[idx]; \
             if (q->kind != FJ_MB_INTER && q->kind != FJ_MB_ABSENT && (int)q->intra_level > lvl) lvl = q->intra_level; } } while (0)
-        DEP(x > 0, a - 1);
-        DEP(y > 0, a - w);
-        DEP(y > 0 && x + 1 < w, a - w + 1);
-        DEP(y > 0 && x > 0, a - w - 1);
+        DEP(x > 0 && (need & FJ_AVAIL_A), a - 1);
+        DEP(y > 0 && (need & FJ_AVAIL_B), a - w);
+        DEP(y > 0 && x + 1 < w && (need & FJ_AVAIL_C), a - w + 1);
+        DEP(y > 0 && x > 0 && (need & FJ_AVAIL_D), a - w - 1);
 #undef DEP
         r->intra_level = (uint16_t)(lvl + 1);
         if ((uint32_t)(lvl + 1) > max_level) max_level = (uint32_t)(lvl + 1);

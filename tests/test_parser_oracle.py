@@ -95,10 +95,35 @@ def test_frame_job_schedules_are_consistent(pic, captured):
     level_of = np.full(n, -1)
     for l in range(len(lvl) - 1):
         level_of[idx[lvl[l]:lvl[l + 1]]] = l
+    def needed(r):          # neighbours whose samples the MB's prediction modes read (A=1 B=2 C=4 D=8)
+        kind, avail, pred = int(r[0]), int(r[3]), int(r[4])
+        need = 0
+        if kind == 2:
+            need |= (2, 1, 3, 11)[pred & 3]
+        elif kind == 1:
+            for z in range(16):
+                bx, by = ((z >> 2) & 1) * 2 + (z & 1), (z >> 3) * 2 + ((z >> 1) & 1)
+                if bx and by:
+                    continue
+                m = (int(r[24 + (z >> 1)]) >> ((z & 1) * 4)) & 15
+                left, top, corner = m in (1, 2, 4, 5, 6, 8), m in (0, 2, 3, 4, 5, 6, 7), m in (4, 5, 6)
+                if bx == 0 and (left or corner):
+                    need |= 1
+                if by == 0 and (top or corner):
+                    need |= 2
+                if bx == 0 and by == 0 and corner:
+                    need |= 8
+                if bx == 3 and by == 0 and m in (3, 7):
+                    need |= 4
+        if kind != 3:
+            need |= (3, 1, 2, 11)[(pred >> 2) & 3]
+        return need & avail
+
     for a in intra[:: max(1, len(intra) // 500)]:
         x, y = a % w, a // w
-        for ok, nb in ((x > 0, a - 1), (y > 0, a - w), (y > 0 and x + 1 < w, a - w + 1), (y > 0 and x > 0, a - w - 1)):
-            if ok and level_of[nb] >= 0:
+        need = needed(rec[a])
+        for bit, ok, nb in ((1, x > 0, a - 1), (2, y > 0, a - w), (4, y > 0 and x + 1 < w, a - w + 1), (8, y > 0 and x > 0, a - w - 1)):
+            if ok and (need & bit) and level_of[nb] >= 0:
                 assert level_of[nb] < level_of[a]
     # inter MBs: copy runs + general index partition them
     run_mb = copy[:, 0].astype(int) | (copy[:, 1].astype(int) << 8)
