@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdCroppingParams", "h264bsdSampleAspectRatio", "h264bsdCheckValidParamSets", "h264bsdFlushBuffer",
     "h264bsdProfile", "h264bsdAlloc", "h264bsdFree", "h264bsdConvertToRGBA", "h264bsdConvertToBGRA",
     "h264bsdConvertToYCbCrA",
-    "h264bsdmiInitCapture", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush",
+    "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush",
     "h264bsdmiReplayCreate", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
@@ -76,6 +76,8 @@ def lib():
     for n in ("h264bsdConvertToRGBA", "h264bsdConvertToBGRA", "h264bsdConvertToYCbCrA"):
         getattr(L, n).argtypes = [u32, u32, vp, vp]
         getattr(L, n).restype = None
+    L.h264bsdmiNextOutputInfo.argtypes = [vp, P32, P32, P32]
+    L.h264bsdmiNextOutputInfo.restype = ctypes.c_int
     L.h264bsdmiJobFinalize.argtypes = [ctypes.c_void_p, u32, u32]
     L.h264bsdmiSetDevice.argtypes = [ctypes.c_int]
     L.h264bsdmiReplayCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32]
@@ -144,6 +146,12 @@ class Decoder:
             return None
         arr = np.frombuffer(ctypes.string_at(p, nbytes), dtype=dtype)
         return arr, int(a.value), int(b.value), int(c.value)
+
+    def next_output_info(self):
+        """(slot, picId, isIdr, numErrMbs) of the next output picture, or None (works in capture mode)"""
+        a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        slot = self._L.h264bsdmiNextOutputInfo(self._st, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return None if slot < 0 else (slot, int(a.value), int(b.value), int(c.value))
 
     def frame_bytes(self):
         return self.pic_width() * self.pic_height() * 384

@@ -103,6 +103,14 @@ u8 *h264bsdNextOutputPicture(storage_t *s, u32 *picId, u32 *isIdrPic, u32 *numEr
     return a->hd->sink.fetch(a->hd->sink.user, o->slot);
 }
 
+int h264bsdmiNextOutputInfo(storage_t *s, u32 *picId, u32 *isIdrPic, u32 *numErrMbs)
+{
+    ApiDec *a = dec_of(s);
+    if (!a) return -1;
+    const OutPic *o = pop_output(a, picId, isIdrPic, numErrMbs);
+    return o ? (int)o->slot : -1;
+}
+
 static u32 *next_converted(storage_t *s, u32 *picId, u32 *isIdrPic, u32 *numErrMbs, int fmt)
 {
     ApiDec *a = dec_of(s);

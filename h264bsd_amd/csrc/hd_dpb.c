@@ -193,7 +193,17 @@ int hd_dpb_check_gaps(Dpb *d, uint32_t frame_num, int is_ref_pic, int gaps_allow
             if (sliding_window(d)) return -1;
             while (fullness(d) >= d->dpb_size)
                 if (bump_one(d)) break;
-            int s = hd_dpb_alloc_current(d);
+            /* A non-existing frame has no pixels, so it may sit on a slot whose picture was just bumped into
+             * the output queue (the picture being decoded may not).  The reference gets the same effect by
+             * swapping frame-buffer pointers after the loop (dpb.c:1318-1345); without it a full DPB plus a
+             * gap would leave no slot for the current picture. */
+            int s = -1;
+            for (uint32_t i = 0; i < d->n_slots && s < 0; i++) {
+                if (is_ref(&d->pic[i]) || d->pic[i].to_be_displayed) continue;
+                for (uint32_t k = d->out_idx; k < d->n_out; k++)
+                    if (d->out[k].slot == i) { s = (int)i; break; }
+            }
+            if (s < 0) s = hd_dpb_alloc_current(d);
             if (s < 0) return -1;
             DpbPic *p = &d->pic[s];
             memset(p, 0, sizeof(*p));

@@ -22,6 +22,11 @@ extern "C" {
  * return NULL (there are no pixels).  cb's blob pointer is valid only during the call. */
 typedef void (*h264bsdmi_job_cb)(void *user, const u8 *blob, u32 bytes);
 u32 h264bsdmiInitCapture(storage_t *pStorage, u32 noOutputReordering, h264bsdmi_job_cb cb, void *user);
+/* Pop the next picture of the output queue like h264bsdNextOutputPicture() (reference
+ * src/h264bsd_decoder.c:1045-1066 -> h264bsdDpbOutputPicture, src/h264bsd_dpb.c:1415), but return the DPB
+ * slot that holds it (the FjHeader.cur_slot of the job that wrote it) instead of pixels; -1 when the queue
+ * is empty.  Works in capture mode, where it is the only way to observe the output order. */
+int h264bsdmiNextOutputInfo(storage_t *pStorage, u32 *picId, u32 *isIdrPic, u32 *numErrMbs);
 
 /* Complete a frame job built outside the parser (tests, tools): given a buffer whose FjHeader geometry /
  * rec_off / mv_off / coef_off, records, motion vectors and n_coef_blocks coefficient blocks are filled in,

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/synth_golden.json: for every synthetic stream of tests/test_synth_streams.py the sha1 of
+the stream, the h264bsdDecode call trace and (sha1 of the frame, picId, isIdr, numErrMbs) of every output
+picture in output order — all from the compiled REFERENCE decoder (oracle/_ref, built from /root/reference by
+oracle/Makefile).  Run in the build container: python tests/golden/make_synth_golden.py"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import synth                      # noqa: E402
+from synth_configs import CONFIGS  # noqa: E402
+from h264writer import StreamWriter  # noqa: E402
+
+out = {}
+for name, cfg in CONFIGS.items():
+    data = StreamWriter(**cfg).build()
+    trace, pics = synth.decode_reference(data)
+    assert not any(t[0] >= 3 for t in trace) and not any(p[3] for p in pics), f"{name}: the reference reports errors"
+    assert len(pics) == cfg.get("n_pics", 6), name
+    out[name] = dict(stream_sha1=hashlib.sha1(data).hexdigest(), bytes=len(data), trace=trace, pics=pics)
+    print(name, len(data), "bytes", len(pics), "pictures")
+json.dump(out, open(os.path.join(HERE, "synth_golden.json"), "w"), indent=0)

@@ -1,0 +1,95 @@
+"""Decode a byte stream with (a) the compiled reference and (b) this repo's host parser + a pixel back end,
+returning comparable traces: the h264bsdDecode call trace and the output pictures in output order.
+
+Back ends for (b): "oracle" (CPU, frame jobs rendered by oracle/pixel_oracle.c — for the -m "not gpu" tests)
+or "gpu" (the product: h264bsdInit + HIP engine through the C ABI)."""
+import ctypes
+import hashlib
+
+import numpy as np
+
+import h264bsd_amd
+from h264bsd_amd import capi
+from oracle import pyoracle
+
+
+def decode_reference(data):
+    """-> (trace, [(sha1 of frame, picId, isIdr, numErrMbs)])"""
+    ref = pyoracle.RefDecoder()
+    lib = ref.lib
+    buf = ctypes.create_string_buffer(data, len(data))
+    base = ctypes.addressof(buf)
+    dec = lib.h264bsdAlloc()
+    assert lib.h264bsdInit(dec, 0) == 0
+    off, trace, pics = 0, [], []
+    rb = ctypes.c_uint32(0)
+    a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+
+    def drain():
+        wmb, hmb = lib.h264bsdPicWidth(dec), lib.h264bsdPicHeight(dec)
+        while True:
+            p = lib.h264bsdNextOutputPicture(dec, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+            if not p:
+                break
+            pics.append((hashlib.sha1(ctypes.string_at(p, wmb * hmb * 384)).hexdigest(), a.value, b.value, c.value))
+    pic_id = stall = 0
+    while off < len(data):
+        r = lib.h264bsdDecode(dec, base + off, len(data) - off, pic_id, ctypes.byref(rb))
+        trace.append((int(r), int(rb.value)))
+        off += rb.value
+        if r == 1:
+            pic_id += 1
+            drain()
+        stall = stall + 1 if rb.value == 0 else 0
+        if stall > 3:
+            break
+    lib.h264bsdFlushBuffer(dec)
+    drain()
+    lib.h264bsdShutdown(dec)
+    lib.h264bsdFree(dec)
+    return trace, pics
+
+
+def decode_ours(data, backend="oracle"):
+    pics, trace = [], []
+    state = {"dpb": None}
+
+    def on_job(blob):
+        if state["dpb"] is None or pyoracle.blob_header(blob)["n_slots"] != len(state["dpb"].slots) or \
+                state["dpb"].frame_bytes != pyoracle.blob_header(blob)["n_mbs"] * 384:
+            state["dpb"] = pyoracle.OracleDpb(blob)
+        state["dpb"].decode(blob)
+
+    dec = capi.Decoder(capture=on_job if backend == "oracle" else None)
+    buf = ctypes.create_string_buffer(data, len(data))
+    base, off = ctypes.addressof(buf), 0
+
+    def drain():
+        while True:
+            if backend == "oracle":
+                o = dec.next_output_info()
+                if o is None:
+                    break
+                slot, pid, idr, nerr = o
+                frame = state["dpb"].slots[slot][: state["dpb"].frame_bytes]
+            else:
+                o = dec.next_output_picture()
+                if o is None:
+                    break
+                frame, pid, idr, nerr = o
+            pics.append((hashlib.sha1(np.ascontiguousarray(frame).tobytes()).hexdigest(), pid, idr, nerr))
+    pic_id = stall = 0
+    while off < len(data):
+        r, rb = dec.decode(base + off, len(data) - off, pic_id)
+        trace.append((r, rb))
+        off += rb
+        if r == 1:
+            pic_id += 1
+            drain()
+        stall = stall + 1 if rb == 0 else 0
+        if stall > 3:
+            break
+    dec.flush_buffer()
+    drain()
+    dec.close()
+    return trace, pics

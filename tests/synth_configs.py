@@ -1,0 +1,32 @@
+"""The synthetic baseline streams of the corner-feature tests: features the three bundled
+x264 streams never use.  Every entry is a keyword set for tests/h264writer.StreamWriter; the reference's answers for
+them are in tests/golden/synth_golden.json (tests/golden/make_synth_golden.py)."""
+from h264writer import random_config
+
+CONFIGS = {
+    "plain_ip":            dict(n_pics=12, wmb=6, hmb=5, seed=2),
+    "multi_slice_idc012":  dict(n_pics=10, wmb=5, hmb=4, seed=3, slices_per_pic=3, idc=(0, 1, 2)),
+    "ipcm":                dict(n_pics=8, seed=4, p_pcm=0.2, slices_per_pic=2),
+    "constrained_intra":   dict(n_pics=10, seed=5, constrained_intra=1, wmb=6, hmb=4, slices_per_pic=2),
+    "multi_ref":           dict(n_pics=12, seed=6, num_ref_frames=3, num_ref_idx_active=3, wmb=5, hmb=4),
+    "ref_list_reordering": dict(n_pics=12, seed=7, num_ref_frames=4, num_ref_idx_active=2, reorder=True, wmb=5, hmb=4),
+    "fmo_interleaved":     dict(n_pics=10, seed=8, wmb=6, hmb=4, fmo=dict(type=0, groups=3, run_length=[3, 5, 2]), slices_per_pic=2),
+    "fmo_dispersed":       dict(n_pics=8, seed=9, wmb=6, hmb=4, fmo=dict(type=1, groups=4)),
+    "fmo_foreground":      dict(n_pics=8, seed=10, wmb=6, hmb=5, fmo=dict(type=2, groups=3, rects=[(1, 14), (16, 28)])),
+    "fmo_raster_scan":     dict(n_pics=8, seed=11, wmb=6, hmb=5, fmo=dict(type=4, groups=2, direction=0, rate=7)),
+    "fmo_wipe":            dict(n_pics=8, seed=12, wmb=6, hmb=5, fmo=dict(type=5, groups=2, direction=1, rate=4)),
+    "fmo_explicit":        dict(n_pics=8, seed=13, wmb=4, hmb=3, fmo=dict(type=6, groups=3, ids=[0, 1, 2, 0, 2, 2, 1, 1, 0, 0, 1, 2])),
+    "aso":                 dict(n_pics=10, seed=14, wmb=5, hmb=4, slices_per_pic=4, aso=True),
+    "mmco_long_term":      dict(n_pics=30, seed=19, num_ref_frames=5, num_ref_idx_active=4, mmco=True, reorder=True, poc_type=0),
+    "poc0_display_reorder": dict(n_pics=12, seed=16, poc_type=0, poc_pattern=[0, 3, 1, 2], num_ref_frames=3, wmb=5, hmb=4),
+    "poc1_nonref_idr":     dict(n_pics=12, seed=17, poc_type=1, num_ref_frames=2, non_ref_every=3, idr_period=5),
+    "frame_num_gaps":      dict(n_pics=20, seed=18, num_ref_frames=3, num_ref_idx_active=2, gaps=1, reorder=True),
+    "gaps_full_dpb":       dict(wmb=5, hmb=6, n_pics=23, seed=29, poc_type=0, num_ref_frames=1, num_ref_idx_active=1, slices_per_pic=3,
+                                idc=(2,), chroma_qp_offset=-7, aso=True, non_ref_every=4, gaps=1, reorder=True),
+    "everything":          dict(n_pics=40, seed=20, num_ref_frames=4, num_ref_idx_active=3, mmco=True, reorder=True, gaps=1, poc_type=0,
+                                poc_pattern=[0, 2, 1], slices_per_pic=2, non_ref_every=4, idr_period=13, wmb=5, hmb=4),
+    "high_qp":             dict(n_pics=10, seed=21, wmb=6, hmb=4, max_qp=51, chroma_qp_offset=12, slices_per_pic=2, idc=(0, 2)),
+    "vga_multi_slice":     dict(n_pics=4, seed=22, wmb=40, hmb=30, slices_per_pic=3, num_ref_frames=2, num_ref_idx_active=2, idc=(0, 2)),
+}
+for _s in range(160, 200):
+    CONFIGS[f"random_{_s}"] = random_config(_s)

@@ -1,0 +1,64 @@
+"""Corner features of the baseline profile on synthetic streams.
+
+tests/h264writer.py writes random but valid streams that use what the bundled x264 streams never do: several
+slices per picture, arbitrary slice order, every slice-group map type, I_PCM, constrained intra prediction,
+disable_deblocking_filter_idc 0/1/2 with offsets, several reference frames with list reordering, adaptive marking
+(MMCO 1-6, long-term frames), frame_num gaps, POC types 0/1/2 with display reordering, non-reference pictures,
+repeated IDRs.  The expected answers (h264bsdDecode call trace, output order, picId/isIdr/numErrMbs and a hash of
+every output frame) come from the compiled reference decoder (tests/golden/make_synth_golden.py).
+
+CPU test: host parser + CPU oracle.  GPU test: the product (h264bsdInit + HIP engine) through the C ABI."""
+import hashlib
+import json
+import os
+
+import pytest
+
+import synth
+from h264writer import StreamWriter
+from synth_configs import CONFIGS
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth_golden.json")))
+_streams = {}
+
+
+def stream_of(name):
+    if name not in _streams:
+        data = StreamWriter(**CONFIGS[name]).build()
+        if hashlib.sha1(data).hexdigest() != GOLD[name]["stream_sha1"]:
+            pytest.skip("the writer produced a different stream than the one the golden answers were made from "
+                        "(numpy random stream changed?) — regenerate with tests/golden/make_synth_golden.py")
+        _streams[name] = data
+    return _streams[name]
+
+
+def check(name, backend):
+    data = stream_of(name)
+    trace, pics = synth.decode_ours(data, backend)
+    g = GOLD[name]
+    assert [list(t) for t in trace] == g["trace"], "h264bsdDecode call trace differs from the reference"
+    assert [p[1:] for p in pics] == [tuple(p[1:]) for p in g["pics"]], "output order / picId / isIdr / numErrMbs differ"
+    bad = [i for i, (p, q) in enumerate(zip(pics, g["pics"])) if p[0] != q[0]]
+    assert not bad, f"output pictures {bad} are not bit-exact"
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_parser_and_oracle_match_reference(built, name):
+    check(name, "oracle")
+
+
+def test_golden_matches_live_reference(built):
+    """the committed answers are what oracle/_ref says today (a few streams; skipped where _ref is absent)"""
+    from oracle import pyoracle
+    if not os.path.exists(pyoracle.REF_SO):
+        pytest.skip("oracle/_ref not built")
+    for name in ("everything", "gaps_full_dpb", "mmco_long_term", "fmo_explicit"):
+        trace, pics = synth.decode_reference(stream_of(name))
+        assert [list(t) for t in trace] == GOLD[name]["trace"]
+        assert [list(p) for p in pics] == GOLD[name]["pics"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_gpu_matches_reference(built, name):
+    check(name, "gpu")
