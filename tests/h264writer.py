@@ -40,18 +40,22 @@ class BitWriter:
             self.u(1, 1 - v)
 
     def align_zero(self):
-        while len(self.bits) % 8:
-            self.bits.append(0)
+        self.bits.append(2)            # marker: resolved in bytes(), so that bit strings can be spliced before it
 
     def trailing(self):
         self.bits.append(1)
-        while len(self.bits) % 8:
-            self.bits.append(0)
+        self.bits.append(2)
 
     def bytes(self):
-        assert len(self.bits) % 8 == 0
-        b = np.packbits(np.array(self.bits, dtype=np.uint8))
-        return b.tobytes()
+        out = []
+        for b in self.bits:
+            if b == 2:
+                while len(out) % 8:
+                    out.append(0)
+            else:
+                out.append(b)
+        assert len(out) % 8 == 0
+        return np.packbits(np.array(out, dtype=np.uint8)).tobytes()
 
 
 def nal(nal_ref_idc, nal_type, rbsp, start_code=b"\x00\x00\x00\x01"):
@@ -317,7 +321,7 @@ class StreamWriter:
                       idc=(0,), p_pcm=0.0, constrained_intra=0, fmo=None, idr_period=0, poc_pattern=None, reorder=False,
                       mmco=False, chroma_qp_offset=0, p_intra_in_p=0.2, p_skip=0.3, log2_max_frame_num=4,
                       num_reorder_frames=None, max_qp=28, aso=False, non_ref_every=0, gaps=0,
-                      offset_non_ref=1)
+                      offset_non_ref=1, redundant=False)
         self.c.update(cfg)
         self.rng = np.random.default_rng(self.c["seed"])
         self.sps = dict(poc_type=self.c["poc_type"], num_ref_frames=self.c["num_ref_frames"], wmb=self.c["wmb"], hmb=self.c["hmb"],
@@ -326,7 +330,7 @@ class StreamWriter:
                         max_dec_frame_buffering=max(self.c["num_ref_frames"], 1) if self.c["num_reorder_frames"] is not None else None)
         self.pps = dict(num_ref_idx_active=self.c["num_ref_idx_active"], constrained_intra=self.c["constrained_intra"],
                         fmo=self.c["fmo"], chroma_qp_offset=self.c["chroma_qp_offset"], pic_init_qp=26,
-                        pic_order_present=0, deblocking_control=1)
+                        pic_order_present=0, deblocking_control=1, redundant_pic_cnt_present=int(bool(self.c["redundant"])))
 
     # -- helpers
     def _avail(self, mbs, a, sid, dx, dy):
@@ -531,18 +535,21 @@ class StreamWriter:
         max_lt = None              # MaxLongTermFrameIdx ("no long-term frame indices" = None)
         idr_id = 0
         since_idr = 0
+        avoid_fn = None
         for pic in range(c["n_pics"]):
             is_idr = pic == 0 or bool(c["idr_period"] and pic % c["idr_period"] == 0)
             is_ref = is_idr or not (c["non_ref_every"] and pic % c["non_ref_every"] == c["non_ref_every"] - 1)
             if is_idr:
                 refs = []; cur_abs = 0; since_idr = 0; max_lt = None
-            elif c["gaps"] and r.random() < 0.25 and (len(refs) < nrf or any(f["lt"] is None for f in refs)):
-                # skip 1..2 frame numbers: the decoder inserts "non-existing" frames (8.2.5.2)
+            elif c["gaps"] and r.random() < 0.25 and (len(refs) < nrf or any(f["lt"] is None for f in refs)) and avoid_fn is None:
+                # skip 1..2 frame numbers: the decoder inserts "non-existing" frames (8.2.5.2).  (Not right after an
+                # MMCO-5 picture: landing on its frame_num again would hide the access-unit boundary.)
                 for _ in range(int(r.integers(1, 3))):
                     refs.append(dict(abs=cur_abs, exist=False, lt=None))
                     while len(refs) > nrf:
                         refs.remove(min([f for f in refs if f["lt"] is None], key=lambda f: f["abs"]))
                     cur_abs += 1
+            avoid_fn = None
             cur_fn = cur_abs % max_fn
             can_p = not is_idr and any(f["exist"] for f in refs)
             is_p = can_p and r.random() < 0.85
@@ -565,7 +572,7 @@ class StreamWriter:
                         kind = int(r.choice([1, 2, 3, 3, 4, 6, 5] if c["mmco"] else [1]))
                         # the reference rejects more than one op 4 / 5 / 6 and ops 1-3 next to op 5 (slice_header.c DecRefPicMarking)
                         if (kind in (4, 5, 6) and any(o[0] == kind for o in ops)) or \
-                                (kind == 5 and any(o[0] in (1, 2, 3) for o in ops)) or (kind in (1, 2, 3) and mmco5):
+                                (kind == 5 and any(o[0] in (1, 2, 3, 6) for o in ops)) or (kind in (1, 2, 3) and mmco5):
                             continue
                         shorts = [f for f in after if f["lt"] is None]
                         longs = [f for f in after if f["lt"] is not None]
@@ -647,6 +654,7 @@ class StreamWriter:
             if c["aso"]:
                 slices = [slices[i] for i in r.permutation(len(slices)).tolist()]
             mbs = [MbState() for _ in range(n)]
+            copies = []
             for sid, members in enumerate(slices):
                 bw = BitWriter()
                 bw.ue(members[0])
@@ -664,6 +672,7 @@ class StreamWriter:
                     bw.u(nb, (2 * disp) % (1 << nb))
                 elif c["poc_type"] == 1:
                     bw.se(0)
+                head, bw = bw, BitWriter()        # redundant_pic_cnt goes between `head` and the rest
                 usable = [0]
                 if slice_is_p:
                     lst = self._init_list(refs, cur_abs, cur_fn, max_fn)
@@ -732,7 +741,22 @@ class StreamWriter:
                         self._write_mb_intra(bw, mbs, a, sid, cur, slice_is_p, c["constrained_intra"], kind)
                     i += 1
                 bw.trailing()
-                out += nal((1 + int(r.integers(0, 3))) if is_ref else 0, 5 if is_idr else 1, bw.bytes())
+
+                def emit(rpc):
+                    full = BitWriter()
+                    full.bits = list(head.bits)
+                    if c["redundant"]:
+                        full.ue(rpc)
+                    full.bits += bw.bits
+                    return nal((1 + int(r.integers(0, 3))) if is_ref else 0, 5 if is_idr else 1, full.bytes())
+                out += emit(0)
+                if c["redundant"]:
+                    # exact duplicates as redundant slices: before the picture is complete they are parsed again over
+                    # already decoded macroblocks (reference slice_data.c:134,195), afterwards they are skipped
+                    # (decoder.c:308)
+                    copies.append(emit)
+                    if r.random() < 0.6:
+                        out += copies[int(r.integers(0, len(copies)))](int(r.integers(1, 3)))
             # ---- what the decoder holds after this picture
             if is_idr:
                 idr_id = (idr_id + 1) % 16
@@ -745,6 +769,7 @@ class StreamWriter:
                     cur_abs = 0
                     refs.append(dict(abs=0, exist=True, lt=cur_lt))
                     since_idr = 0
+                    avoid_fn = cur_fn
                 else:
                     refs.append(dict(abs=cur_abs, exist=True, lt=cur_lt))
                 cur_abs += 1
@@ -792,4 +817,4 @@ def random_config(seed):
                 poc_pattern=[None, [0, 2, 1], [0, 3, 1, 2], [0, 4, 2, 1, 3]][int(r.integers(0, 4))],
                 reorder=bool(r.integers(0, 2)), mmco=bool(r.integers(0, 2)), chroma_qp_offset=int(r.integers(-12, 13)),
                 aso=bool(r.integers(0, 2)), non_ref_every=int(r.choice([0, 0, 3, 4])), gaps=int(r.integers(0, 2)),
-                max_qp=int(r.choice([24, 28, 40, 51])))
+                max_qp=int(r.choice([24, 28, 40, 51])), redundant=bool(r.integers(0, 4) == 0))

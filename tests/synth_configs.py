@@ -25,6 +25,10 @@ CONFIGS = {
                                 idc=(2,), chroma_qp_offset=-7, aso=True, non_ref_every=4, gaps=1, reorder=True),
     "everything":          dict(n_pics=40, seed=20, num_ref_frames=4, num_ref_idx_active=3, mmco=True, reorder=True, gaps=1, poc_type=0,
                                 poc_pattern=[0, 2, 1], slices_per_pic=2, non_ref_every=4, idr_period=13, wmb=5, hmb=4),
+    "redundant_slices":    dict(n_pics=12, seed=32, wmb=6, hmb=4, slices_per_pic=3, redundant=True, p_pcm=0.15, num_ref_frames=2,
+                                num_ref_idx_active=2, idc=(0, 2), aso=True),
+    "redundant_fmo":       dict(n_pics=10, seed=33, wmb=6, hmb=4, slices_per_pic=2, redundant=True, fmo=dict(type=1, groups=3), reorder=True,
+                                num_ref_frames=3, num_ref_idx_active=2),
     "high_qp":             dict(n_pics=10, seed=21, wmb=6, hmb=4, max_qp=51, chroma_qp_offset=12, slices_per_pic=2, idc=(0, 2)),
     "vga_multi_slice":     dict(n_pics=4, seed=22, wmb=40, hmb=30, slices_per_pic=3, num_ref_frames=2, num_ref_idx_active=2, idc=(0, 2)),
 }
