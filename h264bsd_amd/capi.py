@@ -24,11 +24,20 @@ EXPORTED_SYMBOLS = [
     "h264bsdCroppingParams", "h264bsdSampleAspectRatio", "h264bsdCheckValidParamSets", "h264bsdFlushBuffer",
     "h264bsdProfile", "h264bsdAlloc", "h264bsdFree", "h264bsdConvertToRGBA", "h264bsdConvertToBGRA",
     "h264bsdConvertToYCbCrA",
-    "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush",
+    "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush",
     "h264bsdmiReplayCreate", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
 ]
+
+class DevicePicture(ctypes.Structure):
+    """h264bsdmi_device_picture (include/h264bsd_mi355x.h)"""
+    _fields_ = [("data", ctypes.c_void_p), ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("pitch", ctypes.c_uint32),
+                ("format", ctypes.c_uint32), ("picId", ctypes.c_uint32), ("isIdrPic", ctypes.c_uint32),
+                ("numErrMbs", ctypes.c_uint32), ("stream", ctypes.c_void_p)]
+
+
+FMT_RGBA, FMT_BGRA, FMT_YCBCRA, FMT_I420 = 0, 1, 2, 3
 
 JOB_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint32)
 P32 = ctypes.POINTER(ctypes.c_uint32)
@@ -45,12 +54,31 @@ def build(force=False):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  A process that loads this
+    library first and imports torch later would end up with torch bound to a runtime it was not built for
+    ("No HIP GPUs are available").  When torch is installed, load its runtime first so that both share it — the
+    configuration `import torch` before `h264bsd_amd.lib()` gives anyway.  Plain C consumers are unaffected."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
+    _share_torch_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     vp, u32, u8p = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p
     L.h264bsdAlloc.restype = vp
@@ -78,6 +106,8 @@ def lib():
         getattr(L, n).restype = None
     L.h264bsdmiNextOutputInfo.argtypes = [vp, P32, P32, P32]
     L.h264bsdmiNextOutputInfo.restype = ctypes.c_int
+    L.h264bsdmiNextOutputPictureDevice.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DevicePicture)]
+    L.h264bsdmiNextOutputPictureDevice.restype = ctypes.c_int
     L.h264bsdmiJobFinalize.argtypes = [ctypes.c_void_p, u32, u32]
     L.h264bsdmiSetDevice.argtypes = [ctypes.c_int]
     L.h264bsdmiReplayCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32]
@@ -152,6 +182,26 @@ class Decoder:
         a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
         slot = self._L.h264bsdmiNextOutputInfo(self._st, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
         return None if slot < 0 else (slot, int(a.value), int(b.value), int(c.value))
+
+    def next_output_picture_device(self, fmt=FMT_I420, crop=False):
+        """Pop the next output picture and leave it in HBM.  Returns (tensor, picId, isIdr, numErrMbs) or None;
+        tensor is a zero-copy torch.uint8 CUDA tensor: [h*3/2, w] for I420 (Y rows, then Cb and Cr rows of w/2 bytes
+        packed back to back), [h, w, 4] for the converted formats.  It aliases decoder memory: valid until the next
+        decode()/close() of this instance — clone() to keep it."""
+        import torch
+        pic = DevicePicture()
+        rc = self._L.h264bsdmiNextOutputPictureDevice(self._st, fmt, 1 if crop else 0, ctypes.byref(pic))
+        if rc == 0:
+            return None
+        if rc < 0:
+            raise RuntimeError(f"h264bsdmiNextOutputPictureDevice failed ({rc})")
+        n = pic.width * pic.height * 3 // 2 if fmt == FMT_I420 else pic.width * pic.height * 4
+
+        class _Buf:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (pic.data, False), "version": 2}
+        t = torch.as_tensor(_Buf(), device="cuda")
+        t = t.view(pic.height * 3 // 2, pic.width) if fmt == FMT_I420 else t.view(pic.height, pic.width, 4)
+        return t, int(pic.picId), int(pic.isIdrPic), int(pic.numErrMbs)
 
     def frame_bytes(self):
         return self.pic_width() * self.pic_height() * 384

@@ -111,6 +111,38 @@ int h264bsdmiNextOutputInfo(storage_t *s, u32 *picId, u32 *isIdrPic, u32 *numErr
     return o ? (int)o->slot : -1;
 }
 
+int h264bsdmiNextOutputPictureDevice(storage_t *s, int format, int crop, h264bsdmi_device_picture *out)
+{
+    ApiDec *a = dec_of(s);
+    if (!a || !out || format < 0 || format > 3) return -1;
+    if (!a->hd->sink.fetch_device) return -1;               /* capture mode: there are no pixels */
+    const Sps *sps = a->hd->active_sps;
+    if (!sps) return 0;
+    u32 id = 0, idr = 0, nerr = 0;
+    const OutPic *o = pop_output(a, &id, &idr, &nerr);
+    if (!o) return 0;
+    u32 x0 = 0, y0 = 0, w = 16 * sps->width_mbs, h = 16 * sps->height_mbs;
+    if (crop && sps->cropping) {
+        x0 = 2 * sps->crop_left;
+        y0 = 2 * sps->crop_top;
+        w -= 2 * (sps->crop_left + sps->crop_right);
+        h -= 2 * (sps->crop_top + sps->crop_bottom);
+    }
+    void *stream = NULL;
+    void *p = a->hd->sink.fetch_device(a->hd->sink.user, o->slot, format, x0, y0, w, h, &stream);
+    if (!p) return -2;
+    out->data = p;
+    out->width = w;
+    out->height = h;
+    out->pitch = format == H264BSDMI_FMT_I420 ? w : 4 * w;
+    out->format = (u32)format;
+    out->picId = id;
+    out->isIdrPic = idr;
+    out->numErrMbs = nerr;
+    out->stream = stream;
+    return 1;
+}
+
 static u32 *next_converted(storage_t *s, u32 *picId, u32 *isIdrPic, u32 *numErrMbs, int fmt)
 {
     ApiDec *a = dec_of(s);

@@ -308,6 +308,29 @@ uint32_t *sink_fetch_converted(void *user, uint32_t slot, int fmt)
     return s->h_conv;
 }
 
+void *sink_fetch_device(void *user, uint32_t slot, int fmt, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void **stream)
+{
+    SinkUser *u = static_cast<SinkUser *>(user);
+    std::lock_guard<std::mutex> lk(u->e->mu);
+    StreamCtx *s = u->s;
+    if (slot >= s->n_slots || flush_locked(u->e)) return nullptr;
+    const uint32_t fw = s->wmb * 16, fh = s->hmb * 16;
+    if (!w || !h || x0 + w > fw || y0 + h > fh) return nullptr;
+    uint8_t *frame = s->d_frames + (size_t)slot * s->frame_bytes;
+    void *ret = frame;
+    if (!(fmt == 3 && x0 == 0 && y0 == 0 && w == fw && h == fh)) {          /* anything but the zero-copy case */
+        const size_t bytes = (size_t)fw * fh * 4;
+        if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
+        const uint32_t n = fmt == 3 ? w * h * 3 / 2 : w * h;
+        hipLaunchKernelGGL(h264k::k_output, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, u->e->stream,
+                           frame, reinterpret_cast<uint8_t *>(s->d_conv), fw, fh, fmt, x0, y0, w, h);
+        ret = s->d_conv;
+    }
+    if (hipStreamSynchronize(u->e->stream) != hipSuccess) return nullptr;
+    if (stream) *stream = u->e->stream;
+    return ret;
+}
+
 void sink_close(void *user)
 {
     SinkUser *u = static_cast<SinkUser *>(user);
@@ -342,6 +365,7 @@ int eng_attach(JobSink *sink)
     sink->submit = sink_submit;
     sink->fetch = sink_fetch;
     sink->fetch_converted = sink_fetch_converted;
+    sink->fetch_device = sink_fetch_device;
     sink->close = sink_close;
     return 0;
 }

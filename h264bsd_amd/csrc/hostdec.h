@@ -221,6 +221,8 @@ typedef struct JobSink {
     uint8_t *(*fetch)(void *user, uint32_t slot);
     /* colour conversion of a slot into a host buffer of width*height u32; fmt 0 RGBA 1 BGRA 2 YCbCrA */
     uint32_t *(*fetch_converted)(void *user, uint32_t slot, int fmt);
+    /* slot (cropped to x0,y0,w,h; fmt 0..2 converted, 3 = I420) as a DEVICE pointer; *stream = the HIP stream used */
+    void *(*fetch_device)(void *user, uint32_t slot, int fmt, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void **stream);
     void (*close)(void *user);
 } JobSink;
 

@@ -1194,6 +1194,46 @@ __global__ __launch_bounds__(256) void k_convert(const uint8_t *__restrict__ yuv
     }
 }
 
+/* Device-resident output: the window (x0,y0,w,h) of a decoded frame (even offsets and sizes) either converted
+ * (fmt 0..2, one pixel per lane, tightly packed w*h u32) or as a tight I420 picture (fmt 3: w*h Y, then the two
+ * (w/2)*(h/2) chroma planes, one byte per lane).  Same arithmetic as k_convert. */
+__global__ __launch_bounds__(256) void k_output(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint32_t width,
+                                                uint32_t height, int fmt, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
+{
+    const uint8_t *cb_pl = src + (size_t)width * height;
+    const uint8_t *cr_pl = cb_pl + (size_t)(width >> 1) * (height >> 1);
+    if (fmt == 3) {
+        const uint32_t ny = w * h, nc = (w >> 1) * (h >> 1);
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ny + 2 * nc; i += gridDim.x * blockDim.x) {
+            uint8_t v;
+            if (i < ny) v = src[(size_t)(y0 + i / w) * width + x0 + i % w];
+            else {
+                const uint32_t j = (i - ny) % nc, cw = w >> 1;
+                const uint8_t *pl = i - ny < nc ? cb_pl : cr_pl;
+                v = pl[(size_t)((y0 >> 1) + j / cw) * (width >> 1) + (x0 >> 1) + j % cw];
+            }
+            dst[i] = v;
+        }
+        return;
+    }
+    uint32_t *out = reinterpret_cast<uint32_t *>(dst);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        const uint32_t y = y0 + i / w, x = x0 + i % w;
+        const int Yv = src[(size_t)y * width + x];
+        const int cb = cb_pl[(size_t)(y >> 1) * (width >> 1) + (x >> 1)], cr = cr_pl[(size_t)(y >> 1) * (width >> 1) + (x >> 1)];
+        uint32_t px;
+        if (fmt == 2) px = 0xFF000000u | ((uint32_t)cr << 16) | ((uint32_t)cb << 8) | (uint32_t)Yv;
+        else {
+            const int c = Yv - 16, d = cb - 128, e = cr - 128;
+            const uint32_t r = clip255((298 * c + 409 * e + 128) >> 8);
+            const uint32_t g = clip255((298 * c - 100 * d - 208 * e + 128) >> 8);
+            const uint32_t b = clip255((298 * c + 516 * d + 128) >> 8);
+            px = fmt == 0 ? 0xFF000000u | (b << 16) | (g << 8) | r : 0xFF000000u | (r << 16) | (g << 8) | b;
+        }
+        out[i] = px;
+    }
+}
+
 /* ------------------------------------------------------------------ on-device verification */
 /* sum over 32-bit words w[i] of (w[i] ^ i*0x9E3779B1) * (2i+1)  (mod 2^64); one block per frame */
 __global__ __launch_bounds__(256) void k_checksum(const uint8_t *__restrict__ base, size_t stride, uint32_t words,

@@ -34,6 +34,28 @@ int h264bsdmiNextOutputInfo(storage_t *pStorage, u32 *picId, u32 *isIdrPic, u32 
  * as the parser does.  cur_slot / n_slots / is_idr stay as the caller set them.  0 = ok. */
 int h264bsdmiJobFinalize(u8 *job, u32 capacity, u32 n_coef_blocks);
 
+/* ---- device-resident output ----
+ * The reference hands pictures over as host pointers (h264bsdNextOutputPicture*, src/h264bsd_decoder.c:1045-1161)
+ * and leaves cropping to the application (h264bsdCroppingParams, :970-1001).  On an MI355X box the consumer of
+ * decoded video is normally another GPU program, so this variant pops the next output picture like
+ * h264bsdNextOutputPicture() but leaves it in HBM: 3.13 MB per 1080p frame never cross PCIe. */
+#define H264BSDMI_FMT_RGBA   0   /* bytes R,G,B,A   (h264bsdConvertToRGBA)   */
+#define H264BSDMI_FMT_BGRA   1
+#define H264BSDMI_FMT_YCBCRA 2
+#define H264BSDMI_FMT_I420   3   /* planar Y, Cb, Cr as the reference's u8* picture */
+typedef struct h264bsdmi_device_picture {
+    void *data;               /* DEVICE pointer; valid until the next h264bsdDecode()/h264bsdShutdown() of this instance */
+    u32   width, height;      /* in samples, after cropping when requested                               */
+    u32   pitch;              /* bytes per row: width for I420 luma (chroma planes: width/2), 4*width otherwise */
+    u32   format;
+    u32   picId, isIdrPic, numErrMbs;
+    void *stream;             /* hipStream_t the producing work ran on; it has been synchronised on return */
+} h264bsdmi_device_picture;
+/* format: H264BSDMI_FMT_*; crop != 0 applies the SPS frame-cropping rectangle on the device.
+ * I420 without cropping is zero-copy (the pointer aims into the decoded-picture buffer); every other combination
+ * is produced by one kernel into a per-instance HBM buffer.  Returns 1 = picture, 0 = no picture, <0 = error. */
+int h264bsdmiNextOutputPictureDevice(storage_t *pStorage, int format, int crop, h264bsdmi_device_picture *out);
+
 /* ---- device engine ---- */
 /* Number of usable GPUs (0 when the HIP runtime finds none); selects the device for this process. */
 int  h264bsdmiDeviceCount(void);

@@ -68,3 +68,56 @@ def test_many_instances_round_robin_are_batched_and_exact(built, golden):
     assert pics == [73] * N
     for d in decs:
         d.close()
+
+
+def _decode_n(dec, data, n_pics, pull):
+    """run the decode loop, calling pull() after every PIC_RDY, until n_pics pictures came out"""
+    buf = ctypes.create_string_buffer(data, len(data))
+    base, off, out = ctypes.addressof(buf), 0, []
+    while off < len(data) and len(out) < n_pics:
+        r, rb = dec.decode(base + off, len(data) - off)
+        off += rb
+        if r == 1:
+            while True:
+                p = pull()
+                if p is None:
+                    break
+                out.append(p)
+    return out
+
+
+@pytest.mark.parametrize("fmt", [3, 0, 1, 2])
+@pytest.mark.parametrize("crop", [False, True])
+def test_device_resident_output(built, golden, fmt, crop):
+    """h264bsdmiNextOutputPictureDevice: pictures stay in HBM (zero-copy torch view), optionally cropped to the SPS
+    rectangle and colour-converted on the device; contents equal the host API's (golden frames / oracle conversion)"""
+    import numpy as np
+    import torch
+    from oracle import pyoracle
+    name = "test_640x360"                     # 640x368 coded, cropped to 640x360
+    g = golden[name]
+    data = stream_bytes(name)
+    W, H = 16 * g["width_mbs"], 16 * g["height_mbs"]
+    dec = built.Decoder()
+    pics = _decode_n(dec, data, 3, lambda: (lambda p: None if p is None else (p[0].clone(), p[1:]))(
+        dec.next_output_picture_device(fmt, crop)))
+    flag, left, cw, top, ch = dec.cropping_params()
+    assert flag == 1 and (cw, ch) == (640, 360)
+    dec.close()
+    ref = built.Decoder()
+    frames = _decode_n(ref, data, 3, ref.next_output_picture)
+    ref.close()
+    assert len(pics) == 3
+    for (t, meta), (frame, pid, idr, err) in zip(pics, frames):
+        assert t.is_cuda and t.dtype == torch.uint8 and meta == (pid, idr, err)
+        x0, y0, w, h = (left, top, cw, ch) if crop else (0, 0, W, H)
+        y = frame[: W * H].reshape(H, W)[y0:y0 + h, x0:x0 + w]
+        c = frame[W * H:].reshape(2, H // 2, W // 2)[:, y0 // 2:(y0 + h) // 2, x0 // 2:(x0 + w) // 2]
+        if fmt == 3:
+            want = np.concatenate([y.reshape(-1), c.reshape(-1)])
+            assert tuple(t.shape) == (h * 3 // 2, w)
+            assert np.array_equal(t.cpu().numpy().reshape(-1), want)
+        else:
+            full = pyoracle.oracle_convert(fmt, W, H, frame).reshape(H, W)[y0:y0 + h, x0:x0 + w]
+            assert tuple(t.shape) == (h, w, 4)
+            assert np.array_equal(t.cpu().numpy().reshape(h, w * 4).view(np.uint32), full)
