@@ -33,7 +33,19 @@
 #define FJ_MB_I4x4    1
 #define FJ_MB_I16x16  2
 #define FJ_MB_IPCM    3
+#define FJ_MB_CONCEAL_I 4 /* lost macroblock, synthesised from its decoded neighbours (reference ConcealMb,
+                             src/h264bsd_conceal.c:266-560): avail = FJ_CONC_* neighbours used, coef_idx = position
+                             in the concealment order (later ones may read earlier ones)                      */
+#define FJ_MB_CONCEAL_P 5 /* lost macroblock of a P picture: copy of the co-located macroblock of DPB slot
+                             ref_slot[0] (conceal.c:318-343); travels in the copy list like a mv-0 P_Skip       */
 #define FJ_MB_ABSENT  255 /* macroblock not covered by any decoded slice: pixels left untouched */
+
+/* FjMbRec.avail of a FJ_MB_CONCEAL_I macroblock: which neighbours were decoded (or already concealed) when the
+ * reference's concealment loop reaches it */
+#define FJ_CONC_LEFT  1
+#define FJ_CONC_ABOVE 2
+#define FJ_CONC_RIGHT 4
+#define FJ_CONC_BELOW 8
 
 /* FjMbRec.avail bits: neighbour usable for intra prediction (in picture, same slice, and not an
  * inter MB when constrained_intra_pred is on) — reference src/h264bsd_neighbour.c:370-381,

@@ -20,6 +20,7 @@
 
 HostDec *hd_create(int no_output_reordering);
 void hd_destroy(HostDec *d);
+#define ERR_RETURN do { if (getenv("HD_TRACE")) fprintf(stderr, "TRACE hd_decode error at line %d\n", __LINE__); return HD_ERROR; } while (0)
 int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes);
 
 HostDec *hd_create(int no_output_reordering)
@@ -92,18 +93,24 @@ int hd_job_begin(HostDec *d)
  * Dependency level of every intra macroblock: 0 when none of the intra neighbours whose samples its
  * prediction modes actually read (subset of A, B, C, D) precedes it, else 1 + the deepest of them.  Intra MBs of one level are mutually independent, so the device can
  * reconstruct level by level (all inter MBs first). */
+static int in_intra_schedule(int kind)
+{
+    return kind == FJ_MB_I4x4 || kind == FJ_MB_I16x16 || kind == FJ_MB_IPCM || kind == FJ_MB_CONCEAL_I;
+}
+
 int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
 {
     FjHeader *h = (FjHeader *)job;
     const uint32_t n = h->n_mbs, w = h->width_mbs;
     FjMbRec *recs = (FjMbRec *)(job + h->rec_off);
-    uint32_t max_level = 0, n_intra = 0, n_absent = 0;
+    uint32_t max_level = 0, n_intra = 0, n_absent = 0, n_conceal = 0;
     uint8_t any_dbk = 0;
     for (uint32_t a = 0; a < n; a++) {
         FjMbRec *r = &recs[a];
         any_dbk |= r->dbk;
         if (r->kind == FJ_MB_ABSENT) n_absent++;
-        if (r->kind == FJ_MB_INTER || r->kind == FJ_MB_ABSENT) continue;
+        if (r->kind == FJ_MB_CONCEAL_I) n_conceal++;
+        if (!in_intra_schedule(r->kind) || r->kind == FJ_MB_CONCEAL_I) continue;   /* concealment: second pass below */
         const uint32_t x = a % w, y = a / w;
         int lvl = -1;
         /* which neighbouring macroblocks does the prediction of this one actually read? (8.3.1.2, 8.3.3, 8.3.4) */
@@ -131,7 +138,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
         }
         need &= r->avail;             /* an unavailable neighbour is never read (its samples are replaced by 128) */
 #define DEP(cond, idx) do { if (cond) { const FjMbRec *q = &recs[idx]; \
-            if (q->kind != FJ_MB_INTER && q->kind != FJ_MB_ABSENT && (int)q->intra_level > lvl) lvl = q->intra_level; } } while (0)
+            if (in_intra_schedule(q->kind) && (int)q->intra_level > lvl) lvl = q->intra_level; } } while (0)
         DEP(x > 0 && (need & FJ_AVAIL_A), a - 1);
         DEP(y > 0 && (need & FJ_AVAIL_B), a - w);
         DEP(y > 0 && x + 1 < w && (need & FJ_AVAIL_C), a - w + 1);
@@ -140,6 +147,36 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
         r->intra_level = (uint16_t)(lvl + 1);
         if ((uint32_t)(lvl + 1) > max_level) max_level = (uint32_t)(lvl + 1);
         n_intra++;
+    }
+    if (n_conceal) {
+        /* Synthesised macroblocks read the neighbours that were decoded or concealed BEFORE them in the reference's
+         * concealment order (coef_idx), on any of the four sides: walk them in that order. */
+        uint32_t *ord = (uint32_t *)malloc(n_conceal * sizeof(uint32_t));
+        if (!ord) return -1;
+        uint32_t k = 0;
+        for (uint32_t a = 0; a < n; a++) if (recs[a].kind == FJ_MB_CONCEAL_I) ord[k++] = a;
+        for (uint32_t i = 1; i < k; i++) {              /* insertion sort by sequence number */
+            const uint32_t v = ord[i];
+            uint32_t j = i;
+            while (j > 0 && recs[ord[j - 1]].coef_idx > recs[v].coef_idx) { ord[j] = ord[j - 1]; j--; }
+            ord[j] = v;
+        }
+        for (uint32_t i = 0; i < k; i++) {
+            const uint32_t a = ord[i], x = a % w;
+            FjMbRec *r = &recs[a];
+            int lvl = -1;
+#define DEP(cond, idx) do { if (cond) { const FjMbRec *q = &recs[idx]; \
+            if (in_intra_schedule(q->kind) && (int)q->intra_level > lvl) lvl = q->intra_level; } } while (0)
+            DEP((r->avail & FJ_CONC_LEFT) && x > 0, a - 1);
+            DEP((r->avail & FJ_CONC_RIGHT) && x + 1 < w, a + 1);
+            DEP((r->avail & FJ_CONC_ABOVE) && a >= w, a - w);
+            DEP((r->avail & FJ_CONC_BELOW) && a + w < n, a + w);
+#undef DEP
+            r->intra_level = (uint16_t)(lvl + 1);
+            if ((uint32_t)(lvl + 1) > max_level) max_level = (uint32_t)(lvl + 1);
+            n_intra++;
+        }
+        free(ord);
     }
     const uint32_t n_levels = n_intra ? max_level + 1 : 0;
     h->n_coef_blocks = coef_blocks;
@@ -154,6 +191,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
         if (!cls) return -1;
         uint32_t n_gen = 0;
         for (uint32_t a = 0; a < n; a++) {
+            if (recs[a].kind == FJ_MB_CONCEAL_P) { cls[a] = 6; continue; }      /* copy list, never "uniform" (bit0) */
             if (recs[a].kind != FJ_MB_INTER) continue;
             const int16_t *m0 = mvs[a][0];
             int uni = recs[a].coded == 0 && recs[a].ref_slot[0] == recs[a].ref_slot[1] &&
@@ -225,13 +263,13 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
         uint16_t *idx = (uint16_t *)(job + h->idx_off);
         memset(lvl_start, 0, (n_levels + 1) * 4u);
         for (uint32_t a = 0; a < n; a++)
-            if (recs[a].kind != FJ_MB_INTER && recs[a].kind != FJ_MB_ABSENT) lvl_start[recs[a].intra_level + 1]++;
+            if (in_intra_schedule(recs[a].kind)) lvl_start[recs[a].intra_level + 1]++;
         for (uint32_t l = 0; l < n_levels; l++) lvl_start[l + 1] += lvl_start[l];
         uint32_t *cursor = (uint32_t *)malloc((n_levels + 1) * 4u);
         if (!cursor) return -1;
         memcpy(cursor, lvl_start, (n_levels + 1) * 4u);
         for (uint32_t a = 0; a < n; a++)
-            if (recs[a].kind != FJ_MB_INTER && recs[a].kind != FJ_MB_ABSENT) idx[cursor[recs[a].intra_level]++] = (uint16_t)a;
+            if (in_intra_schedule(recs[a].kind)) idx[cursor[recs[a].intra_level]++] = (uint16_t)a;
         free(cursor);
     }
     {   /* zero the alignment gaps so that a frame job is a pure function of the bitstream */
@@ -252,7 +290,7 @@ int hd_job_finish(HostDec *d, int is_idr)
 {
     FjHeader *h = (FjHeader *)d->job;
     if (fj_finalize(d->job, d->job_cap, d->coef_blocks)) return -1;
-    h->cur_slot = (uint8_t)d->dpb.cur;
+    h->cur_slot = (uint8_t)hd_dpb_cur_slot(&d->dpb);
     h->n_slots = (uint8_t)d->dpb.n_slots;
     h->is_idr = (uint8_t)is_idr;
     h->pic_seq = d->pic_seq++;
@@ -431,6 +469,114 @@ static int store_pps(HostDec *d, Pps *p)
     return 0;
 }
 
+/* ---------------------------------------------------------------- error handling: lost macroblocks */
+/* A slice whose data failed to parse: un-decode its macroblocks from the failure point back (an I slice keeps
+ * everything up to max(width,10) macroblocks before the last good one, a P slice loses everything) and to its end
+ * — reference h264bsdMarkSliceCorrupted, src/h264bsd_slice_data.c:298-354. */
+static void mark_slice_corrupted(HostDec *d, uint32_t first_mb)
+{
+    FjMbRec *recs = (FjMbRec *)(d->job + ((FjHeader *)d->job)->rec_off);
+    const uint32_t sid = d->slice_id;
+    uint32_t addr = first_mb;
+    if (d->last_mb_addr) {
+        const uint32_t lim = d->width_mbs > 10 ? d->width_mbs : 10;
+        uint32_t i = d->last_mb_addr - 1, cnt = 0;
+        while (i > addr) {
+            if (d->mb[i].slice_id == sid && ++cnt >= lim) break;
+            i--;
+        }
+        addr = i;
+    }
+    if (getenv("HD_TRACE")) fprintf(stderr, "TRACE corrupt: first %u last %u start %u sid %u\n", first_mb, d->last_mb_addr, addr, sid);
+    do {
+        MbInfo *m = &d->mb[addr];
+        if (getenv("HD_TRACE")) fprintf(stderr, "TRACE   mb %u sid %u decoded %u\n", addr, m->slice_id, m->decoded);
+        if (m->slice_id != sid || !m->decoded) break;
+        if (--m->decoded == 0) recs[addr].kind = FJ_MB_ABSENT;
+        addr = hd_next_mb_in_group(d->slice_group_map, d->pic_size_mbs, addr);
+    } while (addr);
+}
+
+/* Plan the concealment of every macroblock that is still not decoded when the access unit ends — reference
+ * h264bsdConceal, src/h264bsd_conceal.c:124-260.  The PIXELS are produced on the device: a lost macroblock of a P
+ * picture becomes a copy of the co-located macroblock of the first usable reference (FJ_MB_CONCEAL_P, copy list);
+ * otherwise it is synthesised from the neighbours decoded or concealed before it in the reference's walking order
+ * (FJ_MB_CONCEAL_I, scheduled with the intra macroblocks).  Concealed macroblocks are deblocked as intra, QP 40,
+ * offsets 0 (conceal.c:305-313); a wholly lost picture is a copy / grey and is not filtered (:180-206).
+ * Returns the number of concealed macroblocks (numErrMbs of the picture). */
+static uint32_t plan_concealment(HostDec *d, int p_type)
+{
+    FjHeader *h = (FjHeader *)d->job;
+    FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
+    int16_t (*mvs)[16][2] = (int16_t (*)[16][2])(d->job + h->mv_off);
+    const uint32_t n = d->pic_size_mbs, w = d->width_mbs, hgt = d->height_mbs;
+    int ref_slot = -1;
+    if (p_type)
+        for (uint32_t i = 0; i < 16 && ref_slot < 0; i++) ref_slot = hd_dpb_ref_slot(&d->dpb, i);
+    uint32_t first = 0;
+    while (first < n && !d->mb[first].decoded) first++;
+    if (getenv("HD_TRACE")) { fprintf(stderr, "TRACE conceal p_type %d ref %d decoded:", p_type, ref_slot); for (uint32_t a = 0; a < n; a++) fprintf(stderr, " %u", d->mb[a].decoded); fprintf(stderr, "\n"); }
+    uint32_t seq = 0, count = 0;
+
+#define CONCEAL_ONE(a_, whole_) do { \
+        const uint32_t a__ = (a_); \
+        FjMbRec *r = &recs[a__]; \
+        memset(r, 0, sizeof(*r)); \
+        memset(mvs[a__], 0, 64); \
+        r->qp_y = 40; r->qp_c = 36;          /* QPc of QP 40 with chroma_qp_index_offset 0 */ \
+        r->dbk = (whole_) ? 0 : (uint8_t)(FJ_DBK_INNER | ((a__ % w) ? FJ_DBK_LEFT : 0) | (a__ >= w ? FJ_DBK_TOP : 0)); \
+        r->coef_idx = seq++; \
+        if (ref_slot >= 0) { \
+            r->kind = FJ_MB_CONCEAL_P; \
+            memset(r->ref_slot, ref_slot, 4); \
+        } else { \
+            const uint32_t row__ = a__ / w, col__ = a__ % w; \
+            r->kind = FJ_MB_CONCEAL_I; \
+            r->avail = (uint8_t)((row__ && d->mb[a__ - w].decoded ? FJ_CONC_ABOVE : 0) | \
+                                 (row__ != hgt - 1 && d->mb[a__ + w].decoded ? FJ_CONC_BELOW : 0) | \
+                                 (col__ && d->mb[a__ - 1].decoded ? FJ_CONC_LEFT : 0) | \
+                                 (col__ != w - 1 && d->mb[a__ + 1].decoded ? FJ_CONC_RIGHT : 0)); \
+        } \
+        d->mb[a__].decoded = 1; \
+        count++; \
+    } while (0)
+
+    if (first == n) {
+        /* nothing of the picture survived */
+        if (ref_slot >= 0) {
+            for (uint32_t a = 0; a < n; a++) CONCEAL_ONE(a, 1);
+        } else {
+            /* constant 128: every macroblock is an I_PCM that reads the same twelve blocks of 0x80 bytes */
+            uint8_t *grey = d->job + h->coef_off + (size_t)d->coef_blocks * 32u;
+            memset(grey, 128, 384);
+            for (uint32_t a = 0; a < n; a++) {
+                FjMbRec *r = &recs[a];
+                memset(r, 0, sizeof(*r));
+                memset(mvs[a], 0, 64);
+                r->kind = FJ_MB_IPCM;
+                r->coef_idx = d->coef_blocks;
+                d->mb[a].decoded = 1;
+            }
+            d->coef_blocks += 12;
+            count = n;
+        }
+        return count;
+    }
+    const uint32_t row = first / w, col = first % w;
+    /* the row of the first good macroblock: leftwards from it, then rightwards */
+    for (uint32_t j = col; j--;) CONCEAL_ONE(row * w + j, 0);
+    for (uint32_t j = col + 1; j < w; j++) if (!d->mb[row * w + j].decoded) CONCEAL_ONE(row * w + j, 0);
+    /* the rows above it: column by column, upwards */
+    if (row)
+        for (uint32_t j = 0; j < w; j++)
+            for (uint32_t i = row; i--;) CONCEAL_ONE(i * w + j, 0);
+    /* the rows below it, in raster order */
+    for (uint32_t i = row + 1; i < hgt; i++)
+        for (uint32_t j = 0; j < w; j++) if (!d->mb[i * w + j].decoded) CONCEAL_ONE(i * w + j, 0);
+#undef CONCEAL_ONE
+    return count;
+}
+
 /* ---------------------------------------------------------------- one NAL unit */
 int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes)
 {
@@ -440,52 +586,62 @@ int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, 
     } else {
         rc = hd_extract_nal(d, stream, len, read_bytes);
         if (rc == -2) return HD_MEMALLOC_ERROR;
-        if (rc) return HD_ERROR;
+        if (rc) ERR_RETURN;
         d->prev_bytes_consumed = *read_bytes;
         d->prev_buf_ptr = stream;
     }
     d->prev_buf_not_finished = 0;
 
     BitReader br = { d->nal_buf, d->nal_size * 8u, 0 };
-    if (d->nal_size == 0) return HD_ERROR;
+    if (d->nal_size == 0) ERR_RETURN;
     br_get1(&br);                                                   /* forbidden_zero_bit: not enforced (reference nal_unit.c:77) */
     const int nal_ref_idc = (int)br_get(&br, 2);
     const int nal_type = (int)br_get(&br, 5);
-    if (nal_type == 2 || nal_type == 3 || nal_type == 4) return HD_ERROR;   /* data partitioning */
-    if ((nal_type == 5 || nal_type == 7 || nal_type == 8) && nal_ref_idc == 0) return HD_ERROR;
-    if ((nal_type == 6 || (nal_type >= 9 && nal_type <= 12)) && nal_ref_idc != 0) return HD_ERROR;
+    if (nal_type == 2 || nal_type == 3 || nal_type == 4) ERR_RETURN;   /* data partitioning */
+    if ((nal_type == 5 || nal_type == 7 || nal_type == 8) && nal_ref_idc == 0) ERR_RETURN;
+    if ((nal_type == 6 || (nal_type >= 9 && nal_type <= 12)) && nal_ref_idc != 0) ERR_RETURN;
     if (nal_type == 0 || nal_type >= 13) return HD_RDY;
 
-    int boundary = 0;
+    int boundary = 0, conceal_pending = 0;
     rc = check_access_unit_boundary(d, &br, nal_type, nal_ref_idc, &boundary);
     if (rc == -2) return HD_PARAM_SET_ERROR;
-    if (rc) return HD_ERROR;
+    if (rc) ERR_RETURN;
 
     if (boundary) {
         if (d->pic_started && d->active_sps) {
-            /* a picture was left unfinished: the reference conceals it here (decoder.c:226-266).
-             * Concealment is out of scope: drop the partial picture and report the damage. */
-            if (d->pending_activation) return HD_ERROR;
-            d->pic_started = 0;
-            d->valid_slice_in_au = 0;
-            d->skip_redundant = 0;
-            d->job_open = 0;
-            d->dpb.cur = -1;
-            if (d->mb) reset_picture_state(d);
-            fprintf(stderr, "h264bsd-mi355x: incomplete picture dropped (error concealment not implemented)\n");
+            /* a picture was left unfinished: conceal what is missing and deliver it (decoder.c:226-266); the NAL
+             * unit in hand is decoded on the next call (readBytes 0) */
+            if (d->pending_activation) ERR_RETURN;
             *read_bytes = 0;
             d->prev_buf_not_finished = 1;
-            return HD_ERROR;
+            d->skip_redundant = 0;
+            if (!d->valid_slice_in_au) {
+                /* no slice header of the picture was ever decoded: the reference conceals into a scratch image that
+                 * is neither stored nor output (decoder.c:244-249, 478: MarkDecRefPic only for a valid slice), so no
+                 * pixels are needed — only the state changes: POC from the previous header, PIC_RDY */
+                hd_dpb_init_ref_list(&d->dpb);
+                if (d->mb) reset_picture_state(d);
+                (void)hd_decode_poc(&d->poc, d->active_sps, &d->slice, d->cur_nal_type, d->cur_nal_ref_idc);
+                d->pic_started = 0;
+                return HD_PIC_RDY;
+            }
+            conceal_pending = 1;
+        } else {
+            d->valid_slice_in_au = 0;
+            d->skip_redundant = 0;
         }
-        d->valid_slice_in_au = 0;
-        d->skip_redundant = 0;
     }
 
     int pic_ready = 0;
+    uint32_t err_mbs = 0;
+    if (conceal_pending) {
+        err_mbs = plan_concealment(d, d->slice.is_p);
+        pic_ready = 1;
+    } else
     switch (nal_type) {
     case 7: {
         Sps s;
-        if (hd_parse_sps(&br, &s)) return HD_ERROR;
+        if (hd_parse_sps(&br, &s)) ERR_RETURN;
         if (store_sps(d, &s)) return HD_MEMALLOC_ERROR;
         break;
     }
@@ -493,7 +649,7 @@ int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, 
         Pps p;
         rc = hd_parse_pps(&br, &p);
         if (rc == -2) return HD_MEMALLOC_ERROR;
-        if (rc) return HD_ERROR;
+        if (rc) ERR_RETURN;
         if (store_pps(d, &p)) return HD_MEMALLOC_ERROR;
         break;
     }
@@ -505,7 +661,7 @@ int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, 
         if (start_of_picture) {
             uint32_t pps_id;
             d->current_pic_id = pic_id;
-            if (hd_peek_pps_id(&br, &pps_id)) return HD_ERROR;
+            if (hd_peek_pps_id(&br, &pps_id)) ERR_RETURN;
             const int old_sps = d->active_sps_id;
             rc = activate_param_sets(d, pps_id, nal_type == 5);
             if (rc) {
@@ -522,15 +678,15 @@ int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, 
                 return HD_HDRS_RDY;
             }
         }
-        if (d->pending_activation) return HD_ERROR;
+        if (d->pending_activation) ERR_RETURN;
         SliceHdr sh;
-        if (hd_parse_slice_header(&br, &sh, d->active_sps, d->active_pps, nal_type, nal_ref_idc)) return HD_ERROR;
+        if (hd_parse_slice_header(&br, &sh, d->active_sps, d->active_pps, nal_type, nal_ref_idc)) ERR_RETURN;
         if (start_of_picture) {
             if (nal_type != 5) {
                 if (hd_dpb_check_gaps(&d->dpb, sh.frame_num, nal_ref_idc != 0, d->active_sps->gaps_in_frame_num_allowed))
-                    return HD_ERROR;
+                    ERR_RETURN;
             }
-            if (hd_dpb_alloc_current(&d->dpb) < 0) return HD_ERROR;
+            if (hd_dpb_alloc_current(&d->dpb) < 0) ERR_RETURN;
             if (hd_job_begin(d)) return HD_MEMALLOC_ERROR;
         }
         d->slice = sh;
@@ -538,8 +694,12 @@ int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, 
         d->cur_nal_type = (uint8_t)nal_type;
         d->cur_nal_ref_idc = (uint8_t)nal_ref_idc;
         hd_slice_group_map(d->slice_group_map, d->active_pps, sh.slice_group_change_cycle, d->width_mbs, d->height_mbs);
-        if (hd_dpb_reorder_ref_list(&d->dpb, &d->slice)) return HD_ERROR;
-        if (hd_decode_slice_data(d, &br, &d->slice, nal_ref_idc)) return HD_ERROR;
+        hd_dpb_init_ref_list(&d->dpb);
+        if (hd_dpb_reorder_ref_list(&d->dpb, &d->slice)) ERR_RETURN;
+        if (hd_decode_slice_data(d, &br, &d->slice, nal_ref_idc)) {
+            mark_slice_corrupted(d, d->slice.first_mb);
+            ERR_RETURN;
+        }
         if (end_of_picture(d)) { pic_ready = 1; d->skip_redundant = 1; }
         break;
     }
@@ -551,14 +711,14 @@ int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, 
     /* picture complete: queue the frame job, then do the bookkeeping the reference does after
      * deblocking (decoder.c:473-510) */
     const int is_idr = d->cur_nal_type == 5;
-    if (hd_job_finish(d, is_idr)) return HD_ERROR;
+    if (hd_job_finish(d, is_idr)) ERR_RETURN;
     if (d->sink.submit && d->sink.submit(d->sink.user, d->job, ((FjHeader *)d->job)->total_bytes)) {
         fprintf(stderr, "h264bsd-mi355x: frame job submission failed\n");
-        return HD_ERROR;
+        ERR_RETURN;
     }
     reset_picture_state(d);
     int32_t poc = hd_decode_poc(&d->poc, d->active_sps, &d->slice, d->cur_nal_type, d->cur_nal_ref_idc);
-    hd_dpb_mark_current(&d->dpb, &d->slice, d->cur_nal_ref_idc != 0, is_idr, poc, d->current_pic_id, 0);
+    hd_dpb_mark_current(&d->dpb, &d->slice, d->cur_nal_ref_idc != 0, is_idr, poc, d->current_pic_id, err_mbs);
     d->pic_started = 0;
     d->valid_slice_in_au = 0;
     return HD_PIC_RDY;

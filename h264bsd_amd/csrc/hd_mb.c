@@ -43,6 +43,11 @@ typedef struct MbCtx {
     uint32_t addr, mbx, mby;
     MbInfo *cur, *A, *B, *C, *D;   /* NULL when outside the picture or another slice */
     uint16_t done;                 /* raster bit per 4x4 block of cur whose mv/ref is final */
+    int p2err;                     /* an error the reference only finds when it RECONSTRUCTS the macroblock
+                                      (h264bsdDecodeMacroblock: missing reference picture, motion vector range, intra
+                                      mode without its neighbours) — i.e. after the whole macroblock_layer() has been
+                                      parsed and after mb.decoded was incremented (macroblock_layer.c:988).  Recorded
+                                      here, acted upon once parsing of the macroblock has succeeded. */
 } MbCtx;
 
 static inline MbInfo *usable(MbInfo *m, uint32_t slice_id) { return (m && m->slice_id == slice_id) ? m : NULL; }
@@ -139,14 +144,19 @@ static int set_partition(MbCtx *c, int x, int y, int w, int h, int ref, const in
 
 static int resolve_ref(MbCtx *c, int quadrant, int ref_idx)
 {
-    const Dpb *dpb = &c->d->dpb;
-    if (ref_idx < 0 || ref_idx > 32) return -1;
-    int slot = dpb->list[ref_idx];
-    if (slot < 0 || dpb->pic[slot].status == DPB_NON_EXISTING || dpb->pic[slot].status == DPB_UNUSED) return -1;
+    if (ref_idx < 0) return -1;
+    const int slot = hd_dpb_ref_slot(&c->d->dpb, (uint32_t)ref_idx);
+    if (slot < 0) return -1;
     c->cur->ref_idx[quadrant] = (int8_t)ref_idx;
     c->cur->ref_slot[quadrant] = (uint8_t)slot;
     return 0;
 }
+
+/* error exits below report where they happened when HD_TRACE is set in the environment (debugging aid) */
+#include <stdio.h>
+#include <stdlib.h>
+#define FAIL do { if (getenv("HD_TRACE")) fprintf(stderr, "TRACE hd_mb fail at line %d\n", __LINE__); return -1; } while (0)
+#define P2ERR(c_) do { if (getenv("HD_TRACE")) fprintf(stderr, "TRACE hd_mb p2err at line %d\n", __LINE__); (c_)->p2err = 1; } while (0)
 
 static uint32_t read_te(BitReader *br, uint32_t n_active)
 {
@@ -168,23 +178,23 @@ static int parse_inter(MbCtx *c, int p_type)
         if (n_active > 1)
             for (int i = 0; i < nparts; i++) {
                 ref[i] = read_te(br, n_active);
-                if (br_overrun(br) || ref[i] >= n_active) return -1;
+                if (br_overrun(br) || ref[i] >= n_active) FAIL;
             }
         for (int i = 0; i < nparts; i++) { mvd[i][0] = (int16_t)br_se(br); mvd[i][1] = (int16_t)br_se(br); }
-        if (br_overrun(br)) return -1;
+        if (br_overrun(br)) FAIL;
         for (int i = 0; i < nparts; i++) {
             int x = 0, y = 0, w = 4, h = 4, shape = 0;
             if (p_type == 1) { y = 2 * i; h = 2; shape = 1 + i; }
             if (p_type == 2) { x = 2 * i; w = 2; shape = 3 + i; }
             /* reference of the quadrants covered by this partition must be known before prediction
              * of the next partition looks at it */
-            if (p_type == 0) { for (int q = 0; q < 4; q++) if (resolve_ref(c, q, (int)ref[0])) return -1; }
-            else if (p_type == 1) { if (resolve_ref(c, 2 * i, (int)ref[i]) || resolve_ref(c, 2 * i + 1, (int)ref[i])) return -1; }
-            else { if (resolve_ref(c, i, (int)ref[i]) || resolve_ref(c, i + 2, (int)ref[i])) return -1; }
+            if (p_type == 0) { for (int q = 0; q < 4; q++) if (resolve_ref(c, q, (int)ref[0])) P2ERR(c); }
+            else if (p_type == 1) { if (resolve_ref(c, 2 * i, (int)ref[i]) || resolve_ref(c, 2 * i + 1, (int)ref[i])) P2ERR(c); }
+            else { if (resolve_ref(c, i, (int)ref[i]) || resolve_ref(c, i + 2, (int)ref[i])) P2ERR(c); }
             predict_mv(c, x, y, w, (int)ref[i], shape, mvp);
             mv[0] = (int16_t)(mvp[0] + mvd[i][0]);
             mv[1] = (int16_t)(mvp[1] + mvd[i][1]);
-            if (set_partition(c, x, y, w, h, (int)ref[i], mv)) return -1;
+            if (set_partition(c, x, y, w, h, (int)ref[i], mv)) P2ERR(c);
         }
         return 0;
     }
@@ -193,21 +203,21 @@ static int parse_inter(MbCtx *c, int p_type)
     uint32_t sub[4], ref[4] = { 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) {
         sub[i] = br_ue(br);
-        if (br_overrun(br) || sub[i] > 3) return -1;
+        if (br_overrun(br) || sub[i] > 3) FAIL;
     }
     if (n_active > 1 && p_type != 4)
         for (int i = 0; i < 4; i++) {
             ref[i] = read_te(br, n_active);
-            if (br_overrun(br) || ref[i] >= n_active) return -1;
+            if (br_overrun(br) || ref[i] >= n_active) FAIL;
         }
     static const uint8_t nsub[4] = { 1, 2, 2, 4 };
     int k = 0;
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < nsub[sub[i]]; j++, k++) { mvd[k][0] = (int16_t)br_se(br); mvd[k][1] = (int16_t)br_se(br); }
-    if (br_overrun(br)) return -1;
+    if (br_overrun(br)) FAIL;
     k = 0;
     for (int i = 0; i < 4; i++) {
-        if (resolve_ref(c, i, (int)ref[i])) return -1;
+        if (resolve_ref(c, i, (int)ref[i])) P2ERR(c);
         const int bx = (i & 1) * 2, by = (i >> 1) * 2;
         const int sw = (sub[i] == 0 || sub[i] == 1) ? 2 : 1;   /* 8x8, 8x4 are 2 blocks wide */
         const int shh = (sub[i] == 0 || sub[i] == 2) ? 2 : 1;  /* 8x8, 4x8 are 2 blocks high */
@@ -219,7 +229,7 @@ static int parse_inter(MbCtx *c, int p_type)
             predict_mv(c, x, y, sw, (int)ref[i], 0, mvp);
             mv[0] = (int16_t)(mvp[0] + mvd[k][0]);
             mv[1] = (int16_t)(mvp[1] + mvd[k][1]);
-            if (set_partition(c, x, y, sw, shh, (int)ref[i], mv)) return -1;
+            if (set_partition(c, x, y, sw, shh, (int)ref[i], mv)) P2ERR(c);
         }
     }
     return 0;
@@ -229,11 +239,12 @@ static int infer_skip(MbCtx *c)
 {
     int16_t mv[2] = { 0, 0 };
     c->done = 0;
-    for (int q = 0; q < 4; q++) if (resolve_ref(c, q, 0)) return -1;
+    for (int q = 0; q < 4; q++) if (resolve_ref(c, q, 0)) P2ERR(c);
     Nb a = nb_at(c, -1, 0), b = nb_at(c, 0, -1);
     if (a.avail && b.avail && !(a.ref == 0 && a.mx == 0 && a.my == 0) && !(b.ref == 0 && b.mx == 0 && b.my == 0))
         predict_mv(c, 0, 0, 4, 0, 0, mv);
-    return set_partition(c, 0, 0, 4, 4, 0, mv);
+    if (set_partition(c, 0, 0, 4, 4, 0, mv)) P2ERR(c);
+    return 0;
 }
 
 /* ---------------------------------------------------------------- Intra4x4PredMode, 8.3.1.1 */
@@ -280,14 +291,14 @@ static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, ui
     if (is_i16) {
         int16_t *blk = next_block(d, coefs);
         n = hd_cavlc_block(br, nc_luma(c, 0), 16, blk);
-        if (n < 0) return -1;
+        if (n < 0) FAIL;
         if (n) { coded |= FJ_CODED_LUMA_DC; d->coef_blocks++; }
     }
     for (int z = 0; z < 16; z++) {
         if (!(cbp & (1u << (z >> 2)))) { m->tc[z] = 0; continue; }
         int16_t *blk = next_block(d, coefs);
         n = hd_cavlc_block(br, nc_luma(c, z), is_i16 ? 15 : 16, blk);
-        if (n < 0) return -1;
+        if (n < 0) FAIL;
         m->tc[z] = (uint8_t)n;
         if (n) { coded |= 1u << z; d->coef_blocks++; }
     }
@@ -295,22 +306,48 @@ static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, ui
     if (cbp & 0x30) {
         int16_t *blk = next_block(d, coefs);
         int n0 = hd_cavlc_block(br, -1, 4, blk);
-        if (n0 < 0) return -1;
+        if (n0 < 0) FAIL;
         int n1 = hd_cavlc_block(br, -1, 4, blk + 4);
-        if (n1 < 0) return -1;
+        if (n1 < 0) FAIL;
         if (n0 || n1) { coded |= FJ_CODED_CHROMA_DC; d->coef_blocks++; }
     }
     if (cbp & 0x20) {
         for (int k = 0; k < 8; k++) {
             int16_t *blk = next_block(d, coefs);
             n = hd_cavlc_block(br, nc_chroma(c, k >> 2, k & 3), 15, blk);
-            if (n < 0) return -1;
+            if (n < 0) FAIL;
             m->tc[16 + k] = (uint8_t)n;
             if (n) { coded |= 1u << (16 + k); d->coef_blocks++; }
         }
     }
     *coded_out = coded;
     return 0;
+}
+
+/* Does every prediction mode of this intra macroblock have the neighbour samples it reads?  The reference
+ * checks this while predicting (src/h264bsd_intra_prediction.c:655-680 Intra16x16, :770-830 Intra4x4 per block,
+ * :880-900 chroma) and fails the macroblock otherwise. */
+static int intra_modes_have_neighbours(const FjMbRec *rec, const MbInfo *m, int is_i16, int chroma_mode)
+{
+    const int A = (rec->avail & FJ_AVAIL_A) != 0, B = (rec->avail & FJ_AVAIL_B) != 0, D = (rec->avail & FJ_AVAIL_D) != 0;
+    if (is_i16) {
+        const int mode = rec->pred & 3;
+        if ((mode == 0 && !B) || (mode == 1 && !A) || (mode == 3 && !(A && B && D))) return 0;
+    } else {
+        for (int z = 0; z < 16; z++) {
+            const int bx = Z_X[z], by = Z_Y[z], mode = m->i4mode[z];
+            const int a = bx > 0 || A, b = by > 0 || B;
+            const int dd = (bx > 0 && by > 0) ? 1 : bx > 0 ? B : by > 0 ? A : D;
+            switch (mode) {
+            case 0: case 3: case 7: if (!b) return 0; break;
+            case 1: case 8: if (!a) return 0; break;
+            case 4: case 5: case 6: if (!(a && b && dd)) return 0; break;
+            default: break;
+            }
+        }
+    }
+    if ((chroma_mode == 1 && !A) || (chroma_mode == 2 && !B) || (chroma_mode == 3 && !(A && B && D))) return 0;
+    return 1;
 }
 
 /* ---------------------------------------------------------------- one macroblock */
@@ -350,24 +387,24 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
     if (skipped) {
         m->mb_type = 0;
         m->kind = FJ_MB_INTER;
-        if (infer_skip(&c)) return -1;
+        if (infer_skip(&c)) FAIL;
         memset(m->tc, 0, sizeof(m->tc));
         m->qp = (uint8_t)*qp;
         rec.kind = FJ_MB_INTER;
     } else {
         uint32_t t = br_ue(br);
-        if (br_overrun(br)) return -1;
+        if (br_overrun(br)) FAIL;
         int itype = -1, ptype = -1;
         if (sh->is_p) { if (t < 5) ptype = (int)t; else itype = (int)t - 5; }
         else itype = (int)t;
-        if (itype > 25) return -1;
+        if (itype > 25) FAIL;
         m->mb_type = (uint8_t)(ptype >= 0 ? ptype + 1 : itype + 6);
 
         if (itype == 25) {                                   /* I_PCM */
-            while (br->pos & 7) if (br_get1(br)) return -1;
+            while (br->pos & 7) if (br_get1(br)) FAIL;
             uint8_t *dst = (uint8_t *)(coefs + 16u * d->coef_blocks);
             for (int i = 0; i < 384; i++) dst[i] = (uint8_t)br_get(br, 8);
-            if (br_overrun(br)) return -1;
+            if (br_overrun(br)) FAIL;
             d->coef_blocks += 12;
             m->kind = FJ_MB_IPCM;
             m->qp = 0;
@@ -378,7 +415,7 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
             int is_i16 = 0;
             if (ptype >= 0) {
                 m->kind = FJ_MB_INTER;
-                if (parse_inter(&c, ptype)) return -1;
+                if (parse_inter(&c, ptype)) FAIL;
                 rec.kind = FJ_MB_INTER;
             } else {
                 /* intra: availability of the four neighbours for prediction */
@@ -390,7 +427,7 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
                 if (itype == 0) {
                     /* the mode derivation must see the neighbours' kinds but the current MB's own
                      * previous kind must not leak in: set kind after the modes are known */
-                    if (parse_i4_modes(&c)) return -1;
+                    if (parse_i4_modes(&c)) FAIL;
                     m->kind = FJ_MB_I4x4;
                     rec.kind = FJ_MB_I4x4;
                     for (int z = 0; z < 16; z++) rec.i4mode[z >> 1] |= (uint8_t)(m->i4mode[z] << ((z & 1) * 4));
@@ -401,7 +438,8 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
                     rec.pred = (uint8_t)((itype - 1) & 3);
                 }
                 uint32_t cm = br_ue(br);
-                if (br_overrun(br) || cm > 3) return -1;
+                if (br_overrun(br) || cm > 3) FAIL;
+                if (!intra_modes_have_neighbours(&rec, m, is_i16, (int)cm)) P2ERR(&c);
                 rec.pred |= (uint8_t)(cm << 2);
             }
             if (is_i16) {
@@ -409,14 +447,14 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
                 if (itype >= 13) cbp |= 15;
             } else {
                 uint32_t code = br_ue(br);
-                if (br_overrun(br) || code > 47) return -1;
+                if (br_overrun(br) || code > 47) FAIL;
                 cbp = ptype >= 0 ? cbp_inter[code] : cbp_intra[code];
             }
             memset(m->tc, 0, sizeof(m->tc));
             if (cbp || is_i16) {
                 int32_t dq = br_se(br);
-                if (br_overrun(br) || dq < -26 || dq > 25) return -1;
-                if (parse_residual(&c, is_i16, cbp, coefs, &rec.coded)) return -1;
+                if (br_overrun(br) || dq < -26 || dq > 25) FAIL;
+                if (parse_residual(&c, is_i16, cbp, coefs, &rec.coded)) FAIL;
                 *qp += dq;
                 if (*qp < 0) *qp += 52; else if (*qp >= 52) *qp -= 52;
             }
@@ -424,6 +462,7 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
         }
     }
     m->decoded++;
+    if (c.p2err) FAIL;
 
     if (!first_decode) {          /* redundant re-decode: keep the primary's record and pixels */
         d->coef_blocks = coef_start;
@@ -452,7 +491,7 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
 }
 
 /* ---------------------------------------------------------------- slice_data(), 7.3.4 */
-static uint32_t next_mb_in_group(const uint32_t *map, uint32_t n, uint32_t addr)
+uint32_t hd_next_mb_in_group(const uint32_t *map, uint32_t n, uint32_t addr)
 {
     const uint32_t g = map[addr];
     for (uint32_t i = addr + 1; i < n; i++) if (map[i] == g) return i;
@@ -471,25 +510,25 @@ int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_
 
     do {
         MbInfo *m = &d->mb[addr];
-        if (!sh->redundant_pic_cnt && m->decoded) return -1;
+        if (!sh->redundant_pic_cnt && m->decoded) FAIL;
         m->slice_id = d->slice_id;
         if (sh->is_p && !prev_skipped) {
             skip_run = br_ue(br);
-            if (br_overrun(br) || skip_run > d->pic_size_mbs - addr) return -1;
+            if (br_overrun(br) || skip_run > d->pic_size_mbs - addr) FAIL;
             if (skip_run) prev_skipped = 1;
         }
         int skipped = 0;
         if (skip_run) { skip_run--; skipped = 1; }
         else prev_skipped = 0;
-        if (decode_mb(d, br, sh, pps, addr, skipped, &qp)) return -1;
+        if (decode_mb(d, br, sh, pps, addr, skipped, &qp)) FAIL;
         if (m->decoded == 1) count++;
         more = br_more_rbsp_data(br) || skip_run;
         if (!sh->is_p) d->last_mb_addr = addr;
-        addr = next_mb_in_group(d->slice_group_map, d->pic_size_mbs, addr);
-        if (more && !addr) return -1;
+        addr = hd_next_mb_in_group(d->slice_group_map, d->pic_size_mbs, addr);
+        if (more && !addr) FAIL;
     } while (more);
 
-    if (d->num_decoded_mbs + count > d->pic_size_mbs) return -1;
+    if (d->num_decoded_mbs + count > d->pic_size_mbs) FAIL;
     d->num_decoded_mbs += count;
     return 0;
 }

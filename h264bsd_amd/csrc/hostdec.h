@@ -190,6 +190,7 @@ typedef struct DpbPic {
     int32_t  pic_num;       /* FrameNumWrap-derived PicNum, or LongTermPicNum for long-term */
     int32_t  poc;
     uint32_t pic_id, num_err_mbs;
+    uint8_t  slot;          /* frame buffer (DPB slot in HBM) that holds / will hold this picture's pixels */
 } DpbPic;
 
 typedef struct OutPic { uint8_t slot; uint8_t is_idr; uint32_t pic_id, num_err_mbs; } OutPic;
@@ -203,9 +204,9 @@ typedef struct Dpb {
     uint32_t num_ref_frames, fullness;
     uint32_t prev_ref_frame_num;
     uint8_t  last_contains_mmco5;
-    int32_t  cur;           /* slot of the picture being decoded, -1 none */
-    DpbPic   pic[FJ_MAX_SLOTS];
-    int8_t   list[33];          /* RefPicList0: index -> slot, -1 = none */
+    int32_t  cur;           /* position of the picture being decoded (always dpb_size), -1 none */
+    DpbPic   pic[FJ_MAX_SLOTS]; /* by POSITION, like the reference's dpbStorage_t.buffer[] (see hd_dpb.c) */
+    int8_t   list[33];          /* RefPicList0: index -> position, -1 = none; persists between pictures */
     OutPic   out[FJ_MAX_SLOTS + 1];
     uint32_t n_out, out_idx;
 } Dpb;
@@ -294,6 +295,8 @@ void hd_slice_group_map(uint32_t *map, const Pps *pps, uint32_t change_cycle, ui
 /* hd_dpb.c */
 int  hd_dpb_reset(Dpb *dpb, uint32_t dpb_size, uint32_t max_ref_frames, uint32_t max_frame_num, int no_reordering);
 int  hd_dpb_alloc_current(Dpb *dpb);
+int  hd_dpb_cur_slot(const Dpb *dpb);
+int  hd_dpb_ref_slot(const Dpb *dpb, uint32_t ref_idx);
 void hd_dpb_init_ref_list(Dpb *dpb);
 int  hd_dpb_reorder_ref_list(Dpb *dpb, const SliceHdr *sh);
 int  hd_dpb_check_gaps(Dpb *dpb, uint32_t frame_num, int is_ref, int gaps_allowed);
@@ -307,6 +310,7 @@ void hd_cavlc_init(void);
  * max_coeff: 16, 15 (AC: scan positions 1..15) or 4 (chroma DC, nc == -1). */
 int hd_cavlc_block(BitReader *br, int nc, int max_coeff, int16_t *coef);
 /* hd_mb.c */
+uint32_t hd_next_mb_in_group(const uint32_t *map, uint32_t n, uint32_t addr);
 int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_ref_idc);
 /* hd_api.c helpers used across files */
 int  hd_job_begin(HostDec *d);

@@ -406,6 +406,78 @@ static int check_blob(const uint8_t *blob)
 
 /* un-deblocked picture into slots[cur_slot]; macroblocks are processed in raster order, which
  * satisfies every dependency (the reference decodes in slice order; pixels do not depend on it) */
+/* ------------------------------------------------------------------ concealment of lost macroblocks */
+/* reference Transform(), src/h264bsd_conceal.c:589-637: inverse transform when only the DC, the lowest horizontal
+ * (d[1]) and the lowest vertical (d[4]) coefficient can be non-zero */
+static void conceal_transform(int *d)
+{
+    if (!d[1] && !d[4]) {
+        for (int i = 1; i < 16; i++) d[i] = d[0];
+        return;
+    }
+    int t0 = d[0], t1 = d[1];
+    d[0] = t0 + t1; d[1] = t0 + (t1 >> 1); d[2] = t0 - (t1 >> 1); d[3] = t0 - t1;
+    t0 = d[4];
+    d[5] = d[6] = d[7] = t0;
+    for (int c = 0; c < 4; c++) {
+        t0 = d[c]; t1 = d[4 + c];
+        d[c] = t0 + t1; d[4 + c] = t0 + (t1 >> 1); d[8 + c] = t0 - (t1 >> 1); d[12 + c] = t0 - t1;
+    }
+}
+
+/* One plane of reference ConcealMb (src/h264bsd_conceal.c:346-560): `size` = 16 (luma) or 8 (chroma); the block is
+ * rebuilt from the sums of four groups of size/4 border samples on each usable side. */
+static void conceal_plane(u8 *pl, int stride, int x0, int y0, int size, unsigned used)
+{
+    const int g = size / 4, sh = size == 16 ? 0 : 1;      /* luma shifts are one larger than chroma */
+    int fp[16] = { 0 }, a[4] = { 0 }, b[4] = { 0 }, l[4] = { 0 }, r[4] = { 0 };
+    int j = 0, hor = 0, ver = 0;
+    const int A = (used & FJ_CONC_ABOVE) != 0, B = (used & FJ_CONC_BELOW) != 0, L = (used & FJ_CONC_LEFT) != 0,
+              R = (used & FJ_CONC_RIGHT) != 0;
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < g; i++) {
+            if (A) a[k] += pl[(size_t)(y0 - 1) * stride + x0 + k * g + i];
+            if (B) b[k] += pl[(size_t)(y0 + size) * stride + x0 + k * g + i];
+            if (L) l[k] += pl[(size_t)(y0 + k * g + i) * stride + x0 - 1];
+            if (R) r[k] += pl[(size_t)(y0 + k * g + i) * stride + x0 + size];
+        }
+    if (A) { j++; hor++; fp[0] += a[0] + a[1] + a[2] + a[3]; fp[1] += a[0] + a[1] - a[2] - a[3]; }
+    if (B) { j++; hor++; fp[0] += b[0] + b[1] + b[2] + b[3]; fp[1] += b[0] + b[1] - b[2] - b[3]; }
+    if (L) { j++; ver++; fp[0] += l[0] + l[1] + l[2] + l[3]; fp[4] += l[0] + l[1] - l[2] - l[3]; }
+    if (R) { j++; ver++; fp[0] += r[0] + r[1] + r[2] + r[3]; fp[4] += r[0] + r[1] - r[2] - r[3]; }
+    if (!hor && L && R) fp[1] = (l[0] + l[1] + l[2] + l[3] - r[0] - r[1] - r[2] - r[3]) >> (5 - sh);
+    else if (hor) fp[1] >>= (3 - sh + hor);
+    if (!ver && A && B) fp[4] = (a[0] + a[1] + a[2] + a[3] - b[0] - b[1] - b[2] - b[3]) >> (5 - sh);
+    else if (ver) fp[4] >>= (3 - sh + ver);
+    switch (j) {
+    case 1: fp[0] >>= (4 - sh); break;
+    case 2: fp[0] >>= (5 - sh); break;
+    case 3: fp[0] = (21 * fp[0]) >> (10 - sh); break;      /* ~ *4/3 >> 6 */
+    default: fp[0] >>= (6 - sh); break;
+    }
+    conceal_transform(fp);
+    for (int y = 0; y < size; y++)
+        for (int x = 0; x < size; x++)
+            pl[(size_t)(y0 + y) * stride + x0 + x] = (u8)clip255(fp[4 * (y / g) + x / g]);
+}
+
+static void conceal_mb(const FjMbRec *r, Frame *f, u8 *const *slots, int wmb, int hmb, int mbx, int mby)
+{
+    if (r->kind == FJ_MB_CONCEAL_P) {
+        Frame ref = frame_view(slots[r->ref_slot[0]], wmb, hmb);
+        for (int y = 0; y < 16; y++)
+            memcpy(f->y + (size_t)(mby * 16 + y) * f->w + mbx * 16, ref.y + (size_t)(mby * 16 + y) * f->w + mbx * 16, 16);
+        for (int y = 0; y < 8; y++) {
+            memcpy(f->cb + (size_t)(mby * 8 + y) * (f->w / 2) + mbx * 8, ref.cb + (size_t)(mby * 8 + y) * (f->w / 2) + mbx * 8, 8);
+            memcpy(f->cr + (size_t)(mby * 8 + y) * (f->w / 2) + mbx * 8, ref.cr + (size_t)(mby * 8 + y) * (f->w / 2) + mbx * 8, 8);
+        }
+        return;
+    }
+    conceal_plane(f->y, f->w, mbx * 16, mby * 16, 16, r->avail);
+    conceal_plane(f->cb, f->w / 2, mbx * 8, mby * 8, 8, r->avail);
+    conceal_plane(f->cr, f->w / 2, mbx * 8, mby * 8, 8, r->avail);
+}
+
 int oracle_recon(const uint8_t *blob, uint8_t *const *slots)
 {
     if (check_blob(blob)) return -1;
@@ -415,10 +487,12 @@ int oracle_recon(const uint8_t *blob, uint8_t *const *slots)
     const int16_t *coefs = (const int16_t *)(blob + h->coef_off);
     Frame f = frame_view(slots[h->cur_slot], h->width_mbs, h->height_mbs);
     int res_y[256], res_c[128];
+    uint32_t n_conceal = 0;
     for (uint32_t a = 0; a < h->n_mbs; a++) {
         const FjMbRec *r = &recs[a];
         const int mbx = (int)(a % h->width_mbs), mby = (int)(a / h->width_mbs);
         if (r->kind == FJ_MB_ABSENT) continue;
+        if (r->kind == FJ_MB_CONCEAL_I || r->kind == FJ_MB_CONCEAL_P) { n_conceal++; continue; }
         if (r->kind == FJ_MB_IPCM) {
             const u8 *s = (const u8 *)(coefs + 16 * (size_t)r->coef_idx);
             for (int y = 0; y < 16; y++) memcpy(f.y + (size_t)(mby * 16 + y) * f.w + mbx * 16, s + 16 * y, 16);
@@ -436,6 +510,24 @@ int oracle_recon(const uint8_t *blob, uint8_t *const *slots)
             else recon_intra16x16(r, &f, mbx, mby, res_y);
             recon_intra_chroma(r, &f, mbx, mby, res_c);
         }
+    }
+    /* lost macroblocks, in the order the reference's concealment loop visits them (FjMbRec.coef_idx) */
+    if (n_conceal) {
+        uint32_t *ord = (uint32_t *)malloc(sizeof(uint32_t) * h->n_mbs);
+        if (!ord) return -1;
+        for (uint32_t i = 0; i < h->n_mbs; i++) ord[i] = 0xFFFFFFFFu;
+        for (uint32_t a = 0; a < h->n_mbs; a++) {
+            const FjMbRec *r = &recs[a];
+            if (r->kind != FJ_MB_CONCEAL_I && r->kind != FJ_MB_CONCEAL_P) continue;
+            if (r->coef_idx >= h->n_mbs || ord[r->coef_idx] != 0xFFFFFFFFu) { free(ord); return -1; }
+            ord[r->coef_idx] = a;
+        }
+        for (uint32_t i = 0; i < h->n_mbs; i++) {
+            const uint32_t a = ord[i];
+            if (a == 0xFFFFFFFFu) continue;
+            conceal_mb(&recs[a], &f, slots, h->width_mbs, h->height_mbs, (int)(a % h->width_mbs), (int)(a / h->width_mbs));
+        }
+        free(ord);
     }
     return 0;
 }
@@ -455,7 +547,11 @@ static const u8 tc0_tab[52][3] = {
 static const u8 qpc_tab[52] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23,
     24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39 };
 
-static inline int is_intra_kind(int k) { return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM; }
+static inline int is_intra_kind(int k)
+{
+    /* concealed macroblocks are filtered as Intra4x4 (reference conceal.c:309) */
+    return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM || k == FJ_MB_CONCEAL_I || k == FJ_MB_CONCEAL_P;
+}
 
 /* boundary strength between the 4x4 block (qx,qy) of MB q and its left (dir 0) / upper (dir 1)
  * neighbour block, which lies in MB p (== q for inner edges) */
