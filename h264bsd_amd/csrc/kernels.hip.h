@@ -305,7 +305,11 @@ __device__ __forceinline__ void chroma_pred2(const uint8_t *__restrict__ p, int 
 }
 
 /* ------------------------------------------------------------------ deblocking records */
-__device__ __forceinline__ bool is_intra_kind(int k) { return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM; }
+/* concealed macroblocks are filtered as Intra4x4 (reference src/h264bsd_conceal.c:309) */
+__device__ __forceinline__ bool is_intra_kind(int k)
+{
+    return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM || k == FJ_MB_CONCEAL_I || k == FJ_MB_CONCEAL_P;
+}
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -598,6 +602,84 @@ __global__ __launch_bounds__(256, 6) void k_recon_inter(const FrameDesc *__restr
 constexpr int TS = 32;   /* intra luma tile: row 0 = row above, rows 1..16 = MB; byte 3 = left column / corner,
                             bytes 4..19 = MB columns (dword aligned), bytes 20..23 of row 0 = above-right */
 
+/* ---- concealment of a lost macroblock from its neighbours (reference ConcealMb, src/h264bsd_conceal.c:346-560) ----
+ * Per plane the block is rebuilt from three numbers: t0 (mean of the border samples of the usable sides), t1 (left-
+ * right slope) and v (top-bottom slope), pushed through the reference's 3-coefficient inverse transform; every
+ * (size/4)x(size/4) sub-block is constant.  S = sum of a side's border samples, D = first half minus second half. */
+__device__ __forceinline__ void conceal_coeffs(int SA, int DA, int SB, int DB, int SL, int DL, int SR, int DR,
+                                               bool A, bool B, bool L, bool R, int sh, int &t0, int &t1, int &v)
+{
+    const int hor = (int)A + (int)B, ver = (int)L + (int)R, j = hor + ver;
+    int f0 = (A ? SA : 0) + (B ? SB : 0) + (L ? SL : 0) + (R ? SR : 0);
+    int f1 = (A ? DA : 0) + (B ? DB : 0), f4 = (L ? DL : 0) + (R ? DR : 0);
+    if (!hor && L && R) f1 = (SL - SR) >> (5 - sh);
+    else if (hor) f1 >>= (3 - sh + hor);
+    if (!ver && A && B) f4 = (SA - SB) >> (5 - sh);
+    else if (ver) f4 >>= (3 - sh + ver);
+    f0 = j == 1 ? f0 >> (4 - sh) : j == 2 ? f0 >> (5 - sh) : j == 3 ? (21 * f0) >> (10 - sh) : f0 >> (6 - sh);
+    t0 = f0; t1 = f1; v = f4;
+}
+/* value of sub-block (bx, by) after the reference's Transform() (conceal.c:589-637) */
+__device__ __forceinline__ int conceal_value(int t0, int t1, int v, int bx, int by)
+{
+    const int h = bx == 0 ? t0 + t1 : bx == 1 ? t0 + (t1 >> 1) : bx == 2 ? t0 - (t1 >> 1) : t0 - t1;
+    return clip255(by == 0 ? h + v : by == 1 ? h + (v >> 1) : by == 2 ? h - (v >> 1) : h - v);
+}
+
+__device__ __forceinline__ void conceal_mb(const FrameDesc &fd, uint32_t mb, int lane, unsigned used)
+{
+    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
+    const int mbx = mb % wmb, mby = mb / wmb;
+    uint8_t *cur = fd.cur;
+    const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
+    const bool A = used & FJ_CONC_ABOVE, B = used & FJ_CONC_BELOW, L = used & FJ_CONC_LEFT, R = used & FJ_CONC_RIGHT;
+    /* luma: lanes 0-15 above, 16-31 below, 32-47 left, 48-63 right, one border sample each */
+    {
+        const int side = lane >> 4, k = lane & 15;
+        uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
+        int s = 0;
+        if (side == 0 && A) s = Y[-(ptrdiff_t)W + k];
+        if (side == 1 && B) s = Y[(size_t)16 * W + k];
+        if (side == 2 && L) s = Y[(size_t)k * W - 1];
+        if (side == 3 && R) s = Y[(size_t)k * W + 16];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        const int o = __shfl_xor(s, 8);
+        const int S = s + o, D = (lane & 8) ? o - s : s - o;
+        int t0, t1, v;
+        conceal_coeffs(__shfl(S, 0), __shfl(D, 0), __shfl(S, 16), __shfl(D, 16), __shfl(S, 32), __shfl(D, 32), __shfl(S, 48),
+                       __shfl(D, 48), A, B, L, R, 0, t0, t1, v);
+        const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
+        const uint32_t px = (uint32_t)conceal_value(t0, t1, v, bx, by) * 0x01010101u;
+        *reinterpret_cast<uint32_t *>(Y + (size_t)(by * 4 + row) * W + bx * 4) = px;
+    }
+    /* chroma: lane = 32*plane + 8*side + k */
+    {
+        const int plane = lane >> 5, side = (lane >> 3) & 3, k = lane & 7;
+        uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+        int s = 0;
+        if (side == 0 && A) s = P[-(ptrdiff_t)CW + k];
+        if (side == 1 && B) s = P[(size_t)8 * CW + k];
+        if (side == 2 && L) s = P[(size_t)k * CW - 1];
+        if (side == 3 && R) s = P[(size_t)k * CW + 8];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+        const int o = __shfl_xor(s, 4);
+        const int S = s + o, D = (lane & 4) ? o - s : s - o;
+        int t0[2], t1[2], v[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            conceal_coeffs(__shfl(S, 32 * p), __shfl(D, 32 * p), __shfl(S, 32 * p + 8), __shfl(D, 32 * p + 8), __shfl(S, 32 * p + 16),
+                           __shfl(D, 32 * p + 16), __shfl(S, 32 * p + 24), __shfl(D, 32 * p + 24), A, B, L, R, 1, t0[p], t1[p], v[p]);
+        if (lane < 32) {
+            /* lane -> plane (lane>>4), row y = (lane>>1)&7, half = lane&1: four samples = two 2x2 sub-block values */
+            const int pl = lane >> 4, y = (lane >> 1) & 7, half = lane & 1;
+            uint8_t *Q = cur + ysz + (pl ? csz : 0) + (size_t)(mby * 8 + y) * CW + mbx * 8 + half * 4;
+            const int a0 = conceal_value(t0[pl], t1[pl], v[pl], half * 2, y >> 1);
+            const int a1 = conceal_value(t0[pl], t1[pl], v[pl], half * 2 + 1, y >> 1);
+            *reinterpret_cast<uint32_t *>(Q) = (uint32_t)a0 * 0x00000101u | (uint32_t)a1 * 0x01010000u;
+        }
+    }
+}
+
 /* one intra macroblock by one wavefront; tile = 17*TS bytes, ctile = 2 x 9*16 bytes (wave-private LDS) */
 __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0)
 {
@@ -610,6 +692,10 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
     uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
 
+    if (rec.kind == FJ_MB_CONCEAL_I) {
+        conceal_mb(fd, mb, lane, rec.avail);
+        return;
+    }
     if (rec.kind == FJ_MB_IPCM) {
         const uint8_t *s = reinterpret_cast<const uint8_t *>(coef);
         *reinterpret_cast<uint32_t *>(Y + (size_t)(lane >> 2) * W + (lane & 3) * 4) = *reinterpret_cast<const uint32_t *>(s + 4 * lane);

@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import synth                      # noqa: E402
-from synth_configs import CONFIGS  # noqa: E402
+from synth_configs import CONFIGS, DAMAGED  # noqa: E402
+from damage import damage  # noqa: E402
 from h264writer import StreamWriter  # noqa: E402
 
 out = {}
@@ -24,4 +25,9 @@ for name, cfg in CONFIGS.items():
     assert len(pics) == cfg.get("n_pics", 6), name
     out[name] = dict(stream_sha1=hashlib.sha1(data).hexdigest(), bytes=len(data), trace=trace, pics=pics)
     print(name, len(data), "bytes", len(pics), "pictures")
+for name, (cfg, dmg) in DAMAGED.items():
+    data = damage(StreamWriter(**cfg).build(), **dmg)
+    trace, pics = synth.decode_reference(data)
+    out[name] = dict(stream_sha1=hashlib.sha1(data).hexdigest(), bytes=len(data), trace=trace, pics=pics)
+    print(name, len(data), "bytes", len(pics), "pictures", sum(p[3] for p in pics), "concealed macroblocks")
 json.dump(out, open(os.path.join(HERE, "synth_golden.json"), "w"), indent=0)

@@ -34,3 +34,17 @@ CONFIGS = {
 }
 for _s in range(160, 200):
     CONFIGS[f"random_{_s}"] = random_config(_s)
+
+
+# ---- damaged streams: (writer keywords, damage keywords).  Slice NAL units are dropped or cut
+# short; the decoder must report the same errors, conceal the same macroblocks the same way and keep the same DPB
+# state as the reference.  Streams with redundant slices or bit flips are left out on purpose: there the reference's
+# own behaviour depends on stale metadata / out-of-bounds CAVLC writes ("known deviations").
+def _damaged(seed):
+    cfg = random_config(seed)
+    cfg["gaps"] = 0
+    cfg["redundant"] = False
+    return cfg, dict(seed=seed, p_drop=0.2, p_flip=0.0, p_trunc=0.2)
+
+
+DAMAGED = {f"damaged_{_s}": _damaged(_s) for _s in range(0, 48)}

@@ -1,0 +1,60 @@
+"""Damaged streams: lost and truncated slices.
+
+The reference reports H264BSD_ERROR for the broken NAL unit, un-decodes the macroblocks of the corrupt slice
+(src/h264bsd_slice_data.c:298-354), conceals every macroblock that is still missing when the access unit ends
+(src/h264bsd_conceal.c) — copy from the first usable reference in P pictures, synthesis from the neighbours otherwise,
+filtered as intra with QP 40 — delivers the picture with numErrMbs set and keeps decoding.  These tests require the
+same call trace, the same output order, the same numErrMbs and bit-identical pictures (concealed pixels included)
+for 48 damaged synthetic streams; expected answers from the compiled reference (tests/golden/make_synth_golden.py).
+
+CPU test: host parser (planning) + CPU oracle.  GPU test: the product through the C ABI (concealment runs in the
+HIP kernels: copies in k_copy, synthesis in k_frame_intra)."""
+import hashlib
+import json
+import os
+
+import pytest
+
+import synth
+from damage import damage
+from h264writer import StreamWriter
+from synth_configs import DAMAGED
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth_golden.json")))
+_streams = {}
+
+
+def stream_of(name):
+    if name not in _streams:
+        cfg, dmg = DAMAGED[name]
+        data = damage(StreamWriter(**cfg).build(), **dmg)
+        if hashlib.sha1(data).hexdigest() != GOLD[name]["stream_sha1"]:
+            pytest.skip("stream differs from the one the golden answers were made from — regenerate the golden file")
+        _streams[name] = data
+    return _streams[name]
+
+
+def check(name, backend):
+    trace, pics = synth.decode_ours(stream_of(name), backend)
+    g = GOLD[name]
+    assert [list(t) for t in trace] == g["trace"], "h264bsdDecode call trace differs from the reference"
+    assert [p[1:] for p in pics] == [tuple(p[1:]) for p in g["pics"]], "output order / picId / isIdr / numErrMbs differ"
+    bad = [i for i, (p, q) in enumerate(zip(pics, g["pics"])) if p[0] != q[0]]
+    assert not bad, f"output pictures {bad} are not bit-exact"
+
+
+def test_the_set_really_exercises_concealment():
+    n_err = sum(p[3] for name in DAMAGED for p in GOLD[name]["pics"])
+    n_calls = sum(1 for name in DAMAGED for t in GOLD[name]["trace"] if t[0] == 3)
+    assert n_err > 1500 and n_calls > 100
+
+
+@pytest.mark.parametrize("name", list(DAMAGED))
+def test_parser_and_oracle_match_reference(built, name):
+    check(name, "oracle")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(DAMAGED))
+def test_gpu_matches_reference(built, name):
+    check(name, "gpu")
