@@ -9,9 +9,9 @@
  *   - PIC_RDY when the last macroblock of a picture has been parsed (:457-462, :473-510).
  * What is different by design: at PIC_RDY no pixel exists yet.  The picture has been turned into a
  * frame job and queued on the JobSink; pixels materialise when the application pulls the picture.
- * Error concealment (reference src/h264bsd_conceal.c) is not implemented: an access-unit boundary
- * in the middle of a picture, or a corrupt slice, is reported as HD_ERROR and the picture is
- * dropped.
+ * Damaged streams: a corrupt slice is un-decoded (mark_slice_corrupted), and a picture that is still incomplete
+ * when the next access unit starts is completed by concealment records (plan_concealment) whose pixels the
+ * kernels produce; the call returns PIC_RDY with read_bytes == 0 like the reference (decoder.c:226-266).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,6 +20,7 @@
 
 HostDec *hd_create(int no_output_reordering);
 void hd_destroy(HostDec *d);
+/* error exits of hd_decode report where they happened when HD_TRACE is set in the environment (debugging aid) */
 #define ERR_RETURN do { if (getenv("HD_TRACE")) fprintf(stderr, "TRACE hd_decode error at line %d\n", __LINE__); return HD_ERROR; } while (0)
 int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes);
 

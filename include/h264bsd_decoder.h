@@ -9,7 +9,9 @@
  *   - the input buffer is NOT modified (the reference unescapes in place, byte_stream.c:193-235);
  *   - pixels are produced on the GPU: h264bsdDecode() only parses and queues a frame job, the
  *     picture is materialised (and copied to host memory) by h264bsdNextOutputPicture*();
- *   - no error concealment: damaged pictures are reported as H264BSD_ERROR and dropped.
+ *   - damaged streams are handled like the reference (H264BSD_ERROR for the broken NAL unit, lost macroblocks
+ *     concealed as src/h264bsd_conceal.c does, numErrMbs reported); the one check that cannot be mirrored on the
+ *     host — residual samples outside [-512,511], src/h264bsd_transform.c:184-188 — clips instead of failing.
  */
 #ifndef H264BSD_MI355X_DECODER_H
 #define H264BSD_MI355X_DECODER_H

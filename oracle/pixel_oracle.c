@@ -24,6 +24,9 @@
  *   write-back / residual add                 src/h264bsd_image.c:81,172
  *   deblocking                       8.7      src/h264bsd_deblocking.c:575-1745 (h264bsdFilterPicture)
  *   colour conversion                         src/h264bsd_decoder.c:1163-1370 (h264bsdConvertTo*)
+ *   concealment of lost macroblocks           src/h264bsd_conceal.c:266-637 (ConcealMb, Transform); the walking
+ *                                             order of h264bsdConceal (:124-260) arrives in the frame job
+ * (tests/test_damaged_streams.py pins the concealment against the compiled reference on damaged streams)
  * Known, deliberate gap: the reference turns a residual outside [-512,511] into a decode error
  * (transform.c:184-188); the oracle (like the kernels) just clips after prediction.
  */

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import synth                      # noqa: E402
-from synth_configs import CONFIGS, DAMAGED  # noqa: E402
+from synth_configs import CONFIGS, DAMAGED, DAMAGED_BUNDLED  # noqa: E402
 from damage import damage  # noqa: E402
 from h264writer import StreamWriter  # noqa: E402
 
@@ -27,6 +27,11 @@ for name, cfg in CONFIGS.items():
     print(name, len(data), "bytes", len(pics), "pictures")
 for name, (cfg, dmg) in DAMAGED.items():
     data = damage(StreamWriter(**cfg).build(), **dmg)
+    trace, pics = synth.decode_reference(data)
+    out[name] = dict(stream_sha1=hashlib.sha1(data).hexdigest(), bytes=len(data), trace=trace, pics=pics)
+    print(name, len(data), "bytes", len(pics), "pictures", sum(p[3] for p in pics), "concealed macroblocks")
+for name, (stream, dmg) in DAMAGED_BUNDLED.items():
+    data = damage(open(os.path.join(HERE, stream + ".h264"), "rb").read(), **dmg)
     trace, pics = synth.decode_reference(data)
     out[name] = dict(stream_sha1=hashlib.sha1(data).hexdigest(), bytes=len(data), trace=trace, pics=pics)
     print(name, len(data), "bytes", len(pics), "pictures", sum(p[3] for p in pics), "concealed macroblocks")

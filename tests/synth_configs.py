@@ -48,3 +48,6 @@ def _damaged(seed):
 
 
 DAMAGED = {f"damaged_{_s}": _damaged(_s) for _s in range(0, 48)}
+
+# a bundled x264 stream (one slice per picture, 40x23 macroblocks) with slices cut short: concealment at picture scale
+DAMAGED_BUNDLED = {"damaged_bundled_640x360": ("test_640x360", dict(seed=7, p_drop=0.04, p_flip=0.0, p_trunc=0.3))}
