@@ -24,7 +24,8 @@ EXPORTED_SYMBOLS = [
     "h264bsdCroppingParams", "h264bsdSampleAspectRatio", "h264bsdCheckValidParamSets", "h264bsdFlushBuffer",
     "h264bsdProfile", "h264bsdAlloc", "h264bsdFree", "h264bsdConvertToRGBA", "h264bsdConvertToBGRA",
     "h264bsdConvertToYCbCrA",
-    "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush",
+    "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync",
+    "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads",
     "h264bsdmiReplayCreate", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
@@ -108,6 +109,10 @@ def lib():
     L.h264bsdmiNextOutputInfo.restype = ctypes.c_int
     L.h264bsdmiNextOutputPictureDevice.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DevicePicture)]
     L.h264bsdmiNextOutputPictureDevice.restype = ctypes.c_int
+    L.h264bsdmiDecodePicture.argtypes = [vp, u8p, u32, u32, P32, P32]
+    L.h264bsdmiDecodePicture.restype = u32
+    L.h264bsdmiDecodePictureBatch.argtypes = [u32, ctypes.POINTER(vp), ctypes.POINTER(vp), P32, P32, P32, P32, P32]
+    L.h264bsdmiSetParserThreads.argtypes = [ctypes.c_int]
     L.h264bsdmiJobFinalize.argtypes = [ctypes.c_void_p, u32, u32]
     L.h264bsdmiSetDevice.argtypes = [ctypes.c_int]
     L.h264bsdmiReplayCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32]
@@ -147,6 +152,8 @@ class Decoder:
         self._cb = None
         if capture is None:
             rc = L.h264bsdInit(self._st, no_output_reordering)
+        elif capture == "discard":           # parser only, frame jobs dropped (parser benchmarks)
+            rc = L.h264bsdmiInitCapture(self._st, no_output_reordering, ctypes.cast(None, JOB_CB), None)
         else:
             self._cb = JOB_CB(lambda user, p, n: capture(ctypes.string_at(p, n)))
             rc = L.h264bsdmiInitCapture(self._st, no_output_reordering, self._cb, None)
@@ -264,6 +271,48 @@ class Decoder:
             elif r >= H264BSD_ERROR:
                 break
         return trace
+
+
+class BatchDriver:
+    """Advance many Decoder instances picture by picture on the library's parser threads
+    (h264bsdmiDecodePictureBatch): one call parses the next picture of every stream that still has data."""
+
+    def __init__(self, decoders, streams):
+        """streams: one bytes object per decoder (each is copied once into a private buffer)"""
+        self.L = lib()
+        self.n = len(decoders)
+        self.decoders = decoders
+        self._bufs = [ctypes.create_string_buffer(b, len(b)) for b in streams]
+        self.size = [len(b) for b in streams]
+        self.off = [0] * self.n
+        self.pictures = [0] * self.n
+        VP = ctypes.c_void_p * self.n
+        U32 = ctypes.c_uint32 * self.n
+        self._dec = VP(*[d._st for d in decoders])
+        self._ptr, self._len, self._pid = VP(), U32(), U32()
+        self._status, self._consumed, self._errs = U32(), U32(), U32()
+
+    def step(self):
+        """parse the next picture of every unfinished stream; returns the indices that produced a picture"""
+        live = [k for k in range(self.n) if self.off[k] < self.size[k]]
+        if not live:
+            return []
+        for i, k in enumerate(live):
+            self._dec[i] = self.decoders[k]._st
+            self._ptr[i] = ctypes.addressof(self._bufs[k]) + self.off[k]
+            self._len[i] = self.size[k] - self.off[k]
+            self._pid[i] = self.pictures[k]
+        rc = self.L.h264bsdmiDecodePictureBatch(len(live), self._dec, self._ptr, self._len, self._pid, self._status,
+                                                self._consumed, self._errs)
+        if rc != 0:
+            raise RuntimeError("h264bsdmiDecodePictureBatch failed")
+        ready = []
+        for i, k in enumerate(live):
+            self.off[k] += self._consumed[i]
+            if self._status[i] == H264BSD_PIC_RDY:
+                self.pictures[k] += 1
+                ready.append(k)
+        return ready
 
 
 def capture_stream(data):

@@ -7,9 +7,14 @@
  * and fails loudly (stderr + HANTRO_NOK) when no gfx950 device is usable.  The only GPU-less mode is
  * h264bsdmiInitCapture(), which produces frame jobs and never pixels.
  */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include "../../include/h264bsd_mi355x.h"
 #include "hostdec.h"
 #include "engine.h"
@@ -235,3 +240,143 @@ int h264bsdmiJobFinalize(u8 *job, u32 capacity, u32 n_coef_blocks) { return fj_f
 void h264bsdConvertToRGBA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(0, width, height, data, pOutput); }
 void h264bsdConvertToBGRA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(1, width, height, data, pOutput); }
 void h264bsdConvertToYCbCrA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(2, width, height, data, pOutput); }
+
+/* ================================================================== host parse pipeline */
+u32 h264bsdmiDecodePicture(storage_t *s, u8 *buf, u32 len, u32 picId, u32 *consumed, u32 *nErrors)
+{
+    u32 off = 0, last = H264BSD_RDY, errs = 0, stalls = 0;
+    while (off < len) {
+        u32 rb = 0;
+        last = h264bsdDecode(s, buf + off, len - off, picId, &rb);
+        off += rb;
+        if (last == H264BSD_PIC_RDY) break;
+        if (last >= H264BSD_ERROR) errs++;
+        stalls = rb ? 0 : stalls + 1;              /* HDRS_RDY and friends repeat the same NAL once; never spin */
+        if (stalls > 3) break;
+    }
+    if (consumed) *consumed = off;
+    if (nErrors) *nErrors = errs;
+    return last == H264BSD_PIC_RDY ? last : (u32)H264BSD_RDY;
+}
+
+/* A small persistent pool: workers sleep on a condition variable, a batch is an index range handed out by an atomic
+ * counter (pictures differ a lot in parse time: I pictures cost several times a P picture). */
+typedef struct Batch {
+    u32 n;
+    storage_t *const *dec;
+    u8 *const *buf;
+    const u32 *len, *pic_id;
+    u32 *status, *consumed, *n_errors;
+    atomic_uchar *taken;                    /* one flag per item */
+    int active;                             /* pool threads currently inside this batch (guarded by g_pool.mu) */
+} Batch;
+
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t wake, idle;
+    pthread_t th[64];
+    int n_threads, started, want, pin;
+    unsigned generation;
+    Batch *batch;
+    pthread_mutex_t api_mu;                 /* one batch at a time */
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, { 0 }, 0, 0, 0, 0, 0, NULL,
+             PTHREAD_MUTEX_INITIALIZER };
+
+/* Worker `me` of `nw` takes the items i = me, me+nw, ... first (so that a stream is normally parsed by the same
+ * thread — and from the same NUMA node — every round) and then helps with whatever is left. */
+static void batch_run_item(Batch *b, u32 i)
+{
+    b->status[i] = h264bsdmiDecodePicture(b->dec[i], b->buf[i], b->len[i], b->pic_id ? b->pic_id[i] : 0,
+                                          &b->consumed[i], b->n_errors ? &b->n_errors[i] : NULL);
+}
+
+static void batch_work(Batch *b, u32 me, u32 nw)
+{
+    for (u32 i = me; i < b->n; i += nw)
+        if (!atomic_exchange(&b->taken[i], 1)) batch_run_item(b, i);
+    for (u32 i = 0; i < b->n; i++)
+        if (!atomic_load(&b->taken[i]) && !atomic_exchange(&b->taken[i], 1)) batch_run_item(b, i);
+}
+
+static void *pool_main(void *arg)
+{
+    const u32 me = (u32)(size_t)arg;        /* 1.. ; the caller's thread is worker 0 */
+    if (g_pool.pin) {
+        /* spread the workers over the CPUs (worker k -> CPU k * ncpu / nthreads): first-touch then places each
+         * stream's parser state on the node of the thread that owns it */
+        const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET((int)(((long)me * ncpu) / (g_pool.want > 0 ? g_pool.want : 1)) % (int)ncpu, &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    unsigned seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.generation == seen) pthread_cond_wait(&g_pool.wake, &g_pool.mu);
+        seen = g_pool.generation;
+        Batch *b = g_pool.batch;
+        if (!b) continue;
+        b->active++;
+        const u32 nw = (u32)g_pool.n_threads;
+        pthread_mutex_unlock(&g_pool.mu);
+        batch_work(b, me, nw);
+        pthread_mutex_lock(&g_pool.mu);
+        if (--b->active == 0) pthread_cond_broadcast(&g_pool.idle);
+    }
+    return NULL;
+}
+
+static int pool_default_threads(void)
+{
+    const char *e = getenv("H264BSDMI_THREADS");
+    long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return (int)n;
+}
+
+int h264bsdmiSetParserThreads(int n)
+{
+    pthread_mutex_lock(&g_pool.mu);
+    if (n < 1) n = pool_default_threads();
+    if (n > 64) n = 64;
+    g_pool.want = n;
+    g_pool.pin = getenv("H264BSDMI_PIN") ? atoi(getenv("H264BSDMI_PIN")) : 0;
+    /* the caller's thread works too: n threads in total = n-1 pool threads (threads are only ever added) */
+    while (g_pool.started < n - 1) {
+        if (pthread_create(&g_pool.th[g_pool.started], NULL, pool_main, (void *)(size_t)(g_pool.started + 1))) break;
+        pthread_detach(g_pool.th[g_pool.started]);
+        g_pool.started++;
+    }
+    g_pool.n_threads = g_pool.started + 1;
+    const int r = g_pool.n_threads;
+    pthread_mutex_unlock(&g_pool.mu);
+    return r;
+}
+
+int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *dec, u8 *const *buf, const u32 *len, const u32 *picId,
+                                u32 *status, u32 *consumed, u32 *nErrors)
+{
+    if (!dec || !buf || !len || !status || !consumed) return -1;
+    if (!n) return 0;
+    pthread_mutex_lock(&g_pool.api_mu);
+    if (!g_pool.n_threads) h264bsdmiSetParserThreads(0);
+    atomic_uchar *taken = (atomic_uchar *)calloc(n, sizeof(atomic_uchar));
+    if (!taken) { pthread_mutex_unlock(&g_pool.api_mu); return -1; }
+    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, taken, 0 };
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.batch = &b;
+    g_pool.generation++;
+    pthread_cond_broadcast(&g_pool.wake);
+    const u32 nw = (u32)g_pool.n_threads;
+    pthread_mutex_unlock(&g_pool.mu);
+    batch_work(&b, 0, nw);
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.batch = NULL;                    /* late wakers find nothing; those inside are counted in b.active */
+    while (b.active) pthread_cond_wait(&g_pool.idle, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+    free(taken);
+    pthread_mutex_unlock(&g_pool.api_mu);
+    return 0;
+}

@@ -49,6 +49,7 @@ struct StreamCtx {
     uint8_t *h_frame[FJ_MAX_SLOTS] = {};
     uint32_t *h_conv = nullptr, *d_conv = nullptr;
     std::mutex qmu;                         /* guards pending / free_bufs (submit runs on the caller's threads) */
+    PendingJob acquired = { nullptr, 0, 0 };   /* staging buffer the parser is currently filling (sink_acquire) */
     std::deque<PendingJob> pending;
     std::vector<PendingJob> free_bufs;      /* recycled pinned staging buffers */
 };
@@ -61,6 +62,10 @@ struct Engine {
     uint8_t *d_arena = nullptr; size_t arena_cap = 0;      /* device copies of the blobs of one tick */
     FrameDesc *d_desc = nullptr; size_t desc_cap = 0;
     uint8_t *conv_in = nullptr; uint32_t *conv_out = nullptr; size_t conv_cap = 0; /* eng_convert_host scratch */
+    FrameDesc *h_desc = nullptr; int h_desc_flip = 0; unsigned desc_ticks = 0;    /* pinned descriptor staging, 2 halves */
+    hipEvent_t desc_ev[2] = { nullptr, nullptr };
+    std::vector<std::pair<StreamCtx *, PendingJob>> inflight;   /* staging buffers of enqueued, unfinished ticks */
+    hipEvent_t inflight_done = nullptr;
 };
 
 unsigned long long *g_tail_prof = nullptr;   /* debug: per-wave cycle accounting of k_frame_tail (block 0) */
@@ -79,6 +84,9 @@ Engine *engine_get()
     else if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
     if (hipSetDevice(e->device) != hipSuccess) { delete e; return nullptr; }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return nullptr; }
+    if (hipEventCreateWithFlags(&e->desc_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->desc_ev[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->inflight_done, hipEventDisableTiming) != hipSuccess) { delete e; return nullptr; }
     g_engine = e;
     return e;
 }
@@ -173,9 +181,26 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
 }
 
 /* ---- lazy execution of the queued jobs of all decoder instances ---- */
-int flush_locked(Engine *e)
+/* Recycle the pinned staging buffers of ticks whose copies have completed (all of them after wait != 0). */
+int reap_locked(Engine *e, bool wait)
+{
+    if (e->inflight.empty()) return 0;
+    if (wait) HIP_TRY(hipStreamSynchronize(e->stream));
+    else if (hipEventQuery(e->inflight_done) != hipSuccess) return 0;
+    for (auto &f : e->inflight) {
+        std::lock_guard<std::mutex> ql(f.first->qmu);
+        f.first->free_bufs.push_back(f.second);
+    }
+    e->inflight.clear();
+    return 0;
+}
+
+/* Enqueue one tick per round of pending jobs (at most one picture per stream and tick).  wait: block until the
+ * pixels exist; otherwise return once everything is enqueued (the staging buffers stay owned by `inflight`). */
+int flush_locked(Engine *e, bool wait = true)
 {
     HIP_TRY(hipSetDevice(e->device));
+    if (reap_locked(e, false)) return -1;
     for (;;) {
         std::vector<StreamCtx *> part;
         size_t bytes = 0;
@@ -183,37 +208,45 @@ int flush_locked(Engine *e)
             std::lock_guard<std::mutex> ql(s->qmu);
             if (!s->pending.empty()) { part.push_back(s); bytes += (s->pending.front().bytes + 255u) & ~255u; }
         }
-        if (part.empty()) return 0;
+        if (part.empty()) break;
         if (bytes > e->arena_cap) {
+            HIP_TRY(hipStreamSynchronize(e->stream));          /* earlier ticks may still read the old arena */
             if (e->d_arena) HIP_TRY(hipFree(e->d_arena));
             e->arena_cap = bytes + bytes / 4;
             HIP_TRY(hipMalloc((void **)&e->d_arena, e->arena_cap));
         }
         if (part.size() > e->desc_cap) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
             if (e->d_desc) HIP_TRY(hipFree(e->d_desc));
+            if (e->h_desc) HIP_TRY(hipHostFree(e->h_desc));
             e->desc_cap = part.size() * 2;
             HIP_TRY(hipMalloc((void **)&e->d_desc, e->desc_cap * sizeof(FrameDesc)));
+            HIP_TRY(hipHostMalloc((void **)&e->h_desc, 2 * e->desc_cap * sizeof(FrameDesc), hipHostMallocDefault));
+            e->h_desc_flip = 0;
         }
-        std::vector<FrameDesc> descs(part.size());
+        /* descriptors are staged in pinned memory (two halves, alternating) so that the copy can be asynchronous;
+         * before reusing a half, the tick that used it two ticks ago must have consumed it */
+        if (e->desc_ticks >= 2) HIP_TRY(hipEventSynchronize(e->desc_ev[e->h_desc_flip]));
+        FrameDesc *descs = e->h_desc + (size_t)e->h_desc_flip * e->desc_cap;
         TickShape shape;
         size_t off = 0;
         for (size_t i = 0; i < part.size(); i++) {
             StreamCtx *s = part[i];
             PendingJob j;
-            { std::lock_guard<std::mutex> ql(s->qmu); j = s->pending.front(); }
+            { std::lock_guard<std::mutex> ql(s->qmu); j = s->pending.front(); s->pending.pop_front(); }
             HIP_TRY(hipMemcpyAsync(e->d_arena + off, j.host, j.bytes, hipMemcpyHostToDevice, e->stream));
             make_desc(descs[i], j.host, e->d_arena + off, s->d_frames, s->frame_bytes, s->d_dbk, &shape);
             off += (j.bytes + 255u) & ~255u;
+            e->inflight.emplace_back(s, j);
         }
-        HIP_TRY(hipMemcpyAsync(e->d_desc, descs.data(), descs.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_desc, descs, part.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipEventRecord(e->desc_ev[e->h_desc_flip], e->stream));
+        e->h_desc_flip ^= 1;
+        e->desc_ticks++;
         if (launch_tick(e->stream, e->d_desc, shape, nullptr, nullptr)) return -1;
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        for (StreamCtx *s : part) {
-            std::lock_guard<std::mutex> ql(s->qmu);
-            s->free_bufs.push_back(s->pending.front());
-            s->pending.pop_front();
-        }
     }
+    if (!e->inflight.empty()) HIP_TRY(hipEventRecord(e->inflight_done, e->stream));
+    return wait ? reap_locked(e, true) : 0;
 }
 
 /* ---- JobSink implementation ---- */
@@ -225,6 +258,8 @@ void stream_release(StreamCtx *s)
     s->pending.clear();
     for (auto &j : s->free_bufs) hipHostFree(j.host);
     s->free_bufs.clear();
+    if (s->acquired.host) hipHostFree(s->acquired.host);
+    s->acquired = PendingJob{ nullptr, 0, 0 };
     if (s->d_frames) hipFree(s->d_frames);
     if (s->d_dbk) hipFree(s->d_dbk);
     s->d_dbk = nullptr;
@@ -251,12 +286,10 @@ int sink_configure(void *user, uint32_t wmb, uint32_t hmb, uint32_t n_slots)
     return 0;
 }
 
-int sink_submit(void *user, const uint8_t *blob, uint32_t bytes)
+/* staging buffer for a frame job of up to `bytes`: recycled pinned memory of this stream, else a new allocation */
+static int take_buffer(SinkUser *u, uint32_t bytes, PendingJob *out)
 {
-    /* runs on the application's threads, concurrently for different decoder instances: only the stream's own
-     * queue lock is taken, and not while the job is copied into pinned memory */
-    SinkUser *u = static_cast<SinkUser *>(user);
-    PendingJob j = { nullptr, bytes, 0 };
+    PendingJob j = { nullptr, 0, 0 };
     {
         std::lock_guard<std::mutex> ql(u->s->qmu);
         for (size_t i = 0; i < u->s->free_bufs.size(); i++)
@@ -268,11 +301,43 @@ int sink_submit(void *user, const uint8_t *blob, uint32_t bytes)
     }
     if (!j.host) {
         HIP_TRY(hipSetDevice(u->e->device));
-        j.cap = bytes + bytes / 2 + 65536;                  /* pinned: recycled across pictures */
+        j.cap = bytes + 65536;                              /* pinned: recycled across pictures */
         HIP_TRY(hipHostMalloc((void **)&j.host, j.cap, hipHostMallocDefault));
     }
+    *out = j;
+    return 0;
+}
+
+/* The parser builds the next frame job directly in pinned staging memory (JobSink.acquire): nothing is copied on
+ * the host between parsing and the H2D transfer. */
+uint8_t *sink_acquire(void *user, uint32_t bytes)
+{
+    SinkUser *u = static_cast<SinkUser *>(user);
+    StreamCtx *s = u->s;
+    if (s->acquired.host && s->acquired.cap >= bytes) return s->acquired.host;     /* previous picture was abandoned */
+    if (s->acquired.host) {
+        std::lock_guard<std::mutex> ql(s->qmu);
+        s->free_bufs.push_back(s->acquired);
+        s->acquired = PendingJob{ nullptr, 0, 0 };
+    }
+    if (take_buffer(u, bytes, &s->acquired)) return nullptr;
+    return s->acquired.host;
+}
+
+int sink_submit(void *user, const uint8_t *blob, uint32_t bytes)
+{
+    /* runs on the application's / the parser pool's threads, concurrently for different decoder instances: only the
+     * stream's own queue lock is taken */
+    SinkUser *u = static_cast<SinkUser *>(user);
+    PendingJob j;
+    if (u->s->acquired.host && blob == u->s->acquired.host) {
+        j = u->s->acquired;
+        u->s->acquired = PendingJob{ nullptr, 0, 0 };
+    } else {
+        if (take_buffer(u, bytes, &j)) return -1;
+        memcpy(j.host, blob, bytes);
+    }
     j.bytes = bytes;
-    memcpy(j.host, blob, bytes);
     std::lock_guard<std::mutex> ql(u->s->qmu);
     u->s->pending.push_back(j);
     return 0;
@@ -337,6 +402,7 @@ void sink_close(void *user)
     {
         std::lock_guard<std::mutex> lk(u->e->mu);
         hipSetDevice(u->e->device);
+        reap_locked(u->e, true);
         hipStreamSynchronize(u->e->stream);
         stream_release(u->s);
         auto &v = u->e->streams;
@@ -362,6 +428,7 @@ int eng_attach(JobSink *sink)
     }
     sink->user = u;
     sink->configure = sink_configure;
+    sink->acquire = sink_acquire;
     sink->submit = sink_submit;
     sink->fetch = sink_fetch;
     sink->fetch_converted = sink_fetch_converted;
@@ -415,6 +482,14 @@ int h264bsdmiFlush(void)
     if (!e) return -1;
     std::lock_guard<std::mutex> lk(e->mu);
     return flush_locked(e);
+}
+
+int h264bsdmiFlushAsync(void)
+{
+    Engine *e = engine_get();
+    if (!e) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return flush_locked(e, false);
 }
 
 /* ------------------------------------------------------------------ replay sets */

@@ -50,7 +50,7 @@ typedef struct MbCtx {
                                       here, acted upon once parsing of the macroblock has succeeded. */
 } MbCtx;
 
-static inline MbInfo *usable(MbInfo *m, uint32_t slice_id) { return (m && m->slice_id == slice_id) ? m : NULL; }
+static inline MbInfo *usable(HostDec *d, uint32_t idx, uint32_t slice_id) { return d->mb_slice_id[idx] == slice_id ? &d->mb[idx] : NULL; }
 static inline int is_inter(const MbInfo *m) { return m->kind == FJ_MB_INTER; }
 
 /* ---------------------------------------------------------------- nC, 9.2.1 */
@@ -365,12 +365,12 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
     c.addr = addr; c.mbx = addr % d->width_mbs; c.mby = addr / d->width_mbs;
     MbInfo *m = c.cur = &d->mb[addr];
     const uint32_t sid = d->slice_id;
-    c.A = c.mbx ? usable(m - 1, sid) : NULL;
-    c.B = c.mby ? usable(m - d->width_mbs, sid) : NULL;
-    c.C = (c.mby && c.mbx + 1 < d->width_mbs) ? usable(m - d->width_mbs + 1, sid) : NULL;
-    c.D = (c.mby && c.mbx) ? usable(m - d->width_mbs - 1, sid) : NULL;
+    c.A = c.mbx ? usable(d, addr - 1, sid) : NULL;
+    c.B = c.mby ? usable(d, addr - d->width_mbs, sid) : NULL;
+    c.C = (c.mby && c.mbx + 1 < d->width_mbs) ? usable(d, addr - d->width_mbs + 1, sid) : NULL;
+    c.D = (c.mby && c.mbx) ? usable(d, addr - d->width_mbs - 1, sid) : NULL;
 
-    const int first_decode = m->decoded == 0;
+    const int first_decode = d->mb_decoded[addr] == 0;
     const uint32_t coef_start = d->coef_blocks;
     FjMbRec rec;
     memset(&rec, 0, sizeof(rec));
@@ -461,8 +461,15 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
             m->qp = (uint8_t)*qp;
         }
     }
-    m->decoded++;
-    if (c.p2err) FAIL;
+    d->mb_decoded[addr]++;
+    if (c.p2err) {
+        if (first_decode) {            /* counted as decoded, never reconstructed: an inert, defined record */
+            memset(&recs[addr], 0, sizeof(FjMbRec));
+            recs[addr].kind = FJ_MB_ABSENT;
+            memset(mvs[addr], 0, 64);
+        }
+        FAIL;
+    }
 
     if (!first_decode) {          /* redundant re-decode: keep the primary's record and pixels */
         d->coef_blocks = coef_start;
@@ -484,6 +491,7 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
         }
         d->n_inter++;
     } else {
+        memset(mvs[addr], 0, 64);      /* the sections are not pre-zeroed: keep the job a pure function of the stream */
         d->n_intra++;
     }
     recs[addr] = rec;
@@ -509,9 +517,8 @@ int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_
     d->last_mb_addr = 0;
 
     do {
-        MbInfo *m = &d->mb[addr];
-        if (!sh->redundant_pic_cnt && m->decoded) FAIL;
-        m->slice_id = d->slice_id;
+        if (!sh->redundant_pic_cnt && d->mb_decoded[addr]) FAIL;
+        d->mb_slice_id[addr] = d->slice_id;
         if (sh->is_p && !prev_skipped) {
             skip_run = br_ue(br);
             if (br_overrun(br) || skip_run > d->pic_size_mbs - addr) FAIL;
@@ -521,7 +528,7 @@ int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_
         if (skip_run) { skip_run--; skipped = 1; }
         else prev_skipped = 0;
         if (decode_mb(d, br, sh, pps, addr, skipped, &qp)) FAIL;
-        if (m->decoded == 1) count++;
+        if (d->mb_decoded[addr] == 1) count++;
         more = br_more_rbsp_data(br) || skip_run;
         if (!sh->is_p) d->last_mb_addr = addr;
         addr = hd_next_mb_in_group(d->slice_group_map, d->pic_size_mbs, addr);

@@ -170,8 +170,7 @@ typedef struct MbInfo {
     uint8_t  kind;          /* FJ_MB_* of the last decode of this MB                             */
     uint8_t  mb_type;       /* reference numbering: 0 P_Skip, 1..5 P, 6 I4x4, 7..30 I16x16, 31 PCM */
     uint8_t  qp;
-    uint8_t  decoded;       /* times decoded in the current picture                              */
-    uint32_t slice_id;      /* 0 = not part of the current picture yet                           */
+    uint8_t  pad_;
     uint8_t  tc[24];        /* total_coeff per 4x4 block, H.264 block order (luma 0-15, Cb, Cr)   */
     int8_t   i4mode[16];    /* Intra4x4PredMode, H.264 block order                                */
     int8_t   ref_idx[4];
@@ -216,7 +215,11 @@ typedef struct JobSink {
     void *user;
     /* (re)configure for a sequence: n_slots frames of frame_bytes each. 0 = ok */
     int  (*configure)(void *user, uint32_t width_mbs, uint32_t height_mbs, uint32_t n_slots);
-    /* one finished picture; blob is only valid during the call. 0 = ok */
+    /* optional: a buffer of at least `bytes` for the NEXT frame job to be built in place (the engine hands out pinned
+     * staging memory, so that no copy is needed between the parser and the H2D transfer).  The buffer returns to the
+     * sink with submit() — or with the next acquire() when the picture is abandoned. */
+    uint8_t *(*acquire)(void *user, uint32_t bytes);
+    /* one finished picture; blob is only valid during the call unless it came from acquire(). 0 = ok */
     int  (*submit)(void *user, const uint8_t *blob, uint32_t bytes);
     /* make slot's pixels available at host address; returns pointer or NULL */
     uint8_t *(*fetch)(void *user, uint32_t slot);
@@ -245,6 +248,10 @@ typedef struct HostDec {
     uint32_t pic_size_mbs, width_mbs, height_mbs;
     MbInfo  *mb;
     uint32_t *slice_group_map;
+    /* per-picture state that is reset for every picture lives in compact arrays of its own, not in MbInfo: the
+     * reset touches 5 bytes per macroblock instead of a cache line (the parser is memory-bound at scale) */
+    uint8_t  *mb_decoded;   /* times decoded in the current picture                                 */
+    uint32_t *mb_slice_id;  /* slice that last touched the macroblock; 0 = none in this picture       */
     uint32_t num_decoded_mbs, slice_id;
     uint32_t last_mb_addr;
 
@@ -268,6 +275,7 @@ typedef struct HostDec {
 
     /* frame job under construction */
     uint8_t *job; uint32_t job_cap;
+    uint8_t  job_from_sink;  /* job points into memory handed out by sink.acquire (not ours to free) */
     uint32_t coef_blocks;  /* blocks written so far */
     uint32_t n_inter, n_intra;
     uint8_t  job_open;

@@ -56,6 +56,22 @@ typedef struct h264bsdmi_device_picture {
  * is produced by one kernel into a per-instance HBM buffer.  Returns 1 = picture, 0 = no picture, <0 = error. */
 int h264bsdmiNextOutputPictureDevice(storage_t *pStorage, int format, int crop, h264bsdmi_device_picture *out);
 
+/* ---- host parse pipeline at scale ----
+ * h264bsdDecode() consumes one NAL unit of one stream per call; a caller that feeds hundreds of streams needs the
+ * loop of posix/test_h264bsd.c:146-177 for each of them and its own threading.  These entry points move both into
+ * the library. */
+/* Feed NAL units of one instance until a picture is complete: calls h264bsdDecode() on buf, buf+readBytes, ...
+ * and stops after H264BSD_PIC_RDY or when the buffer is used up.  H264BSD_RDY / H264BSD_HDRS_RDY continue, errors
+ * are counted in *nErrors (may be NULL) and skipped like the reference harness does.  Returns the last status
+ * (H264BSD_PIC_RDY, or H264BSD_RDY at the end of the buffer); *consumed = bytes to advance. */
+u32 h264bsdmiDecodePicture(storage_t *pStorage, u8 *buf, u32 len, u32 picId, u32 *consumed, u32 *nErrors);
+/* The same for n independent instances at once, on the library's parser threads (the caller's thread helps).
+ * status[i] / consumed[i] / nErrors[i] (nErrors may be NULL) as above.  Instances must be distinct. */
+int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *pStorage, u8 *const *buf, const u32 *len, const u32 *picId,
+                                u32 *status, u32 *consumed, u32 *nErrors);
+/* Number of parser threads (default: online CPUs, at most 64; env H264BSDMI_THREADS).  Returns the value in use. */
+int h264bsdmiSetParserThreads(int n);
+
 /* ---- device engine ---- */
 /* Number of usable GPUs (0 when the HIP runtime finds none); selects the device for this process. */
 int  h264bsdmiDeviceCount(void);
@@ -63,6 +79,10 @@ int  h264bsdmiSetDevice(int device);
 /* Run every queued frame job of every decoder instance of this process now (they are otherwise run
  * lazily, when the first picture is pulled).  Returns 0 on success. */
 int  h264bsdmiFlush(void);
+/* Like h264bsdmiFlush() but returns as soon as the copies and kernels are enqueued, so that parsing the next
+ * pictures overlaps the reconstruction of these.  Any call that needs pixels (h264bsdNextOutputPicture*,
+ * h264bsdmiFlush) waits for the outstanding work first. */
+int  h264bsdmiFlushAsync(void);
 
 /* ---- HBM-resident replay (bench / parity tests): kernels only, no host parsing in the loop ----
  * A replay set holds n_streams independent copies of one captured stream: every copy owns private

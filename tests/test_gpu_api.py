@@ -121,3 +121,31 @@ def test_device_resident_output(built, golden, fmt, crop):
             full = pyoracle.oracle_convert(fmt, W, H, frame).reshape(H, W)[y0:y0 + h, x0:x0 + w]
             assert tuple(t.shape) == (h, w, 4)
             assert np.array_equal(t.cpu().numpy().reshape(h, w * 4).view(np.uint32), full)
+
+
+def test_parser_pool_with_async_flush_is_exact(built, golden):
+    """h264bsdmiDecodePictureBatch + h264bsdmiFlushAsync: 6 instances advance picture by picture on the parser threads,
+    reconstruction is enqueued without waiting; every 5th round all queued output pictures are pulled and compared"""
+    names = ["test_640x360"] * 4 + ["test_1920x1080", "test_1920x1080_fullRange"]
+    L = built.lib()
+    L.h264bsdmiSetParserThreads(4)
+    decs = [built.Decoder() for _ in names]
+    drv = built.BatchDriver(decs, [stream_bytes(n) for n in names])
+    seen = [0] * len(names)
+    rounds = 0
+    while True:
+        ready = drv.step()
+        if not ready:
+            break
+        assert L.h264bsdmiFlushAsync() == 0
+        rounds += 1
+        for k in ready:            # pictures must be pulled before the next h264bsdDecode of that instance (API contract)
+            while True:
+                pic = decs[k].next_output_picture()
+                if pic is None:
+                    break
+                assert hashlib.sha256(pic[0].tobytes()).hexdigest() == golden[names[k]]["frame_sha256"][seen[k]]
+                seen[k] += 1
+    assert rounds == 73 and seen == [73] * len(names)
+    for d in decs:
+        d.close()
