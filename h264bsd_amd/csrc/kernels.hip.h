@@ -626,7 +626,7 @@ __device__ __forceinline__ int conceal_value(int t0, int t1, int v, int bx, int 
     return clip255(by == 0 ? h + v : by == 1 ? h + (v >> 1) : by == 2 ? h - (v >> 1) : h - v);
 }
 
-__device__ __forceinline__ void conceal_mb(const FrameDesc &fd, uint32_t mb, int lane, unsigned used)
+__device__ __noinline__ void conceal_mb(const FrameDesc &fd, uint32_t mb, int lane, unsigned used)
 {
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mbx = mb % wmb, mby = mb / wmb;
@@ -692,10 +692,6 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
     uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
 
-    if (rec.kind == FJ_MB_CONCEAL_I) {
-        conceal_mb(fd, mb, lane, rec.avail);
-        return;
-    }
     if (rec.kind == FJ_MB_IPCM) {
         const uint8_t *s = reinterpret_cast<const uint8_t *>(coef);
         *reinterpret_cast<uint32_t *>(Y + (size_t)(lane >> 2) * W + (lane & 3) * 4) = *reinterpret_cast<const uint32_t *>(s + 4 * lane);
@@ -1141,8 +1137,13 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
     uint8_t *my = lds + wave * 1024;
     for (uint32_t l = 0; l < fd.n_levels; l++) {
         const uint32_t first = fd.lvl[l], count = fd.lvl[l + 1] - first;
-        for (uint32_t i = wave; i < count; i += TAIL_WAVES)
-            intra_mb(fd, fd.idx[first + i], lane, my, my + 17 * TS);
+        for (uint32_t i = wave; i < count; i += TAIL_WAVES) {
+            const uint32_t mb = fd.idx[first + i];
+            /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
+            const uint32_t head = *reinterpret_cast<const uint32_t *>(&fd.recs[mb]);     /* kind, qp_y, qp_c, avail */
+            if ((head & 255u) == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
+            else intra_mb(fd, mb, lane, my, my + 17 * TS);
+        }
         __syncthreads();
     }
 }
