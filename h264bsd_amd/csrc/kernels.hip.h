@@ -459,17 +459,22 @@ constexpr int IW_STRIDE = 36;                        /* luma window: 21 rows x 2
 constexpr int IC_STRIDE = 20;                        /* chroma windows: 9 rows x 16 bytes, two planes */
 constexpr int INTER_WAVE_LDS = 21 * IW_STRIDE + 2 * 9 * IC_STRIDE;
 
-__global__ __launch_bounds__(256, 6) void k_recon_inter(const FrameDesc *__restrict__ frames)
+#ifndef INTER_OCC
+#define INTER_OCC 7      /* 72 VGPRs, 10 spilled: measured best (6: 71.5 ms, 7: 67.4, 8: 68.3, 5: 79.9 per step) */
+#endif
+__global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * INTER_WAVE_LDS];
     const FrameDesc &fd = frames[blockIdx.y];
-    const uint32_t gi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform: the list entry, the record and
+                                                                                 everything derived live in scalar registers */
+    const uint32_t gi = blockIdx.x * 4 + wave;
     if (gi >= fd.n_gen) return;
     const FjGen ge = fd.gen[gi];
     const uint32_t mb = ge.mb;
     const FjMbRec rec = fd.recs[mb];                  /* only the QPs are needed from it (in flight meanwhile) */
     const int lane = threadIdx.x & 63;
-    uint8_t *lw = lds + (threadIdx.x >> 6) * INTER_WAVE_LDS, *lc = lw + 21 * IW_STRIDE;
+    uint8_t *lw = lds + wave * INTER_WAVE_LDS, *lc = lw + 21 * IW_STRIDE;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mbx = mb % wmb, mby = mb / wmb;
     const int16_t *mvs = fd.mvs + 32 * (size_t)mb;
