@@ -1178,7 +1178,13 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *
     uint16_t *queue = reinterpret_cast<uint16_t *>(dep + ((n_mbs + 15) & ~15));
     uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + ((n_mbs + 7) & ~7));   /* [0] head, [1] tail, [2] total */
     uint8_t *wlds = lds + (wave * 2 + half) * WORKER_LDS;
-    (void)prof; (void)hmb;
+    (void)hmb;
+    /* debug accounting (h264bsdmiDebugTailProfile): workgroup 0 only, per wavefront: [0] cycles with nothing ready,
+     * [1] cycles filtering, [2] cycles waiting for own stores, [3] macroblocks filtered (both halves), [4] total */
+    unsigned long long *tp = (prof && blockIdx.x == 0) ? prof + wave * 8 : nullptr;
+    unsigned long long t_idle = 0, t_work = 0, t_store = 0, n_done = 0;
+    const unsigned long long t_begin = tp ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long t_mark = t_begin;
 
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(fd.dbk + (size_t)n_mbs * DBK_REC_BYTES);
@@ -1220,6 +1226,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
+        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int run = mb_cur;                                  /* -1 in a half that has nothing ready */
         DbkPrefetch cp = pf_cur;
@@ -1227,6 +1234,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *
         const bool want_pf = run >= 0 && mb_nxt >= 0;
         DbkPrefetch np = {};
         deblock_mb(fd, run, hl, cp, wlds, want_pf ? mb_nxt : -1, np);
+        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && hl == 0)); }
         if (run >= 0) {
             /* release: stores done -> dependants */
             __builtin_amdgcn_s_waitcnt(0);
@@ -1251,6 +1259,10 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *
             if (hl == 0) c = atomicAdd(&ctr[0], 1u);
             s_nxt = __shfl(c, half * 32); mb_nxt = -1;
         }
+        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_store += t - t_mark; t_mark = t; }
+    }
+    if (tp && lane == 0) {
+        tp[0] += t_idle; tp[1] += t_work; tp[2] += t_store; tp[3] += n_done; tp[4] += __builtin_readcyclecounter() - t_begin;
     }
 }
 

@@ -1,17 +1,23 @@
-import sys, ctypes, numpy as np
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""Cycle accounting of k_frame_dbk's dataflow loop (workgroup 0 = stream 0, per wavefront) for a few ticks of the
+256-stream 1080p replay: how much of a wave's life is spent with nothing ready / filtering / waiting for stores."""
+import sys, os, ctypes, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import h264bsd_amd as h
-L=h.lib()
-jobs,_,_=h.capture_stream(open('/root/repo/tests/golden/test_1920x1080.h264','rb').read())
-rep=h.Replay(jobs, n_streams=256)
-rep.run(0,10); rep.sync()
-for tick in (10, 20, 40):
+L = h.lib()
+jobs, _, _ = h.capture_stream(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "test_1920x1080.h264"), "rb").read())
+rep = h.Replay(jobs, n_streams=256)
+done = 0
+for tick in (0, 10, 20, 41):
+    if tick > done:
+        rep.run(done, tick - done); rep.sync()
     L.h264bsdmiDebugTailProfile(1, None)
-    rep.run(tick,1); rep.sync()
-    out=np.zeros((16,8),dtype=np.uint64)
+    rep.run(tick, 1); rep.sync()
+    done = tick + 1
+    out = np.zeros((16, 8), dtype=np.uint64)
     L.h264bsdmiDebugTailProfile(0, ctypes.c_void_p(out.ctypes.data))
-    print('tick',tick,'timings',{k:v for k,v in rep.timings().items()})
-    print(' cols: setup filter barrier nfilt maxlevel | load V H store (cycles, per wave)')
-    for w in (0,7,15): print(' wave',w, out[w,:5], out[w,5], out[w,6], out[w,7]&0xffffffff, out[w,7]>>32)
-    if tick==10: rep.run(11,9); rep.sync()
-    if tick==20: rep.run(21,19); rep.sync()
+    t = rep.timings()
+    tot = out[:, 4].astype(float).sum()
+    print(f"tick {tick}: k_frame_dbk {t['k_frame_dbk'][0]:.3f} ms; MBs filtered by WG0: {int(out[:,3].sum())}; "
+          f"idle {out[:,0].sum()/tot:.0%}  filter {out[:,1].sum()/tot:.0%}  store-wait+release {out[:,2].sum()/tot:.0%}; "
+          f"wave cycles {tot/16:.0f} avg")
