@@ -165,7 +165,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     if (timed) HIP_TRY(hipEventRecord(tt->ev[4], st));
     if (s.any_deblock && (stages & 4u)) {
         const uint32_t nl = s.max_w + 2 * s.max_h, n = s.max_mbs;
-        const size_t lds = (size_t)h264k::TAIL_WORKERS * h264k::WORKER_LDS + 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64;
+        const size_t lds = (size_t)h264k::TAIL_WORKERS * h264k::WORKER_LDS + 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 16 + 384 + 64;
         (void)nl;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
@@ -753,10 +753,10 @@ int h264bsdmiDebugTailProfile(int enable, unsigned long long *out)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     if (enable) {
-        if (!g_tail_prof) HIP_TRY(hipMalloc((void **)&g_tail_prof, 16 * 8 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(g_tail_prof, 0, 16 * 8 * sizeof(unsigned long long)));
+        if (!g_tail_prof) HIP_TRY(hipMalloc((void **)&g_tail_prof, 16 * 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(g_tail_prof, 0, 16 * 16 * sizeof(unsigned long long)));
     } else if (g_tail_prof) {
-        if (out) HIP_TRY(hipMemcpy(out, g_tail_prof, 16 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (out) HIP_TRY(hipMemcpy(out, g_tail_prof, 16 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         HIP_TRY(hipFree(g_tail_prof));
         g_tail_prof = nullptr;
     }

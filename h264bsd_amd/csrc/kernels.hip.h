@@ -886,45 +886,6 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
 #undef I4_L
 
 /* ------------------------------------------------------------------ deblocking */
-/* Edge filter, branch-free per lane (8.7.2.3 / 8.7.2.4): every lane computes the bS<4 result and — only if
- * some lane of the wavefront has bS = 4 — the bS=4 result, then selects.  Chroma lines run through the SAME
- * instruction stream (chroma = true): only p0/q0 change, tc = tc0 + 1, and bS=4 uses the weak formula, which is
- * exactly the luma filter with ap = aq = false.  v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 */
-__device__ __forceinline__ void filter_edge8(int v[8], int bs, int alpha, int beta, int tc0, bool chroma)
-{
-    const int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
-    const bool fs = bs != 0 && abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta;
-    const bool ap = !chroma && abs(p2 - p0) < beta, aq = !chroma && abs(q2 - q0) < beta;
-    const bool strong = bs == 4;
-    /* bS < 4 */
-    const int tc = tc0 + (chroma ? 1 : (ap ? 1 : 0) + (aq ? 1 : 0));
-    const int d = clip3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
-    const int avg = (p0 + q0 + 1) >> 1;
-    int r_p0 = clip255(p0 + d), r_q0 = clip255(q0 - d);
-    int r_p1 = p1 + clip3(-tc0, tc0, (p2 + avg - 2 * p1) >> 1);
-    int r_q1 = q1 + clip3(-tc0, tc0, (q2 + avg - 2 * q1) >> 1);
-    int r_p2 = p2, r_q2 = q2;
-    bool m_p1 = ap, m_q1 = aq, m_p2 = false, m_q2 = false;
-    if (__ballot(strong && fs)) {                       /* wave-uniform: intra edges only */
-        const bool sm = abs(p0 - q0) < ((alpha >> 2) + 2);
-        const bool sp = sm && ap, sq = sm && aq;
-        const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
-        const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
-        if (strong) {
-            r_p0 = s_p0; r_q0 = s_q0;
-            r_p1 = (p2 + p1 + p0 + q0 + 2) >> 2; r_q1 = (p0 + q0 + q1 + q2 + 2) >> 2;
-            r_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3; r_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-            m_p1 = sp; m_q1 = sq; m_p2 = sp; m_q2 = sq;
-        }
-    }
-    v[3] = fs ? r_p0 : p0;
-    v[4] = fs ? r_q0 : q0;
-    v[2] = fs && m_p1 ? r_p1 : p1;
-    v[5] = fs && m_q1 ? r_q1 : q1;
-    v[1] = fs && m_p2 ? r_p2 : p2;
-    v[6] = fs && m_q2 ? r_q2 : q2;
-}
-
 struct EdgeThr { int alpha, beta, ia; };
 __device__ __forceinline__ EdgeThr thr_of(uint32_t ia, uint32_t ib)
 {
@@ -935,36 +896,112 @@ __device__ __forceinline__ EdgeThr thr_of(uint32_t ia, uint32_t ib)
 
 constexpr int LS = 36;                               /* deblock luma tile: 20 rows x 20 cols; 9-dword stride = no bank conflicts for row-per-lane reads */
 constexpr int CS = 20;                               /* deblock chroma tiles: 10 rows x 12 cols, 5-dword stride */
-constexpr int WORKER_LDS = 1280;                     /* LDS per deblocking worker (= half a wavefront)   */
+constexpr int WORKER_LDS = 1280;                     /* LDS per deblocking worker (= a quarter wavefront) */
+
+/* ---- packed edge filter: TWO lines per lane (v_pk_*_i16) ----
+ * A lane owns two adjacent sample rows (vertical edges) or columns (horizontal edges); every register holds the
+ * same sample position of both lines as two 16-bit halves.  The two lines lie in the same 4-sample segment of the
+ * edge, so they share bS, alpha, beta and tc0.  Conditions become 0 / -1 half-word masks ((a - b) >> 15), selection
+ * is bitwise (v_bfi).  Same arithmetic as 8.7.2.3 / 8.7.2.4, same result as filter_edge8. */
+typedef short s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2 pk(int x) { return (s2){ (short)x, (short)x }; }
+__device__ __forceinline__ s2 pk_lt(s2 a, s2 b) { return (a - b) >> pk(15); }                  /* a < b ? -1 : 0 */
+__device__ __forceinline__ s2 pk_abs(s2 a) { return __builtin_elementwise_max(a, -a); }
+__device__ __forceinline__ s2 pk_clip(s2 lo, s2 hi, s2 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi); }
+__device__ __forceinline__ s2 pk_sel(s2 m, s2 a, s2 b) { return (a & m) | (b & ~m); }
+
+__device__ __forceinline__ void filter_edge8_pk(s2 v[8], int bs, int alpha, int beta, int tc0, bool chroma)
+{
+    const s2 p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
+    const s2 B = pk(beta), zero = pk(0);
+    const s2 on = pk(bs != 0 ? -1 : 0), lum = pk(chroma ? 0 : -1);
+    const s2 d0 = pk_abs(p0 - q0);
+    const s2 fs = on & pk_lt(d0, pk(alpha)) & pk_lt(pk_abs(p1 - p0), B) & pk_lt(pk_abs(q1 - q0), B);
+    const s2 ap = lum & pk_lt(pk_abs(p2 - p0), B), aq = lum & pk_lt(pk_abs(q2 - q0), B);
+    /* bS < 4 */
+    const s2 t0 = pk(tc0);
+    const s2 tc = chroma ? t0 + pk(1) : t0 - ap - aq;                     /* masks are -1 where true */
+    const s2 d = pk_clip(-tc, tc, (((q0 - p0) << pk(2)) + (p1 - q1) + pk(4)) >> pk(3));
+    const s2 avg = (p0 + q0 + pk(1)) >> pk(1);
+    s2 r_p0 = pk_clip(zero, pk(255), p0 + d), r_q0 = pk_clip(zero, pk(255), q0 - d);
+    s2 r_p1 = p1 + pk_clip(-t0, t0, (p2 + avg - (p1 << pk(1))) >> pk(1));
+    s2 r_q1 = q1 + pk_clip(-t0, t0, (q2 + avg - (q1 << pk(1))) >> pk(1));
+    s2 r_p2 = p2, r_q2 = q2;
+    s2 m_p1 = ap, m_q1 = aq, m_p2 = zero, m_q2 = zero;
+    const bool strong = bs == 4;
+    if (__ballot(strong)) {                              /* wave-uniform: intra edges only */
+        const s2 sm = pk_lt(d0, pk((alpha >> 2) + 2));
+        const s2 sp = sm & ap, sq = sm & aq;
+        const s2 p0q0 = p0 + q0;
+        const s2 s_p0 = pk_sel(sp, (p2 + ((p1 + p0q0) << pk(1)) + q1 + pk(4)) >> pk(3), ((p1 << pk(1)) + p0 + q1 + pk(2)) >> pk(2));
+        const s2 s_q0 = pk_sel(sq, (p1 + ((p0q0 + q1) << pk(1)) + q2 + pk(4)) >> pk(3), ((q1 << pk(1)) + q0 + p1 + pk(2)) >> pk(2));
+        if (strong) {
+            r_p0 = s_p0; r_q0 = s_q0;
+            r_p1 = (p2 + p1 + p0q0 + pk(2)) >> pk(2); r_q1 = (p0q0 + q1 + q2 + pk(2)) >> pk(2);
+            r_p2 = ((p3 << pk(1)) + p2 + (p2 << pk(1)) + p1 + p0q0 + pk(4)) >> pk(3);
+            r_q2 = ((q3 << pk(1)) + q2 + (q2 << pk(1)) + q1 + p0q0 + pk(4)) >> pk(3);
+            m_p1 = sp; m_q1 = sq; m_p2 = sp; m_q2 = sq;
+        }
+    }
+    v[3] = pk_sel(fs, r_p0, p0);
+    v[4] = pk_sel(fs, r_q0, q0);
+    v[2] = pk_sel(fs & m_p1, r_p1, p1);
+    v[5] = pk_sel(fs & m_q1, r_q1, q1);
+    v[1] = pk_sel(fs & m_p2, r_p2, p2);
+    v[6] = pk_sel(fs & m_q2, r_q2, q2);
+}
+
+__device__ __forceinline__ s2 as_s2(uint32_t x) { s2 r; __builtin_memcpy(&r, &x, 4); return r; }
+__device__ __forceinline__ uint32_t as_u32(s2 x) { uint32_t r; __builtin_memcpy(&r, &x, 4); return r; }
+/* v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8 bytes {lo = 0..3, hi = 4..7}; selector 12 = 0x00 */
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
 /* Everything a worker can fetch about a macroblock BEFORE its neighbours are final: the deblocking
- * record and the macroblock's own (still un-filtered) samples.  Issued one diagonal ahead. */
-struct DbkPrefetch { uint32_t y0, y1, c, bsb; uint4 thr; };
+ * record and the macroblock's own (still un-filtered) samples.  Issued one slot ahead.
+ * A worker is a QUARTER of a wavefront (16 lanes, ql = lane & 15). */
+struct DbkPrefetch { uint32_t y[4]; uint2 c; uint32_t bsb; uint4 thr; uint32_t s_ly, s_ty, s_lc, s_tc; };
 
-__device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int hl, DbkPrefetch &p)
+__device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int ql, DbkPrefetch &p)
 {
     if (mb < 0) return;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mbx = mb % wmb, mby = mb / wmb;
     const uint8_t *Y = fd.cur + (size_t)(mby * 16) * W + mbx * 16;
-    const int row = hl >> 2, cw = hl & 3;
-    p.y0 = *reinterpret_cast<const uint32_t *>(Y + (size_t)row * W + 4 * cw);
-    p.y1 = *reinterpret_cast<const uint32_t *>(Y + (size_t)(row + 8) * W + 4 * cw);
-    const int plane = hl >> 4, r = (hl >> 1) & 7, ccw = hl & 1;
+    const int row = ql >> 2, cw = ql & 3;                       /* luma rows row, row+4, row+8, row+12; word cw */
+#pragma unroll
+    for (int i = 0; i < 4; i++) p.y[i] = *reinterpret_cast<const uint32_t *>(Y + (size_t)(row + 4 * i) * W + 4 * cw);
+    const int plane = ql >> 3, r = ql & 7;                      /* one 8-byte chroma row */
     const uint8_t *P = fd.cur + (size_t)W * H + (plane ? (size_t)CW * CH : 0) + (size_t)(mby * 8) * CW + mbx * 8;
-    p.c = *reinterpret_cast<const uint32_t *>(P + (size_t)r * CW + 4 * ccw);
+    p.c = *reinterpret_cast<const uint2 *>(P + (size_t)r * CW);
     const uint8_t *rec = fd.dbk + (size_t)mb * DBK_REC_BYTES;
-    p.bsb = rec[hl >> 1];
+    p.bsb = rec[ql];                                            /* strengths: byte ql = nibbles 2ql, 2ql+1 */
     p.thr = *reinterpret_cast<const uint4 *>(rec + 16);
+    /* The strips of the left / upper neighbour (final by now: this macroblock was only published after them).
+     * Whether they are needed is in the record that is still in flight, so they are fetched unconditionally —
+     * one memory round trip per macroblock instead of two. */
+    p.s_ly = p.s_ty = p.s_lc = p.s_tc = 0;
+    if (mbx > 0) {
+        p.s_ly = *reinterpret_cast<const uint32_t *>(Y + (size_t)ql * W - 4);
+        p.s_lc = *reinterpret_cast<const uint32_t *>(P + (size_t)r * CW - 4);
+    }
+    if (mby > 0) {
+        p.s_ty = *reinterpret_cast<const uint32_t *>(Y + (ptrdiff_t)((ql >> 2) - 4) * W + 4 * (ql & 3));
+        if (ql < 8) {
+            const uint8_t *PC0 = fd.cur + (size_t)W * H + (size_t)(mby * 8) * CW + mbx * 8;
+            p.s_tc = *reinterpret_cast<const uint32_t *>(PC0 + ((ql >> 2) ? (size_t)CW * CH : 0) + (ptrdiff_t)(((ql >> 1) & 1) - 2) * CW + 4 * (ql & 1));
+        }
+    }
 }
 
-/* In-loop filter of one macroblock by one worker = 32 lanes (hl = lane & 31): vertical edges, then
- * horizontal edges (8.7).  mb < 0: this half of the wavefront idles.  w = worker-private LDS. */
-__device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, const DbkPrefetch &p, uint8_t *w,
-                                           int nxt, DbkPrefetch &nxt_pf, unsigned long long *tp = nullptr)
+/* In-loop filter of one macroblock by one worker = 16 lanes: vertical edges, then horizontal edges (8.7).
+ * mb < 0: this quarter of the wavefront idles.  w = worker-private LDS.  q16 = 16 * (quarter index). */
+__device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, int q16, const DbkPrefetch &p, uint8_t *w,
+                                           int nxt, DbkPrefetch &nxt_pf, const uint8_t *tabs, unsigned long long *tp = nullptr)
 {
 #define DTICK() (tp ? __builtin_readcyclecounter() : 0ull)
     const unsigned long long d0 = DTICK();
+    /* threshold tables in LDS (tabs: alpha[64] | beta[64] | tc0[64][4]): a lane-indexed __constant__ lookup is a
+     * global load, and these sit on the critical path of every edge */
     uint8_t *lt = w, *ct0 = w + 20 * LS, *bs_s = w + 20 * LS + 2 * 10 * CS;
     const bool act = mb >= 0;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
@@ -973,119 +1010,107 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, 
     const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
     uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
     uint8_t *PC = cur + ysz + (size_t)(mby * 8) * CW + mbx * 8;
-    /* the left / upper neighbour is touched only if that macroblock edge has a non-zero strength:
-     * lane hl holds byte hl>>1; left edge = nibbles 0..3 = bytes 0,1 (lanes 0..3), top edge = nibbles 16..19 =
-     * bytes 8,9 (lanes 16..19) */
-    const unsigned long long bl = __ballot(act && (hl >> 2) == 0 && p.bsb != 0), bt = __ballot(act && (hl >> 2) == 4 && p.bsb != 0);
-    const uint32_t hsel = (threadIdx.x & 32) ? 32 : 0;
-    /* whole phases are skipped when no lane of the wavefront has a non-zero strength in that direction:
-     * bytes 0..7 (lanes hl < 16) = vertical edges, bytes 8..15 (lanes hl >= 16) = horizontal edges */
-    const bool any_v = __ballot(act && hl < 16 && p.bsb != 0) != 0ull, any_h = __ballot(act && hl >= 16 && p.bsb != 0) != 0ull;
-    const bool f_left = (p.thr.w & FJ_DBK_LEFT) && ((uint32_t)(bl >> hsel) != 0u);
-    const bool f_top = (p.thr.w & FJ_DBK_TOP) && ((uint32_t)(bt >> hsel) != 0u);
+    /* lane ql holds strength byte ql: bytes 0..7 = vertical edges (0,1 = left MB edge), 8..15 = horizontal edges
+     * (8,9 = top MB edge).  The neighbours are touched only if that macroblock edge has a non-zero strength. */
+    const bool nz = act && p.bsb != 0;
+    const uint32_t mine = (uint32_t)(__ballot(nz) >> q16) & 0xFFFFu;
+    const bool any_v = __ballot(nz && ql < 8) != 0ull, any_h = __ballot(nz && ql >= 8) != 0ull;   /* wave-wide phase skips */
+    const bool f_left = (p.thr.w & FJ_DBK_LEFT) && (mine & 0x0003u);
+    const bool f_top = (p.thr.w & FJ_DBK_TOP) && (mine & 0x0300u);
 
-    /* neighbour strips (the only samples that depend on the previous diagonals): 56 words, issued
-     * first; then the NEXT diagonal's prefetch goes out behind them so that it flies during the filter */
-    uint32_t strip[2] = { 0, 0 };
+    /* neighbour strips (the only samples that depend on earlier macroblocks): issued first; then the NEXT slot's
+     * prefetch goes out behind them so that it flies during the filter */
+    const uint32_t s_ly = f_left ? p.s_ly : 0u, s_lc = f_left ? p.s_lc : 0u, s_ty = f_top ? p.s_ty : 0u, s_tc = f_top ? p.s_tc : 0u;
+    dbk_prefetch(fd, nxt, ql, nxt_pf);
     if (act) {
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int s = hl + 32 * it;
-            if (s < 16) {
-                if (f_left) strip[it] = *reinterpret_cast<const uint32_t *>(Y + (size_t)s * W - 4);
-            } else if (s < 32) {
-                const int r = (s - 16) >> 2, cw = (s - 16) & 3;
-                if (f_top) strip[it] = *reinterpret_cast<const uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * cw);
-            } else if (s < 48) {
-                const int plane = (s - 32) >> 3, r = (s - 32) & 7;
-                if (f_left) strip[it] = *reinterpret_cast<const uint32_t *>(PC + (plane ? csz : 0) + (size_t)r * CW - 4);
-            } else if (s < 56) {
-                const int plane = (s - 48) >> 2, r = ((s - 48) >> 1) & 1, cw = (s - 48) & 1;
-                if (f_top) strip[it] = *reinterpret_cast<const uint32_t *>(PC + (plane ? csz : 0) + (ptrdiff_t)(r - 2) * CW + 4 * cw);
-            }
-        }
-    }
-    dbk_prefetch(fd, nxt, hl, nxt_pf);
-    if (act) {
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int s = hl + 32 * it;
-            if (s < 16) *reinterpret_cast<uint32_t *>(&lt[(4 + s) * LS]) = strip[it];
-            else if (s < 32) *reinterpret_cast<uint32_t *>(&lt[((s - 16) >> 2) * LS + 4 + 4 * ((s - 16) & 3)]) = strip[it];
-            else if (s < 48) *reinterpret_cast<uint32_t *>(&ct0[((s - 32) >> 3) * 10 * CS + (2 + ((s - 32) & 7)) * CS]) = strip[it];
-            else if (s < 56) *reinterpret_cast<uint32_t *>(&ct0[((s - 48) >> 2) * 10 * CS + (((s - 48) >> 1) & 1) * CS + 4 + 4 * ((s - 48) & 1)]) = strip[it];
-        }
+        *reinterpret_cast<uint32_t *>(&lt[(4 + ql) * LS]) = s_ly;                                        /* left 4 columns  */
+        *reinterpret_cast<uint32_t *>(&lt[(ql >> 2) * LS + 4 + 4 * (ql & 3)]) = s_ty;                    /* upper 4 rows    */
+        *reinterpret_cast<uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS]) = s_lc;
+        if (ql < 8) *reinterpret_cast<uint32_t *>(&ct0[(ql >> 2) * 10 * CS + ((ql >> 1) & 1) * CS + 4 + 4 * (ql & 1)]) = s_tc;
         /* own samples (prefetched) and boundary strengths */
-        {
-            const int row = hl >> 2, cw = hl & 3;
-            *reinterpret_cast<uint32_t *>(&lt[(4 + row) * LS + 4 + 4 * cw]) = p.y0;
-            *reinterpret_cast<uint32_t *>(&lt[(12 + row) * LS + 4 + 4 * cw]) = p.y1;
-            const int plane = hl >> 4, r = (hl >> 1) & 7, ccw = hl & 1;
-            *reinterpret_cast<uint32_t *>(&ct0[plane * 10 * CS + (2 + r) * CS + 4 + 4 * ccw]) = p.c;
-            bs_s[hl] = (uint8_t)((p.bsb >> (4 * (hl & 1))) & 15u);
+        const int row = ql >> 2, cw = ql & 3;
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<uint32_t *>(&lt[(4 + row + 4 * i) * LS + 4 + 4 * cw]) = p.y[i];
+        {   /* (tile rows are 20 bytes apart: dword accesses only) */
+            uint32_t *cdst = reinterpret_cast<uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS + 4]);
+            cdst[0] = p.c.x; cdst[1] = p.c.y;
         }
+        bs_s[2 * ql] = (uint8_t)(p.bsb & 15u);
+        bs_s[2 * ql + 1] = (uint8_t)((p.bsb >> 4) & 15u);
     }
     /* thresholds: classes luma left/top/inner = 0,1,2 ; chroma left/top/inner = 3,4,5 */
     const uint4 r1 = p.thr;
-    const bool chroma = hl >= 16;
+    const bool chroma = ql >= 8;
     const uint32_t ia_in = chroma ? (r1.y >> 8) & 255u : (r1.x >> 16) & 255u, ib_in = chroma ? (r1.z >> 24) & 255u : r1.z & 255u;
     const uint32_t ia_l = chroma ? (r1.x >> 24) & 255u : r1.x & 255u, ib_l = chroma ? (r1.z >> 8) & 255u : (r1.y >> 16) & 255u;
     const uint32_t ia_t = chroma ? r1.y & 255u : (r1.x >> 8) & 255u, ib_t = chroma ? (r1.z >> 16) & 255u : (r1.y >> 24) & 255u;
-    const int al_in = c_alpha[ia_in & 63u], be_in = c_beta[ib_in & 63u];
-    const int al_l = c_alpha[ia_l & 63u], be_l = c_beta[ib_l & 63u];
-    const int al_t = c_alpha[ia_t & 63u], be_t = c_beta[ib_t & 63u];
+    const int al_in = tabs[ia_in & 63u], be_in = tabs[64 + (ib_in & 63u)];
+    const int al_l = tabs[ia_l & 63u], be_l = tabs[64 + (ib_l & 63u)];
+    const int al_t = tabs[ia_t & 63u], be_t = tabs[64 + (ib_t & 63u)];
     wave_sync();
     const unsigned long long d1 = DTICK();
 
-    /* ---- vertical edges: a lane owns one sample row across all edges.  Lanes 0..15 = luma rows (20 bytes, edges
-     * at byte 4,8,12,16), lanes 16..31 = chroma rows (12 bytes, edges at byte 4 and 8 = luma edges 0 and 2): one
-     * instruction stream for both ---- */
+    /* Lanes 0..7 own luma line pairs (2ql, 2ql+1), lanes 8..15 chroma line pairs of plane (ql-8)>>2; both lines of a
+     * pair lie in edge segment kseg, chroma tiles are 12 bytes wide / 10 rows high with their edges on luma edges 0, 2 */
+    const int cplane = (ql - 8) >> 2, cpair = (ql - 8) & 3;
+    const int kseg = chroma ? cpair : (ql >> 1);
+
+    /* ---- vertical edges: a lane owns two sample rows across all edges ---- */
     if (act && any_v) {
-        const int cplane = (hl - 16) >> 3, crow_ = (hl - 16) & 7;
-        uint8_t *rowp = chroma ? &ct0[cplane * 10 * CS + (2 + crow_) * CS] : &lt[(4 + hl) * LS];
-        const int kseg = chroma ? (crow_ >> 1) : (hl >> 2);
-        int px[20];
+        uint8_t *rowp = chroma ? &ct0[cplane * 10 * CS + (2 + 2 * cpair) * CS] : &lt[(4 + 2 * ql) * LS];
+        const int rstride = chroma ? CS : LS;
+        s2 px[20];
 #pragma unroll
         for (int w4 = 0; w4 < 5; w4++) {
-            const uint32_t v = (w4 < 3 || !chroma) ? *reinterpret_cast<const uint32_t *>(rowp + 4 * w4) : 0u;
-            px[4 * w4] = v & 255; px[4 * w4 + 1] = (v >> 8) & 255; px[4 * w4 + 2] = (v >> 16) & 255; px[4 * w4 + 3] = v >> 24;
+            const bool have = w4 < 3 || !chroma;
+            const uint32_t a = have ? *reinterpret_cast<const uint32_t *>(rowp + 4 * w4) : 0u;
+            const uint32_t b = have ? *reinterpret_cast<const uint32_t *>(rowp + rstride + 4 * w4) : 0u;
+            px[4 * w4 + 0] = as_s2(perm(b, a, 0x0C040C00u));
+            px[4 * w4 + 1] = as_s2(perm(b, a, 0x0C050C01u));
+            px[4 * w4 + 2] = as_s2(perm(b, a, 0x0C060C02u));
+            px[4 * w4 + 3] = as_s2(perm(b, a, 0x0C070C03u));
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int bs = chroma ? (e < 2 ? bs_s[8 * e + kseg] : 0) : bs_s[4 * e + kseg];
             const uint32_t ia = e ? ia_in : ia_l;
-            if (__ballot(bs != 0)) filter_edge8(px + 4 * e, bs, e ? al_in : al_l, e ? be_in : be_l, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0, chroma);
+            if (__ballot(bs != 0)) filter_edge8_pk(px + 4 * e, bs, e ? al_in : al_l, e ? be_in : be_l, bs > 0 && bs < 4 ? tabs[128 + 4 * (ia & 63u) + bs - 1] : 0, chroma);
         }
 #pragma unroll
         for (int w4 = 0; w4 < 5; w4++)
-            if (w4 < 3 || !chroma)
-                *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = pack4(px[4 * w4], px[4 * w4 + 1], px[4 * w4 + 2], px[4 * w4 + 3]);
+            if (w4 < 3 || !chroma) {
+                const uint32_t x0 = as_u32(px[4 * w4]), x1 = as_u32(px[4 * w4 + 1]), x2 = as_u32(px[4 * w4 + 2]), x3 = as_u32(px[4 * w4 + 3]);
+                /* row A = low halves, row B = high halves */
+                *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = perm(x1, x0, 0x0C0C0400u) | perm(x3, x2, 0x04000C0Cu);
+                *reinterpret_cast<uint32_t *>(rowp + rstride + 4 * w4) = perm(x1, x0, 0x0C0C0602u) | perm(x3, x2, 0x06020C0Cu);
+            }
     }
     wave_sync();
     const unsigned long long d2 = DTICK();
 
-    /* ---- horizontal edges: a lane owns one sample column; chroma columns (10 rows) sit at px[2..11] so that
-     * their edges (rows 2 and 6 of the tile) fall on px[4] and px[8] like the first two luma edges ---- */
+    /* ---- horizontal edges: a lane owns two adjacent sample columns; chroma columns (10 rows) sit at px[2..11] so
+     * that their edges (rows 2 and 6 of the tile) fall on px[4] and px[8] like the first two luma edges ---- */
     if (act && any_h) {
-        const int cplane = (hl - 16) >> 3, ccol_ = (hl - 16) & 7;
-        uint8_t *colp = chroma ? &ct0[cplane * 10 * CS + 4 + ccol_] : &lt[4 + hl];
-        const int kseg = chroma ? (ccol_ >> 1) : (hl >> 2);
-        int px[20];
+        uint8_t *colp = chroma ? &ct0[cplane * 10 * CS + 4 + 2 * cpair] : &lt[4 + 2 * ql];
+        s2 px[20];
 #pragma unroll
         for (int r = 0; r < 20; r++) {
-            if (!chroma) px[r] = colp[r * LS];
-            else px[r] = (r >= 2 && r < 12) ? colp[(r - 2) * CS] : 0;
+            uint32_t v = 0;
+            if (!chroma) v = *reinterpret_cast<const uint16_t *>(colp + r * LS);
+            else if (r >= 2 && r < 12) v = *reinterpret_cast<const uint16_t *>(colp + (r - 2) * CS);
+            px[r] = as_s2(perm(0u, v, 0x0C010C00u));
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int bs = chroma ? (e < 2 ? bs_s[16 + 8 * e + kseg] : 0) : bs_s[16 + 4 * e + kseg];
             const uint32_t ia = e ? ia_in : ia_t;
-            if (__ballot(bs != 0)) filter_edge8(px + 4 * e, bs, e ? al_in : al_t, e ? be_in : be_t, bs > 0 && bs < 4 ? c_tc0[ia & 63u][bs - 1] : 0, chroma);
+            if (__ballot(bs != 0)) filter_edge8_pk(px + 4 * e, bs, e ? al_in : al_t, e ? be_in : be_t, bs > 0 && bs < 4 ? tabs[128 + 4 * (ia & 63u) + bs - 1] : 0, chroma);
         }
 #pragma unroll
         for (int r = 1; r < 20; r++) {
-            if (!chroma) colp[r * LS] = (uint8_t)px[r];
-            else if (r >= 3 && r < 12) colp[(r - 2) * CS] = (uint8_t)px[r];
+            const uint16_t o = (uint16_t)perm(0u, as_u32(px[r]), 0x0C0C0200u);
+            if (!chroma) *reinterpret_cast<uint16_t *>(colp + r * LS) = o;
+            else if (r >= 3 && r < 12) *reinterpret_cast<uint16_t *>(colp + (r - 2) * CS) = o;
         }
     }
     wave_sync();
@@ -1093,45 +1118,40 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int hl, 
 
     /* ---- store: own macroblock, the 3 (1) columns of the left and rows of the upper neighbour ---- */
     if (act) {
+        const int row = ql >> 2, cw = ql & 3;
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int r = (hl >> 2) + 8 * it, cw = hl & 3;       /* 16 rows x 4 words */
-            *reinterpret_cast<uint32_t *>(Y + (size_t)r * W + 4 * cw) = *reinterpret_cast<const uint32_t *>(&lt[(4 + r) * LS + 4 + 4 * cw]);
-        }
+        for (int i = 0; i < 4; i++)
+            *reinterpret_cast<uint32_t *>(Y + (size_t)(row + 4 * i) * W + 4 * cw) = *reinterpret_cast<const uint32_t *>(&lt[(4 + row + 4 * i) * LS + 4 + 4 * cw]);
         {
-            const int plane = hl >> 4, r = (hl >> 1) & 7, cw = hl & 1;
-            *reinterpret_cast<uint32_t *>(PC + (plane ? csz : 0) + (size_t)r * CW + 4 * cw) =
-                *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + (2 + r) * CS + 4 + 4 * cw]);
+            const uint32_t *csrc = reinterpret_cast<const uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS + 4]);
+            *reinterpret_cast<uint2 *>(PC + ((ql >> 3) ? csz : 0) + (size_t)(ql & 7) * CW) = make_uint2(csrc[0], csrc[1]);
         }
         if (f_left) {
-            if (hl < 16) *reinterpret_cast<uint32_t *>(Y + (size_t)hl * W - 4) = *reinterpret_cast<const uint32_t *>(&lt[(4 + hl) * LS]);
-            else {
-                const int plane = (hl - 16) >> 3, r = (hl - 16) & 7;
-                *reinterpret_cast<uint32_t *>(PC + (plane ? csz : 0) + (size_t)r * CW - 4) = *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + (2 + r) * CS]);
-            }
+            *reinterpret_cast<uint32_t *>(Y + (size_t)ql * W - 4) = *reinterpret_cast<const uint32_t *>(&lt[(4 + ql) * LS]);
+            *reinterpret_cast<uint32_t *>(PC + ((ql >> 3) ? csz : 0) + (size_t)(ql & 7) * CW - 4) =
+                *reinterpret_cast<const uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS]);
         }
         if (f_top) {
-            if (hl < 12) {
-                const int r = 1 + hl / 4, cw = hl % 4;               /* tile rows 1..3 */
-                *reinterpret_cast<uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * cw) = *reinterpret_cast<const uint32_t *>(&lt[r * LS + 4 + 4 * cw]);
-            } else if (hl >= 16 && hl < 20) {
-                const int i = hl - 16, plane = i >> 1, cw = i & 1;
-                *reinterpret_cast<uint32_t *>(PC + (plane ? csz : 0) - (ptrdiff_t)CW + 4 * cw) = *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + 1 * CS + 4 + 4 * cw]);
+            if (ql < 12) {
+                const int r = 1 + ql / 4, cw2 = ql % 4;                /* tile rows 1..3 */
+                *reinterpret_cast<uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * cw2) = *reinterpret_cast<const uint32_t *>(&lt[r * LS + 4 + 4 * cw2]);
+            } else {
+                const int i = ql - 12, plane = i >> 1, cw2 = i & 1;    /* chroma tile row 1 of both planes */
+                *reinterpret_cast<uint32_t *>(PC + (plane ? csz : 0) - (ptrdiff_t)CW + 4 * cw2) = *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + 1 * CS + 4 + 4 * cw2]);
             }
         }
     }
     wave_sync();          /* tiles are reused by this worker's next macroblock */
-    if (tp) { const unsigned long long d4 = DTICK(); tp[0] += d1 - d0; tp[1] += d2 - d1; tp[2] += d3 - d2; tp[3] += d4 - d3; }
+    if (tp) { const unsigned long long d4 = DTICK(); tp[8] += d1 - d0; tp[9] += d2 - d1; tp[10] += d3 - d2; tp[11] += d4 - d3; }
 #undef DTICK
 }
 
-/* ------------------------------------------------------------------ per-picture persistent kernels */
 /* ONE 1024-thread workgroup per picture (a picture never leaves its CU); the waves of the workgroup take
  * the macroblocks of a dependency level, __syncthreads() separates levels: no kernel boundary and no
  * inter-workgroup traffic inside a picture.  Occupancy comes from batching streams (256 pictures = one
  * workgroup per CU). */
 constexpr int TAIL_WAVES = 16;
-constexpr int TAIL_WORKERS = 2 * TAIL_WAVES;
+constexpr int TAIL_WORKERS = 4 * TAIL_WAVES;      /* deblocking workers = quarter wavefronts */
 
 /* intra macroblocks, level by level (levels computed by the host parser, hd_core.c) */
 __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames)
@@ -1161,28 +1181,31 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
  *   dep[mb]   number of filtered macroblocks among those three that are not finished yet
  *   queue[]   ready list: every filtered macroblock is pushed exactly once, when its dep reaches 0
  *   head/tail claim / publish cursors (LDS atomics)
- * 32 workers (half wavefronts) claim queue slots in order, wait for the slot to be published, filter the
- * macroblock (one slot ahead is prefetched: record + own samples), wait for their stores, then release the
- * three dependants (x+1,y), (x,y+1), (x-1,y+1).  No level barriers: a worker never idles while a macroblock
- * is ready.  Same-CU visibility of the stores needs only s_waitcnt vmcnt(0) before the LDS release.
- * Dynamic LDS: 32 x WORKER_LDS tiles | any[n_mbs] u8 | dep[n_mbs] u8 | queue[n_mbs] u16 | counters. */
+ * A worker is a QUARTER wavefront (16 lanes, two sample lines per lane, packed 16-bit arithmetic): 64 workers.  A
+ * free wavefront pulls up to four READY macroblocks at once (compare-and-swap on head), one per quarter, fetches their
+ * samples, records and neighbour strips in one memory round trip, filters, waits for its stores, then releases the
+ * three dependants (x+1,y), (x,y+1), (x-1,y+1).  No level barriers; ready macroblocks are packed into as few
+ * wavefronts as possible because the loop is instruction-issue bound (a step costs the same with one busy quarter as
+ * with four).  Same-CU visibility of the stores needs only s_waitcnt vmcnt(0) before the LDS release.
+ * Dynamic LDS: 64 x WORKER_LDS tiles | any[n_mbs] u8 | dep[n_mbs] u8 | queue[n_mbs] u16 | counters | threshold tables. */
 __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const FrameDesc &fd = frames[blockIdx.x];
     if (!fd.any_deblock) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, hl = lane & 31;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, quarter = lane >> 4, ql = lane & 15, q16 = 16 * quarter;
     const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
     uint8_t *anyf = lds + TAIL_WORKERS * WORKER_LDS;
     uint8_t *dep = anyf + ((n_mbs + 15) & ~15);
     uint16_t *queue = reinterpret_cast<uint16_t *>(dep + ((n_mbs + 15) & ~15));
     uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + ((n_mbs + 7) & ~7));   /* [0] head, [1] tail, [2] total */
-    uint8_t *wlds = lds + (wave * 2 + half) * WORKER_LDS;
+    uint8_t *tabs = reinterpret_cast<uint8_t *>(ctr + 4);                       /* alpha[64] | beta[64] | tc0[64][4] */
+    uint8_t *wlds = lds + (wave * 4 + quarter) * WORKER_LDS;
     (void)hmb;
     /* debug accounting (h264bsdmiDebugTailProfile): workgroup 0 only, per wavefront: [0] cycles with nothing ready,
      * [1] cycles filtering, [2] cycles waiting for own stores, [3] macroblocks filtered (both halves), [4] total */
-    unsigned long long *tp = (prof && blockIdx.x == 0) ? prof + wave * 8 : nullptr;
-    unsigned long long t_idle = 0, t_work = 0, t_store = 0, n_done = 0;
+    unsigned long long *tp = (prof && blockIdx.x == 0) ? prof + wave * 16 : nullptr;
+    unsigned long long t_idle = 0, t_work = 0, t_store = 0, n_done = 0, n_steps = 0;
     const unsigned long long t_begin = tp ? __builtin_readcyclecounter() : 0ull;
     unsigned long long t_mark = t_begin;
 
@@ -1195,6 +1218,12 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *
         }
         for (int i = tid; i < (n_mbs + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
         if (tid < 4) ctr[tid] = 0;
+        if (tid < 64) {
+            tabs[tid] = tid < 52 ? c_alpha[tid] : 0;
+            tabs[64 + tid] = tid < 52 ? c_beta[tid] : 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) tabs[128 + 4 * tid + k] = tid < 52 ? c_tc0[tid][k] : 0;
+        }
     }
     __syncthreads();
     for (int mb = tid; mb < n_mbs; mb += blockDim.x) {
@@ -1209,60 +1238,59 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *
     const uint32_t total = ctr[2];
     volatile uint16_t *vq = queue;
 
-    /* every worker owns two claimed slots: cur (being waited for / filtered) and nxt (prefetched when ready) */
-    uint32_t s_cur = 0, s_nxt = 0;
-    if (hl == 0) { s_cur = atomicAdd(&ctr[0], 1u); s_nxt = atomicAdd(&ctr[0], 1u); }
-    s_cur = __shfl(s_cur, half * 32); s_nxt = __shfl(s_nxt, half * 32);
-    int mb_cur = -1, mb_nxt = -1;
-    bool pf_valid = false;
+    /* Pull model: a free wavefront takes up to four READY macroblocks at once (one per quarter).  Ready macroblocks
+     * are therefore packed into as few wavefronts as possible — the loop is instruction-issue bound, so a step that
+     * runs with one busy quarter costs as much as a full one — and a wavefront with nothing to do issues nothing. */
     uint32_t spins = 0;                  /* safety net: a scheduling bug must end in wrong pixels, never in a hung GPU */
-    DbkPrefetch pf_cur = {};
+    volatile uint32_t *vctr = ctr;
     for (;;) {
-        /* look for published slots */
-        if (mb_cur < 0 && s_cur < total) { const int v = vq[s_cur]; if (v != 0xFFFF) mb_cur = v; }
-        if (mb_nxt < 0 && s_nxt < total) { const int v = vq[s_nxt]; if (v != 0xFFFF) mb_nxt = v; }
-        if (!__any(mb_cur >= 0)) {
-            if (__all(s_cur >= total) || ++spins > (1u << 24)) break;
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-        }
-        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int run = mb_cur;                                  /* -1 in a half that has nothing ready */
-        DbkPrefetch cp = pf_cur;
-        if (run >= 0 && !pf_valid) dbk_prefetch(fd, run, hl, cp); /* not prefetched ahead: fetch now */
-        const bool want_pf = run >= 0 && mb_nxt >= 0;
-        DbkPrefetch np = {};
-        deblock_mb(fd, run, hl, cp, wlds, want_pf ? mb_nxt : -1, np);
-        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && hl == 0)); }
-        if (run >= 0) {
-            /* release: stores done -> dependants */
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (hl < 3) {
-                const int x = run % wmb, y = run / wmb;
-                int dmb = -1;
-                if (hl == 0) { if (x + 1 < wmb) dmb = run + 1; }
-                else if (hl == 1) { if (y + 1 < hmb) dmb = run + wmb; }
-                else { if (y + 1 < hmb && x > 0) dmb = run + wmb - 1; }
-                if (dmb >= 0 && anyf[dmb]) {
-                    /* byte-wide counters: decrement through a 32-bit LDS atomic on the containing word */
-                    uint32_t *w = reinterpret_cast<uint32_t *>(dep + (dmb & ~3));
-                    const uint32_t sh = 8u * (dmb & 3);
-                    const uint32_t old = atomicSub(w, 1u << sh);
-                    if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)dmb;
-                }
+        uint32_t base = 0, k = 0;
+        if (lane == 0) {
+            const uint32_t h = vctr[0], t = vctr[1];
+            if (t > h) {
+                k = t - h < 4u ? t - h : 4u;
+                if (atomicCAS(&ctr[0], h, h + k) != h) k = 0;       /* lost the race: look again */
+                base = h;
+            } else if (h >= total) {
+                k = 0xFFFFFFFFu;                                    /* everything has been claimed */
             }
-            /* advance: nxt becomes cur, claim a new nxt */
-            s_cur = s_nxt; mb_cur = mb_nxt; pf_cur = np; pf_valid = want_pf;
-            uint32_t c = 0;
-            if (hl == 0) c = atomicAdd(&ctr[0], 1u);
-            s_nxt = __shfl(c, half * 32); mb_nxt = -1;
+        }
+        base = __shfl(base, 0); k = __shfl(k, 0);
+        if (k == 0xFFFFFFFFu || ++spins > (1u << 24)) break;
+        if (k == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
+        int run = -1;
+        if ((uint32_t)quarter < k) {
+            int v;
+            do { v = vq[base + quarter]; } while (v == 0xFFFF);     /* the publisher bumps the cursor, then writes the slot */
+            run = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        DbkPrefetch cp = {}, np = {};
+        dbk_prefetch(fd, run, ql, cp);
+        deblock_mb(fd, run, ql, q16, cp, wlds, -1, np, tabs, (tp && lane == 0) ? tp : nullptr);
+        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && ql == 0)); n_steps++; }
+        /* release: stores done -> dependants */
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (run >= 0 && ql < 3) {
+            const int x = run % wmb, y = run / wmb;
+            int dmb = -1;
+            if (ql == 0) { if (x + 1 < wmb) dmb = run + 1; }
+            else if (ql == 1) { if (y + 1 < hmb) dmb = run + wmb; }
+            else { if (y + 1 < hmb && x > 0) dmb = run + wmb - 1; }
+            if (dmb >= 0 && anyf[dmb]) {
+                /* byte-wide counters: decrement through a 32-bit LDS atomic on the containing word */
+                uint32_t *w = reinterpret_cast<uint32_t *>(dep + (dmb & ~3));
+                const uint32_t sh = 8u * (dmb & 3);
+                const uint32_t old = atomicSub(w, 1u << sh);
+                if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)dmb;
+            }
         }
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_store += t - t_mark; t_mark = t; }
     }
     if (tp && lane == 0) {
-        tp[0] += t_idle; tp[1] += t_work; tp[2] += t_store; tp[3] += n_done; tp[4] += __builtin_readcyclecounter() - t_begin;
+        tp[0] += t_idle; tp[1] += t_work; tp[2] += t_store; tp[3] += n_done; tp[4] += __builtin_readcyclecounter() - t_begin; tp[5] += n_steps;
     }
 }
 

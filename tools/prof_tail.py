@@ -14,10 +14,12 @@ for tick in (0, 10, 20, 41):
     L.h264bsdmiDebugTailProfile(1, None)
     rep.run(tick, 1); rep.sync()
     done = tick + 1
-    out = np.zeros((16, 8), dtype=np.uint64)
+    out = np.zeros((16, 16), dtype=np.uint64)
     L.h264bsdmiDebugTailProfile(0, ctypes.c_void_p(out.ctypes.data))
     t = rep.timings()
     tot = out[:, 4].astype(float).sum()
     print(f"tick {tick}: k_frame_dbk {t['k_frame_dbk'][0]:.3f} ms; MBs filtered by WG0: {int(out[:,3].sum())}; "
           f"idle {out[:,0].sum()/tot:.0%}  filter {out[:,1].sum()/tot:.0%}  store-wait+release {out[:,2].sum()/tot:.0%}; "
-          f"wave cycles {tot/16:.0f} avg")
+          f"wave cycles {tot/16:.0f} avg; steps/wave {out[:,5].mean():.0f}, MBs per step {out[:,3].sum()/max(1,out[:,5].sum()):.2f}, "
+          f"cycles per step {out[:,1].sum()/max(1,out[:,5].sum()):.0f} = load {out[:,8].sum()/max(1,out[:,5].sum()):.0f} + V {out[:,9].sum()/max(1,out[:,5].sum()):.0f} "
+          f"+ H {out[:,10].sum()/max(1,out[:,5].sum()):.0f} + store {out[:,11].sum()/max(1,out[:,5].sum()):.0f}")
