@@ -159,7 +159,14 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     }
     if (timed) HIP_TRY(hipEventRecord(tt->ev[3], st));
     if (s.max_levels && (stages & 2u)) {
-        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * h264k::TAIL_WAVES), 0, st, d_desc);
+        const uint32_t n = s.max_mbs;
+        const size_t lds = (size_t)h264k::TAIL_WAVES * 1024 + 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64;
+        static size_t lds_enabled = 0;
+        if (lds > lds_enabled) {
+            HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_intra, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_enabled = lds;
+        }
+        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * h264k::TAIL_WAVES), lds, st, d_desc);
         if (launches) launches[3]++;
     }
     if (timed) HIP_TRY(hipEventRecord(tt->ev[4], st));

@@ -60,6 +60,18 @@
 #define FJ_DBK_TOP   2
 #define FJ_DBK_INNER 4
 
+/* FjMbRec.ref_slot[0] of a macroblock in the intra schedule (kinds I4x4, I16x16, IPCM, CONCEAL_I): the neighbours whose
+ * samples it reads.  It may start as soon as those of them that are themselves in the intra schedule are done
+ * (everything else was reconstructed by the earlier kernels).  Bit b and bit b^4 are opposite directions. */
+#define FJ_NEED_L   0x01  /* (x-1, y)   */
+#define FJ_NEED_UL  0x02  /* (x-1, y-1) */
+#define FJ_NEED_U   0x04  /* (x,   y-1) */
+#define FJ_NEED_UR  0x08  /* (x+1, y-1) */
+#define FJ_NEED_R   0x10  /* (x+1, y)   */
+#define FJ_NEED_DR  0x20  /* (x+1, y+1) */
+#define FJ_NEED_D   0x40  /* (x,   y+1) */
+#define FJ_NEED_DL  0x80  /* (x-1, y+1) */
+
 /* FjMbRec.coded bits */
 #define FJ_CODED_LUMA_DC   (1u << 24) /* Intra16x16 DC block present                        */
 #define FJ_CODED_CHROMA_DC (1u << 25) /* chroma DC block (Cb[0..3], Cr[4..7]) present        */
@@ -128,7 +140,7 @@ typedef struct FjMbRec {
     uint32_t coded;           /* bit z (0..15): luma 4x4 block z (H.264 block order) has coefficients;
                                  16..19 Cb AC, 20..23 Cr AC (raster 2x2); 24 luma DC; 25 chroma DC */
     uint32_t coef_idx;        /* first coefficient block of this MB (16 x int16 each)         */
-    uint8_t  ref_slot[4];     /* reference DPB slot per 8x8 quadrant (raster)                 */
+    uint8_t  ref_slot[4];     /* inter: reference DPB slot per 8x8 quadrant (raster); intra schedule: [0] = FJ_NEED_* */
     int8_t   cqp_off;         /* chroma_qp_index_offset of the MB's PPS (deblock QPc)         */
     uint8_t  dbk_trivial;     /* 1: every boundary strength of this MB is zero by construction (host-proved) */
     uint16_t intra_level;     /* dependency level among intra MBs of the picture              */

@@ -154,6 +154,12 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
         r->intra_level = (uint16_t)(lvl + 1);
         if ((uint32_t)(lvl + 1) > max_level) max_level = (uint32_t)(lvl + 1);
         n_intra++;
+        /* the same information for the device's dataflow scheduler: which of the 8 surrounding macroblocks this one
+         * waits for (FJ_NEED_*; the device ignores neighbours that are not in the intra schedule).  Intra
+         * macroblocks have no reference slots, so the mask travels in ref_slot[0]. */
+        r->ref_slot[0] = (uint8_t)(((need & FJ_AVAIL_A) ? FJ_NEED_L : 0) | ((need & FJ_AVAIL_D) ? FJ_NEED_UL : 0) |
+                                   ((need & FJ_AVAIL_B) ? FJ_NEED_U : 0) | ((need & FJ_AVAIL_C) ? FJ_NEED_UR : 0));
+        r->ref_slot[1] = r->ref_slot[2] = r->ref_slot[3] = 0;
     }
     if (n_conceal) {
         /* Synthesised macroblocks read the neighbours that were decoded or concealed BEFORE them in the reference's
@@ -182,6 +188,9 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
             r->intra_level = (uint16_t)(lvl + 1);
             if ((uint32_t)(lvl + 1) > max_level) max_level = (uint32_t)(lvl + 1);
             n_intra++;
+            r->ref_slot[0] = (uint8_t)(((r->avail & FJ_CONC_LEFT) ? FJ_NEED_L : 0) | ((r->avail & FJ_CONC_ABOVE) ? FJ_NEED_U : 0) |
+                                       ((r->avail & FJ_CONC_RIGHT) ? FJ_NEED_R : 0) | ((r->avail & FJ_CONC_BELOW) ? FJ_NEED_D : 0));
+            r->ref_slot[1] = r->ref_slot[2] = r->ref_slot[3] = 0;
         }
         free(ord);
     }

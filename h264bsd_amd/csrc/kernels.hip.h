@@ -1153,23 +1153,94 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
 constexpr int TAIL_WAVES = 16;
 constexpr int TAIL_WORKERS = 4 * TAIL_WAVES;      /* deblocking workers = quarter wavefronts */
 
-/* intra macroblocks, level by level (levels computed by the host parser, hd_core.c) */
+/* Intra (and concealed) macroblocks of one picture, dataflow-scheduled inside one workgroup.  A macroblock of the
+ * intra schedule waits for those of the neighbours named by its FJ_NEED_* mask that are themselves in the schedule
+ * (inter macroblocks were reconstructed by the earlier kernels).  LDS: dep[mb] = outstanding predecessors (0xFF = not
+ * scheduled), need[mb] = the mask, a ready queue with claim / publish cursors.  A free wavefront takes ONE ready
+ * macroblock, reconstructs it (intra_mb / conceal_mb), waits for its stores and then releases the neighbours that
+ * wait for it.  No level barriers: the picture's time is its dependency critical path, not levels x slowest wave.
+ * Dynamic LDS: 16 x 1 KB tiles | need[n_mbs] | dep[n_mbs] | queue[n_mbs] u16 | counters. */
 __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[TAIL_WAVES * 1024];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const FrameDesc &fd = frames[blockIdx.x];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (!fd.n_levels) return;
+    const uint32_t total = fd.lvl[fd.n_levels];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
     uint8_t *my = lds + wave * 1024;
-    for (uint32_t l = 0; l < fd.n_levels; l++) {
-        const uint32_t first = fd.lvl[l], count = fd.lvl[l + 1] - first;
-        for (uint32_t i = wave; i < count; i += TAIL_WAVES) {
-            const uint32_t mb = fd.idx[first + i];
-            /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
-            const uint32_t head = *reinterpret_cast<const uint32_t *>(&fd.recs[mb]);     /* kind, qp_y, qp_c, avail */
-            if ((head & 255u) == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
-            else intra_mb(fd, mb, lane, my, my + 17 * TS);
+    uint8_t *need = lds + TAIL_WAVES * 1024;
+    uint8_t *dep = need + ((n_mbs + 15) & ~15);
+    uint16_t *queue = reinterpret_cast<uint16_t *>(dep + ((n_mbs + 15) & ~15));
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + ((n_mbs + 7) & ~7));   /* [0] head, [1] tail */
+
+    for (int i = tid; i < (n_mbs + 3) / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dep)[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < (n_mbs + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
+    if (tid < 4) ctr[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < total; i += blockDim.x) {
+        const uint32_t mb = fd.idx[i];
+        need[mb] = fd.recs[mb].ref_slot[0];
+        dep[mb] = 0xFE;                                   /* scheduled, count pending */
+    }
+    __syncthreads();
+    /* neighbour b of (x,y): b = 0 L, 1 UL, 2 U, 3 UR, 4 R, 5 DR, 6 D, 7 DL  (b ^ 4 = opposite direction) */
+    auto neighbour = [&](int mb, int b) -> int {
+        const int x = mb % wmb, y = mb / wmb;
+        const int dx = (b == 2 || b == 6) ? 0 : (b >= 3 && b <= 5) ? 1 : -1;
+        const int dy = (b >= 1 && b <= 3) ? -1 : (b >= 5) ? 1 : 0;
+        const int nx = x + dx, ny = y + dy;
+        return (nx < 0 || ny < 0 || nx >= wmb || ny >= hmb) ? -1 : ny * wmb + nx;
+    };
+    for (uint32_t i = tid; i < total; i += blockDim.x) {
+        const int mb = fd.idx[i];
+        const uint32_t nd = need[mb];
+        int cnt = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++)
+            if ((nd >> b) & 1u) {
+                const int s = neighbour(mb, b);
+                if (s >= 0 && dep[s] != 0xFF) cnt++;
+            }
+        dep[mb] = (uint8_t)cnt;                            /* byte store: other threads only test != 0xFF */
+        if (cnt == 0) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)mb;
+    }
+    __syncthreads();
+
+    volatile uint16_t *vq = queue;
+    volatile uint32_t *vctr = ctr;
+    uint32_t spins = 0;                  /* safety net: a scheduling bug must end in wrong pixels, never in a hung GPU */
+    for (;;) {
+        uint32_t slot = 0xFFFFFFFFu;
+        if (lane == 0) {
+            const uint32_t h = vctr[0], t = vctr[1];
+            if (t > h) { if (atomicCAS(&ctr[0], h, h + 1) == h) slot = h; else slot = 0xFFFFFFFEu; }
+            else if (h >= total) slot = 0xFFFFFFFDu;
+            else slot = 0xFFFFFFFEu;
         }
-        __syncthreads();
+        slot = __shfl(slot, 0);
+        if (slot == 0xFFFFFFFDu || ++spins > (1u << 24)) break;
+        if (slot == 0xFFFFFFFEu) { __builtin_amdgcn_s_sleep(1); continue; }
+        int v;
+        do { v = vq[slot]; } while (v == 0xFFFF);          /* the publisher bumps the cursor, then writes the slot */
+        const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(v);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
+        const uint32_t head = *reinterpret_cast<const uint32_t *>(&fd.recs[mb]);     /* kind, qp_y, qp_c, avail */
+        if ((head & 255u) == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
+        else intra_mb(fd, mb, lane, my, my + 17 * TS);
+        /* release: stores done -> the neighbours that wait for this macroblock */
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane < 8) {
+            const int s = neighbour((int)mb, lane);
+            if (s >= 0 && dep[s] != 0xFF && ((need[s] >> (lane ^ 4)) & 1u)) {
+                uint32_t *w = reinterpret_cast<uint32_t *>(dep + (s & ~3));
+                const uint32_t sh = 8u * (s & 3);
+                const uint32_t old = atomicSub(w, 1u << sh);
+                if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)s;
+            }
+        }
     }
 }
 
