@@ -158,28 +158,37 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         if (launches) launches[2]++;
     }
     if (timed) HIP_TRY(hipEventRecord(tt->ev[3], st));
+    /* The two per-picture kernels keep per-macroblock scheduling state in LDS next to their wavefronts' tiles: for
+     * pictures that leave less than 16 wavefronts' worth of tile space in the 160 KB of a CU, fewer wavefronts run. */
+    constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
     if (s.max_levels && (stages & 2u)) {
         const uint32_t n = s.max_mbs;
-        const size_t lds = (size_t)h264k::TAIL_WAVES * 1024 + 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64;
+        const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64;
+        if (arrays + 1024 > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_intra\n", n); return -1; }
+        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::TAIL_WAVES, (LDS_BUDGET - arrays) / 1024);
+        const size_t lds = (size_t)waves * 1024 + arrays;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
             HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_intra, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_enabled = lds;
         }
-        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * h264k::TAIL_WAVES), lds, st, d_desc);
+        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc);
         if (launches) launches[3]++;
     }
     if (timed) HIP_TRY(hipEventRecord(tt->ev[4], st));
     if (s.any_deblock && (stages & 4u)) {
-        const uint32_t nl = s.max_w + 2 * s.max_h, n = s.max_mbs;
-        const size_t lds = (size_t)h264k::TAIL_WORKERS * h264k::WORKER_LDS + 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 16 + 384 + 64;
-        (void)nl;
+        const uint32_t n = s.max_mbs;
+        const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 16 + 384 + 64;
+        const size_t per_wave = 4 * (size_t)h264k::WORKER_LDS;
+        if (arrays + per_wave > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_dbk\n", n); return -1; }
+        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::TAIL_WAVES, (LDS_BUDGET - arrays) / per_wave);
+        const size_t lds = (size_t)waves * per_wave + arrays;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
             HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_dbk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_enabled = lds;
         }
-        hipLaunchKernelGGL(h264k::k_frame_dbk, dim3(s.n_frames), dim3(64 * h264k::TAIL_WAVES), lds, st, d_desc, g_tail_prof);
+        hipLaunchKernelGGL(h264k::k_frame_dbk, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, g_tail_prof);
         if (launches) launches[4]++;
     }
     if (timed) HIP_TRY(hipEventRecord(tt->ev[5], st));

@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
     uint8_t *my = lds + wave * 1024;
-    uint8_t *need = lds + TAIL_WAVES * 1024;
+    uint8_t *need = lds + (blockDim.x >> 6) * 1024;      /* the host launches fewer wavefronts when n_mbs leaves less LDS */
     uint8_t *dep = need + ((n_mbs + 15) & ~15);
     uint16_t *queue = reinterpret_cast<uint16_t *>(dep + ((n_mbs + 15) & ~15));
     uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + ((n_mbs + 7) & ~7));   /* [0] head, [1] tail */
@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *
     if (!fd.any_deblock) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, quarter = lane >> 4, ql = lane & 15, q16 = 16 * quarter;
     const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
-    uint8_t *anyf = lds + TAIL_WORKERS * WORKER_LDS;
+    uint8_t *anyf = lds + (blockDim.x >> 4) * WORKER_LDS;   /* 4 workers per launched wavefront (fewer wavefronts for huge pictures) */
     uint8_t *dep = anyf + ((n_mbs + 15) & ~15);
     uint16_t *queue = reinterpret_cast<uint16_t *>(dep + ((n_mbs + 15) & ~15));
     uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + ((n_mbs + 7) & ~7));   /* [0] head, [1] tail, [2] total */

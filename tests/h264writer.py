@@ -321,10 +321,10 @@ class StreamWriter:
                       idc=(0,), p_pcm=0.0, constrained_intra=0, fmo=None, idr_period=0, poc_pattern=None, reorder=False,
                       mmco=False, chroma_qp_offset=0, p_intra_in_p=0.2, p_skip=0.3, log2_max_frame_num=4,
                       num_reorder_frames=None, max_qp=28, aso=False, non_ref_every=0, gaps=0,
-                      offset_non_ref=1, redundant=False)
+                      offset_non_ref=1, redundant=False, level=40)
         self.c.update(cfg)
         self.rng = np.random.default_rng(self.c["seed"])
-        self.sps = dict(poc_type=self.c["poc_type"], num_ref_frames=self.c["num_ref_frames"], wmb=self.c["wmb"], hmb=self.c["hmb"],
+        self.sps = dict(level=self.c["level"], poc_type=self.c["poc_type"], num_ref_frames=self.c["num_ref_frames"], wmb=self.c["wmb"], hmb=self.c["hmb"],
                         log2_max_frame_num=self.c["log2_max_frame_num"], gaps=self.c["gaps"],
                         offset_non_ref=self.c["offset_non_ref"], num_reorder_frames=self.c["num_reorder_frames"],
                         max_dec_frame_buffering=max(self.c["num_ref_frames"], 1) if self.c["num_reorder_frames"] is not None else None)
