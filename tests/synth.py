@@ -13,14 +13,14 @@ from h264bsd_amd import capi
 from oracle import pyoracle
 
 
-def decode_reference(data):
+def decode_reference(data, no_output_reordering=0):
     """-> (trace, [(sha1 of frame, picId, isIdr, numErrMbs)])"""
     ref = pyoracle.RefDecoder()
     lib = ref.lib
     buf = ctypes.create_string_buffer(data, len(data))
     base = ctypes.addressof(buf)
     dec = lib.h264bsdAlloc()
-    assert lib.h264bsdInit(dec, 0) == 0
+    assert lib.h264bsdInit(dec, no_output_reordering) == 0
     off, trace, pics = 0, [], []
     rb = ctypes.c_uint32(0)
     a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
@@ -50,7 +50,7 @@ def decode_reference(data):
     return trace, pics
 
 
-def decode_ours(data, backend="oracle"):
+def decode_ours(data, backend="oracle", no_output_reordering=0):
     pics, trace = [], []
     state = {"dpb": None}
 
@@ -60,7 +60,7 @@ def decode_ours(data, backend="oracle"):
             state["dpb"] = pyoracle.OracleDpb(blob)
         state["dpb"].decode(blob)
 
-    dec = capi.Decoder(capture=on_job if backend == "oracle" else None)
+    dec = capi.Decoder(no_output_reordering, capture=on_job if backend == "oracle" else None)
     buf = ctypes.create_string_buffer(data, len(data))
     base, off = ctypes.addressof(buf), 0
 

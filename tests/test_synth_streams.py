@@ -62,3 +62,14 @@ def test_golden_matches_live_reference(built):
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_gpu_matches_reference(built, name):
     check(name, "gpu")
+
+
+@pytest.mark.parametrize("name", ["poc0_display_reorder", "mmco_long_term", "everything", "frame_num_gaps", "poc1_nonref_idr"])
+def test_no_output_reordering_mode_matches_live_reference(built, name):
+    """h264bsdInit(storage, noOutputReordering = 1): DPB of max(num_ref_frames, 1) frames, pictures are output in
+    decoding order (reference src/h264bsd_dpb.c:1014-1040, :806-815); compared with oracle/_ref directly"""
+    from oracle import pyoracle
+    if not os.path.exists(pyoracle.REF_SO):
+        pytest.skip("oracle/_ref not built")
+    data = stream_of(name)
+    assert synth.decode_ours(data, "oracle", 1) == synth.decode_reference(data, 1)
