@@ -73,3 +73,30 @@ def test_no_output_reordering_mode_matches_live_reference(built, name):
         pytest.skip("oracle/_ref not built")
     data = stream_of(name)
     assert synth.decode_ours(data, "oracle", 1) == synth.decode_reference(data, 1)
+
+
+SEQUENCE_CHANGES = [("multi_ref", "fmo_dispersed"), ("fmo_dispersed", "multi_ref", "poc0_display_reorder"),
+                    ("poc0_display_reorder", "fmo_dispersed", "poc0_display_reorder"), ("multi_ref", "multi_ref")]
+
+
+def _concat(names):
+    return b"".join(stream_of(n) for n in names)
+
+
+@pytest.mark.parametrize("names", SEQUENCE_CHANGES, ids=["+".join(n) for n in SEQUENCE_CHANGES])
+def test_sequence_parameter_set_changes(built, names):
+    """a new SPS at an IDR (other picture size / DPB size): second HDRS_RDY, DPB re-initialised, pictures still waiting
+    for output are lost exactly as in the reference (src/h264bsd_storage.c:297-419, h264bsdResetDpb)"""
+    from oracle import pyoracle
+    if not os.path.exists(pyoracle.REF_SO):
+        pytest.skip("oracle/_ref not built")
+    data = _concat(names)
+    assert synth.decode_ours(data, "oracle") == synth.decode_reference(data)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("names", SEQUENCE_CHANGES, ids=["+".join(n) for n in SEQUENCE_CHANGES])
+def test_gpu_sequence_parameter_set_changes(built, names):
+    """the engine re-allocates the stream's frame buffers at the second activation"""
+    data = _concat(names)
+    assert synth.decode_ours(data, "gpu") == synth.decode_ours(data, "oracle")
