@@ -321,7 +321,7 @@ class StreamWriter:
                       idc=(0,), p_pcm=0.0, constrained_intra=0, fmo=None, idr_period=0, poc_pattern=None, reorder=False,
                       mmco=False, chroma_qp_offset=0, p_intra_in_p=0.2, p_skip=0.3, log2_max_frame_num=4,
                       num_reorder_frames=None, max_qp=28, aso=False, non_ref_every=0, gaps=0,
-                      offset_non_ref=1, redundant=False, level=40)
+                      offset_non_ref=1, redundant=False, level=40, min_qp=6, huge_levels=False)
         self.c.update(cfg)
         self.rng = np.random.default_rng(self.c["seed"])
         self.sps = dict(level=self.c["level"], poc_type=self.c["poc_type"], num_ref_frames=self.c["num_ref_frames"], wmb=self.c["wmb"], hmb=self.c["hmb"],
@@ -365,6 +365,15 @@ class StreamWriter:
         if self.qp > 28:            # keep the reconstructed residual inside [-512, 511] (reference transform.c:184-188)
             amp, big = 1, 0.0
             density *= 0.5 if self.qp <= 40 else 0.15
+        if self.c["huge_levels"] and self.qp <= 6 and r.random() < 0.5:
+            # level_prefix 14 / 15 escapes and suffixLength growth (9.2.2.1): one huge level (+ a few small ones behind
+            # it in scan order); at QP <= 6 a single coefficient of this size still reconstructs inside [-512, 511]
+            pos = int(r.integers(0, n))
+            c[pos] = int(r.integers(16, 900)) * (1 if r.random() < 0.5 else -1)
+            for i in range(pos + 1, n):
+                if r.random() < 0.15:
+                    c[i] = 1 if r.random() < 0.5 else -1
+            return c
         for i in range(n):
             if r.random() < density:
                 v = int(r.integers(1, amp + 1)) * (1 if r.random() < 0.5 else -1)
@@ -440,7 +449,7 @@ class StreamWriter:
         cur.tc = [0] * 24
         if not (cbp or is16):
             return
-        lo, hi = max(-26, 6 - self.qp), min(25, self.c["max_qp"] - self.qp)
+        lo, hi = max(-26, self.c["min_qp"] - self.qp), min(25, self.c["max_qp"] - self.qp)
         dq = int(r.integers(lo, hi + 1)) if r.random() < 0.3 else 0
         bw.se(dq)
         self.qp += dq
@@ -708,7 +717,7 @@ class StreamWriter:
                             for v in op[1:]:
                                 bw.ue(v)
                         bw.ue(0)
-                self.qp = 26 + int(r.integers(-6, 3))
+                self.qp = 26 + int(r.integers(-6, 3)) if not self.c["huge_levels"] else int(r.integers(0, 7))
                 bw.se(self.qp - 26)
                 idc = int(r.choice(c["idc"]))
                 bw.ue(idc)

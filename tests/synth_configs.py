@@ -30,6 +30,9 @@ CONFIGS = {
     "redundant_fmo":       dict(n_pics=10, seed=33, wmb=6, hmb=4, slices_per_pic=2, redundant=True, fmo=dict(type=1, groups=3), reorder=True,
                                 num_ref_frames=3, num_ref_idx_active=2),
     "high_qp":             dict(n_pics=10, seed=21, wmb=6, hmb=4, max_qp=51, chroma_qp_offset=12, slices_per_pic=2, idc=(0, 2)),
+    # level_prefix escapes (levels up to +-900 at QP 0..6) and the low-QP dequantisation branches
+    "huge_levels_low_qp":  dict(n_pics=10, seed=50, wmb=5, hmb=4, huge_levels=True, min_qp=0, max_qp=6, slices_per_pic=2,
+                                num_ref_frames=2, num_ref_idx_active=2),
     # the largest picture level 5.1 allows (36,864 macroblocks): the per-picture kernels must shed wavefronts to fit their
     # per-macroblock scheduling state into the CU's LDS
     "max_frame_size_4096x2304": dict(n_pics=2, seed=40, wmb=256, hmb=144, level=51, slices_per_pic=2, idc=(0,), p_skip=0.8),
