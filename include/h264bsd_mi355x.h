@@ -106,7 +106,8 @@ int  h264bsdmiReplayConvert(h264bsdmi_replay *r, u32 slot, int fmt);
 int  h264bsdmiReplayFetchConverted(h264bsdmi_replay *r, u32 stream, u32 *dst);
 /* HIP-event timing (events on the engine's own stream) of the last h264bsdmiReplayRun(), summed over its
  * ticks: out_ms[0..4] = k_copy, k_recon_inter, k_dbk, k_frame_intra, k_frame_dbk; out_ms[5] = whole run;
- * launches[0..4] = number of launches of each kernel. */
+ * launches[0..4] = number of launches of each kernel.  k_dbk runs on a second stream concurrently with the
+ * reconstruction kernels, so the five times add up to more than out_ms[5]. */
 int  h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[6], u32 launches[5]);
 /* Split the streams of the set into n_groups (1..8) groups, each on its own HIP stream, so that the
  * latency-bound per-picture kernel of one group overlaps the throughput-bound kernels of another.
@@ -114,7 +115,8 @@ int  h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[6], u32 launches[5
  * running launches (they exceed out[3], the whole run). */
 int  h264bsdmiReplaySetGroups(h264bsdmi_replay *r, u32 n_groups);
 /* Test hook: which stages h264bsdmiReplayRun() launches: bit0 inter reconstruction, bit1 intra
- * reconstruction, bit2 deblocking (default 7 = all). */
+ * reconstruction, bit2 deblocking (default 7 = all); bit3: keep k_dbk on the main stream instead of overlapping
+ * it with the reconstruction kernels on a second stream (A/B measurements). */
 int  h264bsdmiReplaySetStages(h264bsdmi_replay *r, unsigned mask);
 /* Debug hook: cycle accounting of k_frame_tail's deblocking loop for workgroup 0 of every launch between
  * enable=1 and enable=0 (which copies out[16 waves][8]: cycles in {choose MB, filter, extra rounds, wait for
