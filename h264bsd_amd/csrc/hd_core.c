@@ -105,61 +105,137 @@ static int in_intra_schedule(int kind)
     return kind == FJ_MB_I4x4 || kind == FJ_MB_I16x16 || kind == FJ_MB_IPCM || kind == FJ_MB_CONCEAL_I;
 }
 
+/* per-thread scratch of fj_finalize (lists are built in one raster pass and copied behind the sections whose sizes
+ * are only known afterwards); grows on demand, never shrinks */
+static __thread uint8_t *tl_scratch;
+static __thread size_t tl_scratch_cap;
+
 int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
 {
     FjHeader *h = (FjHeader *)job;
     const uint32_t n = h->n_mbs, w = h->width_mbs;
     FjMbRec *recs = (FjMbRec *)(job + h->rec_off);
-    uint32_t max_level = 0, n_intra = 0, n_absent = 0, n_conceal = 0;
+    const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(job + h->mv_off);
+    {
+        const size_t need_bytes = (size_t)n * (1 + 8 + 16 + 2 + 2) + ((size_t)n + 2) * 4 + 64;
+        if (tl_scratch_cap < need_bytes) {
+            free(tl_scratch);
+            tl_scratch = (uint8_t *)malloc(need_bytes);
+            tl_scratch_cap = tl_scratch ? need_bytes : 0;
+            if (!tl_scratch) return -1;
+        }
+    }
+    /* scratch layout (16-byte entries first for alignment) */
+    FjGen *gen_tmp = (FjGen *)tl_scratch;
+    FjCopy *copy_tmp = (FjCopy *)(gen_tmp + n);
+    uint32_t *hist = (uint32_t *)(copy_tmp + n);                 /* intra MBs per level */
+    uint16_t *dbk_tmp = (uint16_t *)(hist + n + 2);
+    uint16_t *ilist = dbk_tmp + n;                               /* intra-schedule MBs in raster order */
+    uint8_t *cls = (uint8_t *)(ilist + n);
+    uint32_t max_level = 0, n_intra = 0, n_absent = 0, n_conceal = 0, n_copy = 0, n_gen = 0, n_dbk = 0;
     uint8_t any_dbk = 0;
+    memset(hist, 0, ((size_t)n + 2) * 4);
+
+    /* ---- one raster pass: intra dependency levels + FJ_NEED masks, classification of the inter macroblocks, copy
+     * runs, general-inter entries, deblocking index ---- */
     for (uint32_t a = 0; a < n; a++) {
         FjMbRec *r = &recs[a];
         any_dbk |= r->dbk;
+        cls[a] = 0;
         if (r->kind == FJ_MB_ABSENT) n_absent++;
-        if (r->kind == FJ_MB_CONCEAL_I) n_conceal++;
-        if (!in_intra_schedule(r->kind) || r->kind == FJ_MB_CONCEAL_I) continue;   /* concealment: second pass below */
-        const uint32_t x = a % w, y = a / w;
-        int lvl = -1;
-        /* which neighbouring macroblocks does the prediction of this one actually read? (8.3.1.2, 8.3.3, 8.3.4) */
-        unsigned need = 0;
-        if (r->kind == FJ_MB_I16x16) {
-            const int m = r->pred & 3;
-            need |= m == 0 ? FJ_AVAIL_B : m == 1 ? FJ_AVAIL_A : m == 2 ? (FJ_AVAIL_A | FJ_AVAIL_B) : (FJ_AVAIL_A | FJ_AVAIL_B | FJ_AVAIL_D);
-        } else if (r->kind == FJ_MB_I4x4) {
-            for (int z = 0; z < 16; z++) {
-                const int bx = ((z >> 2) & 1) * 2 + (z & 1), by = (z >> 3) * 2 + ((z >> 1) & 1);
-                if (bx && by) continue;
-                const int m = (r->i4mode[z >> 1] >> ((z & 1) * 4)) & 15;
-                const int uses_left = m == 1 || m == 2 || m == 4 || m == 5 || m == 6 || m == 8;
-                const int uses_top = m == 0 || m == 2 || m == 3 || m == 4 || m == 5 || m == 6 || m == 7;
-                const int uses_corner = m == 4 || m == 5 || m == 6;
-                if (bx == 0 && (uses_left || uses_corner)) need |= FJ_AVAIL_A;
-                if (by == 0 && (uses_top || uses_corner)) need |= FJ_AVAIL_B;
-                if (bx == 0 && by == 0 && uses_corner) need |= FJ_AVAIL_D;
-                if (bx == 3 && by == 0 && (m == 3 || m == 7)) need |= FJ_AVAIL_C;
+        else if (r->kind == FJ_MB_CONCEAL_I) n_conceal++;
+        else if (in_intra_schedule(r->kind)) {
+            const uint32_t x = a % w, y = a / w;
+            int lvl = -1;
+            /* which neighbouring macroblocks does the prediction of this one actually read? (8.3.1.2, 8.3.3, 8.3.4) */
+            unsigned need = 0;
+            if (r->kind == FJ_MB_I16x16) {
+                const int m = r->pred & 3;
+                need |= m == 0 ? FJ_AVAIL_B : m == 1 ? FJ_AVAIL_A : m == 2 ? (FJ_AVAIL_A | FJ_AVAIL_B) : (FJ_AVAIL_A | FJ_AVAIL_B | FJ_AVAIL_D);
+            } else if (r->kind == FJ_MB_I4x4) {
+                for (int z = 0; z < 16; z++) {
+                    const int bx = ((z >> 2) & 1) * 2 + (z & 1), by = (z >> 3) * 2 + ((z >> 1) & 1);
+                    if (bx && by) continue;
+                    const int m = (r->i4mode[z >> 1] >> ((z & 1) * 4)) & 15;
+                    const int uses_left = m == 1 || m == 2 || m == 4 || m == 5 || m == 6 || m == 8;
+                    const int uses_top = m == 0 || m == 2 || m == 3 || m == 4 || m == 5 || m == 6 || m == 7;
+                    const int uses_corner = m == 4 || m == 5 || m == 6;
+                    if (bx == 0 && (uses_left || uses_corner)) need |= FJ_AVAIL_A;
+                    if (by == 0 && (uses_top || uses_corner)) need |= FJ_AVAIL_B;
+                    if (bx == 0 && by == 0 && uses_corner) need |= FJ_AVAIL_D;
+                    if (bx == 3 && by == 0 && (m == 3 || m == 7)) need |= FJ_AVAIL_C;
+                }
             }
-        }
-        if (r->kind != FJ_MB_IPCM) {
-            const int m = (r->pred >> 2) & 3;
-            need |= m == 0 ? (FJ_AVAIL_A | FJ_AVAIL_B) : m == 1 ? FJ_AVAIL_A : m == 2 ? FJ_AVAIL_B : (FJ_AVAIL_A | FJ_AVAIL_B | FJ_AVAIL_D);
-        }
-        need &= r->avail;             /* an unavailable neighbour is never read (its samples are replaced by 128) */
+            if (r->kind != FJ_MB_IPCM) {
+                const int m = (r->pred >> 2) & 3;
+                need |= m == 0 ? (FJ_AVAIL_A | FJ_AVAIL_B) : m == 1 ? FJ_AVAIL_A : m == 2 ? FJ_AVAIL_B : (FJ_AVAIL_A | FJ_AVAIL_B | FJ_AVAIL_D);
+            }
+            need &= r->avail;             /* an unavailable neighbour is never read (its samples are replaced by 128) */
 #define DEP(cond, idx) do { if (cond) { const FjMbRec *q = &recs[idx]; \
             if (in_intra_schedule(q->kind) && (int)q->intra_level > lvl) lvl = q->intra_level; } } while (0)
-        DEP(x > 0 && (need & FJ_AVAIL_A), a - 1);
-        DEP(y > 0 && (need & FJ_AVAIL_B), a - w);
-        DEP(y > 0 && x + 1 < w && (need & FJ_AVAIL_C), a - w + 1);
-        DEP(y > 0 && x > 0 && (need & FJ_AVAIL_D), a - w - 1);
+            DEP(x > 0 && (need & FJ_AVAIL_A), a - 1);
+            DEP(y > 0 && (need & FJ_AVAIL_B), a - w);
+            DEP(y > 0 && x + 1 < w && (need & FJ_AVAIL_C), a - w + 1);
+            DEP(y > 0 && x > 0 && (need & FJ_AVAIL_D), a - w - 1);
 #undef DEP
-        r->intra_level = (uint16_t)(lvl + 1);
-        if ((uint32_t)(lvl + 1) > max_level) max_level = (uint32_t)(lvl + 1);
-        n_intra++;
-        /* the same information for the device's dataflow scheduler: which of the 8 surrounding macroblocks this one
-         * waits for (FJ_NEED_*; the device ignores neighbours that are not in the intra schedule).  Intra
-         * macroblocks have no reference slots, so the mask travels in ref_slot[0]. */
-        r->ref_slot[0] = (uint8_t)(((need & FJ_AVAIL_A) ? FJ_NEED_L : 0) | ((need & FJ_AVAIL_D) ? FJ_NEED_UL : 0) |
-                                   ((need & FJ_AVAIL_B) ? FJ_NEED_U : 0) | ((need & FJ_AVAIL_C) ? FJ_NEED_UR : 0));
-        r->ref_slot[1] = r->ref_slot[2] = r->ref_slot[3] = 0;
+            r->intra_level = (uint16_t)(lvl + 1);
+            if ((uint32_t)(lvl + 1) > max_level) max_level = (uint32_t)(lvl + 1);
+            hist[lvl + 1]++;
+            ilist[n_intra++] = (uint16_t)a;
+            /* the same information for the device's dataflow scheduler: which of the 8 surrounding macroblocks this
+             * one waits for (FJ_NEED_*; the device ignores neighbours that are not in the intra schedule).  Intra
+             * macroblocks have no reference slots, so the mask travels in ref_slot[0]. */
+            r->ref_slot[0] = (uint8_t)(((need & FJ_AVAIL_A) ? FJ_NEED_L : 0) | ((need & FJ_AVAIL_D) ? FJ_NEED_UL : 0) |
+                                       ((need & FJ_AVAIL_B) ? FJ_NEED_U : 0) | ((need & FJ_AVAIL_C) ? FJ_NEED_UR : 0));
+            r->ref_slot[1] = r->ref_slot[2] = r->ref_slot[3] = 0;
+        } else if (r->kind == FJ_MB_CONCEAL_P) {
+            cls[a] = 6;                                            /* copy list, never "uniform" (bit0) */
+        } else if (r->kind == FJ_MB_INTER) {
+            /* cls bit0: uniform (16 equal mvs, one reference, no coefficients); bit1: additionally whole-sample for
+             * luma and chroma -> pure copy */
+            const int16_t *m0 = mvs[a][0];
+            const int one_ref = r->ref_slot[0] == r->ref_slot[1] && r->ref_slot[0] == r->ref_slot[2] && r->ref_slot[0] == r->ref_slot[3];
+            int same_mv = one_ref;
+            for (int k = 1; same_mv && k < 16; k++) same_mv = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
+            const int uni = same_mv && r->coded == 0;
+            cls[a] = (uint8_t)(uni ? (((m0[0] | m0[1]) & 7) == 0 ? 3 : 1) : 0);
+            if (!(cls[a] & 2)) {
+                FjGen *gi = &gen_tmp[n_gen++];
+                gi->mb = (uint16_t)a; gi->uniform = (uint8_t)same_mv; gi->slot = r->ref_slot[0];
+                gi->mvx = m0[0]; gi->mvy = m0[1]; gi->coef_idx = r->coef_idx; gi->coded = r->coded;
+            }
+        }
+        if (cls[a] & 2) {
+            /* copy list: runs of up to 4 horizontally adjacent copy MBs with equal reference and mv */
+            const int16_t *m0 = mvs[a][0];
+            FjCopy *last = n_copy ? &copy_tmp[n_copy - 1] : NULL;
+            if (last && last->count < 4 && (uint32_t)last->mb + last->count == a && a % w != 0 &&
+                last->slot == r->ref_slot[0] && last->dx == (m0[0] >> 2) && last->dy == (m0[1] >> 2)) {
+                last->count++;
+            } else {
+                copy_tmp[n_copy].mb = (uint16_t)a; copy_tmp[n_copy].slot = r->ref_slot[0]; copy_tmp[n_copy].count = 1;
+                copy_tmp[n_copy].dx = (int16_t)(m0[0] >> 2); copy_tmp[n_copy].dy = (int16_t)(m0[1] >> 2);
+                n_copy++;
+            }
+        }
+        {
+            /* deblocking: a uniform MB whose filtered left/top neighbours are uniform too, with the same reference and
+             * mv components closer than 4 quarter samples, has all-zero strengths (8.7.2.1) — never visited again */
+            int trivial = r->kind == FJ_MB_ABSENT || r->dbk == 0;
+            if (!trivial && (cls[a] & 1)) {
+                trivial = 1;
+                const uint32_t nb[2] = { a - 1, a - w };
+                const uint8_t want[2] = { (uint8_t)(r->dbk & FJ_DBK_LEFT), (uint8_t)(r->dbk & FJ_DBK_TOP) };
+                for (int k = 0; k < 2 && trivial; k++) {
+                    if (!want[k]) continue;
+                    const uint32_t p = nb[k];
+                    int dx = mvs[a][0][0] - mvs[p][0][0], dy = mvs[a][0][1] - mvs[p][0][1];
+                    trivial = (cls[p] & 1) && recs[p].ref_slot[0] == r->ref_slot[0] && dx > -4 && dx < 4 && dy > -4 && dy < 4;
+                }
+            }
+            r->dbk_trivial = (uint8_t)trivial;
+            if (!trivial) dbk_tmp[n_dbk++] = (uint16_t)a;
+        }
     }
     if (n_conceal) {
         /* Synthesised macroblocks read the neighbours that were decoded or concealed BEFORE them in the reference's
@@ -187,6 +263,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
 #undef DEP
             r->intra_level = (uint16_t)(lvl + 1);
             if ((uint32_t)(lvl + 1) > max_level) max_level = (uint32_t)(lvl + 1);
+            hist[lvl + 1]++;
             n_intra++;
             r->ref_slot[0] = (uint8_t)(((r->avail & FJ_CONC_LEFT) ? FJ_NEED_L : 0) | ((r->avail & FJ_CONC_ABOVE) ? FJ_NEED_U : 0) |
                                        ((r->avail & FJ_CONC_RIGHT) ? FJ_NEED_R : 0) | ((r->avail & FJ_CONC_BELOW) ? FJ_NEED_D : 0));
@@ -194,99 +271,34 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
         }
         free(ord);
     }
+    /* ---- sections behind the coefficients: level starts | intra index | copy runs | general-inter | deblocking index */
     const uint32_t n_levels = n_intra ? max_level + 1 : 0;
     h->n_coef_blocks = coef_blocks;
     h->lvl_off = fj_align32(h->coef_off + coef_blocks * 32u);
     h->idx_off = fj_align32(h->lvl_off + (n_levels + 1) * 4u);
     h->copy_off = fj_align32(h->idx_off + n_intra * 2u);
-    {
-        /* Classify the inter macroblocks.  cls bit0: uniform (16 equal mvs, one reference, no coefficients);
-         * bit1: additionally whole-sample for luma and chroma -> pure copy. */
-        const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(job + h->mv_off);
-        uint8_t *cls = (uint8_t *)calloc(n, 1);
-        if (!cls) return -1;
-        uint32_t n_gen = 0;
-        for (uint32_t a = 0; a < n; a++) {
-            if (recs[a].kind == FJ_MB_CONCEAL_P) { cls[a] = 6; continue; }      /* copy list, never "uniform" (bit0) */
-            if (recs[a].kind != FJ_MB_INTER) continue;
-            const int16_t *m0 = mvs[a][0];
-            int uni = recs[a].coded == 0 && recs[a].ref_slot[0] == recs[a].ref_slot[1] &&
-                      recs[a].ref_slot[0] == recs[a].ref_slot[2] && recs[a].ref_slot[0] == recs[a].ref_slot[3];
-            for (int k = 1; uni && k < 16; k++) uni = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
-            cls[a] = (uint8_t)(uni ? (((m0[0] | m0[1]) & 7) == 0 ? 3 : 1) : 0);
-            if (!(cls[a] & 2)) n_gen++;
-        }
-        /* copy list: runs of up to 4 horizontally adjacent copy MBs with equal reference and mv */
-        FjCopy *cp = (FjCopy *)(job + h->copy_off);
-        uint32_t n_copy = 0;
-        for (uint32_t a = 0; a < n; a++) {
-            if (!(cls[a] & 2)) continue;
-            const int16_t *m0 = mvs[a][0];
-            FjCopy *last = n_copy ? &cp[n_copy - 1] : NULL;
-            if (last && last->count < 4 && (uint32_t)last->mb + last->count == a && a % w != 0 &&
-                last->slot == recs[a].ref_slot[0] && last->dx == (m0[0] >> 2) && last->dy == (m0[1] >> 2)) {
-                last->count++;
-            } else {
-                if ((uint8_t *)&cp[n_copy + 1] > job + cap) { free(cls); return -1; }
-                cp[n_copy].mb = (uint16_t)a; cp[n_copy].slot = recs[a].ref_slot[0]; cp[n_copy].count = 1;
-                cp[n_copy].dx = (int16_t)(m0[0] >> 2); cp[n_copy].dy = (int16_t)(m0[1] >> 2);
-                n_copy++;
-            }
-        }
-        h->n_copy = n_copy;
-        h->n_gen = n_gen;
-        h->gen_off = fj_align32(h->copy_off + n_copy * 8u);
-        FjGen *gi = (FjGen *)(job + h->gen_off);
-        for (uint32_t a = 0; a < n; a++) {
-            if (recs[a].kind != FJ_MB_INTER || (cls[a] & 2)) continue;
-            const int16_t *m0 = mvs[a][0];
-            int uni = recs[a].ref_slot[0] == recs[a].ref_slot[1] && recs[a].ref_slot[0] == recs[a].ref_slot[2] &&
-                      recs[a].ref_slot[0] == recs[a].ref_slot[3];
-            for (int k = 1; uni && k < 16; k++) uni = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
-            gi->mb = (uint16_t)a; gi->uniform = (uint8_t)uni; gi->slot = recs[a].ref_slot[0];
-            gi->mvx = m0[0]; gi->mvy = m0[1]; gi->coef_idx = recs[a].coef_idx; gi->coded = recs[a].coded;
-            gi++;
-        }
-        /* deblocking: a uniform MB whose filtered left/top neighbours are uniform too, with the same reference and
-         * mv components closer than 4 quarter samples, has all-zero strengths (8.7.2.1) — never visited again */
-        h->dbk_off = fj_align32(h->gen_off + n_gen * 16u);
-        uint16_t *di = (uint16_t *)(job + h->dbk_off);
-        uint32_t n_dbk = 0;
-        for (uint32_t a = 0; a < n; a++) {
-            FjMbRec *r = &recs[a];
-            int trivial = r->kind == FJ_MB_ABSENT || r->dbk == 0;
-            if (!trivial && (cls[a] & 1)) {
-                trivial = 1;
-                const uint32_t nb[2] = { a - 1, a - w };
-                const uint8_t need[2] = { (uint8_t)(r->dbk & FJ_DBK_LEFT), (uint8_t)(r->dbk & FJ_DBK_TOP) };
-                for (int k = 0; k < 2 && trivial; k++) {
-                    if (!need[k]) continue;
-                    const uint32_t p = nb[k];
-                    int dx = mvs[a][0][0] - mvs[p][0][0], dy = mvs[a][0][1] - mvs[p][0][1];
-                    trivial = (cls[p] & 1) && recs[p].ref_slot[0] == r->ref_slot[0] && dx > -4 && dx < 4 && dy > -4 && dy < 4;
-                }
-            }
-            r->dbk_trivial = (uint8_t)trivial;
-            if (!trivial) di[n_dbk++] = (uint16_t)a;
-        }
-        h->n_dbk = n_dbk;
-        h->total_bytes = fj_align32(h->dbk_off + n_dbk * 2u);
-        free(cls);
-        if (h->total_bytes > cap) return -1;
-    }
-    {   /* intra schedule: counting sort of the intra MB addresses by dependency level */
+    h->n_copy = n_copy;
+    h->n_gen = n_gen;
+    h->gen_off = fj_align32(h->copy_off + n_copy * 8u);
+    h->dbk_off = fj_align32(h->gen_off + n_gen * 16u);
+    h->n_dbk = n_dbk;
+    h->total_bytes = fj_align32(h->dbk_off + n_dbk * 2u);
+    if (h->total_bytes > cap) return -1;
+    memcpy(job + h->copy_off, copy_tmp, (size_t)n_copy * 8u);
+    memcpy(job + h->gen_off, gen_tmp, (size_t)n_gen * 16u);
+    memcpy(job + h->dbk_off, dbk_tmp, (size_t)n_dbk * 2u);
+    {   /* intra schedule: the scheduled MB addresses sorted by dependency level, ascending address inside a level */
         uint32_t *lvl_start = (uint32_t *)(job + h->lvl_off);
         uint16_t *idx = (uint16_t *)(job + h->idx_off);
-        memset(lvl_start, 0, (n_levels + 1) * 4u);
-        for (uint32_t a = 0; a < n; a++)
-            if (in_intra_schedule(recs[a].kind)) lvl_start[recs[a].intra_level + 1]++;
-        for (uint32_t l = 0; l < n_levels; l++) lvl_start[l + 1] += lvl_start[l];
-        uint32_t *cursor = (uint32_t *)malloc((n_levels + 1) * 4u);
-        if (!cursor) return -1;
-        memcpy(cursor, lvl_start, (n_levels + 1) * 4u);
-        for (uint32_t a = 0; a < n; a++)
-            if (in_intra_schedule(recs[a].kind)) idx[cursor[recs[a].intra_level]++] = (uint16_t)a;
-        free(cursor);
+        lvl_start[0] = 0;
+        for (uint32_t l = 0; l < n_levels; l++) lvl_start[l + 1] = lvl_start[l] + hist[l];
+        for (uint32_t l = 0; l < n_levels; l++) hist[l] = lvl_start[l];           /* hist becomes the cursor */
+        if (!n_conceal) {
+            for (uint32_t i = 0; i < n_intra; i++) idx[hist[recs[ilist[i]].intra_level]++] = ilist[i];
+        } else {
+            for (uint32_t a = 0; a < n; a++)
+                if (in_intra_schedule(recs[a].kind)) idx[hist[recs[a].intra_level]++] = (uint16_t)a;
+        }
     }
     {   /* zero the alignment gaps so that a frame job is a pure function of the bitstream */
         const uint32_t ends[6] = { h->coef_off + coef_blocks * 32u, h->lvl_off + (n_levels + 1) * 4u,
