@@ -29,3 +29,37 @@ def test_batch_parse_equals_serial_parse(built, threads):
         assert got[k] == want[n], f"instance {k} ({n}) produced different frame jobs under the parser pool"
     for d in decs:
         d.close()
+
+
+def test_decode_picture_loop_counts_errors_and_conceals(built):
+    """h264bsdmiDecodePicture on a damaged stream: the same pictures (concealment included) and as many error returns as
+    the plain h264bsdDecode loop sees (tests/golden/synth_golden.json holds the reference's trace for the stream)"""
+    import ctypes
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from damage import damage
+    from h264writer import StreamWriter
+    from synth_configs import DAMAGED
+    name = "damaged_7"
+    cfg, dmg = DAMAGED[name]
+    data = damage(StreamWriter(**cfg).build(), **dmg)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth_golden.json")))[name]
+    L = built.lib()
+    jobs = []
+    dec = built.Decoder(capture=jobs.append)
+    buf = ctypes.create_string_buffer(data, len(data))
+    off, n_err, n_pic = 0, 0, 0
+    consumed, errs = ctypes.c_uint32(), ctypes.c_uint32()
+    for _ in range(10000):
+        if off >= len(data):
+            break
+        st = L.h264bsdmiDecodePicture(dec._st, ctypes.addressof(buf) + off, len(data) - off, n_pic, ctypes.byref(consumed),
+                                      ctypes.byref(errs))
+        off += consumed.value
+        n_err += errs.value
+        n_pic += st == built.H264BSD_PIC_RDY
+    dec.close()
+    assert n_err == sum(1 for t in gold["trace"] if t[0] >= 3)
+    assert n_pic == sum(1 for t in gold["trace"] if t[0] == 1)
