@@ -1070,11 +1070,16 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
             px[4 * w4 + 2] = as_s2(perm(b, a, 0x0C060C02u));
             px[4 * w4 + 3] = as_s2(perm(b, a, 0x0C070C03u));
         }
+        /* strengths and tc0 of the four edges up front: two rounds of independent LDS reads instead of eight dependent ones */
+        int bsv[4], tcv[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) bsv[e] = chroma ? (e < 2 ? bs_s[8 * e + kseg] : 0) : bs_s[4 * e + kseg];
+#pragma unroll
+        for (int e = 0; e < 4; e++) tcv[e] = tabs[128 + 4 * ((e ? ia_in : ia_l) & 63u) + ((bsv[e] - 1) & 3)];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const int bs = chroma ? (e < 2 ? bs_s[8 * e + kseg] : 0) : bs_s[4 * e + kseg];
-            const uint32_t ia = e ? ia_in : ia_l;
-            if (__ballot(bs != 0)) filter_edge8_pk(px + 4 * e, bs, e ? al_in : al_l, e ? be_in : be_l, bs > 0 && bs < 4 ? tabs[128 + 4 * (ia & 63u) + bs - 1] : 0, chroma);
+            const int bs = bsv[e];
+            if (__ballot(bs != 0)) filter_edge8_pk(px + 4 * e, bs, e ? al_in : al_l, e ? be_in : be_l, bs > 0 && bs < 4 ? tcv[e] : 0, chroma);
         }
 #pragma unroll
         for (int w4 = 0; w4 < 5; w4++)
@@ -1100,11 +1105,15 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
             else if (r >= 2 && r < 12) v = *reinterpret_cast<const uint16_t *>(colp + (r - 2) * CS);
             px[r] = as_s2(perm(0u, v, 0x0C010C00u));
         }
+        int bsv[4], tcv[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) bsv[e] = chroma ? (e < 2 ? bs_s[16 + 8 * e + kseg] : 0) : bs_s[16 + 4 * e + kseg];
+#pragma unroll
+        for (int e = 0; e < 4; e++) tcv[e] = tabs[128 + 4 * ((e ? ia_in : ia_t) & 63u) + ((bsv[e] - 1) & 3)];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const int bs = chroma ? (e < 2 ? bs_s[16 + 8 * e + kseg] : 0) : bs_s[16 + 4 * e + kseg];
-            const uint32_t ia = e ? ia_in : ia_t;
-            if (__ballot(bs != 0)) filter_edge8_pk(px + 4 * e, bs, e ? al_in : al_t, e ? be_in : be_t, bs > 0 && bs < 4 ? tabs[128 + 4 * (ia & 63u) + bs - 1] : 0, chroma);
+            const int bs = bsv[e];
+            if (__ballot(bs != 0)) filter_edge8_pk(px + 4 * e, bs, e ? al_in : al_t, e ? be_in : be_t, bs > 0 && bs < 4 ? tcv[e] : 0, chroma);
         }
 #pragma unroll
         for (int r = 1; r < 20; r++) {
