@@ -197,7 +197,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
             HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_intra, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_enabled = lds;
         }
-        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc);
+        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, g_tail_prof);
         if (launches) launches[3]++;
     }
     if (timed) HIP_TRY(hipEventRecord(tt->ev[4], st));
@@ -804,10 +804,10 @@ int h264bsdmiDebugTailProfile(int enable, unsigned long long *out)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     if (enable) {
-        if (!g_tail_prof) HIP_TRY(hipMalloc((void **)&g_tail_prof, 16 * 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(g_tail_prof, 0, 16 * 16 * sizeof(unsigned long long)));
+        if (!g_tail_prof) HIP_TRY(hipMalloc((void **)&g_tail_prof, (16 * 16 + 16 * 8) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(g_tail_prof, 0, (16 * 16 + 16 * 8) * sizeof(unsigned long long)));
     } else if (g_tail_prof) {
-        if (out) HIP_TRY(hipMemcpy(out, g_tail_prof, 16 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (out) HIP_TRY(hipMemcpy(out, g_tail_prof, (16 * 16 + 16 * 8) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         HIP_TRY(hipFree(g_tail_prof));
         g_tail_prof = nullptr;
     }

@@ -779,6 +779,21 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
         else has_tr = bx < 3 && z_of(bx + 1, by - 1) < z;
         for (int d = 0; d < 10; d++) {
             if (bx + 2 * by == d) {
+                /* the 13 neighbour samples of the block in seven INDEPENDENT LDS reads (one latency instead of a chain
+                 * of byte reads inside the mode switch): corner | top 0..7 (64-bit, above-right replaced when it is
+                 * not available) | left 0..3 (32-bit); elements are cut out with shifts */
+                const uint8_t *trow = &tile[by4 * TS + bx4];
+                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(trow), w1 = *reinterpret_cast<const uint32_t *>(trow + 4),
+                               w2 = *reinterpret_cast<const uint32_t *>(trow + 8);
+                const uint32_t l0 = tile[(by4 + 1) * TS + 3 + bx4], l1 = tile[(by4 + 2) * TS + 3 + bx4],
+                               l2 = tile[(by4 + 3) * TS + 3 + bx4], l3 = tile[(by4 + 4) * TS + 3 + bx4];
+                const int CN = (int)(w0 >> 24);
+                const unsigned long long TW = (unsigned long long)w1 | ((unsigned long long)(has_tr ? w2 : (w1 >> 24) * 0x01010101u) << 32);
+                const uint32_t LW = l0 | (l1 << 8) | (l2 << 16) | (l3 << 24);
+#undef I4_T
+#undef I4_L
+#define I4_T(k) (((k) < 0) ? CN : (int)((TW >> (8 * (k))) & 255u))
+#define I4_L(k) (((k) < 0) ? CN : (int)((LW >> (8 * (k))) & 255u))
                 int pr[4];
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
@@ -1169,7 +1184,7 @@ constexpr int TAIL_WORKERS = 4 * TAIL_WAVES;      /* deblocking workers = quarte
  * macroblock, reconstructs it (intra_mb / conceal_mb), waits for its stores and then releases the neighbours that
  * wait for it.  No level barriers: the picture's time is its dependency critical path, not levels x slowest wave.
  * Dynamic LDS: 16 x 1 KB tiles | need[n_mbs] | dep[n_mbs] | queue[n_mbs] u16 | counters. */
-__global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames)
+__global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames, unsigned long long *prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const FrameDesc &fd = frames[blockIdx.x];
@@ -1219,6 +1234,10 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
     volatile uint16_t *vq = queue;
     volatile uint32_t *vctr = ctr;
     uint32_t spins = 0;                  /* safety net: a scheduling bug must end in wrong pixels, never in a hung GPU */
+    /* debug accounting (h264bsdmiDebugTailProfile, second half of the buffer): workgroup 0, per wavefront:
+     * [0] cycles with nothing ready, [1] cycles reconstructing, [2] cycles waiting for stores + release, [3] MBs */
+    unsigned long long *tp = (prof && blockIdx.x == 0) ? prof + 256 + wave * 8 : nullptr;
+    unsigned long long t_idle = 0, t_work = 0, t_rel = 0, n_done = 0, t_mark = tp ? __builtin_readcyclecounter() : 0ull;
     for (;;) {
         uint32_t slot = 0xFFFFFFFFu;
         if (lane == 0) {
@@ -1234,10 +1253,12 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
         do { v = vq[slot]; } while (v == 0xFFFF);          /* the publisher bumps the cursor, then writes the slot */
         const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(v);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
         /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
         const uint32_t head = *reinterpret_cast<const uint32_t *>(&fd.recs[mb]);     /* kind, qp_y, qp_c, avail */
         if ((head & 255u) == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
         else intra_mb(fd, mb, lane, my, my + 17 * TS);
+        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done++; }
         /* release: stores done -> the neighbours that wait for this macroblock */
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1250,7 +1271,9 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
                 if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)s;
             }
         }
+        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_rel += t - t_mark; t_mark = t; }
     }
+    if (tp && lane == 0) { tp[0] += t_idle; tp[1] += t_work; tp[2] += t_rel; tp[3] += n_done; }
 }
 
 /* In-loop deblocking of one picture.  The filter of macroblock (x,y) touches its own samples, the last

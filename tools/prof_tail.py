@@ -14,10 +14,13 @@ for tick in (0, 10, 20, 41):
     L.h264bsdmiDebugTailProfile(1, None)
     rep.run(tick, 1); rep.sync()
     done = tick + 1
-    out = np.zeros((16, 16), dtype=np.uint64)
-    L.h264bsdmiDebugTailProfile(0, ctypes.c_void_p(out.ctypes.data))
+    buf = np.zeros(16 * 16 + 16 * 8, dtype=np.uint64); out = buf[:256].reshape(16, 16); intra = buf[256:].reshape(16, 8)
+    L.h264bsdmiDebugTailProfile(0, ctypes.c_void_p(buf.ctypes.data))
     t = rep.timings()
     tot = out[:, 4].astype(float).sum()
+    it = float(intra[:, :3].sum()) or 1.0
+    print(f"tick {tick}: k_frame_intra {t['k_frame_intra'][0]:.3f} ms; MBs by WG0: {int(intra[:,3].sum())}; idle {intra[:,0].sum()/it:.0%} work {intra[:,1].sum()/it:.0%} "
+          f"store-wait+release {intra[:,2].sum()/it:.0%}; cycles per MB: work {intra[:,1].sum()/max(1,intra[:,3].sum()):.0f} release {intra[:,2].sum()/max(1,intra[:,3].sum()):.0f}")
     print(f"tick {tick}: k_frame_dbk {t['k_frame_dbk'][0]:.3f} ms; MBs filtered by WG0: {int(out[:,3].sum())}; "
           f"idle {out[:,0].sum()/tot:.0%}  filter {out[:,1].sum()/tot:.0%}  store-wait+release {out[:,2].sum()/tot:.0%}; "
           f"wave cycles {tot/16:.0f} avg; steps/wave {out[:,5].mean():.0f}, MBs per step {out[:,3].sum()/max(1,out[:,5].sum()):.2f}, "
