@@ -149,3 +149,37 @@ def test_parser_pool_with_async_flush_is_exact(built, golden):
     assert rounds == 73 and seen == [73] * len(names)
     for d in decs:
         d.close()
+
+
+def test_lifecycle_edge_cases(built, golden):
+    """things an application may do in any order: pull before anything was decoded, flush an empty decoder, shut down
+    with pictures still queued and never pulled, re-init the same storage, decode again after h264bsdFlushBuffer"""
+    L = built.lib()
+    name = "test_640x360"
+    g = golden[name]
+    data = stream_bytes(name)
+    dec = built.Decoder()
+    assert dec.next_output_picture() is None            # nothing decoded yet
+    dec.flush_buffer()
+    assert dec.next_output_picture() is None
+    assert dec.pic_width() == 0 and dec.check_valid_param_sets() == 0
+    buf = ctypes.create_string_buffer(data, len(data))
+    base, off, n_ready = ctypes.addressof(buf), 0, 0
+    while off < len(data) and n_ready < 5:              # five pictures queued, none pulled
+        r, rb = dec.decode(base + off, len(data) - off)
+        off += rb
+        n_ready += r == 1
+    dec.close()                                         # shutdown with queued, never reconstructed pictures
+    # a fresh instance on a new storage decodes the whole stream correctly afterwards
+    dec = built.Decoder()
+    shas = []
+    dec.decode_stream(data, on_picture=lambda f, pid, idr, err: shas.append(hashlib.sha256(f.tobytes()).hexdigest()))
+    assert shas == g["frame_sha256"]
+    # h264bsdFlushBuffer at the end of the stream, then the same stream again on the same instance (starts with an IDR)
+    dec.flush_buffer()
+    assert dec.next_output_picture() is None
+    shas2 = []
+    dec.decode_stream(data, on_picture=lambda f, pid, idr, err: shas2.append(hashlib.sha256(f.tobytes()).hexdigest()))
+    assert shas2 == g["frame_sha256"]
+    dec.close()
+    assert L.h264bsdmiFlush() == 0                      # nothing left anywhere
