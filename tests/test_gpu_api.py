@@ -183,3 +183,33 @@ def test_lifecycle_edge_cases(built, golden):
     assert shas2 == g["frame_sha256"]
     dec.close()
     assert L.h264bsdmiFlush() == 0                      # nothing left anywhere
+
+
+def test_concurrent_application_threads(built, golden):
+    """8 application threads, each with its own decoder instances, decode and pull pictures at the same time: the engine
+    serialises the device work, every picture must still be exact"""
+    import threading
+    name = "test_640x360"
+    want = golden[name]["frame_sha256"]
+    data = stream_bytes(name)
+    errors = []
+
+    def work(tid):
+        try:
+            for rep in range(2):
+                dec = built.Decoder()
+                shas = []
+                dec.decode_stream(data, on_picture=lambda f, pid, idr, err: shas.append(hashlib.sha256(f.tobytes()).hexdigest()))
+                dec.close()
+                if shas != want:
+                    errors.append((tid, rep, len(shas)))
+        except Exception as e:          # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a decoder thread is stuck"
+    assert not errors, errors
