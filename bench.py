@@ -76,7 +76,6 @@ def main():
 
     import torch
     import h264bsd_amd
-    from oracle import pyoracle
 
     if not torch.cuda.is_available() or h264bsd_amd.device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: the product has no CPU pixel path")
@@ -96,7 +95,7 @@ def main():
     golden = json.load(open(os.path.join(gdir, "golden.json")))[STREAM]
     data = open(os.path.join(gdir, STREAM + ".h264"), "rb").read()
     jobs, _, info = h264bsd_amd.capture_stream(data)                 # host parse, once
-    heads = [pyoracle.blob_header(j) for j in jobs]
+    heads = [h264bsd_amd.job_header(j) for j in jobs]
     n_pics, n_mbs = len(jobs), heads[0]["n_mbs"]
     rep = h264bsd_amd.Replay(jobs, n_streams=args.streams)          # jobs + DPBs resident in HBM
 

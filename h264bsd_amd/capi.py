@@ -315,6 +315,19 @@ class BatchDriver:
         return ready
 
 
+def job_header(blob):
+    """Decode the FjHeader of a frame job (h264bsd_amd/csrc/framejob.h)."""
+    import struct
+    (magic, total, wmb, hmb, n_mbs, cur, is_idr, n_slots, any_dbk, rec_off, mv_off, lvl_off, idx_off, coef_off,
+     n_intra, n_levels, n_coef, n_inter, pic_seq) = struct.unpack_from("<IIHHIBBBBIIIIIIIIII", blob, 0)
+    if magic != 0x314A4648:
+        raise ValueError("not a frame job")
+    return dict(total_bytes=total, width_mbs=wmb, height_mbs=hmb, n_mbs=n_mbs, cur_slot=cur, is_idr=is_idr,
+                n_slots=n_slots, any_deblock=any_dbk, rec_off=rec_off, mv_off=mv_off, lvl_off=lvl_off,
+                idx_off=idx_off, coef_off=coef_off, n_intra=n_intra, n_intra_levels=n_levels,
+                n_coef_blocks=n_coef, n_inter=n_inter, pic_seq=pic_seq)
+
+
 def capture_stream(data):
     """Parse a byte stream on the host only.  Returns (jobs, trace, info): the packed frame job of every
     picture in decode order, the h264bsdDecode call trace, and stream geometry."""

@@ -52,15 +52,9 @@ def oracle_lib():
 
 
 def blob_header(blob):
-    """Decode the FjHeader of a frame job (h264bsd_amd/csrc/framejob.h)."""
-    import struct
-    (magic, total, wmb, hmb, n_mbs, cur, is_idr, n_slots, any_dbk, rec_off, mv_off, lvl_off, idx_off, coef_off,
-     n_intra, n_levels, n_coef, n_inter, pic_seq) = struct.unpack_from("<IIHHIBBBBIIIIIIIIII", blob, 0)
-    assert magic == 0x314A4648, "not a frame job"
-    return dict(total_bytes=total, width_mbs=wmb, height_mbs=hmb, n_mbs=n_mbs, cur_slot=cur, is_idr=is_idr,
-                n_slots=n_slots, any_deblock=any_dbk, rec_off=rec_off, mv_off=mv_off, lvl_off=lvl_off,
-                idx_off=idx_off, coef_off=coef_off, n_intra=n_intra, n_intra_levels=n_levels,
-                n_coef_blocks=n_coef, n_inter=n_inter, pic_seq=pic_seq)
+    """Decode the FjHeader of a frame job: the product's own helper (h264bsd_amd.job_header)."""
+    import h264bsd_amd
+    return h264bsd_amd.job_header(blob)
 
 
 class OracleDpb:

@@ -2,7 +2,7 @@
  * damaged in six ways (byte noise, truncation, garbage burst, bit flips near the start, 200 bit flips, a dropped
  * span), decoded in capture mode, and every frame job is rendered by the (equally instrumented) CPU oracle from an
  * exact-size copy — so an out-of-range slot, coefficient index, list entry or a read past total_bytes is a report.
- * Build + run: tools/fuzz_asan/run.sh <stream.h264> [cases] [seed]     (no GPU needed) */
+ * Build + run: tests/fuzz_asan/run.sh <stream.h264> [cases] [seed]     (no GPU needed) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

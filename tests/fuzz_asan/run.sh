@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/fuzz_asan/run.sh <stream.h264> [cases=500] [seed=1]
+# usage: tests/fuzz_asan/run.sh <stream.h264> [cases=500] [seed=1]
 set -e
 here=$(cd "$(dirname "$0")" && pwd); root=$(cd "$here/../.." && pwd); C=$root/h264bsd_amd/csrc
 out=${TMPDIR:-/tmp}/h264bsd_fuzz_asan

@@ -1,6 +1,6 @@
 """Robustness of the host parser: arbitrarily damaged streams must end in error codes and concealed pictures, never
 in a crash or a hang.  Runs in a child process so that a memory fault shows up as a failed test instead of killing
-pytest.  (tools/fuzz_asan/ is the same idea under ASan/UBSan, with every frame job also rendered by the oracle.)"""
+pytest.  (tests/fuzz_asan/ is the same idea under ASan/UBSan, with every frame job also rendered by the oracle.)"""
 import subprocess
 import sys
 import textwrap
