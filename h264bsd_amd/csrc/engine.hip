@@ -190,7 +190,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         const uint32_t n = s.max_mbs;
         const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64;
         if (arrays + 1024 > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_intra\n", n); return -1; }
-        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::TAIL_WAVES, (LDS_BUDGET - arrays) / 1024);
+        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::TAIL_WAVES, (LDS_BUDGET - arrays) / 1024);   /* 16: throughput-bound (12 waves: +11 %, 8: +41 %) */
         const size_t lds = (size_t)waves * 1024 + arrays;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
@@ -207,7 +207,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 16 + 384 + 64;
         const size_t per_wave = 4 * (size_t)h264k::WORKER_LDS;
         if (arrays + per_wave > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_dbk\n", n); return -1; }
-        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::TAIL_WAVES, (LDS_BUDGET - arrays) / per_wave);
+        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::DBK_WAVES, (LDS_BUDGET - arrays) / per_wave);
         const size_t lds = (size_t)waves * per_wave + arrays;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {

@@ -1175,7 +1175,10 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
  * inter-workgroup traffic inside a picture.  Occupancy comes from batching streams (256 pictures = one
  * workgroup per CU). */
 constexpr int TAIL_WAVES = 16;
-constexpr int TAIL_WORKERS = 4 * TAIL_WAVES;      /* deblocking workers = quarter wavefronts */
+constexpr int DBK_WAVES = 6;                        /* wavefronts of k_frame_dbk: the picture's dependency critical path bounds it, and
+                                                        fewer wavefronts contend less for instruction issue (measured per step: 16 waves
+                                                        96 ms, 12: 94, 8: 89-91, 6: 90, 5: 87, 4: 89, 3: 102) */
+constexpr int TAIL_WORKERS = 4 * DBK_WAVES;       /* deblocking workers = quarter wavefronts */
 
 /* Intra (and concealed) macroblocks of one picture, dataflow-scheduled inside one workgroup.  A macroblock of the
  * intra schedule waits for those of the neighbours named by its FJ_NEED_* mask that are themselves in the schedule
@@ -1291,7 +1294,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
  * wavefronts as possible because the loop is instruction-issue bound (a step costs the same with one busy quarter as
  * with four).  Same-CU visibility of the stores needs only s_waitcnt vmcnt(0) before the LDS release.
  * Dynamic LDS: 64 x WORKER_LDS tiles | any[n_mbs] u8 | dep[n_mbs] u8 | queue[n_mbs] u16 | counters | threshold tables. */
-__global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof)
+__global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const FrameDesc &fd = frames[blockIdx.x];
