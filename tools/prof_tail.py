@@ -23,6 +23,6 @@ for tick in (0, 10, 20, 41):
           f"store-wait+release {intra[:,2].sum()/it:.0%}; cycles per MB: work {intra[:,1].sum()/max(1,intra[:,3].sum()):.0f} release {intra[:,2].sum()/max(1,intra[:,3].sum()):.0f}")
     print(f"tick {tick}: k_frame_dbk {t['k_frame_dbk'][0]:.3f} ms; MBs filtered by WG0: {int(out[:,3].sum())}; "
           f"idle {out[:,0].sum()/tot:.0%}  filter {out[:,1].sum()/tot:.0%}  store-wait+release {out[:,2].sum()/tot:.0%}; "
-          f"wave cycles {tot/16:.0f} avg; steps/wave {out[:,5].mean():.0f}, MBs per step {out[:,3].sum()/max(1,out[:,5].sum()):.2f}, "
+          f"active waves {int((out[:,5] > 0).sum())}; wave cycles {tot/max(1,(out[:,5] > 0).sum()):.0f} avg; steps/wave {out[:,5].sum()/max(1,(out[:,5] > 0).sum()):.0f}, MBs per step {out[:,3].sum()/max(1,out[:,5].sum()):.2f}, "
           f"cycles per step {out[:,1].sum()/max(1,out[:,5].sum()):.0f} = load {out[:,8].sum()/max(1,out[:,5].sum()):.0f} + V {out[:,9].sum()/max(1,out[:,5].sum()):.0f} "
           f"+ H {out[:,10].sum()/max(1,out[:,5].sum()):.0f} + store {out[:,11].sum()/max(1,out[:,5].sum()):.0f}")
