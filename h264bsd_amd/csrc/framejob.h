@@ -120,7 +120,8 @@ typedef struct FjCopy {
  * can be issued one dependent load after the launch descriptor instead of three. */
 typedef struct FjGen {
     uint16_t mb;
-    uint8_t  uniform;         /* 1: 16 equal motion vectors and one reference slot            */
+    uint8_t  uniform;         /* 1: 16 equal motion vectors and one reference slot; 2: one motion vector per 8x8
+                                 quadrant (references in FjMbRec.ref_slot); 0: anything else                   */
     uint8_t  slot;            /* reference slot when uniform                                  */
     int16_t  mvx, mvy;        /* the motion vector when uniform (quarter samples)             */
     uint32_t coef_idx;        /* = FjMbRec.coef_idx                                           */

@@ -201,7 +201,17 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
             cls[a] = (uint8_t)(uni ? (((m0[0] | m0[1]) & 7) == 0 ? 3 : 1) : 0);
             if (!(cls[a] & 2)) {
                 FjGen *gi = &gen_tmp[n_gen++];
-                gi->mb = (uint16_t)a; gi->uniform = (uint8_t)same_mv; gi->slot = r->ref_slot[0];
+                int quad = 0;
+                if (!same_mv) {                               /* one motion vector per 8x8 quadrant (16x8, 8x16, 8x8 partitions)? */
+                    quad = 1;
+                    for (int q = 0; q < 4 && quad; q++) {
+                        const int b0 = (q >> 1) * 8 + (q & 1) * 2;
+                        const int16_t *m = mvs[a][b0];
+                        quad = mvs[a][b0 + 1][0] == m[0] && mvs[a][b0 + 1][1] == m[1] && mvs[a][b0 + 4][0] == m[0] &&
+                               mvs[a][b0 + 4][1] == m[1] && mvs[a][b0 + 5][0] == m[0] && mvs[a][b0 + 5][1] == m[1];
+                    }
+                }
+                gi->mb = (uint16_t)a; gi->uniform = (uint8_t)(same_mv ? 1 : quad ? 2 : 0); gi->slot = r->ref_slot[0];
                 gi->mvx = m0[0]; gi->mvy = m0[1]; gi->coef_idx = r->coef_idx; gi->coded = r->coded;
             }
         }

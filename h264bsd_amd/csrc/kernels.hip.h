@@ -457,7 +457,9 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
  * memory.  Both feed the same textbook interpolation (luma_from_window / chroma_from_rows). */
 constexpr int IW_STRIDE = 36;                        /* luma window: 21 rows x 28 bytes; 9-dword stride: no bank conflicts for row-per-lane reads */
 constexpr int IC_STRIDE = 20;                        /* chroma windows: 9 rows x 16 bytes, two planes */
-constexpr int INTER_WAVE_LDS = 21 * IW_STRIDE + 2 * 9 * IC_STRIDE;
+constexpr int QW_STRIDE = 20;                        /* quadrant luma windows: 13 rows x 16 bytes, 5-dword stride */
+constexpr int QC_STRIDE = 12;                        /* quadrant chroma windows: 5 rows x 8 bytes, 3-dword stride, two planes */
+constexpr int INTER_WAVE_LDS = 1536;                 /* max(21 * IW_STRIDE + 2 * 9 * IC_STRIDE, 4 * 13 * QW_STRIDE + 4 * 2 * 5 * QC_STRIDE) = 1520, rounded */
 
 #ifndef INTER_OCC
 #define INTER_OCC 7      /* 72 VGPRs, 10 spilled: measured best (6: 71.5 ms, 7: 67.4, 8: 68.3, 5: 79.9 per step) */
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
     uint8_t *cur = fd.cur;
     const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
-    const bool uniform = ge.uniform != 0;
+    const bool uniform = ge.uniform == 1, quadwise = ge.uniform == 2;
     uint32_t refs = ge.slot * 0x01010101u, mv_mine = 0;
     const uint32_t mv0 = (uint32_t)(uint16_t)ge.mvx | ((uint32_t)(uint16_t)ge.mvy << 16);
     if (!uniform) {
@@ -552,6 +554,86 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
             const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
             const int cy = cby * 4 + row, cx0 = cbx * 4;
             const uint8_t *s0 = lc + plane * 9 * IC_STRIDE + cy * IC_STRIDE + (cxi - cxs) + cx0, *s1 = s0 + IC_STRIDE;
+            int a[5], b[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) { a[i] = s0[i]; b[i] = s1[i]; }
+            chroma_from_rows(a, b, mvx & 7, mvy & 7, pc);
+            chroma_from_rows(a + 2, b + 2, mvx & 7, mvy & 7, pc + 2);
+        }
+    } else if (quadwise) {
+        /* ---- one motion vector per 8x8 quadrant (16x8, 8x16, 8x8 partitions): four 13x13 luma and four 5x5 (x2 planes)
+         * chroma windows staged in LDS with row-wide dword loads, then the same register-window arithmetic ---- */
+        uint8_t *lq = lw, *cq = lw + 4 * 13 * QW_STRIDE;
+        {
+            /* staging: item d of a quadrant = (row, dword); 4 x 52 luma dwords, 4 x 20 chroma dwords */
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int d = lane + 64 * it;
+                if (d < 208) {
+                    const int q = d / 52, e = d % 52, r = e >> 2, c = e & 3;
+                    const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
+                    const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
+                    const uint8_t *ref = fd.slot[(refs >> (8 * q)) & 255u];
+                    const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
+                    const int xs = xi - (xi & 3);
+                    uint32_t v;
+                    if (xs >= 0 && xs + 16 <= W && yi >= 0 && yi + 13 <= H) {
+                        v = *reinterpret_cast<const uint32_t *>(ref + (size_t)(yi + r) * W + xs + 4 * c);
+                    } else {
+                        const uint8_t *rp = ref + (size_t)clip3(0, H - 1, yi + r) * W;
+                        v = (uint32_t)rp[clip3(0, W - 1, xs + 4 * c)] | ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 1)] << 8) |
+                            ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 2)] << 16) | ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 3)] << 24);
+                    }
+                    *reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + r * QW_STRIDE + 4 * c) = v;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int d = lane + 64 * it;
+                if (d < 80) {
+                    const int q = d / 20, e = d % 20, p = e / 10, r = (e % 10) >> 1, c = e & 1;
+                    const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
+                    const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
+                    const uint8_t *ref = fd.slot[(refs >> (8 * q)) & 255u] + ysz + (p ? csz : 0);
+                    const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
+                    const int cxs = cxi - (cxi & 3);
+                    uint32_t v;
+                    if (cxs >= 0 && cxs + 8 <= CW && cyi >= 0 && cyi + 5 <= CH) {
+                        v = *reinterpret_cast<const uint32_t *>(ref + (size_t)(cyi + r) * CW + cxs + 4 * c);
+                    } else {
+                        const uint8_t *rp = ref + (size_t)clip3(0, CH - 1, cyi + r) * CW;
+                        v = (uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c)] | ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 1)] << 8) |
+                            ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 2)] << 16) | ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 3)] << 24);
+                    }
+                    *reinterpret_cast<uint32_t *>(cq + (q * 2 + p) * 5 * QC_STRIDE + r * QC_STRIDE + 4 * c) = v;
+                }
+            }
+        }
+        wave_sync();
+        {
+            const int q = (by >> 1) * 2 + (bx >> 1);
+            const int mvx = (int16_t)(mv_mine & 0xFFFFu), mvy = (int32_t)mv_mine >> 16;
+            const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2;
+            const int o = (xi & 3) + 4 * (bx & 1), sh = 8 * (o & 3);
+            const uint8_t *src = lq + q * 13 * QW_STRIDE + (4 * (by & 1) + row) * QW_STRIDE + (o & ~3);
+            uint32_t rw[6][3];
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const uint32_t *qq = reinterpret_cast<const uint32_t *>(src + r * QW_STRIDE);
+                const uint32_t q0 = qq[0], q1 = qq[1], q2 = qq[2], q3 = (o & ~3) + 12 < 16 ? qq[3] : 0u;
+                rw[r][0] = (uint32_t)(((unsigned long long)q1 << 32 | q0) >> sh);
+                rw[r][1] = (uint32_t)(((unsigned long long)q2 << 32 | q1) >> sh);
+                rw[r][2] = (uint32_t)(((unsigned long long)q3 << 32 | q2) >> sh);
+            }
+            luma_from_window(rw, mvx & 3, mvy & 3, pl);
+        }
+        if (lane < 32) {
+            const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
+            const int q = cby * 2 + cbx;                             /* a 4x4 chroma block = one luma quadrant */
+            const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
+            const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
+            const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3);
+            const uint8_t *s0 = cq + (q * 2 + plane) * 5 * QC_STRIDE + row * QC_STRIDE + (cxi & 3), *s1 = s0 + QC_STRIDE;
             int a[5], b[5];
 #pragma unroll
             for (int i = 0; i < 5; i++) { a[i] = s0[i]; b[i] = s1[i]; }
