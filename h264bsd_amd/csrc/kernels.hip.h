@@ -241,23 +241,21 @@ __device__ __forceinline__ void luma_from_window(const uint32_t rw[6][3], int fx
 #define VH1(c) tap6(GW(0, c), GW(1, c), GW(2, c), GW(3, c), GW(4, c), GW(5, c))
 #define HB1(r, i) tap6(GW(r, i), GW(r, (i) + 1), GW(r, (i) + 2), GW(r, (i) + 3), GW(r, (i) + 4), GW(r, (i) + 5))
     if (fx == 2 || fy == 2) {                        /* j, f, q, i, k */
-        int h1c[5] = { 0, 0, 0, 0, 0 };
-        if (fx != 2) {
+        /* j is the 6-tap filter over un-rounded intermediate sums, and it may run over the vertical sums of nine columns
+         * just as well as over the horizontal sums of six rows (8.4.2.2.1: both orders are equal): 9 + 4 filters
+         * instead of 24 + 4, and the vertical sums are exactly what i / k need */
+        int v1[9];
 #pragma unroll
-            for (int c = 0; c < 5; c++) h1c[c] = VH1(c + 2);
-        }
+        for (int c = 0; c < 9; c++) v1[c] = VH1(c);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            int b1[6];
-#pragma unroll
-            for (int r = 0; r < 6; r++) b1[r] = HB1(r, i);
-            const int j = clip255((tap6(b1[0], b1[1], b1[2], b1[3], b1[4], b1[5]) + 512) >> 10);
+            const int j = clip255((tap6(v1[i], v1[i + 1], v1[i + 2], v1[i + 3], v1[i + 4], v1[i + 5]) + 512) >> 10);
             int v = j;
             if (fy != 2) {                           /* f / q: with b (row y) or s (row y+1) */
-                const int b = clip255(((fy == 1 ? b1[2] : b1[3]) + 16) >> 5);
+                const int b = clip255(((fy == 1 ? HB1(2, i) : HB1(3, i)) + 16) >> 5);
                 v = (j + b + 1) >> 1;
             } else if (fx != 2) {                    /* i / k: with h (col x) or m (col x+1) */
-                const int hh = clip255(((fx == 1 ? h1c[i] : h1c[i + 1]) + 16) >> 5);
+                const int hh = clip255(((fx == 1 ? v1[i + 2] : v1[i + 3]) + 16) >> 5);
                 v = (j + hh + 1) >> 1;
             }
             out[i] = v;
