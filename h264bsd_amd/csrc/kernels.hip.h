@@ -182,6 +182,20 @@ __device__ __forceinline__ void mb_residual(uint32_t coded, int qp_y, int qp_c, 
 }
 
 /* ------------------------------------------------------------------ inter prediction */
+/* ---- packed 16-bit helpers (two samples per register, v_pk_*_i16) ---- */
+typedef short s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2 pk(int x) { return (s2){ (short)x, (short)x }; }
+__device__ __forceinline__ s2 pk_lt(s2 a, s2 b) { return (a - b) >> pk(15); }                  /* a < b ? -1 : 0 */
+__device__ __forceinline__ s2 pk_abs(s2 a) { return __builtin_elementwise_max(a, -a); }
+__device__ __forceinline__ s2 pk_clip(s2 lo, s2 hi, s2 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi); }
+__device__ __forceinline__ s2 pk_sel(s2 m, s2 a, s2 b) { return (a & m) | (b & ~m); }
+
+__device__ __forceinline__ s2 as_s2(uint32_t x) { s2 r; __builtin_memcpy(&r, &x, 4); return r; }
+__device__ __forceinline__ uint32_t as_u32(s2 x) { uint32_t r; __builtin_memcpy(&r, &x, 4); return r; }
+/* v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8 bytes {lo = 0..3, hi = 4..7}; selector 12 = 0x00 */
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * (b + e) + 20 * (c + d) + f; }
 
 /* Register window of one lane: rows y-2..y+3, columns x-2..x+9 of the reference plane (9 columns used),
@@ -220,21 +234,33 @@ __device__ __forceinline__ void luma_from_window(const uint32_t rw[6][3], int fx
         for (int i = 0; i < 4; i++) out[i] = GW(2, i + 2);
         return;
     }
+    /* The one-dimensional and diagonal classes run on PAIRS of output samples (packed 16-bit: a six-tap sum of bytes lies
+     * in [-2550, 10710]).  CP(r, c) = (sample c, sample c+1) of window row r; the selectors are compile-time constants. */
+#define CP(r, c) as_s2(perm(rw[(r)][((c) + 1) >> 2], rw[(r)][(c) >> 2], \
+                      0x0C000C00u | (uint32_t)((c) & 3) | ((uint32_t)(((((c) + 1) >> 2) != ((c) >> 2)) ? 4 + (((c) + 1) & 3) : (((c) + 1) & 3)) << 16)))
+#define HT2(r, i) (CP(r, i) + CP(r, (i) + 5) - pk(5) * (CP(r, (i) + 1) + CP(r, (i) + 4)) + pk(20) * (CP(r, (i) + 2) + CP(r, (i) + 3)))
+#define VT2(c) (CP(0, c) + CP(5, c) - pk(5) * (CP(1, c) + CP(4, c)) + pk(20) * (CP(2, c) + CP(3, c)))
+#define RND5(x) pk_clip(pk(0), pk(255), ((x) + pk(16)) >> pk(5))
     if (fy == 0) {                                   /* a, b, c: horizontal only (window row 2) */
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int b = clip255((tap6(GW(2, i), GW(2, i + 1), GW(2, i + 2), GW(2, i + 3), GW(2, i + 4), GW(2, i + 5)) + 16) >> 5);
-            out[i] = fx == 2 ? b : (b + (fx == 1 ? GW(2, i + 2) : GW(2, i + 3)) + 1) >> 1;
-        }
+        s2 o01 = RND5(HT2(2, 0)), o23 = RND5(HT2(2, 2));
+        if (fx == 1) { o01 = (o01 + CP(2, 2) + pk(1)) >> pk(1); o23 = (o23 + CP(2, 4) + pk(1)) >> pk(1); }
+        else if (fx == 3) { o01 = (o01 + CP(2, 3) + pk(1)) >> pk(1); o23 = (o23 + CP(2, 5) + pk(1)) >> pk(1); }
+        out[0] = o01.x; out[1] = o01.y; out[2] = o23.x; out[3] = o23.y;
         return;
     }
     if (fx == 0) {                                   /* d, h, n: vertical only */
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int c = i + 2;
-            const int hh = clip255((tap6(GW(0, c), GW(1, c), GW(2, c), GW(3, c), GW(4, c), GW(5, c)) + 16) >> 5);
-            out[i] = fy == 2 ? hh : (hh + (fy == 1 ? GW(2, c) : GW(3, c)) + 1) >> 1;
-        }
+        s2 o01 = RND5(VT2(2)), o23 = RND5(VT2(4));
+        if (fy == 1) { o01 = (o01 + CP(2, 2) + pk(1)) >> pk(1); o23 = (o23 + CP(2, 4) + pk(1)) >> pk(1); }
+        else if (fy == 3) { o01 = (o01 + CP(3, 2) + pk(1)) >> pk(1); o23 = (o23 + CP(3, 4) + pk(1)) >> pk(1); }
+        out[0] = o01.x; out[1] = o01.y; out[2] = o23.x; out[3] = o23.y;
+        return;
+    }
+    if (fx != 2 && fy != 2) {                        /* e, g, p, r: average of the nearest horizontal and vertical half samples */
+        s2 b01, b23, h01, h23;
+        if (fy == 1) { b01 = HT2(2, 0); b23 = HT2(2, 2); } else { b01 = HT2(3, 0); b23 = HT2(3, 2); }
+        if (fx == 1) { h01 = VT2(2); h23 = VT2(4); } else { h01 = VT2(3); h23 = VT2(5); }
+        const s2 o01 = (RND5(b01) + RND5(h01) + pk(1)) >> pk(1), o23 = (RND5(b23) + RND5(h23) + pk(1)) >> pk(1);
+        out[0] = o01.x; out[1] = o01.y; out[2] = o23.x; out[3] = o23.y;
         return;
     }
     /* vertical 6-tap sums at window columns 2..6 (sample columns x .. x+4): h and m candidates */
@@ -262,21 +288,13 @@ __device__ __forceinline__ void luma_from_window(const uint32_t rw[6][3], int fx
         }
         return;
     }
-    /* e, g, p, r: average of the nearest horizontal and vertical half samples */
-    {
-        int h1c[5];
-#pragma unroll
-        for (int c = 0; c < 5; c++) h1c[c] = VH1(c + 2);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int b = clip255(((fy == 1 ? HB1(2, i) : HB1(3, i)) + 16) >> 5);
-            const int hh = clip255(((fx == 1 ? h1c[i] : h1c[i + 1]) + 16) >> 5);
-            out[i] = (b + hh + 1) >> 1;
-        }
-    }
 #undef VH1
 #undef HB1
 #undef GW
+#undef CP
+#undef HT2
+#undef VT2
+#undef RND5
 }
 
 /* 2 chroma samples from the two rows a[0..2], b[0..2] at eighth-sample fraction (fx,fy), 8.4.2.2.2 */
@@ -998,13 +1016,6 @@ constexpr int WORKER_LDS = 1280;                     /* LDS per deblocking worke
  * same sample position of both lines as two 16-bit halves.  The two lines lie in the same 4-sample segment of the
  * edge, so they share bS, alpha, beta and tc0.  Conditions become 0 / -1 half-word masks ((a - b) >> 15), selection
  * is bitwise (v_bfi).  Same arithmetic as 8.7.2.3 / 8.7.2.4, same result as filter_edge8. */
-typedef short s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s2 pk(int x) { return (s2){ (short)x, (short)x }; }
-__device__ __forceinline__ s2 pk_lt(s2 a, s2 b) { return (a - b) >> pk(15); }                  /* a < b ? -1 : 0 */
-__device__ __forceinline__ s2 pk_abs(s2 a) { return __builtin_elementwise_max(a, -a); }
-__device__ __forceinline__ s2 pk_clip(s2 lo, s2 hi, s2 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi); }
-__device__ __forceinline__ s2 pk_sel(s2 m, s2 a, s2 b) { return (a & m) | (b & ~m); }
-
 __device__ __forceinline__ void filter_edge8_pk(s2 v[8], int bs, int alpha, int beta, int tc0, bool chroma)
 {
     const s2 p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
@@ -1045,11 +1056,6 @@ __device__ __forceinline__ void filter_edge8_pk(s2 v[8], int bs, int alpha, int 
     v[1] = pk_sel(fs & m_p2, r_p2, p2);
     v[6] = pk_sel(fs & m_q2, r_q2, q2);
 }
-
-__device__ __forceinline__ s2 as_s2(uint32_t x) { s2 r; __builtin_memcpy(&r, &x, 4); return r; }
-__device__ __forceinline__ uint32_t as_u32(s2 x) { uint32_t r; __builtin_memcpy(&r, &x, 4); return r; }
-/* v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8 bytes {lo = 0..3, hi = 4..7}; selector 12 = 0x00 */
-__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
 /* Everything a worker can fetch about a macroblock BEFORE its neighbours are final: the deblocking
  * record and the macroblock's own (still un-filtered) samples.  Issued one slot ahead.
