@@ -10,6 +10,11 @@ timed region starts; outputs stay in HBM and are verified on the device against 
 checksums (every picture of every stream, in an untimed verification pass, and the final picture after
 the timed region).  A run that is not bit-exact aborts.
 
+`value` is the LOCK-STEP variant (every stream on the same picture index, so the two IDR pictures of the
+stream give two all-intra ticks per step: the worst case).  The same work with odd-numbered streams
+started at the second IDR ("staggered") is measured in the same run and reported
+under `staggered`.
+
 One process per GPU: `python bench.py` (N=1) or
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.  Streams are independent,
 so ranks share nothing on the data path (weak scaling: 256 streams per GPU); torch.distributed (RCCL)
@@ -66,6 +71,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="concurrent streams per GPU")
     ap.add_argument("--groups", type=int, default=1, help="stream groups on separate HIP streams (overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-staggered", action="store_true", help="skip the staggered-start variant (reported next to the lock-step value)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,42 +103,77 @@ def main():
     jobs, _, info = h264bsd_amd.capture_stream(data)                 # host parse, once
     heads = [h264bsd_amd.job_header(j) for j in jobs]
     n_pics, n_mbs = len(jobs), heads[0]["n_mbs"]
-    rep = h264bsd_amd.Replay(jobs, n_streams=args.streams)          # jobs + DPBs resident in HBM
-
-    # ---- untimed verification pass: every picture of every stream against the reference ----
-    for i in range(n_pics):
-        rep.run(i, 1)
-        sums = rep.checksums(heads[i]["cur_slot"])
-        if not (sums == golden["frame_checksum64"][i]).all():
-            raise SystemExit(f"rank {rank}: picture {i} is not bit-exact on {(sums != golden['frame_checksum64'][i]).sum()} streams")
-
-    rep.set_groups(args.groups)
-    for _ in range(args.warmup):
-        rep.run()
-    barrier()
-    t0 = time.perf_counter()
     kernels = h264bsd_amd.Replay.KERNELS
-    k_ms = {k: 0.0 for k in kernels}
-    k_n = {k: 0 for k in kernels}
-    dev_total_ms = 0.0
-    for _ in range(args.steps):
-        rep.run()
-        t = rep.timings()        # waits for the step; HIP events recorded on the engine's own stream
-        for k in kernels:
-            k_ms[k] += t[k][0]
-            k_n[k] += t[k][1]
-        dev_total_ms += t["total_ms"]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    golden_sums = golden["frame_checksum64"]
 
-    sums = rep.checksums(heads[-1]["cur_slot"])
-    if not (sums == golden["frame_checksum64"][-1]).all():
-        raise SystemExit(f"rank {rank}: final picture is not bit-exact")
+    def run_variant(odd_offset):
+        """Verify, warm up and time one variant of the workload.  odd_offset = 0: lock-step (every stream on
+        the same picture index: two all-IDR ticks per step, the worst case); otherwise odd streams start at the
+        second IDR (SURVEY.md §8d config 4 "staggered").  Returns (elapsed s, kernel ms, launches, device ms, job bytes)."""
+        rep = h264bsd_amd.Replay(jobs, n_streams=args.streams, odd_offset=odd_offset)   # jobs + DPBs resident in HBM
 
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        def verify(i):
+            # picture i of the even streams and picture (i + odd_offset) % n of the odd streams
+            for parity, p in ((0, i), (1, (i + odd_offset) % n_pics)):
+                if parity and (not odd_offset or args.streams < 2):
+                    continue
+                sums = rep.checksums(heads[p]["cur_slot"])
+                sel = sums if not odd_offset else sums[parity::2]
+                if not (sel == golden_sums[p]).all():
+                    raise SystemExit(f"rank {rank}: picture {p} is not bit-exact on {(sel != golden_sums[p]).sum()} streams")
+
+        # ---- untimed verification pass: every picture of every stream against the reference ----
+        for i in range(n_pics):
+            rep.run(i, 1)
+            verify(i)
+        rep.set_groups(args.groups)
+        for _ in range(args.warmup):
+            rep.run()
+        barrier()
+        t0 = time.perf_counter()
+        k_ms = {k: 0.0 for k in kernels}
+        k_n = {k: 0 for k in kernels}
+        dev_total_ms = 0.0
+        for _ in range(args.steps):
+            rep.run()
+            t = rep.timings()        # waits for the step; HIP events recorded on the engine's own stream
+            for k in kernels:
+                k_ms[k] += t[k][0]
+                k_n[k] += t[k][1]
+            dev_total_ms += t["total_ms"]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        verify(n_pics - 1)                                     # the final pictures, after the timed region
+        job_bytes = rep.job_bytes
+        rep.close()
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, k_ms, k_n, dev_total_ms, job_bytes
+
+    elapsed, k_ms, k_n, dev_total_ms, job_bytes = run_variant(0)
+    staggered = None
+    if not args.no_staggered and args.streams > 1:
+        idr = [i for i, h in enumerate(heads) if h["is_idr"] and i > 0]
+        if idr:
+            st_elapsed, st_k_ms, _, st_dev_ms, _ = run_variant(idr[0])
+            staggered = dict(odd_stream_offset=idr[0], elapsed=st_elapsed, k_ms=st_k_ms, dev_ms=st_dev_ms)
+
+    # on-box ceiling of a plain device-to-device copy (SURVEY.md §8d: report the fraction of both peaks)
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9      # read + write
+        del src, dst
 
     if rank == 0:
         pics_per_step = n_pics * args.streams * world
@@ -140,7 +181,7 @@ def main():
         # algorithmic bytes: 384 B written per MB + 384 B of reference read per inter MB +
         # the packed syntax actually consumed (the frame jobs)
         n_inter = sum(h["n_inter"] for h in heads)
-        alg_bytes_stream = 384 * n_mbs * n_pics + 384 * n_inter + rep.job_bytes
+        alg_bytes_stream = 384 * n_mbs * n_pics + 384 * n_inter + job_bytes
         alg_per_mb = alg_bytes_stream / (n_mbs * n_pics)
         # dominant kernel: the one with the largest share of device time in the timed region
         dom = max(kernels, key=lambda k: k_ms[k])
@@ -173,13 +214,22 @@ def main():
                          "alg_bytes_per_mb": alg_per_mb, "mbs_per_launch": units_per_launch,
                          "avg_launch_us": avg_launch_us, "launches": launches,
                          "whole_path_GBs": path_gbs, "whole_path_frac": path_gbs / HBM_PEAK_GBS,
+                         "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
+                         "whole_path_frac_of_copy_ceiling": path_gbs / copy_gbs,
                          "device_ms_per_step": dict({k: k_ms[k] / args.steps for k in kernels}, total=dev_total_ms / args.steps),
                          "launches_per_step": {k: k_n[k] // args.steps for k in kernels}},
         }
+        if staggered is not None:
+            # same work per step, odd streams start at the second IDR: I pictures never fill a whole tick
+            out["staggered"] = {"value": mbs / staggered["elapsed"], "unit": "macroblocks/s",
+                                "fps": pics_per_step * args.steps / staggered["elapsed"],
+                                "ms_per_step": staggered["elapsed"] * 1e3 / args.steps,
+                                "odd_stream_offset_pictures": staggered["odd_stream_offset"],
+                                "device_ms_per_step": dict({k: staggered["k_ms"][k] / args.steps for k in kernels},
+                                                           total=staggered["dev_ms"] / args.steps)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data)
         print(json.dumps(out), flush=True)
-    rep.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

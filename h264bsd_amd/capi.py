@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdConvertToYCbCrA",
     "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync",
     "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads",
-    "h264bsdmiReplayCreate", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
+    "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
 ]
@@ -117,6 +117,8 @@ def lib():
     L.h264bsdmiSetDevice.argtypes = [ctypes.c_int]
     L.h264bsdmiReplayCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32]
     L.h264bsdmiReplayCreate.restype = vp
+    L.h264bsdmiReplayCreateStaggered.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32, u32]
+    L.h264bsdmiReplayCreateStaggered.restype = vp
     L.h264bsdmiReplayDestroy.argtypes = [vp]
     L.h264bsdmiReplayDestroy.restype = None
     L.h264bsdmiReplayRun.argtypes = [vp, u32, u32]
@@ -356,14 +358,16 @@ def convert(fmt, width, height, yuv):
 class Replay:
     """HBM-resident replay set: n_streams private copies of one captured stream (kernels only)."""
 
-    def __init__(self, jobs, n_streams):
+    def __init__(self, jobs, n_streams, odd_offset=0):
+        """odd_offset: odd-numbered streams run picture (k + odd_offset) % n_pics in tick k ("staggered")."""
         L = lib()
         self._L = L
         self._keep = [ctypes.create_string_buffer(j, len(j)) for j in jobs]
         ptrs = (ctypes.c_void_p * len(jobs))(*[ctypes.addressof(b) for b in self._keep])
         sizes = (ctypes.c_uint32 * len(jobs))(*[len(j) for j in jobs])
         self.n_pics, self.n_streams = len(jobs), n_streams
-        self._h = L.h264bsdmiReplayCreate(ptrs, sizes, len(jobs), n_streams)
+        self.odd_offset = odd_offset
+        self._h = L.h264bsdmiReplayCreateStaggered(ptrs, sizes, len(jobs), n_streams, odd_offset)
         if not self._h:
             raise RuntimeError("h264bsdmiReplayCreate failed (no HIP device or out of memory)")
         self.frame_bytes = int(L.h264bsdmiReplayFrameBytes(self._h))

@@ -561,8 +561,16 @@ struct h264bsdmi_replay {
 
 h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams)
 {
+    return h264bsdmiReplayCreateStaggered(blobs, bytes, n_pics, n_streams, 0);
+}
+
+/* odd_offset != 0: the "staggered" variant of SURVEY.md §8d config 4 — odd-numbered streams run picture
+ * (i + odd_offset) mod n_pics in tick i (odd_offset must be the index of an IDR picture, so that both the
+ * start and the wrap-around are clean decoder starts); every tick then mixes two different pictures */
+h264bsdmi_replay *h264bsdmiReplayCreateStaggered(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams, u32 odd_offset)
+{
     Engine *e = engine_get();
-    if (!e || !n_pics || !n_streams) {
+    if (!e || !n_pics || !n_streams || odd_offset >= n_pics) {
         if (!e) fprintf(stderr, "h264bsd-mi355x: h264bsdmiReplayCreate: no usable HIP device\n");
         return nullptr;
     }
@@ -600,6 +608,20 @@ h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes
         r->shapes.push_back(s);
         r->cur_slot.push_back(h->cur_slot);
     }
+    if (odd_offset && n_streams > 1) {                 /* a tick is as large as the larger of its two pictures */
+        std::vector<TickShape> mixed(n_pics);
+        for (u32 i = 0; i < n_pics; i++) {
+            const TickShape &a = r->shapes[i], &b = r->shapes[(i + odd_offset) % n_pics];
+            TickShape m = a;
+            m.max_mbs = std::max(a.max_mbs, b.max_mbs);       m.max_copy = std::max(a.max_copy, b.max_copy);
+            m.max_gen = std::max(a.max_gen, b.max_gen);       m.max_dbk = std::max(a.max_dbk, b.max_dbk);
+            m.max_levels = std::max(a.max_levels, b.max_levels);
+            m.max_w = std::max(a.max_w, b.max_w);             m.max_h = std::max(a.max_h, b.max_h);
+            m.any_tail = a.any_tail || b.any_tail;            m.any_deblock = a.any_deblock || b.any_deblock;
+            mixed[i] = m;
+        }
+        r->shapes.swap(mixed);
+    }
     if (ok) ok = hipStreamSynchronize(e->stream) == hipSuccess;
     for (u32 s = 1; ok && s < n_streams; s++)
         ok = hipMemcpyAsync(r->d_blobs + (size_t)s * total, r->d_blobs, total, hipMemcpyDeviceToDevice, e->stream) == hipSuccess;
@@ -607,7 +629,8 @@ h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes
         std::vector<FrameDesc> descs((size_t)n_pics * n_streams);
         for (u32 i = 0; i < n_pics; i++)
             for (u32 s = 0; s < n_streams; s++) {
-                make_desc(descs[(size_t)i * n_streams + s], blobs[i], r->d_blobs + (size_t)s * total + offs[i],
+                const u32 p = (s & 1u) ? (i + odd_offset) % n_pics : i;
+                make_desc(descs[(size_t)i * n_streams + s], blobs[p], r->d_blobs + (size_t)s * total + offs[p],
                           r->d_frames + (size_t)s * frames_per_stream, r->frame_bytes,
                           r->d_dbk + (size_t)s * dbk_stride, nullptr);
             }

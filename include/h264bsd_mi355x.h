@@ -91,6 +91,11 @@ int  h264bsdmiFlushAsync(void);
 typedef struct h264bsdmi_replay h264bsdmi_replay;
 /* blobs[i]/bytes[i]: the n_pics frame jobs of ONE stream in decode order (from h264bsdmiInitCapture). */
 h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams);
+/* The "staggered" variant of the many-streams workload: odd-numbered streams run picture
+ * (k + odd_offset) mod n_pics in tick k, so a tick mixes two different pictures (e.g. an IDR picture of one
+ * half of the streams with a P picture of the other half).  odd_offset must index an IDR picture. */
+h264bsdmi_replay *h264bsdmiReplayCreateStaggered(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
+                                                 u32 odd_offset);
 void h264bsdmiReplayDestroy(h264bsdmi_replay *r);
 /* Enqueue ticks [first, first+count) on the engine stream; asynchronous.  0 = ok. */
 int  h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count);

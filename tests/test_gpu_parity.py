@@ -85,6 +85,28 @@ def test_whole_stream_in_one_submission(built, captured, golden):
         rep.close()
 
 
+def test_staggered_streams_mix_pictures_in_one_tick(built, captured, golden):
+    """odd streams start at the second IDR: every tick mixes two different pictures (an all-intra one with a P
+    picture at the IDR ticks), twice around so that the wrap-around onto the first IDR is covered"""
+    name = "test_640x360"
+    jobs, _, _ = captured(name)
+    g = golden[name]
+    heads = [pyoracle.blob_header(j) for j in jobs]
+    off = [i for i, h in enumerate(heads) if h["is_idr"] and i > 0][0]
+    rep = built.Replay(jobs, n_streams=5, odd_offset=off)
+    try:
+        for lap in range(2):
+            for i in range(len(jobs)):
+                rep.run(i, 1)
+                p = (i + off) % len(jobs)
+                even = rep.checksums(heads[i]["cur_slot"])
+                odd = rep.checksums(heads[p]["cur_slot"])
+                assert [int(x) for x in even[0::2]] == [g["frame_checksum64"][i]] * 3, (lap, i)
+                assert [int(x) for x in odd[1::2]] == [g["frame_checksum64"][p]] * 2, (lap, i, p)
+    finally:
+        rep.close()
+
+
 @pytest.mark.parametrize("name", ["test_640x360", "test_1920x1080_fullRange"])
 def test_on_device_colour_conversion(name, built, captured, golden):
     jobs, _, info = captured(name)
