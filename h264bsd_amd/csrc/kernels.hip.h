@@ -94,14 +94,18 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 }
 
 /* 4x4 transpose across the 4 lanes of a quad: lane q holds row q in v[0..3] -> holds column q */
+/* lane ^ 1 / lane ^ 2 inside a quad: DPP quad_perm moves (one VALU cycle, no LDS crossbar round trip) */
+__device__ __forceinline__ int quad_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false); }   /* quad_perm [1,0,3,2] */
+__device__ __forceinline__ int quad_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false); }   /* quad_perm [2,3,0,1] */
+
 __device__ __forceinline__ void quad_transpose(int v[4], int q)
 {
     const bool o1 = q & 1, o2 = q & 2;
-    int t0 = __shfl_xor(o1 ? v[0] : v[1], 1);
-    int t1 = __shfl_xor(o1 ? v[2] : v[3], 1);
+    int t0 = quad_xor1(o1 ? v[0] : v[1]);
+    int t1 = quad_xor1(o1 ? v[2] : v[3]);
     if (o1) { v[0] = t0; v[2] = t1; } else { v[1] = t0; v[3] = t1; }
-    t0 = __shfl_xor(o2 ? v[0] : v[2], 2);
-    t1 = __shfl_xor(o2 ? v[1] : v[3], 2);
+    t0 = quad_xor2(o2 ? v[0] : v[2]);
+    t1 = quad_xor2(o2 ? v[1] : v[3]);
     if (o2) { v[0] = t0; v[1] = t1; } else { v[2] = t0; v[3] = t1; }
 }
 
@@ -111,7 +115,9 @@ __device__ __forceinline__ void quad_transpose(int v[4], int q)
 __device__ __forceinline__ void idct_quad(int c[4], int q, int qp, bool use_dc, int dc)
 {
     const int m = qp % 6, sh = qp / 6;
-    const int lsa = c_level_scale[m][(q & 1) ? 1 : 0], lsb = c_level_scale[m][(q & 1) ? 2 : 1];
+    /* the QP is wave-uniform: three scalar table reads and a select, not a lane-indexed (= global-memory) lookup */
+    const int ls0 = c_level_scale[m][0], ls1 = c_level_scale[m][1], ls2 = c_level_scale[m][2];
+    const int lsa = (q & 1) ? ls1 : ls0, lsb = (q & 1) ? ls2 : ls1;
     int d0 = (c[0] * lsa) << sh, d1 = (c[1] * lsb) << sh, d2 = (c[2] * lsa) << sh, d3 = (c[3] * lsb) << sh;
     if (use_dc && q == 0) d0 = dc;
     int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
@@ -471,6 +477,10 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
  * 9x9 chroma reference windows are staged ONCE in LDS with row-wide coalesced dword loads and every lane
  * cuts its 6x12-byte register window out of LDS; otherwise every lane fetches its own window from global
  * memory.  Both feed the same textbook interpolation (luma_from_window / chroma_from_rows). */
+/* 16 / 8 bytes at a 4-byte aligned address (global_load_dwordx4 / dwordx2 need dword alignment only) */
+struct __attribute__((packed, aligned(4))) U4a4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(4))) U2a4 { uint32_t x, y; };
+
 constexpr int IW_STRIDE = 36;                        /* luma window: 21 rows x 28 bytes; 9-dword stride: no bank conflicts for row-per-lane reads */
 constexpr int IC_STRIDE = 20;                        /* chroma windows: 9 rows x 16 bytes, two planes */
 constexpr int QW_STRIDE = 20;                        /* quadrant luma windows: 13 rows x 16 bytes, 5-dword stride */
@@ -516,33 +526,30 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
         const int xs = xi - (xi & 3);
         const int cxi = mbx * 8 + (mvx >> 3), cyi = mby * 8 + (mvy >> 3);
         const int cxs = cxi - (cxi & 3);
-        /* ---- stage: luma rows yi..yi+20, bytes xs..xs+27; chroma rows cyi..cyi+8, bytes cxs..cxs+15 ---- */
-        if (xs >= 0 && xs + 28 <= W && yi >= 0 && yi + 21 <= H) {
-#pragma unroll
-            for (int it = 0; it < 3; it++) {
-                const int d = lane + 64 * it;
-                if (d < 147) {
-                    const int r = d / 7, c = d % 7;
-                    *reinterpret_cast<uint32_t *>(lw + r * IW_STRIDE + 4 * c) = *reinterpret_cast<const uint32_t *>(ref + (size_t)(yi + r) * W + xs + 4 * c);
-                }
+        /* ---- stage: luma rows yi..yi+20, bytes xs..xs+27; chroma rows cyi..cyi+8, bytes cxs..cxs+15 ----
+         * ONE 16-byte load per lane brings in both windows: lanes 0..41 = luma (row, half), lanes 42..59 = chroma
+         * (plane, row).  The second luma half starts at min(xs+16, W-16) so that it never leaves the row. */
+        const bool lfast = xs >= 0 && xs + 28 <= W && yi >= 0 && yi + 21 <= H;
+        const bool cfast = cxs >= 0 && cxs + 16 <= CW && cyi >= 0 && cyi + 9 <= CH;
+        {
+            const bool isl = lane < 42;
+            const int ci = lane - 42, cp = ci >= 9, cr = cp ? ci - 9 : ci;
+            const int lr = lane >> 1, lx = (lane & 1) ? min(xs + 16, W - 16) : xs;
+            const uint8_t *src = isl ? ref + (size_t)(yi + lr) * W + lx : ref + ysz + (cp ? csz : 0) + (size_t)(cyi + cr) * CW + cxs;
+            uint8_t *dst = isl ? lw + lr * IW_STRIDE + (lx - xs) : lc + cp * 9 * IC_STRIDE + cr * IC_STRIDE;
+            if (isl ? lfast : (cfast && lane < 60)) {
+                const U4a4 v = *reinterpret_cast<const U4a4 *>(src);
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+                d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
             }
-        } else {
+        }
+        if (!lfast) {
             for (int d = lane; d < 21 * 28; d += 64) {
                 const int r = d / 28, c = d % 28;
                 lw[r * IW_STRIDE + c] = ref[(size_t)clip3(0, H - 1, yi + r) * W + clip3(0, W - 1, xs + c)];
             }
         }
-        if (cxs >= 0 && cxs + 16 <= CW && cyi >= 0 && cyi + 9 <= CH) {
-#pragma unroll
-            for (int it = 0; it < 2; it++) {
-                const int d = lane + 64 * it;
-                if (d < 72) {
-                    const int p = d / 36, r = (d % 36) / 4, c = d % 4;
-                    *reinterpret_cast<uint32_t *>(lc + p * 9 * IC_STRIDE + r * IC_STRIDE + 4 * c) =
-                        *reinterpret_cast<const uint32_t *>(ref + ysz + (p ? csz : 0) + (size_t)(cyi + r) * CW + cxs + 4 * c);
-                }
-            }
-        } else {
+        if (!cfast) {
             for (int d = lane; d < 2 * 9 * 16; d += 64) {
                 const int p = d / 144, r = (d % 144) / 16, c = d % 16;
                 lc[p * 9 * IC_STRIDE + r * IC_STRIDE + c] =
@@ -581,47 +588,44 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
          * chroma windows staged in LDS with row-wide dword loads, then the same register-window arithmetic ---- */
         uint8_t *lq = lw, *cq = lw + 4 * 13 * QW_STRIDE;
         {
-            /* staging: item d of a quadrant = (row, dword); 4 x 52 luma dwords, 4 x 20 chroma dwords */
+            /* staging: one 16-byte luma row per lane (4 quadrants x 13 rows = lanes 0..51), then one 8-byte chroma row
+             * per lane (4 quadrants x 2 planes x 5 rows = lanes 0..39) */
+            if (lane < 52) {
+                const int q = lane / 13, r = lane % 13;
+                const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
+                const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
+                const uint8_t *ref = fd.slot[(refs >> (8 * q)) & 255u];
+                const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
+                const int xs = xi - (xi & 3);
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + r * QW_STRIDE);
+                if (xs >= 0 && xs + 16 <= W && yi >= 0 && yi + 13 <= H) {
+                    const U4a4 v = *reinterpret_cast<const U4a4 *>(ref + (size_t)(yi + r) * W + xs);
+                    d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
+                } else {
+                    const uint8_t *rp = ref + (size_t)clip3(0, H - 1, yi + r) * W;
 #pragma unroll
-            for (int it = 0; it < 4; it++) {
-                const int d = lane + 64 * it;
-                if (d < 208) {
-                    const int q = d / 52, e = d % 52, r = e >> 2, c = e & 3;
-                    const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
-                    const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
-                    const uint8_t *ref = fd.slot[(refs >> (8 * q)) & 255u];
-                    const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
-                    const int xs = xi - (xi & 3);
-                    uint32_t v;
-                    if (xs >= 0 && xs + 16 <= W && yi >= 0 && yi + 13 <= H) {
-                        v = *reinterpret_cast<const uint32_t *>(ref + (size_t)(yi + r) * W + xs + 4 * c);
-                    } else {
-                        const uint8_t *rp = ref + (size_t)clip3(0, H - 1, yi + r) * W;
-                        v = (uint32_t)rp[clip3(0, W - 1, xs + 4 * c)] | ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 1)] << 8) |
-                            ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 2)] << 16) | ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 3)] << 24);
-                    }
-                    *reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + r * QW_STRIDE + 4 * c) = v;
+                    for (int c = 0; c < 4; c++)
+                        d32[c] = (uint32_t)rp[clip3(0, W - 1, xs + 4 * c)] | ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 1)] << 8) |
+                                 ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 2)] << 16) | ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 3)] << 24);
                 }
             }
+            if (lane < 40) {
+                const int q = lane / 10, e = lane % 10, p = e >= 5, r = p ? e - 5 : e;
+                const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
+                const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
+                const uint8_t *ref = fd.slot[(refs >> (8 * q)) & 255u] + ysz + (p ? csz : 0);
+                const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
+                const int cxs = cxi - (cxi & 3);
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(cq + (q * 2 + p) * 5 * QC_STRIDE + r * QC_STRIDE);
+                if (cxs >= 0 && cxs + 8 <= CW && cyi >= 0 && cyi + 5 <= CH) {
+                    const U2a4 v = *reinterpret_cast<const U2a4 *>(ref + (size_t)(cyi + r) * CW + cxs);
+                    d32[0] = v.x; d32[1] = v.y;
+                } else {
+                    const uint8_t *rp = ref + (size_t)clip3(0, CH - 1, cyi + r) * CW;
 #pragma unroll
-            for (int it = 0; it < 2; it++) {
-                const int d = lane + 64 * it;
-                if (d < 80) {
-                    const int q = d / 20, e = d % 20, p = e / 10, r = (e % 10) >> 1, c = e & 1;
-                    const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
-                    const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
-                    const uint8_t *ref = fd.slot[(refs >> (8 * q)) & 255u] + ysz + (p ? csz : 0);
-                    const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
-                    const int cxs = cxi - (cxi & 3);
-                    uint32_t v;
-                    if (cxs >= 0 && cxs + 8 <= CW && cyi >= 0 && cyi + 5 <= CH) {
-                        v = *reinterpret_cast<const uint32_t *>(ref + (size_t)(cyi + r) * CW + cxs + 4 * c);
-                    } else {
-                        const uint8_t *rp = ref + (size_t)clip3(0, CH - 1, cyi + r) * CW;
-                        v = (uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c)] | ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 1)] << 8) |
-                            ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 2)] << 16) | ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 3)] << 24);
-                    }
-                    *reinterpret_cast<uint32_t *>(cq + (q * 2 + p) * 5 * QC_STRIDE + r * QC_STRIDE + 4 * c) = v;
+                    for (int c = 0; c < 2; c++)
+                        d32[c] = (uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c)] | ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 1)] << 8) |
+                                 ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 2)] << 16) | ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 3)] << 24);
                 }
             }
         }
