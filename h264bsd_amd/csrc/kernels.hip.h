@@ -1064,7 +1064,7 @@ __device__ __forceinline__ void filter_edge8_pk(s2 v[8], int bs, int alpha, int 
 /* Everything a worker can fetch about a macroblock BEFORE its neighbours are final: the deblocking
  * record and the macroblock's own (still un-filtered) samples.  Issued one slot ahead.
  * A worker is a QUARTER of a wavefront (16 lanes, ql = lane & 15). */
-struct DbkPrefetch { uint32_t y[4]; uint2 c; uint32_t bsb; uint4 thr; uint32_t s_ly, s_ty, s_lc, s_tc; };
+struct DbkPrefetch { uint4 y; uint2 c; uint32_t bsb; uint4 thr; uint32_t s_ly, s_ty, s_lc, s_tc; };
 
 __device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int ql, DbkPrefetch &p)
 {
@@ -1072,9 +1072,7 @@ __device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int ql
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mbx = mb % wmb, mby = mb / wmb;
     const uint8_t *Y = fd.cur + (size_t)(mby * 16) * W + mbx * 16;
-    const int row = ql >> 2, cw = ql & 3;                       /* luma rows row, row+4, row+8, row+12; word cw */
-#pragma unroll
-    for (int i = 0; i < 4; i++) p.y[i] = *reinterpret_cast<const uint32_t *>(Y + (size_t)(row + 4 * i) * W + 4 * cw);
+    p.y = *reinterpret_cast<const uint4 *>(Y + (size_t)ql * W);   /* luma row ql, one 16-byte request per lane */
     const int plane = ql >> 3, r = ql & 7;                      /* one 8-byte chroma row */
     const uint8_t *P = fd.cur + (size_t)W * H + (plane ? (size_t)CW * CH : 0) + (size_t)(mby * 8) * CW + mbx * 8;
     p.c = *reinterpret_cast<const uint2 *>(P + (size_t)r * CW);
@@ -1133,9 +1131,10 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
         *reinterpret_cast<uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS]) = s_lc;
         if (ql < 8) *reinterpret_cast<uint32_t *>(&ct0[(ql >> 2) * 10 * CS + ((ql >> 1) & 1) * CS + 4 + 4 * (ql & 1)]) = s_tc;
         /* own samples (prefetched) and boundary strengths */
-        const int row = ql >> 2, cw = ql & 3;
-#pragma unroll
-        for (int i = 0; i < 4; i++) *reinterpret_cast<uint32_t *>(&lt[(4 + row + 4 * i) * LS + 4 + 4 * cw]) = p.y[i];
+        {
+            uint32_t *ydst = reinterpret_cast<uint32_t *>(&lt[(4 + ql) * LS + 4]);
+            ydst[0] = p.y.x; ydst[1] = p.y.y; ydst[2] = p.y.z; ydst[3] = p.y.w;
+        }
         {   /* (tile rows are 20 bytes apart: dword accesses only) */
             uint32_t *cdst = reinterpret_cast<uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS + 4]);
             cdst[0] = p.c.x; cdst[1] = p.c.y;
@@ -1232,10 +1231,10 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
 
     /* ---- store: own macroblock, the 3 (1) columns of the left and rows of the upper neighbour ---- */
     if (act) {
-        const int row = ql >> 2, cw = ql & 3;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            *reinterpret_cast<uint32_t *>(Y + (size_t)(row + 4 * i) * W + 4 * cw) = *reinterpret_cast<const uint32_t *>(&lt[(4 + row + 4 * i) * LS + 4 + 4 * cw]);
+        {
+            const uint32_t *ysrc = reinterpret_cast<const uint32_t *>(&lt[(4 + ql) * LS + 4]);
+            *reinterpret_cast<uint4 *>(Y + (size_t)ql * W) = make_uint4(ysrc[0], ysrc[1], ysrc[2], ysrc[3]);
+        }
         {
             const uint32_t *csrc = reinterpret_cast<const uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS + 4]);
             *reinterpret_cast<uint2 *>(PC + ((ql >> 3) ? csz : 0) + (size_t)(ql & 7) * CW) = make_uint2(csrc[0], csrc[1]);
