@@ -896,58 +896,75 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
 #undef I4_L
 #define I4_T(k) (((k) < 0) ? CN : (int)((TW >> (8 * (k))) & 255u))
 #define I4_L(k) (((k) < 0) ? CN : (int)((LW >> (8 * (k))) & 255u))
-                int pr[4];
-#pragma unroll
-                for (int x = 0; x < 4; x++) {
+                /* At most two blocks are active in a step, so at most two of the nine modes occur: every mode sits behind
+                 * a wave-uniform test (a plain switch over the lane's mode executes all nine bodies under predication) */
+                int vv[4] = { 0, 0, 0, 0 };
+#define I4_MODE(m) if (__ballot(mode == (m)) != 0ull) if (mode == (m))
+#define I4_EACH_X _Pragma("unroll") for (int x = 0; x < 4; x++)
+                I4_MODE(0) { I4_EACH_X vv[x] = I4_T(x); }
+                I4_MODE(1) { I4_EACH_X vv[x] = I4_L(y); }
+                I4_MODE(2) {
                     int v;
-                    switch (mode) {
-                    case 0: v = I4_T(x); break;
-                    case 1: v = I4_L(y); break;
-                    case 2:
-                        if (has_top && has_left) v = (I4_T(0) + I4_T(1) + I4_T(2) + I4_T(3) + I4_L(0) + I4_L(1) + I4_L(2) + I4_L(3) + 4) >> 3;
-                        else if (has_left) v = (I4_L(0) + I4_L(1) + I4_L(2) + I4_L(3) + 2) >> 2;
-                        else if (has_top) v = (I4_T(0) + I4_T(1) + I4_T(2) + I4_T(3) + 2) >> 2;
-                        else v = 128;
-                        break;
-                    case 3:
-                        v = (x == 3 && y == 3) ? (I4_T(6) + 3 * I4_T(7) + 2) >> 2 : (I4_T(x + y) + 2 * I4_T(x + y + 1) + I4_T(x + y + 2) + 2) >> 2;
-                        break;
-                    case 4:
+                    if (has_top && has_left) v = (I4_T(0) + I4_T(1) + I4_T(2) + I4_T(3) + I4_L(0) + I4_L(1) + I4_L(2) + I4_L(3) + 4) >> 3;
+                    else if (has_left) v = (I4_L(0) + I4_L(1) + I4_L(2) + I4_L(3) + 2) >> 2;
+                    else if (has_top) v = (I4_T(0) + I4_T(1) + I4_T(2) + I4_T(3) + 2) >> 2;
+                    else v = 128;
+                    I4_EACH_X vv[x] = v;
+                }
+                I4_MODE(3) {
+                    I4_EACH_X vv[x] = (x == 3 && y == 3) ? (I4_T(6) + 3 * I4_T(7) + 2) >> 2 : (I4_T(x + y) + 2 * I4_T(x + y + 1) + I4_T(x + y + 2) + 2) >> 2;
+                }
+                I4_MODE(4) {
+                    I4_EACH_X {
+                        int v;
                         if (x > y) v = (I4_T(x - y - 2) + 2 * I4_T(x - y - 1) + I4_T(x - y) + 2) >> 2;
                         else if (x < y) v = (I4_L(y - x - 2) + 2 * I4_L(y - x - 1) + I4_L(y - x) + 2) >> 2;
                         else v = (I4_T(0) + 2 * I4_T(-1) + I4_L(0) + 2) >> 2;
-                        break;
-                    case 5: {
+                        vv[x] = v;
+                    }
+                }
+                I4_MODE(5) {
+                    I4_EACH_X {
                         const int zz = 2 * x - y;
+                        int v;
                         if (zz >= 0 && !(zz & 1)) v = (I4_T(x - (y >> 1) - 1) + I4_T(x - (y >> 1)) + 1) >> 1;
                         else if (zz >= 0) v = (I4_T(x - (y >> 1) - 2) + 2 * I4_T(x - (y >> 1) - 1) + I4_T(x - (y >> 1)) + 2) >> 2;
                         else if (zz == -1) v = (I4_L(0) + 2 * I4_T(-1) + I4_T(0) + 2) >> 2;
                         else v = (I4_L(y - 1) + 2 * I4_L(y - 2) + I4_L(y - 3) + 2) >> 2;
-                        break;
+                        vv[x] = v;
                     }
-                    case 6: {
+                }
+                I4_MODE(6) {
+                    I4_EACH_X {
                         const int zz = 2 * y - x;
+                        int v;
                         if (zz >= 0 && !(zz & 1)) v = (I4_L(y - (x >> 1) - 1) + I4_L(y - (x >> 1)) + 1) >> 1;
                         else if (zz >= 0) v = (I4_L(y - (x >> 1) - 2) + 2 * I4_L(y - (x >> 1) - 1) + I4_L(y - (x >> 1)) + 2) >> 2;
                         else if (zz == -1) v = (I4_L(0) + 2 * I4_T(-1) + I4_T(0) + 2) >> 2;
                         else v = (I4_T(x - 1) + 2 * I4_T(x - 2) + I4_T(x - 3) + 2) >> 2;
-                        break;
+                        vv[x] = v;
                     }
-                    case 7:
-                        v = !(y & 1) ? (I4_T(x + (y >> 1)) + I4_T(x + (y >> 1) + 1) + 1) >> 1
-                                     : (I4_T(x + (y >> 1)) + 2 * I4_T(x + (y >> 1) + 1) + I4_T(x + (y >> 1) + 2) + 2) >> 2;
-                        break;
-                    default: {
+                }
+                I4_MODE(7) {
+                    I4_EACH_X vv[x] = !(y & 1) ? (I4_T(x + (y >> 1)) + I4_T(x + (y >> 1) + 1) + 1) >> 1
+                                                : (I4_T(x + (y >> 1)) + 2 * I4_T(x + (y >> 1) + 1) + I4_T(x + (y >> 1) + 2) + 2) >> 2;
+                }
+                I4_MODE(8) {
+                    I4_EACH_X {
                         const int zz = x + 2 * y;
+                        int v;
                         if (zz > 5) v = I4_L(3);
                         else if (zz == 5) v = (I4_L(2) + 3 * I4_L(3) + 2) >> 2;
                         else if (!(zz & 1)) v = (I4_L(y + (x >> 1)) + I4_L(y + (x >> 1) + 1) + 1) >> 1;
                         else v = (I4_L(y + (x >> 1)) + 2 * I4_L(y + (x >> 1) + 1) + I4_L(y + (x >> 1) + 2) + 2) >> 2;
-                        break;
+                        vv[x] = v;
                     }
-                    }
-                    pr[x] = clip255(v + ry[x]);
                 }
+#undef I4_MODE
+#undef I4_EACH_X
+                int pr[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) pr[x] = clip255(vv[x] + ry[x]);
                 /* the block's own samples are not inputs of its own prediction: writing is safe */
                 *reinterpret_cast<uint32_t *>(&tile[(by4 + 1 + y) * TS + 4 + bx4]) = pack4(pr[0], pr[1], pr[2], pr[3]);
             }
