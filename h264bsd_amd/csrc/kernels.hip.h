@@ -691,13 +691,23 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
 
     int ry[4], rc[4];
     mb_residual(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, ry, rc);
-    /* ---- residual add, clip, packed stores: luma lane = 4*blk + row; chroma lanes 0..31 = 4*k + row ---- */
-    *reinterpret_cast<uint32_t *>(cur + (size_t)(mby * 16 + by * 4 + row) * W + mbx * 16 + bx * 4) =
+    /* ---- residual add, clip; the macroblock is gathered in LDS (the windows are dead by now) so that it leaves as
+     * whole rows: 16 luma rows of 16 bytes + 16 chroma rows of 8 bytes = 32 memory requests instead of 96 dwords ---- */
+    wave_sync();
+    *reinterpret_cast<uint32_t *>(lw + (by * 4 + row) * 16 + bx * 4) =
         pack4(clip255(pl[0] + ry[0]), clip255(pl[1] + ry[1]), clip255(pl[2] + ry[2]), clip255(pl[3] + ry[3]));
     if (lane < 32) {
         const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
-        *reinterpret_cast<uint32_t *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + cby * 4 + row) * CW + mbx * 8 + cbx * 4) =
+        *reinterpret_cast<uint32_t *>(lw + 256 + plane * 64 + (cby * 4 + row) * 8 + cbx * 4) =
             pack4(clip255(pc[0] + rc[0]), clip255(pc[1] + rc[1]), clip255(pc[2] + rc[2]), clip255(pc[3] + rc[3]));
+    }
+    wave_sync();
+    if (lane < 16) {
+        *reinterpret_cast<uint4 *>(cur + (size_t)(mby * 16 + lane) * W + mbx * 16) = *reinterpret_cast<const uint4 *>(lw + lane * 16);
+    } else if (lane < 32) {
+        const int plane = (lane - 16) >> 3, r = lane & 7;
+        *reinterpret_cast<uint2 *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + r) * CW + mbx * 8) =
+            *reinterpret_cast<const uint2 *>(lw + 256 + plane * 64 + r * 8);
     }
 }
 
