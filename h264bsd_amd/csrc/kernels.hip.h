@@ -187,6 +187,13 @@ __device__ __forceinline__ void mb_residual(uint32_t coded, int qp_y, int qp_c, 
     }
 }
 
+/* DPB slot k of the picture's stream.  The slots of a stream are contiguous (engine.hip make_desc), so the address is
+ * arithmetic: no lane-indexed table lookup (= a dependent global-memory round trip) in front of the sample loads. */
+__device__ __forceinline__ uint8_t *slot_ptr(const FrameDesc &fd, uint32_t k)
+{
+    return fd.slot[0] + (size_t)k * ((size_t)fd.wmb * fd.hmb * 384u);
+}
+
 /* ------------------------------------------------------------------ inter prediction */
 /* ---- packed 16-bit helpers (two samples per register, v_pk_*_i16) ---- */
 typedef short s2 __attribute__((ext_vector_type(2)));
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
         const FjCopy e = fd.copy[on ? first + j : first];
         cnt[j] = on ? e.count : 0;
         mbx[j] = e.mb % wmb; mby[j] = e.mb / wmb;
-        const uint8_t *ref = fd.slot[e.slot];
+        const uint8_t *ref = slot_ptr(fd, e.slot);
         const int x = mbx[j] * 16 + e.dx, y = mby[j] * 16 + e.dy;
         if (x >= 0 && x + 64 <= W && y >= 0 && y + 16 <= H) {
             __builtin_memcpy(&vy[j], ref + (size_t)(y + lrow) * W + x + 16 * lseg, 16);
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
     int pl[4], pc[4] = { 0, 0, 0, 0 };
     if (uniform) {
         const int mvx = (int16_t)(mv0 & 0xFFFFu), mvy = (int32_t)mv0 >> 16;
-        const uint8_t *ref = fd.slot[refs & 255u];
+        const uint8_t *ref = slot_ptr(fd, refs & 255u);
         const int xi = mbx * 16 + (mvx >> 2) - 2, yi = mby * 16 + (mvy >> 2) - 2;
         const int xs = xi - (xi & 3);
         const int cxi = mbx * 8 + (mvx >> 3), cyi = mby * 8 + (mvy >> 3);
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
                 const int q = lane / 13, r = lane % 13;
                 const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
                 const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
-                const uint8_t *ref = fd.slot[(refs >> (8 * q)) & 255u];
+                const uint8_t *ref = slot_ptr(fd, (refs >> (8 * q)) & 255u);
                 const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
                 const int xs = xi - (xi & 3);
                 uint32_t *d32 = reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + r * QW_STRIDE);
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
                 const int q = lane / 10, e = lane % 10, p = e >= 5, r = p ? e - 5 : e;
                 const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
                 const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
-                const uint8_t *ref = fd.slot[(refs >> (8 * q)) & 255u] + ysz + (p ? csz : 0);
+                const uint8_t *ref = slot_ptr(fd, (refs >> (8 * q)) & 255u) + ysz + (p ? csz : 0);
                 const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
                 const int cxs = cxi - (cxi & 3);
                 uint32_t *d32 = reinterpret_cast<uint32_t *>(cq + (q * 2 + p) * 5 * QC_STRIDE + r * QC_STRIDE);
@@ -664,7 +671,7 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
         /* ---- per-lane windows straight from global memory ---- */
         {
             const int mvx = (int16_t)(mv_mine & 0xFFFFu), mvy = (int32_t)mv_mine >> 16;
-            const uint8_t *ref = fd.slot[(refs >> (8 * ((by >> 1) * 2 + (bx >> 1)))) & 255u];
+            const uint8_t *ref = slot_ptr(fd, (refs >> (8 * ((by >> 1) * 2 + (bx >> 1)))) & 255u);
             const int x = mbx * 16 + bx * 4 + (mvx >> 2), y = mby * 16 + by * 4 + row + (mvy >> 2);
             if (((mvx | mvy) & 3) == 0 && x >= 0 && x + 3 < W && y >= 0 && y < H) {
                 const uint32_t v = load_u32_unaligned(ref + (size_t)y * W + x);
@@ -683,7 +690,7 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
                 const int cx = cx0 + 2 * pair;
                 const int lb = (cy >> 1) * 4 + (cx >> 1);             /* owning 4x4 luma block */
                 const int mvx = mvs[2 * lb], mvy = mvs[2 * lb + 1];
-                const uint8_t *ref = fd.slot[(refs >> (8 * ((cy >> 2) * 2 + (cx >> 2)))) & 255u] + ysz + (plane ? csz : 0);
+                const uint8_t *ref = slot_ptr(fd, (refs >> (8 * ((cy >> 2) * 2 + (cx >> 2)))) & 255u) + ysz + (plane ? csz : 0);
                 chroma_pred2(ref, CW, CH, mbx * 8 + cx + (mvx >> 3), mby * 8 + cy + (mvy >> 3), mvx & 7, mvy & 7, pc + 2 * pair);
             }
         }
