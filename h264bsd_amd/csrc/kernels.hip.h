@@ -447,8 +447,9 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
         const uint8_t *ref = slot_ptr(fd, e.slot);
         const int x = mbx[j] * 16 + e.dx, y = mby[j] * 16 + e.dy;
         if (x >= 0 && x + 64 <= W && y >= 0 && y + 16 <= H) {
-            __builtin_memcpy(&vy[j], ref + (size_t)(y + lrow) * W + x + 16 * lseg, 16);
-            __builtin_memcpy(&vc[j], ref + ysz + (plane ? csz : 0) + (size_t)((y >> 1) + crow) * CW + (x >> 1) + 16 * cseg, 16);
+            vy[j] = vc[j] = make_uint4(0, 0, 0, 0);
+            if (lseg < cnt[j]) __builtin_memcpy(&vy[j], ref + (size_t)(y + lrow) * W + x + 16 * lseg, 16);      /* only the MBs of the run */
+            if (2 * cseg < cnt[j]) __builtin_memcpy(&vc[j], ref + ysz + (plane ? csz : 0) + (size_t)((y >> 1) + crow) * CW + (x >> 1) + 16 * cseg, 16);
         } else {                                               /* clamp-to-edge, sample by sample */
             const uint8_t *s = ref + (size_t)clip3(0, H - 1, y + lrow) * W;
             const uint8_t *c = ref + ysz + (plane ? csz : 0) + (size_t)clip3(0, CH - 1, (y >> 1) + crow) * CW;
