@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads",
     "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
-    "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
+    "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
 ]
 
 class DevicePicture(ctypes.Structure):
@@ -129,6 +129,7 @@ def lib():
     L.h264bsdmiReplayFetchConverted.argtypes = [vp, u32, vp]
     L.h264bsdmiReplayTimings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), P32]
     L.h264bsdmiReplaySetStages.argtypes = [vp, ctypes.c_uint]
+    L.h264bsdmiReplaySetTimedKernels.argtypes = [vp, ctypes.c_uint]
     L.h264bsdmiReplaySetGroups.argtypes = [vp, u32]
     L.h264bsdmiReplayJobBytes.argtypes = [vp]
     L.h264bsdmiReplayJobBytes.restype = ctypes.c_ulonglong
@@ -321,13 +322,17 @@ def job_header(blob):
     """Decode the FjHeader of a frame job (h264bsd_amd/csrc/framejob.h)."""
     import struct
     (magic, total, wmb, hmb, n_mbs, cur, is_idr, n_slots, any_dbk, rec_off, mv_off, lvl_off, idx_off, coef_off,
-     n_intra, n_levels, n_coef, n_inter, pic_seq) = struct.unpack_from("<IIHHIBBBBIIIIIIIIII", blob, 0)
+     n_intra, n_levels, n_coef, n_inter, pic_seq, copy_off, n_copy, gen_off, n_gen, dbk_off, n_dbk) = \
+        struct.unpack_from("<IIHHIBBBBIIIIIIIIIIIIIIII", blob, 0)
     if magic != 0x314A4648:
         raise ValueError("not a frame job")
+    # FjCopy entries are 8 bytes {u16 mb, u8 slot, u8 count, i16 dx, i16 dy}: macroblocks moved by k_copy
+    n_copy_mbs = sum(blob[copy_off + 8 * i + 3] for i in range(n_copy))
     return dict(total_bytes=total, width_mbs=wmb, height_mbs=hmb, n_mbs=n_mbs, cur_slot=cur, is_idr=is_idr,
                 n_slots=n_slots, any_deblock=any_dbk, rec_off=rec_off, mv_off=mv_off, lvl_off=lvl_off,
                 idx_off=idx_off, coef_off=coef_off, n_intra=n_intra, n_intra_levels=n_levels,
-                n_coef_blocks=n_coef, n_inter=n_inter, pic_seq=pic_seq)
+                n_coef_blocks=n_coef, n_inter=n_inter, pic_seq=pic_seq, copy_off=copy_off, n_copy=n_copy,
+                gen_off=gen_off, n_gen=n_gen, dbk_off=dbk_off, n_dbk=n_dbk, n_copy_mbs=n_copy_mbs)
 
 
 def capture_stream(data):
@@ -418,6 +423,11 @@ class Replay:
     def set_stages(self, mask):
         self._L.h264bsdmiReplaySetStages(self._h, mask)
 
+    def set_timed_kernels(self, mask):
+        """bit k: KERNELS[k] is bracketed by HIP events in the following run() calls (default all)"""
+        self._timed_mask = mask & 31
+        self._L.h264bsdmiReplaySetTimedKernels(self._h, mask)
+
     KERNELS = ("k_copy", "k_recon_inter", "k_dbk", "k_frame_intra", "k_frame_dbk")
 
     def timings(self):
@@ -426,6 +436,7 @@ class Replay:
         n = (ctypes.c_uint32 * 5)()
         if self._L.h264bsdmiReplayTimings(self._h, ms, n) != 0:
             raise RuntimeError("h264bsdmiReplayTimings failed")
-        out = {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.KERNELS)}
+        tm = getattr(self, "_timed_mask", 31)
+        out = {k: (float(ms[i]) if (tm >> i) & 1 else None, int(n[i])) for i, k in enumerate(self.KERNELS)}
         out["total_ms"] = float(ms[5])
         return out

@@ -146,43 +146,44 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     }
 }
 
-struct TickTimers { hipEvent_t ev[6]; hipEvent_t sev[3] = { nullptr, nullptr, nullptr }; bool on = false; };   /* boundaries of the 5 kernels of a tick; sev = k_copy, k_dbk on the side stream */
+struct TickTimers { hipEvent_t ev[6]; hipEvent_t sev[3] = { nullptr, nullptr, nullptr }; bool on = false; unsigned mask = 31u; };   /* mask bit k: kernel k of KERNELS is timed */   /* boundaries of the 5 kernels of a tick; sev = k_copy, k_dbk on the side stream */
 
 int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5],
                 unsigned stages = 7u, const SideLane *side = nullptr)
 {
     const bool timed = tt && tt->on;
-    if (timed) HIP_TRY(hipEventRecord(tt->ev[0], st));
+    const unsigned tmask = timed ? tt->mask : 0u;
+#define EV_NEEDED(i) ((((tmask << 1) | tmask) >> (i)) & 1u)      /* boundary i closes kernel i-1 and opens kernel i */
+    if (EV_NEEDED(0)) HIP_TRY(hipEventRecord(tt->ev[0], st));
     const bool do_dbk = (stages & 4u) && s.any_deblock && s.max_dbk;
     const bool do_copy = (stages & 1u) && s.max_copy;
     const bool aside = side && side->stream && do_dbk;
     if (aside) {
         HIP_TRY(hipEventRecord(side->fork, st));                 /* after the previous tick's k_frame_dbk: the records are free */
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-        if (timed && tt->sev[0]) HIP_TRY(hipEventRecord(tt->sev[0], side->stream));
-        if (timed && tt->sev[1]) HIP_TRY(hipEventRecord(tt->sev[1], side->stream));
+        if ((tmask & 4u) && tt->sev[1]) HIP_TRY(hipEventRecord(tt->sev[1], side->stream));
         if (do_dbk) {
             hipLaunchKernelGGL(h264k::k_dbk, dim3((s.max_dbk + 7) / 8, s.n_frames), dim3(256), 0, side->stream, d_desc);
             if (launches) launches[2]++;
         }
-        if (timed && tt->sev[2]) HIP_TRY(hipEventRecord(tt->sev[2], side->stream));
+        if ((tmask & 4u) && tt->sev[2]) HIP_TRY(hipEventRecord(tt->sev[2], side->stream));
         HIP_TRY(hipEventRecord(side->join, side->stream));
     }
     if (do_copy) {
         hipLaunchKernelGGL(h264k::k_copy, dim3((s.max_copy + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[0]++;
     }
-    if (timed) HIP_TRY(hipEventRecord(tt->ev[1], st));
+    if (EV_NEEDED(1)) HIP_TRY(hipEventRecord(tt->ev[1], st));
     if ((stages & 1u) && s.max_gen) {
         hipLaunchKernelGGL(h264k::k_recon_inter, dim3((s.max_gen + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[1]++;
     }
-    if (timed) HIP_TRY(hipEventRecord(tt->ev[2], st));
+    if (EV_NEEDED(2)) HIP_TRY(hipEventRecord(tt->ev[2], st));
     if (do_dbk && !aside) {
         hipLaunchKernelGGL(h264k::k_dbk, dim3((s.max_dbk + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[2]++;
     }
-    if (timed) HIP_TRY(hipEventRecord(tt->ev[3], st));
+    if (EV_NEEDED(3)) HIP_TRY(hipEventRecord(tt->ev[3], st));
     /* The two per-picture kernels keep per-macroblock scheduling state in LDS next to their wavefronts' tiles: for
      * pictures that leave less than 16 wavefronts' worth of tile space in the 160 KB of a CU, fewer wavefronts run. */
     constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
@@ -200,7 +201,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, g_tail_prof);
         if (launches) launches[3]++;
     }
-    if (timed) HIP_TRY(hipEventRecord(tt->ev[4], st));
+    if (EV_NEEDED(4)) HIP_TRY(hipEventRecord(tt->ev[4], st));
     if (aside) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
     if (s.any_deblock && (stages & 4u)) {
         const uint32_t n = s.max_mbs;
@@ -217,7 +218,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         hipLaunchKernelGGL(h264k::k_frame_dbk, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, g_tail_prof);
         if (launches) launches[4]++;
     }
-    if (timed) HIP_TRY(hipEventRecord(tt->ev[5], st));
+    if (EV_NEEDED(5)) HIP_TRY(hipEventRecord(tt->ev[5], st));
+#undef EV_NEEDED
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -557,6 +559,7 @@ struct h264bsdmi_replay {
     hipStream_t gstream[8];
     hipEvent_t gdone[8];
     bool overlap_dbk = true;
+    unsigned timed_mask = 31u;
 };
 
 h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams)
@@ -684,7 +687,7 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
     HIP_TRY(hipEventRecord(r->ev_begin, r->e->stream));
     if (r->n_groups <= 1) {
         for (u32 i = first; i < first + count; i++) {
-            r->timers[i].on = true;
+            r->timers[i].on = true; r->timers[i].mask = r->timed_mask;
             if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr)) return -1;
         }
     } else {
@@ -700,7 +703,7 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
                 TickShape sh = r->shapes[i];
                 sh.n_frames = s1 - s0;
                 TickTimers &tt = r->timers[(size_t)g * r->n_pics + i];
-                tt.on = true;
+                tt.on = true; tt.mask = r->timed_mask;
                 /* de-phase the groups once: group g starts when group g-1 has entered its first tail */
                 if (i == first && g > 0) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->timers[(size_t)(g - 1) * r->n_pics + i].ev[3], 0));
                 if (launch_tick(r->gstream[g], r->d_desc + (size_t)i * r->n_streams + s0, sh, &tt, r->launches, r->stages)) return -1;
@@ -752,10 +755,11 @@ int h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[6], u32 launches[5]
             const size_t i = (size_t)g * r->n_pics + i0;
             for (int k = 0; k < 5; k++) {
                 float ms;
+                if (!((r->timed_mask >> k) & 1u)) continue;
                 HIP_TRY(hipEventElapsedTime(&ms, r->timers[i].ev[k], r->timers[i].ev[k + 1]));
                 out_ms[k] += ms;
             }
-            if (r->overlap_dbk && !(r->stages & 8u) && r->n_groups == 1 && r->timers[i].sev[0] &&
+            if ((r->timed_mask & 4u) && r->overlap_dbk && !(r->stages & 8u) && r->n_groups == 1 && r->timers[i].sev[0] &&
                 hipEventQuery(r->timers[i].sev[2]) == hipSuccess) {
                 float ms;                                /* k_copy and k_dbk ran on the side stream, next to the kernels above */
                 if (hipEventElapsedTime(&ms, r->timers[i].sev[1], r->timers[i].sev[2]) == hipSuccess) out_ms[2] += ms;
@@ -808,6 +812,13 @@ int h264bsdmiReplayFetchConverted(h264bsdmi_replay *r, u32 stream, u32 *dst)
     HIP_TRY(hipStreamSynchronize(r->e->stream));
     const size_t n = (size_t)r->wmb * 16 * r->hmb * 16;
     HIP_TRY(hipMemcpy(dst, r->d_conv + (size_t)stream * n, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int h264bsdmiReplaySetTimedKernels(h264bsdmi_replay *r, unsigned mask)
+{
+    if (!r) return -1;
+    r->timed_mask = mask & 31u;     /* bit k: HIP events around kernel k (k_copy, k_recon_inter, k_dbk, k_frame_intra, k_frame_dbk) */
     return 0;
 }
 

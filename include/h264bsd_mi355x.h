@@ -123,6 +123,10 @@ int  h264bsdmiReplaySetGroups(h264bsdmi_replay *r, u32 n_groups);
  * reconstruction, bit2 deblocking (default 7 = all); bit3: keep k_dbk on the main stream instead of overlapping
  * it with the reconstruction kernels on a second stream (A/B measurements). */
 int  h264bsdmiReplaySetStages(h264bsdmi_replay *r, unsigned mask);
+/* Which kernels of a tick are bracketed by HIP events (bit k = kernel k in the order of h264bsdmiReplayTimings,
+ * default 31 = all).  Every event is a barrier packet between two kernels; the bench times all five kernels in
+ * its warm-up steps and only the dominant one in the timed steps. */
+int  h264bsdmiReplaySetTimedKernels(h264bsdmi_replay *r, unsigned mask);
 /* Debug hook: cycle accounting of k_frame_tail's deblocking loop for workgroup 0 of every launch between
  * enable=1 and enable=0 (which copies out[16 waves][8]: cycles in {choose MB, filter, extra rounds, wait for
  * own memory traffic, #filtered, barrier wait}). */

@@ -12,7 +12,8 @@ open(os.path.join(dst, f"{tag}_kernel_stats.txt"), "w").write(open(os.path.join(
 head = ("# rocprofv3 --kernel-trace --pmc <counter> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline\n"
         "# separate passes (FETCH_SIZE | WRITE_SIZE), 256 x 1080p streams; values in KB per dispatch (= per tick);\n"
         "# MI355X_MICROARCH.md: FETCH_SIZE on gfx950 reads 1/2 of a wide (16 B/lane) coalesced stream - the accesses here are\n"
-        "# 4-16 B wide and were NOT rescaled (uncalibrated, reported as collected).\n")
+        "# 4-16 B wide; raw values below are as collected.  Calibration factors from k_copy's known byte count are in\n"
+        "# the traffic table next to this file (tools/refresh_profiles.py).\n")
 body = open(os.path.join(src, "pmc_FETCH_SIZE.txt")).read() + open(os.path.join(src, "pmc_WRITE_SIZE.txt")).read()
 open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w").write(head + body)
 kern = {}
@@ -20,6 +21,20 @@ for l in body.splitlines():
     m = re.match(r"h264k::(\w+)\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+total=\S+ per_dispatch=(\S+)", l)
     if m:
         kern.setdefault(m.group(1), {})["fetch_bytes_per_launch" if m.group(2) == "FETCH_SIZE" else "write_bytes_per_launch"] = float(m.group(3)) * 1024
-json.dump({"source": f"profiles/{tag}_pmc_summary.txt (separate rocprofv3 --pmc passes, uncalibrated)", "kernels": kern},
+# Calibration on a known byte count in our own access pattern (MI355X_MICROARCH.md, HBM section): k_copy moves exactly
+# 384 bytes in and 384 bytes out per copied macroblock, in the same 16-byte-per-lane row pieces the other kernels use.
+sys.path.insert(0, root)
+import h264bsd_amd
+jobs, _, _ = h264bsd_amd.capture_stream(open(os.path.join(root, "tests", "golden", "test_1920x1080.h264"), "rb").read())
+heads = [h264bsd_amd.job_header(j) for j in jobs]
+ticks_with_copies = sum(1 for h in heads if h["n_copy"])
+copy_alg = sum(h["n_copy_mbs"] for h in heads) * 384 * 256 / ticks_with_copies          # bytes per dispatch, each direction
+cal = {"fetch": copy_alg / kern["k_copy"]["fetch_bytes_per_launch"], "write": copy_alg / kern["k_copy"]["write_bytes_per_launch"],
+       "k_copy_algorithmic_bytes_per_launch_each_way": copy_alg,
+       "method": "factor = algorithmic bytes of k_copy / counter value of k_copy; applied to every kernel"}
+for k in kern.values():
+    k["fetch_bytes_per_launch_calibrated"] = k["fetch_bytes_per_launch"] * cal["fetch"]
+    k["write_bytes_per_launch_calibrated"] = k["write_bytes_per_launch"] * cal["write"]
+json.dump({"source": f"profiles/{tag}_pmc_summary.txt (separate rocprofv3 --pmc passes)", "calibration": cal, "kernels": kern},
           open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 print(line[:300]); print(json.dumps(kern)[:600])
