@@ -828,29 +828,38 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
         return;
     }
 
-    int ry[4], rc[4];
-    mb_residual(rec.coded, rec.qp_y, rec.qp_c, rec.kind == FJ_MB_I16x16, coef, lane, ry, rc);
-
     const bool av_a = rec.avail & FJ_AVAIL_A, av_b = rec.avail & FJ_AVAIL_B, av_c = rec.avail & FJ_AVAIL_C, av_d = rec.avail & FJ_AVAIL_D;
-    /* neighbour samples into the tiles (un-deblocked current picture) */
+    /* neighbour samples (un-deblocked current picture): requested BEFORE the residual, whose coefficient loads then
+     * share the same memory round trip; written to the tiles after it */
+    int nb_y = 128, nb_c = 128, nb_y_at = -1, nb_c_at = -1;
     if (lane < 21) {
         const int c = lane;                               /* corner, 16 above, 4 above-right */
         const bool ok = c == 0 ? av_d : c <= 16 ? av_b : av_c;
-        tile[3 + c] = ok ? Y[-(ptrdiff_t)W + (c - 1)] : 128;
+        nb_y_at = 3 + c;
+        if (ok) nb_y = Y[-(ptrdiff_t)W + (c - 1)];
     } else if (lane >= 32 && lane < 48) {
         const int r = lane - 32;
-        tile[(r + 1) * TS + 3] = av_a ? Y[(size_t)r * W - 1] : 128;
+        nb_y_at = (r + 1) * TS + 3;
+        if (av_a) nb_y = Y[(size_t)r * W - 1];
     }
     if (lane < 18) {
         const int plane = lane / 9, c = lane % 9;
         const uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
         const bool ok = c == 0 ? av_d : av_b;
-        ctile0[plane * 144 + c] = ok ? P[-(ptrdiff_t)CW + (c - 1)] : 128;
+        nb_c_at = plane * 144 + c;
+        if (ok) nb_c = P[-(ptrdiff_t)CW + (c - 1)];
     } else if (lane >= 32 && lane < 48) {
         const int plane = (lane - 32) >> 3, r = (lane - 32) & 7;
         const uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
-        ctile0[plane * 144 + (r + 1) * 16] = av_a ? P[(size_t)r * CW - 1] : 128;
+        nb_c_at = plane * 144 + (r + 1) * 16;
+        if (av_a) nb_c = P[(size_t)r * CW - 1];
     }
+
+    int ry[4], rc[4];
+    mb_residual(rec.coded, rec.qp_y, rec.qp_c, rec.kind == FJ_MB_I16x16, coef, lane, ry, rc);
+
+    if (nb_y_at >= 0) tile[nb_y_at] = (uint8_t)nb_y;
+    if (nb_c_at >= 0) ctile0[nb_c_at] = (uint8_t)nb_c;
     wave_sync();
 
     if (rec.kind == FJ_MB_I16x16) {
