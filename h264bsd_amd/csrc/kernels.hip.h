@@ -139,14 +139,44 @@ __device__ __forceinline__ void load_row4(const int16_t *p, bool valid, int c[4]
  *   ry[0..3]: luma, lane = 4*blk + row (blk raster 0..15): samples (row, 0..3) of block blk
  *   rc[0..3]: chroma, lanes 0..31: lane = 4*k + row, k = 4*plane + 2*by + bx
  * Must be called by all 64 lanes (quad shuffles).  coef = first coefficient block of the MB. */
-__device__ __forceinline__ void mb_residual(uint32_t coded, int qp_y, int qp_c, bool is_i16, const int16_t *coef, int lane, int ry[4], int rc[4])
+/* The coefficient rows a lane needs, fetched ahead of their use (k_recon_inter requests them together with the
+ * reference windows): luma row, chroma AC row, chroma DC quartet. */
+struct ResidRows { int2 y, c, cdc; };
+__device__ __forceinline__ ResidRows mb_residual_fetch(uint32_t coded, const int16_t *coef, int lane)
+{
+    ResidRows r;
+    r.y = r.c = r.cdc = make_int2(0, 0);
+    const int q = lane & 3;
+    const int has_ldc = (coded >> 24) & 1, has_cdc = (coded >> 25) & 1;
+    if (coded & 0x0100FFFFu) {                                   /* wave-uniform */
+        const int blk = lane >> 2, bx = blk & 3, by = blk >> 2, z = z_of(bx, by);
+        const int off = has_ldc + __popc(coded & ((1u << z) - 1u));
+        if ((coded >> z) & 1) r.y = *reinterpret_cast<const int2 *>(coef + 16 * off + 4 * q);
+    }
+    if (coded & 0x02FF0000u) {                                   /* wave-uniform */
+        const int k = (lane >> 2) & 7;
+        const int base = has_ldc + __popc(coded & 0xFFFFu);
+        if (has_cdc) r.cdc = *reinterpret_cast<const int2 *>(coef + 16 * base + 4 * (k >> 2));
+        const int off = base + has_cdc + __popc((coded >> 16) & ((1u << k) - 1u));
+        if ((coded >> (16 + k)) & 1) r.c = *reinterpret_cast<const int2 *>(coef + 16 * off + 4 * q);
+    }
+    return r;
+}
+
+__device__ __forceinline__ void unpack_row4(int2 w, int c[4])
+{
+    c[0] = (int16_t)(w.x & 0xFFFF); c[1] = w.x >> 16; c[2] = (int16_t)(w.y & 0xFFFF); c[3] = w.y >> 16;
+}
+
+__device__ __forceinline__ void mb_residual_compute(uint32_t coded, int qp_y, int qp_c, bool is_i16, const int16_t *coef, int lane,
+                                                    const ResidRows &rows, int ry[4], int rc[4])
 {
     const int q = lane & 3;
     const int has_ldc = (coded >> 24) & 1, has_cdc = (coded >> 25) & 1;
     ry[0] = ry[1] = ry[2] = ry[3] = 0;
     rc[0] = rc[1] = rc[2] = rc[3] = 0;
     if (coded & 0x0100FFFFu) {                                   /* wave-uniform */
-        const int blk = lane >> 2, bx = blk & 3, by = blk >> 2, z = z_of(bx, by);
+        const int blk = lane >> 2, bx = blk & 3, by = blk >> 2;
         int dc = 0;
         if (has_ldc) {
             /* 4x4 Hadamard element (by,bx) of the DC block, then the 8.5.10 scaling */
@@ -163,28 +193,29 @@ __device__ __forceinline__ void mb_residual(uint32_t coded, int qp_y, int qp_c, 
             const int ls = c_level_scale[qp_y % 6][0], q6 = qp_y / 6;
             dc = q6 >= 2 ? (acc * ls) << (q6 - 2) : (acc * ls + (1 << (1 - q6))) >> (2 - q6);
         }
-        const bool has_ac = (coded >> z) & 1;
-        const int off = has_ldc + __popc(coded & ((1u << z) - 1u));
-        load_row4(coef + 16 * off + 4 * q, has_ac, ry);
+        unpack_row4(rows.y, ry);
         idct_quad(ry, q, qp_y, is_i16, dc);
     }
     if (coded & 0x02FF0000u) {                                   /* wave-uniform */
         const int k = (lane >> 2) & 7;
-        const int base = has_ldc + __popc(coded & 0xFFFFu);
         int dc = 0;
         if (has_cdc) {
-            const int16_t *c = coef + 16 * base + 4 * (k >> 2);
             const int i = k & 3;
-            const int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-            const int f = c0 + ((i & 1) ? -c1 : c1) + ((i & 2) ? -c2 : c2) + ((i == 1 || i == 2) ? -c3 : c3);
+            int cc[4];
+            unpack_row4(rows.cdc, cc);
+            const int f = cc[0] + ((i & 1) ? -cc[1] : cc[1]) + ((i & 2) ? -cc[2] : cc[2]) + ((i == 1 || i == 2) ? -cc[3] : cc[3]);
             const int ls = c_level_scale[qp_c % 6][0], q6 = qp_c / 6;
             dc = q6 >= 1 ? (f * ls) << (q6 - 1) : (f * ls) >> 1;
         }
-        const bool has_ac = (coded >> (16 + k)) & 1;
-        const int off = base + has_cdc + __popc((coded >> 16) & ((1u << k) - 1u));
-        load_row4(coef + 16 * off + 4 * q, has_ac, rc);
+        unpack_row4(rows.c, rc);
         idct_quad(rc, q, qp_c, true, dc);
     }
+}
+
+__device__ __forceinline__ void mb_residual(uint32_t coded, int qp_y, int qp_c, bool is_i16, const int16_t *coef, int lane, int ry[4], int rc[4])
+{
+    const ResidRows rows = mb_residual_fetch(coded, coef, lane);
+    mb_residual_compute(coded, qp_y, qp_c, is_i16, coef, lane, rows, ry, rc);
 }
 
 /* DPB slot k of the picture's stream.  The slots of a stream are contiguous (engine.hip make_desc), so the address is
@@ -526,6 +557,7 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
         mv_mine = *reinterpret_cast<const uint32_t *>(mvs + 2 * blk);
     }
 
+    const ResidRows rrows = mb_residual_fetch(ge.coded, coef, lane);   /* in flight together with the reference windows */
     int pl[4], pc[4] = { 0, 0, 0, 0 };
     if (uniform) {
         const int mvx = (int16_t)(mv0 & 0xFFFFu), mvy = (int32_t)mv0 >> 16;
@@ -698,7 +730,7 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
     }
 
     int ry[4], rc[4];
-    mb_residual(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, ry, rc);
+    mb_residual_compute(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc);
     /* ---- residual add, clip; the macroblock is gathered in LDS (the windows are dead by now) so that it leaves as
      * whole rows: 16 luma rows of 16 bytes + 16 chroma rows of 8 bytes = 32 memory requests instead of 96 dwords ---- */
     wave_sync();
