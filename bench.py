@@ -13,7 +13,8 @@ the timed region).  A run that is not bit-exact aborts.
 `value` is the LOCK-STEP variant (every stream on the same picture index, so the two IDR pictures of the
 stream give two all-intra ticks per step: the worst case).  The same work with odd-numbered streams
 started at the second IDR ("staggered") is measured in the same run and reported
-under `staggered`.
+under `staggered`; streams that are not in step at all (every stream at its own picture index, with and
+without heavy lanes) under `desynchronised`.
 
 One process per GPU: `python bench.py` (N=1) or
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.  Streams are independent,
@@ -73,6 +74,7 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=4.0, help="untimed load before the warm-up steps (device clock ramp)")
     ap.add_argument("--time-all-kernels", action="store_true", help="bracket all five kernels with events in the timed steps too (A/B of the event overhead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-desync", action="store_true", help="skip the fully desynchronised variants (reported next to the lock-step value)")
     ap.add_argument("--no-staggered", action="store_true", help="skip the staggered-start variant (reported next to the lock-step value)")
     args = ap.parse_args()
 
@@ -181,6 +183,43 @@ def main():
             st_elapsed, _, _, st_dev_ms, _, _, st_breakdown = run_variant(idr[0])
             staggered = dict(odd_stream_offset=idr[0], elapsed=st_elapsed, breakdown=st_breakdown, dev_ms=st_dev_ms)
 
+    # ---- streams that are not in step at all: stream s starts at picture s * n_pics / n_streams.  Every tick then
+    # holds I pictures AND the heaviest P pictures of the stream, and a tick lasts as long as its slowest picture:
+    # (a) common ticks, (b) mostly-intra pictures on 4 extra HIP streams ("heavy lanes"), rejoining 4 ticks later.
+    # Verified at the end of laps 2 and N (a lap = every stream n_pics pictures; the last picture of stream s is
+    # picture offsets[s] - 1, so the 256 streams together cover every picture index).
+    desync = None
+    if not args.no_desync and args.streams > 1:
+        offsets = [(st * n_pics) // args.streams for st in range(args.streams)]
+        slots = sorted(set(h["cur_slot"] for h in heads))
+        desync = {"offsets": "stream s starts at picture floor(s * n_pics / n_streams)"}
+        for key, lanes, delay in (("common_ticks", 0, 0), ("heavy_lanes", 4, 4)):
+            rep = h264bsd_amd.Replay(jobs, n_streams=args.streams, offsets=offsets, heavy_lanes=lanes, heavy_delay=delay)
+
+            def verify_lap():
+                sums = {sl: rep.checksums(sl) for sl in slots}
+                for st in range(args.streams):
+                    last = (offsets[st] - 1) % n_pics
+                    if int(sums[heads[last]["cur_slot"]][st]) != golden_sums[last]:
+                        raise SystemExit(f"rank {rank}: desynchronised set ({key}): stream {st} is not bit-exact")
+            rep.run(); rep.run(); rep.sync()
+            verify_lap()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                rep.run()
+            rep.sync()
+            barrier()
+            dt = time.perf_counter() - t0
+            verify_lap()
+            rep.close()
+            if dist is not None:
+                tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            desync[key] = {"value": n_pics * args.streams * world * n_mbs * args.steps / dt, "unit": "macroblocks/s",
+                           "ms_per_step": dt * 1e3 / args.steps, "lanes": lanes, "rejoin_after_ticks": delay}
+
     # on-box ceiling of a plain device-to-device copy (report the fraction of both peaks)
     copy_gbs = None
     if rank == 0:
@@ -250,6 +289,8 @@ def main():
                                 "odd_stream_offset_pictures": staggered["odd_stream_offset"],
                                 "device_ms_per_step": dict({k: staggered["breakdown"][k][0] for k in kernels},
                                                            total=staggered["dev_ms"] / args.steps)}
+        if desync is not None:
+            out["desynchronised"] = desync
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data)
         print(json.dumps(out), flush=True)

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdConvertToYCbCrA",
     "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync",
     "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads",
-    "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
+    "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
 ]
@@ -119,6 +119,8 @@ def lib():
     L.h264bsdmiReplayCreate.restype = vp
     L.h264bsdmiReplayCreateStaggered.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32, u32]
     L.h264bsdmiReplayCreateStaggered.restype = vp
+    L.h264bsdmiReplayCreateDesync.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32, P32, u32, u32]
+    L.h264bsdmiReplayCreateDesync.restype = vp
     L.h264bsdmiReplayDestroy.argtypes = [vp]
     L.h264bsdmiReplayDestroy.restype = None
     L.h264bsdmiReplayRun.argtypes = [vp, u32, u32]
@@ -363,8 +365,10 @@ def convert(fmt, width, height, yuv):
 class Replay:
     """HBM-resident replay set: n_streams private copies of one captured stream (kernels only)."""
 
-    def __init__(self, jobs, n_streams, odd_offset=0):
-        """odd_offset: odd-numbered streams run picture (k + odd_offset) % n_pics in tick k ("staggered")."""
+    def __init__(self, jobs, n_streams, odd_offset=0, offsets=None, heavy_lanes=0, heavy_delay=4):
+        """odd_offset: odd-numbered streams run picture (k + odd_offset) % n_pics in tick k ("staggered").
+        offsets: first picture of every stream (desynchronised streams); heavy_lanes > 0: mostly intra-coded pictures
+        run on extra HIP streams and rejoin heavy_delay ticks later (run() then always runs one whole lap)."""
         L = lib()
         self._L = L
         self._keep = [ctypes.create_string_buffer(j, len(j)) for j in jobs]
@@ -372,7 +376,11 @@ class Replay:
         sizes = (ctypes.c_uint32 * len(jobs))(*[len(j) for j in jobs])
         self.n_pics, self.n_streams = len(jobs), n_streams
         self.odd_offset = odd_offset
-        self._h = L.h264bsdmiReplayCreateStaggered(ptrs, sizes, len(jobs), n_streams, odd_offset)
+        if offsets is None:
+            offsets = [odd_offset if s & 1 else 0 for s in range(n_streams)]
+        self.offsets = [int(o) for o in offsets]
+        offs = (ctypes.c_uint32 * n_streams)(*self.offsets)
+        self._h = L.h264bsdmiReplayCreateDesync(ptrs, sizes, len(jobs), n_streams, offs, heavy_lanes, heavy_delay)
         if not self._h:
             raise RuntimeError("h264bsdmiReplayCreate failed (no HIP device or out of memory)")
         self.frame_bytes = int(L.h264bsdmiReplayFrameBytes(self._h))

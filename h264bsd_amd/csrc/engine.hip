@@ -552,7 +552,7 @@ struct h264bsdmi_replay {
     std::vector<uint8_t> cur_slot;
     std::vector<TickTimers> timers;
     uint32_t timed_first, timed_count;
-    hipEvent_t ev_begin, ev_end;
+    hipEvent_t ev_begin, ev_end, gdone_any = nullptr;
     uint32_t launches[5];
     unsigned stages;
     uint32_t n_groups;
@@ -560,11 +560,18 @@ struct h264bsdmi_replay {
     hipEvent_t gdone[8];
     bool overlap_dbk = true;
     unsigned timed_mask = 31u;
+    /* desynchronised sets with heavy lanes (h264bsdmiReplayCreateDesync, lanes > 0): a static launch schedule */
+    struct Launch { size_t first; TickShape shape; int lane; int wait_ev; int record_ev; };
+    std::vector<Launch> sched;
+    std::vector<hipEvent_t> sched_ev;
+    hipStream_t lanes[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    uint32_t n_lanes = 0;
+    std::vector<uint32_t> offsets;    /* first picture of every stream */
 };
 
 h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams)
 {
-    return h264bsdmiReplayCreateStaggered(blobs, bytes, n_pics, n_streams, 0);
+    return h264bsdmiReplayCreateDesync(blobs, bytes, n_pics, n_streams, nullptr, 0, 0);
 }
 
 /* odd_offset != 0: the "staggered" variant of SURVEY.md §8d config 4 — odd-numbered streams run picture
@@ -572,8 +579,26 @@ h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes
  * start and the wrap-around are clean decoder starts); every tick then mixes two different pictures */
 h264bsdmi_replay *h264bsdmiReplayCreateStaggered(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams, u32 odd_offset)
 {
+    if (odd_offset >= n_pics) return nullptr;
+    std::vector<u32> offs(n_streams, 0);
+    for (u32 s = 1; s < n_streams; s += 2) offs[s] = odd_offset;
+    return h264bsdmiReplayCreateDesync(blobs, bytes, n_pics, n_streams, offs.data(), 0, 0);
+}
+
+/* Streams that are NOT in step: stream s starts at picture offsets[s] (nullptr = all 0) and runs n_pics pictures,
+ * wrapping around (picture 0 must be an IDR picture).  heavy_lanes == 0: tick i holds picture (i + offsets[s]) mod
+ * n_pics of every stream — a tick then lasts as long as its slowest picture.  heavy_lanes > 0: pictures that are
+ * mostly intra-coded ("heavy", more than a quarter of their macroblocks) leave the common tick and run on one of
+ * heavy_lanes extra HIP streams; their stream of pictures rejoins the common ticks heavy_delay ticks later (an event
+ * makes the common tick wait if the heavy picture is not finished by then).  A static schedule: what a scheduler that
+ * keeps light pictures from waiting for heavy ones achieves. */
+h264bsdmi_replay *h264bsdmiReplayCreateDesync(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
+                                              const u32 *offsets, u32 heavy_lanes, u32 heavy_delay)
+{
+    if (heavy_lanes > 8) return nullptr;
+    for (u32 s = 0; offsets && s < n_streams; s++) if (offsets[s] >= n_pics) return nullptr;
     Engine *e = engine_get();
-    if (!e || !n_pics || !n_streams || odd_offset >= n_pics) {
+    if (!e || !n_pics || !n_streams) {
         if (!e) fprintf(stderr, "h264bsd-mi355x: h264bsdmiReplayCreate: no usable HIP device\n");
         return nullptr;
     }
@@ -581,6 +606,8 @@ h264bsdmi_replay *h264bsdmiReplayCreateStaggered(const u8 *const *blobs, const u
     if (hipSetDevice(e->device) != hipSuccess) return nullptr;
     h264bsdmi_replay *r = new h264bsdmi_replay();
     r->e = e; r->n_pics = n_pics; r->n_streams = n_streams;
+    r->offsets.assign(n_streams, 0);
+    if (offsets) r->offsets.assign(offsets, offsets + n_streams);
     const FjHeader *h0 = reinterpret_cast<const FjHeader *>(blobs[0]);
     r->wmb = h0->width_mbs; r->hmb = h0->height_mbs; r->n_slots = h0->n_slots;
     r->frame_bytes = fj_frame_bytes(r->wmb, r->hmb);
@@ -611,41 +638,78 @@ h264bsdmi_replay *h264bsdmiReplayCreateStaggered(const u8 *const *blobs, const u
         r->shapes.push_back(s);
         r->cur_slot.push_back(h->cur_slot);
     }
-    if (odd_offset && n_streams > 1) {                 /* a tick is as large as the larger of its two pictures */
-        std::vector<TickShape> mixed(n_pics);
-        for (u32 i = 0; i < n_pics; i++) {
-            const TickShape &a = r->shapes[i], &b = r->shapes[(i + odd_offset) % n_pics];
-            TickShape m = a;
-            m.max_mbs = std::max(a.max_mbs, b.max_mbs);       m.max_copy = std::max(a.max_copy, b.max_copy);
-            m.max_gen = std::max(a.max_gen, b.max_gen);       m.max_dbk = std::max(a.max_dbk, b.max_dbk);
-            m.max_levels = std::max(a.max_levels, b.max_levels);
-            m.max_w = std::max(a.max_w, b.max_w);             m.max_h = std::max(a.max_h, b.max_h);
-            m.any_tail = a.any_tail || b.any_tail;            m.any_deblock = a.any_deblock || b.any_deblock;
-            mixed[i] = m;
-        }
-        r->shapes.swap(mixed);
-    }
     if (ok) ok = hipStreamSynchronize(e->stream) == hipSuccess;
     for (u32 s = 1; ok && s < n_streams; s++)
         ok = hipMemcpyAsync(r->d_blobs + (size_t)s * total, r->d_blobs, total, hipMemcpyDeviceToDevice, e->stream) == hipSuccess;
     if (ok) {
         std::vector<FrameDesc> descs((size_t)n_pics * n_streams);
-        for (u32 i = 0; i < n_pics; i++)
-            for (u32 s = 0; s < n_streams; s++) {
-                const u32 p = (s & 1u) ? (i + odd_offset) % n_pics : i;
-                make_desc(descs[(size_t)i * n_streams + s], blobs[p], r->d_blobs + (size_t)s * total + offs[p],
-                          r->d_frames + (size_t)s * frames_per_stream, r->frame_bytes,
-                          r->d_dbk + (size_t)s * dbk_stride, nullptr);
+        auto desc_of = [&](FrameDesc &d, u32 s, u32 p, TickShape *shape) {
+            make_desc(d, blobs[p], r->d_blobs + (size_t)s * total + offs[p], r->d_frames + (size_t)s * frames_per_stream,
+                      r->frame_bytes, r->d_dbk + (size_t)s * dbk_stride, shape);
+        };
+        if (!heavy_lanes) {
+            for (u32 i = 0; i < n_pics; i++) {
+                TickShape shape;                          /* a tick is as large as the largest of its pictures */
+                for (u32 s = 0; s < n_streams; s++) desc_of(descs[(size_t)i * n_streams + s], s, (i + r->offsets[s]) % n_pics, &shape);
+                r->shapes[i] = shape;
             }
-        ok = hipMemcpyAsync(r->d_desc, descs.data(), descs.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream) == hipSuccess &&
-             hipStreamSynchronize(e->stream) == hipSuccess;
+        } else {
+            /* static schedule: common ticks on the engine stream, heavy pictures round-robin on the lanes */
+            std::vector<u32> done(n_streams, 0), ready_at(n_streams, 0);
+            size_t n_desc = 0;
+            u32 left = n_streams, heavy_count = 0;
+            std::vector<std::pair<u32, int>> rejoin;      /* (tick, event of the heavy launch) */
+            auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[p]); return h->n_intra * 4u > h->n_mbs; };
+            for (u32 t = 0; left && t < 16u * n_pics; t++) {
+                h264bsdmi_replay::Launch light{ n_desc, TickShape(), -1, -1, -1 }, heavy{ 0, TickShape(), 0, -1, -1 };
+                std::vector<u32> hs;
+                for (u32 s = 0; s < n_streams; s++) {
+                    if (done[s] >= n_pics || ready_at[s] > t) continue;
+                    const u32 p = (r->offsets[s] + done[s]) % n_pics;
+                    if (is_heavy(p)) hs.push_back(s);
+                    else { desc_of(descs[n_desc++], s, p, &light.shape); if (++done[s] == n_pics) left--; }
+                }
+                for (auto &rj : rejoin) if (rj.first == t) { light.wait_ev = rj.second; }    /* at most one heavy launch per tick */
+                const bool have_light = light.shape.n_frames != 0;
+                if (have_light || light.wait_ev >= 0) {
+                    if (!hs.empty()) { light.record_ev = (int)r->sched_ev.size(); r->sched_ev.push_back(nullptr); }
+                    r->sched.push_back(light);
+                }
+                if (!hs.empty()) {
+                    heavy.first = n_desc;
+                    heavy.lane = (int)(heavy_count++ % heavy_lanes);
+                    heavy.wait_ev = (have_light || light.wait_ev >= 0) ? r->sched.back().record_ev : -1;
+                    for (u32 s : hs) {
+                        desc_of(descs[n_desc++], s, (r->offsets[s] + done[s]) % n_pics, &heavy.shape);
+                        if (++done[s] == n_pics) left--;
+                        ready_at[s] = t + 1 + heavy_delay;
+                    }
+                    heavy.record_ev = (int)r->sched_ev.size(); r->sched_ev.push_back(nullptr);
+                    rejoin.emplace_back(t + 1 + heavy_delay, heavy.record_ev);
+                    r->sched.push_back(heavy);
+                }
+            }
+            if (left || n_desc != descs.size()) ok = false;
+            r->n_lanes = heavy_lanes;
+            /* the heavy pictures' workgroups need a whole compute unit each: highest priority, or they starve behind the
+             * many small workgroups of the common ticks */
+            int prio_least = 0, prio_greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
+            if (getenv("H264BSDMI_LANE_PRIO")) prio_greatest = atoi(getenv("H264BSDMI_LANE_PRIO"));
+            for (u32 k = 0; ok && k < heavy_lanes; k++)
+                ok = hipStreamCreateWithPriority(&r->lanes[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
+            for (auto &ev : r->sched_ev) if (ok) ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        }
+        if (ok) ok = hipMemcpyAsync(r->d_desc, descs.data(), descs.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream) == hipSuccess &&
+                     hipStreamSynchronize(e->stream) == hipSuccess;
     }
     r->timers.resize(n_pics);
     for (auto &t : r->timers) {
         for (auto &ev : t.ev) if (ok) ok = hipEventCreate(&ev) == hipSuccess;
         for (auto &ev : t.sev) if (ok) ok = hipEventCreate(&ev) == hipSuccess;
     }
-    if (ok) ok = hipEventCreate(&r->ev_begin) == hipSuccess && hipEventCreate(&r->ev_end) == hipSuccess;
+    if (ok) ok = hipEventCreate(&r->ev_begin) == hipSuccess && hipEventCreate(&r->ev_end) == hipSuccess &&
+                 hipEventCreateWithFlags(&r->gdone_any, hipEventDisableTiming) == hipSuccess;
     r->timed_first = r->timed_count = 0;
     r->stages = 7u;
     r->n_groups = 1;
@@ -672,8 +736,10 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     hipFree(r->d_blobs); hipFree(r->d_frames); hipFree(r->d_desc); hipFree(r->d_sums); hipFree(r->d_dbk);
     if (r->d_conv) hipFree(r->d_conv);
     for (auto &t : r->timers) for (auto &ev : t.ev) hipEventDestroy(ev);
-    hipEventDestroy(r->ev_begin); hipEventDestroy(r->ev_end);
+    hipEventDestroy(r->ev_begin); hipEventDestroy(r->ev_end); if (r->gdone_any) hipEventDestroy(r->gdone_any);
     for (int g = 0; g < 8; g++) { if (r->gstream[g]) hipStreamDestroy(r->gstream[g]); if (r->gdone[g]) hipEventDestroy(r->gdone[g]); }
+    for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
+    for (auto &st : r->lanes) if (st) hipStreamDestroy(st);
     delete r;
 }
 
@@ -685,7 +751,20 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
     r->timed_first = first; r->timed_count = count;
     for (auto &l : r->launches) l = 0;
     HIP_TRY(hipEventRecord(r->ev_begin, r->e->stream));
-    if (r->n_groups <= 1) {
+    if (!r->sched.empty()) {
+        /* desynchronised set with heavy lanes: one whole lap of the static schedule (first / count are ignored) */
+        r->timed_count = 0;
+        for (const auto &l : r->sched) {
+            hipStream_t st = l.lane < 0 ? r->e->stream : r->lanes[l.lane];
+            if (l.wait_ev >= 0) HIP_TRY(hipStreamWaitEvent(st, r->sched_ev[l.wait_ev], 0));
+            else if (l.lane >= 0) { HIP_TRY(hipEventRecord(r->gdone_any, r->e->stream)); HIP_TRY(hipStreamWaitEvent(st, r->gdone_any, 0)); }
+            if (l.shape.n_frames && launch_tick(st, r->d_desc + l.first, l.shape, nullptr, r->launches, r->stages,
+                                                (l.lane < 0 && r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr)) return -1;
+            if (l.record_ev >= 0) HIP_TRY(hipEventRecord(r->sched_ev[l.record_ev], st));
+        }
+        for (const auto &l : r->sched)                      /* the lap ends when every lane has drained */
+            if (l.lane >= 0) HIP_TRY(hipStreamWaitEvent(r->e->stream, r->sched_ev[l.record_ev], 0));
+    } else if (r->n_groups <= 1) {
         for (u32 i = first; i < first + count; i++) {
             r->timers[i].on = true; r->timers[i].mask = r->timed_mask;
             if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr)) return -1;
@@ -765,7 +844,7 @@ int h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[6], u32 launches[5]
                 if (hipEventElapsedTime(&ms, r->timers[i].sev[1], r->timers[i].sev[2]) == hipSuccess) out_ms[2] += ms;
             }
         }
-    if (r->timed_count) HIP_TRY(hipEventElapsedTime(&out_ms[5], r->ev_begin, r->ev_end));
+    if (r->timed_count || !r->sched.empty()) HIP_TRY(hipEventElapsedTime(&out_ms[5], r->ev_begin, r->ev_end));
     if (launches) for (int k = 0; k < 5; k++) launches[k] = r->launches[k];
     return 0;
 }

@@ -96,6 +96,14 @@ h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes
  * half of the streams with a P picture of the other half).  odd_offset must index an IDR picture. */
 h264bsdmi_replay *h264bsdmiReplayCreateStaggered(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
                                                  u32 odd_offset);
+/* Streams that are not in step at all: stream s starts at picture offsets[s] (NULL = 0 for all) and wraps around
+ * (picture 0 must be an IDR picture).  heavy_lanes = 0: tick k holds picture (k + offsets[s]) mod n_pics of every
+ * stream, so every tick lasts as long as its slowest picture.  heavy_lanes = 1..8: mostly intra-coded pictures
+ * (more than a quarter of their macroblocks) leave the common tick and run on one of heavy_lanes extra HIP streams;
+ * their stream rejoins the common ticks heavy_delay ticks later (guarded by an event).  h264bsdmiReplayRun() then
+ * always runs one whole lap (every stream n_pics pictures) and h264bsdmiReplayTimings() reports only the total. */
+h264bsdmi_replay *h264bsdmiReplayCreateDesync(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
+                                              const u32 *offsets, u32 heavy_lanes, u32 heavy_delay);
 void h264bsdmiReplayDestroy(h264bsdmi_replay *r);
 /* Enqueue ticks [first, first+count) on the engine stream; asynchronous.  0 = ok. */
 int  h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count);

@@ -107,6 +107,29 @@ def test_staggered_streams_mix_pictures_in_one_tick(built, captured, golden):
         rep.close()
 
 
+@pytest.mark.parametrize("lanes,delay", [(0, 0), (2, 2), (3, 5)])
+def test_desynchronised_streams(lanes, delay, built, captured, golden):
+    """every stream at its own picture index (so every tick mixes I pictures and P pictures), with and without
+    heavy lanes; after each lap stream s has just finished picture offsets[s] - 1"""
+    name = "test_640x360"
+    jobs, _, _ = captured(name)
+    g = golden[name]["frame_checksum64"]
+    heads = [pyoracle.blob_header(j) for j in jobs]
+    n, S = len(jobs), 11
+    offsets = [(s * n) // S for s in range(S)]
+    rep = built.Replay(jobs, n_streams=S, offsets=offsets, heavy_lanes=lanes, heavy_delay=delay)
+    try:
+        for lap in range(3):
+            rep.run()
+            rep.sync()
+            sums = {slot: rep.checksums(slot) for slot in set(h["cur_slot"] for h in heads)}
+            for s in range(S):
+                last = (offsets[s] - 1) % n
+                assert int(sums[heads[last]["cur_slot"]][s]) == g[last], (lap, s, last)
+    finally:
+        rep.close()
+
+
 @pytest.mark.parametrize("name", ["test_640x360", "test_1920x1080_fullRange"])
 def test_on_device_colour_conversion(name, built, captured, golden):
     jobs, _, info = captured(name)

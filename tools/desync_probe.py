@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Desynchronised streams (every stream at its own picture index): lap time of the common-tick schedule and of the
+heavy-lane schedules, verified against the golden checksums at the end of a lap.
+usage: desync_probe.py [streams] [K,D ...]"""
+import sys, os, json, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import h264bsd_amd as h
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+name = os.environ.get("STREAM", "test_1920x1080")
+jobs, _, _ = h.capture_stream(open(os.path.join(root, "tests", "golden", name + ".h264"), "rb").read())
+golden = json.load(open(os.path.join(root, "tests", "golden", "golden.json")))[name]["frame_checksum64"]
+heads = [h.job_header(j) for j in jobs]
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+P = len(jobs)
+offsets = [(s * P) // S for s in range(S)]
+cfgs = [(0, 0)] + [tuple(int(x) for x in a.split(",")) for a in sys.argv[2:]]
+for K, D in cfgs:
+    rep = h.Replay(jobs, n_streams=S, offsets=offsets, heavy_lanes=K, heavy_delay=D)
+    def verify():
+        bad = 0
+        sums = {slot: rep.checksums(slot) for slot in set(hd["cur_slot"] for hd in heads)}
+        for s in range(S):
+            last = (offsets[s] - 1) % P
+            bad += int(sums[heads[last]["cur_slot"]][s]) != golden[last]
+        return bad
+    rep.run(); rep.sync(); b1 = verify()
+    rep.run(); rep.sync(); b2 = verify()
+    t = []
+    for _ in range(3):
+        rep.run(); t.append(rep.timings()["total_ms"])
+    b3 = verify()
+    ms = sum(t) / len(t)
+    print(f"lanes {K} delay {D}: {ms:.1f} ms per lap = {S * P * heads[0]['n_mbs'] / ms / 1e3:.1f} M MB/s; mismatching streams after lap 1/2/5: {b1}/{b2}/{b3}")
+    rep.close()
