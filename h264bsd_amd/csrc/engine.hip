@@ -691,11 +691,10 @@ h264bsdmi_replay *h264bsdmiReplayCreateDesync(const u8 *const *blobs, const u32 
             }
             if (left || n_desc != descs.size()) ok = false;
             r->n_lanes = heavy_lanes;
-            /* the heavy pictures' workgroups need a whole compute unit each: highest priority, or they starve behind the
-             * many small workgroups of the common ticks */
+            /* the heavy pictures' workgroups need a whole compute unit each: highest priority (measured: no
+             * difference on this runtime, kept because it states the intent) */
             int prio_least = 0, prio_greatest = 0;
             if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
-            if (getenv("H264BSDMI_LANE_PRIO")) prio_greatest = atoi(getenv("H264BSDMI_LANE_PRIO"));
             for (u32 k = 0; ok && k < heavy_lanes; k++)
                 ok = hipStreamCreateWithPriority(&r->lanes[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
             for (auto &ev : r->sched_ev) if (ok) ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
