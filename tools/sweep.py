@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Parity sweep on the CPU: random valid streams from the bitstream writer (tests/h264writer.py), optionally damaged,
+decoded by the compiled reference (oracle/_ref) and by the host parser + oracle; the h264bsdDecode call traces and the
+output pictures (hash, picId, isIdr, numErrMbs, order) must be identical.  TEST TOOL (uses oracle/): never imported by
+the product.  usage: sweep.py <first seed> <count> [--damage] [--no-reorder-too]"""
+import argparse, os, sys, time
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import h264writer, synth, damage as dmg
+
+ap = argparse.ArgumentParser()
+ap.add_argument("first", type=int); ap.add_argument("count", type=int)
+ap.add_argument("--damage", action="store_true")
+args = ap.parse_args()
+os.dup2(os.open(os.devnull, os.O_WRONLY), 2)      # the reference is built with _ERROR_PRINT
+bad, t0, n_pics = [], time.time(), 0
+for seed in range(args.first, args.first + args.count):
+    try:
+        cfg = h264writer.random_config(seed)
+        if args.damage:                         # as tests/synth_configs.py: no frame_num gaps, no redundant slices
+            cfg["gaps"] = 0                     # (known deviations of the reference on damaged streams)
+            cfg["redundant"] = False
+        data = h264writer.StreamWriter(**cfg).build()
+        if args.damage:
+            data = dmg.damage(data, seed, p_drop=0.2, p_flip=0.0, p_trunc=0.2)
+        nor = seed & 1 if not args.damage else 0
+        ref = synth.decode_reference(data, nor)
+        ours = synth.decode_ours(data, "oracle", nor)
+        n_pics += len(ref[1])
+        if ref != ours:
+            bad.append(seed)
+            print(f"MISMATCH seed {seed}: trace equal {ref[0] == ours[0]}, pictures {len(ref[1])} vs {len(ours[1])}", flush=True)
+    except Exception as e:                      # a writer/config problem is reported, not hidden
+        bad.append(seed)
+        print(f"ERROR seed {seed}: {type(e).__name__}: {e}", flush=True)
+print(f"seeds {args.first}..{args.first + args.count - 1}{' damaged' if args.damage else ''}: {args.count - len(bad)} identical, "
+      f"{len(bad)} not ({bad[:20]}); {n_pics} pictures compared, {time.time() - t0:.0f} s")
