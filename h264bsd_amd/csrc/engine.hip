@@ -170,7 +170,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         HIP_TRY(hipEventRecord(side->join, side->stream));
     }
     if (do_copy) {
-        hipLaunchKernelGGL(h264k::k_copy, dim3((s.max_copy + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
+        hipLaunchKernelGGL(h264k::k_copy, dim3((s.max_copy + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);   /* one run per wavefront */
         if (launches) launches[0]++;
     }
     if (EV_NEEDED(1)) HIP_TRY(hipEventRecord(tt->ev[1], st));

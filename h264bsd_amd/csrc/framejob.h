@@ -108,10 +108,11 @@ typedef struct FjHeader {
 /* An inter macroblock with no coefficients whose 16 motion vectors are equal and whole-sample for
  * luma AND chroma (mv multiple of 8 quarter-samples; 66 % of the inter MBs of the bundled 1080p
  * stream, almost all of them P_Skip with mv 0): reconstruction is a 384-byte copy. */
+#define FJ_COPY_RUN 8         /* longest run of a copy-list entry: 8 MBs = one 128-byte line per luma row */
 typedef struct FjCopy {
     uint16_t mb;              /* address of the first macroblock of the run                   */
     uint8_t  slot;            /* reference DPB slot                                           */
-    uint8_t  count;           /* 1..4 horizontally adjacent MBs with the same slot and mv     */
+    uint8_t  count;           /* 1..FJ_COPY_RUN horizontally adjacent MBs with the same slot and mv */
     int16_t  dx, dy;          /* displacement in luma samples (even)                          */
 } FjCopy;                     /* 8 bytes */
 

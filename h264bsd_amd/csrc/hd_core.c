@@ -216,10 +216,10 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
             }
         }
         if (cls[a] & 2) {
-            /* copy list: runs of up to 4 horizontally adjacent copy MBs with equal reference and mv */
+            /* copy list: runs of up to FJ_COPY_RUN horizontally adjacent copy MBs with equal reference and mv */
             const int16_t *m0 = mvs[a][0];
             FjCopy *last = n_copy ? &copy_tmp[n_copy - 1] : NULL;
-            if (last && last->count < 4 && (uint32_t)last->mb + last->count == a && a % w != 0 &&
+            if (last && last->count < FJ_COPY_RUN && (uint32_t)last->mb + last->count == a && a % w != 0 &&
                 last->slot == r->ref_slot[0] && last->dx == (m0[0] >> 2) && last->dy == (m0[1] >> 2)) {
                 last->count++;
             } else {

@@ -453,60 +453,64 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
 }
 
 /* ------------------------------------------------------------------ whole-sample copy macroblocks */
-/* List entries are runs of up to 4 horizontally adjacent MBs with one displacement: a 64x16 luma block
- * = 16 rows x 64 B (one cache line per row when aligned) and two 32x8 chroma blocks.  One wavefront
- * moves 2 entries: 16 B per lane per access (luma lane = 4*row + 16-byte column; chroma lanes 0..31 =
- * 16*plane + 2*row + column), every load issued before the first store. */
+/* List entries are runs of up to 8 horizontally adjacent MBs with one displacement: a 128x16 luma block
+ * = 16 rows x 128 B (one cache line per row when aligned) and two 64x8 chroma blocks.  One wavefront moves one
+ * entry: 16 B per lane per access — luma piece i = lane + 64 j (j = 0, 1): row i >> 3, macroblock i & 7; chroma: lane =
+ * 32 plane + 4 row + (pair of macroblocks) — every load issued before the first store. */
 __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ frames)
 {
     const FrameDesc &fd = frames[blockIdx.y];
-    const uint32_t first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
-    if (first >= fd.n_copy) return;
+    const uint32_t ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ci >= fd.n_copy) return;
     const int lane = threadIdx.x & 63;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
-    const int lrow = lane >> 2, lseg = lane & 3;                /* luma: MB lseg of the run, row lrow */
-    const int plane = (lane >> 4) & 1, crow = (lane >> 1) & 7, cseg = lane & 1;   /* chroma: 16 B = 2 MBs */
-    uint4 vy[2], vc[2];
-    int mbx[2], mby[2], cnt[2];
+    const int lrow = lane >> 3, lseg = lane & 7;                /* luma: MB lseg of the run, rows lrow and lrow + 8 */
+    const int plane = lane >> 5, crow = (lane >> 2) & 7, cseg = lane & 3;     /* chroma: 16 B = 2 MBs */
+    const FjCopy e = fd.copy[ci];
+    const int cnt = e.count;
+    const int mbx = e.mb % wmb, mby = e.mb / wmb;
+    const uint8_t *ref = slot_ptr(fd, e.slot);
+    const int x = mbx * 16 + e.dx, y = mby * 16 + e.dy;
+    uint4 vy[2], vc;
+    if (x >= 0 && x + 16 * cnt <= W && y >= 0 && y + 16 <= H) {
+        vy[0] = vy[1] = vc = make_uint4(0, 0, 0, 0);
+        if (lseg < cnt) {                                        /* only the MBs of the run */
+            __builtin_memcpy(&vy[0], ref + (size_t)(y + lrow) * W + x + 16 * lseg, 16);
+            __builtin_memcpy(&vy[1], ref + (size_t)(y + lrow + 8) * W + x + 16 * lseg, 16);
+        }
+        if (2 * cseg < cnt) __builtin_memcpy(&vc, ref + ysz + (plane ? csz : 0) + (size_t)((y >> 1) + crow) * CW + (x >> 1) + 16 * cseg, 16);
+    } else {                                                     /* clamp-to-edge, sample by sample */
+        const uint8_t *c = ref + ysz + (plane ? csz : 0) + (size_t)clip3(0, CH - 1, (y >> 1) + crow) * CW;
+        uint32_t b[4];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const bool on = first + j < fd.n_copy;
-        const FjCopy e = fd.copy[on ? first + j : first];
-        cnt[j] = on ? e.count : 0;
-        mbx[j] = e.mb % wmb; mby[j] = e.mb / wmb;
-        const uint8_t *ref = slot_ptr(fd, e.slot);
-        const int x = mbx[j] * 16 + e.dx, y = mby[j] * 16 + e.dy;
-        if (x >= 0 && x + 64 <= W && y >= 0 && y + 16 <= H) {
-            vy[j] = vc[j] = make_uint4(0, 0, 0, 0);
-            if (lseg < cnt[j]) __builtin_memcpy(&vy[j], ref + (size_t)(y + lrow) * W + x + 16 * lseg, 16);      /* only the MBs of the run */
-            if (2 * cseg < cnt[j]) __builtin_memcpy(&vc[j], ref + ysz + (plane ? csz : 0) + (size_t)((y >> 1) + crow) * CW + (x >> 1) + 16 * cseg, 16);
-        } else {                                               /* clamp-to-edge, sample by sample */
-            const uint8_t *s = ref + (size_t)clip3(0, H - 1, y + lrow) * W;
-            const uint8_t *c = ref + ysz + (plane ? csz : 0) + (size_t)clip3(0, CH - 1, (y >> 1) + crow) * CW;
-            uint32_t a[4], b[4];
+        for (int j = 0; j < 2; j++) {
+            const uint8_t *s = ref + (size_t)clip3(0, H - 1, y + lrow + 8 * j) * W;
+            uint32_t a[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                a[q] = b[q] = 0;
+                a[q] = 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    a[q] |= (uint32_t)s[clip3(0, W - 1, x + 16 * lseg + 4 * q + i)] << (8 * i);
-                    b[q] |= (uint32_t)c[clip3(0, CW - 1, (x >> 1) + 16 * cseg + 4 * q + i)] << (8 * i);
-                }
+                for (int i = 0; i < 4; i++) a[q] |= (uint32_t)s[clip3(0, W - 1, x + 16 * lseg + 4 * q + i)] << (8 * i);
             }
             vy[j] = make_uint4(a[0], a[1], a[2], a[3]);
-            vc[j] = make_uint4(b[0], b[1], b[2], b[3]);
         }
-    }
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        if (lseg < cnt[j])
-            *reinterpret_cast<uint4 *>(fd.cur + (size_t)(mby[j] * 16 + lrow) * W + mbx[j] * 16 + 16 * lseg) = vy[j];
-        if (lane < 32 && 2 * cseg < cnt[j]) {
-            uint8_t *dst = fd.cur + ysz + (plane ? csz : 0) + (size_t)(mby[j] * 8 + crow) * CW + mbx[j] * 8 + 16 * cseg;
-            if (2 * cseg + 1 < cnt[j]) *reinterpret_cast<uint4 *>(dst) = vc[j];
-            else *reinterpret_cast<uint2 *>(dst) = make_uint2(vc[j].x, vc[j].y);      /* odd run length: last MB only */
+        for (int q = 0; q < 4; q++) {
+            b[q] = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) b[q] |= (uint32_t)c[clip3(0, CW - 1, (x >> 1) + 16 * cseg + 4 * q + i)] << (8 * i);
         }
+        vc = make_uint4(b[0], b[1], b[2], b[3]);
+    }
+    if (lseg < cnt) {
+        *reinterpret_cast<uint4 *>(fd.cur + (size_t)(mby * 16 + lrow) * W + mbx * 16 + 16 * lseg) = vy[0];
+        *reinterpret_cast<uint4 *>(fd.cur + (size_t)(mby * 16 + lrow + 8) * W + mbx * 16 + 16 * lseg) = vy[1];
+    }
+    if (2 * cseg < cnt) {
+        uint8_t *dst = fd.cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + crow) * CW + mbx * 8 + 16 * cseg;
+        if (2 * cseg + 1 < cnt) *reinterpret_cast<uint4 *>(dst) = vc;
+        else *reinterpret_cast<uint2 *>(dst) = make_uint2(vc.x, vc.y);          /* odd run length: last MB only */
     }
 }
 
