@@ -130,6 +130,6 @@ def test_frame_job_schedules_are_consistent(pic, captured):
     run_cnt = copy[:, 3].astype(int)
     covered = np.concatenate([np.arange(m, m + c) for m, c in zip(run_mb, run_cnt)] + [gen.astype(int)]) if len(inter) else np.array([], int)
     assert sorted(covered.tolist()) == inter.tolist()
-    assert ((run_cnt >= 1) & (run_cnt <= 4)).all() and ((run_mb % w) + run_cnt <= w).all()
+    assert ((run_cnt >= 1) & (run_cnt <= 8)).all() and ((run_mb % w) + run_cnt <= w).all()
     # deblocking index: exactly the MBs not marked trivially strength-free
     assert sorted(dbk.tolist()) == np.nonzero(rec[:, 21] == 0)[0].tolist()
