@@ -2,7 +2,7 @@
 """Parity sweep on the CPU: random valid streams from the bitstream writer (tests/h264writer.py), optionally damaged,
 decoded by the compiled reference (oracle/_ref) and by the host parser + oracle; the h264bsdDecode call traces and the
 output pictures (hash, picId, isIdr, numErrMbs, order) must be identical.  TEST TOOL (uses oracle/): never imported by
-the product.  usage: sweep.py <first seed> <count> [--damage] [--no-reorder-too]"""
+the product.  usage: sweep.py <first seed> <count> [--damage] [--backend gpu]"""
 import argparse, os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
@@ -11,6 +11,7 @@ import h264writer, synth, damage as dmg
 ap = argparse.ArgumentParser()
 ap.add_argument("first", type=int); ap.add_argument("count", type=int)
 ap.add_argument("--damage", action="store_true")
+ap.add_argument("--backend", default="oracle", choices=("oracle", "gpu"), help="gpu = the product through the C ABI (needs an MI355X)")
 args = ap.parse_args()
 os.dup2(os.open(os.devnull, os.O_WRONLY), 2)      # the reference is built with _ERROR_PRINT
 bad, t0, n_pics = [], time.time(), 0
@@ -25,7 +26,7 @@ for seed in range(args.first, args.first + args.count):
             data = dmg.damage(data, seed, p_drop=0.2, p_flip=0.0, p_trunc=0.2)
         nor = seed & 1 if not args.damage else 0
         ref = synth.decode_reference(data, nor)
-        ours = synth.decode_ours(data, "oracle", nor)
+        ours = synth.decode_ours(data, args.backend, nor)
         n_pics += len(ref[1])
         if ref != ours:
             bad.append(seed)
@@ -33,5 +34,5 @@ for seed in range(args.first, args.first + args.count):
     except Exception as e:                      # a writer/config problem is reported, not hidden
         bad.append(seed)
         print(f"ERROR seed {seed}: {type(e).__name__}: {e}", flush=True)
-print(f"seeds {args.first}..{args.first + args.count - 1}{' damaged' if args.damage else ''}: {args.count - len(bad)} identical, "
+print(f"[{args.backend}] seeds {args.first}..{args.first + args.count - 1}{' damaged' if args.damage else ''}: {args.count - len(bad)} identical, "
       f"{len(bad)} not ({bad[:20]}); {n_pics} pictures compared, {time.time() - t0:.0f} s")
