@@ -100,3 +100,35 @@ def test_gpu_sequence_parameter_set_changes(built, names):
     """the engine re-allocates the stream's frame buffers at the second activation"""
     data = _concat(names)
     assert synth.decode_ours(data, "gpu") == synth.decode_ours(data, "oracle")
+
+
+def _live_sweep(first, count, damaged, backend):
+    """fresh random streams against the LIVE reference (oracle/_ref travels to the GPU box as a built artefact)"""
+    from oracle import pyoracle
+    import damage as dmg
+    from h264writer import random_config
+    if not os.path.exists(pyoracle.REF_SO):
+        pytest.skip("oracle/_ref not built")
+    bad = []
+    for seed in range(first, first + count):
+        cfg = random_config(seed)
+        if damaged:
+            cfg["gaps"], cfg["redundant"] = 0, False          # as synth_configs._damaged (known deviations, DESIGN.md §2)
+        data = StreamWriter(**cfg).build()
+        if damaged:
+            data = dmg.damage(data, seed, p_drop=0.2, p_flip=0.0, p_trunc=0.2)
+        nor = 0 if damaged else seed & 1
+        if synth.decode_reference(data, nor) != synth.decode_ours(data, backend, nor):
+            bad.append(seed)
+    assert not bad, f"seeds {bad} differ from the reference"
+
+
+def test_random_streams_match_live_reference(built):
+    _live_sweep(91000, 40, False, "oracle")
+    _live_sweep(91500, 30, True, "oracle")
+
+
+@pytest.mark.gpu
+def test_gpu_random_streams_match_live_reference(built):
+    _live_sweep(92000, 120, False, "gpu")
+    _live_sweep(92500, 80, True, "gpu")
