@@ -38,6 +38,10 @@
                              in the concealment order (later ones may read earlier ones)                      */
 #define FJ_MB_CONCEAL_P 5 /* lost macroblock of a P picture: copy of the co-located macroblock of DPB slot
                              ref_slot[0] (conceal.c:318-343); travels in the copy list like a mv-0 P_Skip       */
+#define FJ_MB_STALE   6   /* intra macroblock that counts as decoded but was never reconstructed (its reconstruction
+                             failed and the reference's slice roll-back does not reach it, src/h264bsd_slice_data.c:
+                             318-333): the pixels stay what the frame buffer held, the deblocking filter treats it as
+                             the intra macroblock it was parsed as (qp_y, dbk, offsets valid; nothing else)        */
 #define FJ_MB_ABSENT  255 /* macroblock not covered by any decoded slice: pixels left untouched */
 
 /* FjMbRec.avail of a FJ_MB_CONCEAL_I macroblock: which neighbours were decoded (or already concealed) when the
@@ -75,6 +79,10 @@
 /* FjMbRec.coded bits */
 #define FJ_CODED_LUMA_DC   (1u << 24) /* Intra16x16 DC block present                        */
 #define FJ_CODED_CHROMA_DC (1u << 25) /* chroma DC block (Cb[0..3], Cr[4..7]) present        */
+#define FJ_CODED_LUMA_DC_RAW (1u << 26) /* with FJ_CODED_LUMA_DC: the block holds the FINAL DC of luma block (bx,by) at
+                                         raster position 4*by+bx — no Hadamard, no scaling.  Only a damaged stream
+                                         produces it (a chroma AC block whose last coefficient lands in the luma DC
+                                         array of an Intra16x16 macroblock that coded no DC, hd_mb.c parse_residual) */
 
 typedef struct FjHeader {
     uint32_t magic;
@@ -102,7 +110,9 @@ typedef struct FjHeader {
     uint32_t n_gen;
     uint32_t dbk_off;         /* uint16 dbk_idx[n_dbk]: MBs whose boundary strengths are not trivially all zero */
     uint32_t n_dbk;
-    uint32_t reserved[11];
+    uint32_t ghost;           /* 1: pre-pass of the picture that follows in the same slot (pixels of a rolled-back slice that a
+                                 FJ_MB_STALE macroblock of that picture shows): reconstruction only, not a picture of its own */
+    uint32_t reserved[10];
 } FjHeader;                   /* 128 bytes */
 
 /* An inter macroblock with no coefficients whose 16 motion vectors are equal and whole-sample for

@@ -10,6 +10,8 @@
  * Replaces (behaviourally) the reference's src/h264bsd_cavlc.c:749-916; the reference's
  * "level_prefix above 15 is an error" rule for baseline streams (:820-834) is kept.
  */
+#include <pthread.h>
+#include <stdlib.h>
 #include <string.h>
 #include "hostdec.h"
 
@@ -117,24 +119,32 @@ static inline int vlc_get(const Vlc *v, BitReader *br)
 }
 
 static Vlc vlc_ct[3], vlc_cdc, vlc_tz[15], vlc_ctz[3], vlc_rb[7];
-static int cavlc_ready;
+int hd_trace;
 
-void hd_cavlc_init(void)
+/* built exactly once per process however many threads create decoder instances at the same time */
+static void cavlc_build_tables(void)
 {
-    if (cavlc_ready) return;
+    const char *t = getenv("HD_TRACE");
+    hd_trace = t && *t && *t != '0';
     for (int t = 0; t < 3; t++) vlc_build(&vlc_ct[t], ct_len[t], ct_code[t], 68);
     vlc_build(&vlc_cdc, cdc_len, cdc_code, 20);
     for (int t = 0; t < 15; t++) vlc_build(&vlc_tz[t], tz_len[t], tz_code[t], 16);
     for (int t = 0; t < 3; t++) vlc_build(&vlc_ctz[t], ctz_len[t], ctz_code[t], 4);
     for (int t = 0; t < 7; t++) vlc_build(&vlc_rb[t], rb_len[t], rb_code[t], 15);
-    cavlc_ready = 1;
+}
+
+void hd_cavlc_init(void)
+{
+    static pthread_once_t once = PTHREAD_ONCE_INIT;
+    pthread_once(&once, cavlc_build_tables);
 }
 
 static const uint8_t zigzag4x4[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
 
-int hd_cavlc_block(BitReader *br, int nc, int max_coeff, int16_t *coef)
+int hd_cavlc_block(BitReader *br, int nc, int max_coeff, int16_t *coef, int *spill)
 {
     int sym;
+    if (spill) *spill = 0;
     if (nc < 0) sym = vlc_get(&vlc_cdc, br);
     else if (nc < 2) sym = vlc_get(&vlc_ct[0], br);
     else if (nc < 4) sym = vlc_get(&vlc_ct[1], br);
@@ -180,7 +190,12 @@ int hd_cavlc_block(BitReader *br, int nc, int max_coeff, int16_t *coef)
     int zeros_left = 0;
     if (total < max_coeff) {
         zeros_left = nc < 0 ? vlc_get(&vlc_ctz[total - 1], br) : vlc_get(&vlc_tz[total - 1], br);
-        if (zeros_left < 0 || total + zeros_left > max_coeff) return -1;
+        /* A 15-coefficient block is parsed with the total_zeros tables of the 16-coefficient case (9.2.3 gives it
+         * tzVlcIndex = total_coeff all the same), which allow total_coeff + total_zeros == 16.  The reference accepts
+         * that (src/h264bsd_cavlc.c:862-873): the coefficient lands one element past the block, i.e. in element 0 of
+         * the NEXT block of residual_t.level[][] (macroblock_layer.c:745-753 pass level[b]+1).  Mirrored: accepted,
+         * the stray level is handed to the caller through *spill. */
+        if (zeros_left < 0 || total + zeros_left > (max_coeff == 15 ? 16 : max_coeff)) return -1;
     }
     /* run_before + placement: level[0] is the highest-frequency coefficient */
     int pos = total + zeros_left - 1;                     /* scan index of level[0] */
@@ -188,7 +203,9 @@ int hd_cavlc_block(BitReader *br, int nc, int max_coeff, int16_t *coef)
     for (int i = 0; i < total; i++) {
         if (pos < 0) return -1;
         int16_t v = (int16_t)level[i];
-        if (nc < 0) coef[pos] = v; else coef[zigzag4x4[pos + first]] = v;
+        if (nc < 0) coef[pos] = v;
+        else if (pos + first < 16) coef[zigzag4x4[pos + first]] = v;
+        else if (spill) *spill = level[i];
         if (i + 1 == total) break;
         int run = 0;
         if (zeros_left > 0) {

@@ -21,7 +21,7 @@
 HostDec *hd_create(int no_output_reordering);
 void hd_destroy(HostDec *d);
 /* error exits of hd_decode report where they happened when HD_TRACE is set in the environment (debugging aid) */
-#define ERR_RETURN do { if (getenv("HD_TRACE")) fprintf(stderr, "TRACE hd_decode error at line %d\n", __LINE__); return HD_ERROR; } while (0)
+#define ERR_RETURN do { if (hd_trace) fprintf(stderr, "TRACE hd_decode error at line %d\n", __LINE__); return HD_ERROR; } while (0)
 int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes);
 
 HostDec *hd_create(int no_output_reordering)
@@ -46,6 +46,8 @@ void hd_destroy(HostDec *d)
     free(d->mb_decoded);
     free(d->mb_slice_id);
     free(d->slice_group_map);
+    free(d->ghost_buf);
+    free(d->mb_ghost);
     free(d->nal_buf);
     if (!d->job_from_sink) free(d->job);
     free(d->conv_buf);
@@ -87,6 +89,7 @@ int hd_job_begin(HostDec *d)
     /* records and motion vectors are NOT pre-initialised: every decoded macroblock writes both, and
      * hd_job_finish() fills in the macroblocks no slice covered (saves two passes over 0.8 MB per 1080p picture) */
     d->coef_blocks = 0;
+    d->coef_cap_blocks = n * 27u + 2u;          /* the share of job_capacity() */
     d->n_inter = d->n_intra = 0;
     d->job_open = 1;
     return 0;
@@ -142,7 +145,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
         FjMbRec *r = &recs[a];
         any_dbk |= r->dbk;
         cls[a] = 0;
-        if (r->kind == FJ_MB_ABSENT) n_absent++;
+        if (r->kind == FJ_MB_ABSENT || r->kind == FJ_MB_STALE) n_absent++;
         else if (r->kind == FJ_MB_CONCEAL_I) n_conceal++;
         else if (in_intra_schedule(r->kind)) {
             const uint32_t x = a % w, y = a / w;
@@ -394,6 +397,7 @@ static int activate_param_sets(HostDec *d, uint32_t pps_id, int is_idr)
         d->mb = (MbInfo *)calloc(d->pic_size_mbs, sizeof(MbInfo));
         free(d->mb_decoded);
         free(d->mb_slice_id);
+        free(d->mb_ghost); d->mb_ghost = NULL; d->ghost_dirty = 0; d->ghost_len = 0;
         d->mb_decoded = (uint8_t *)calloc(d->pic_size_mbs, 1);
         d->mb_slice_id = (uint32_t *)calloc(d->pic_size_mbs, sizeof(uint32_t));
         d->slice_group_map = (uint32_t *)calloc(d->pic_size_mbs, sizeof(uint32_t));
@@ -488,6 +492,9 @@ static void reset_picture_state(HostDec *d)
     d->slice_id = 0;
     memset(d->mb_decoded, 0, d->pic_size_mbs);
     memset(d->mb_slice_id, 0, (size_t)d->pic_size_mbs * sizeof(uint32_t));
+    if (d->ghost_dirty && d->mb_ghost) memset(d->mb_ghost, 0, d->pic_size_mbs);
+    d->ghost_dirty = d->ghost_needed = 0;
+    d->ghost_len = 0;
 }
 
 /* ---------------------------------------------------------------- parameter set storage */
@@ -523,6 +530,100 @@ static int store_pps(HostDec *d, Pps *p)
 }
 
 /* ---------------------------------------------------------------- error handling: lost macroblocks */
+/* Ghost pixels.  The reference reconstructs every macroblock while it parses, so when a slice fails and
+ * h264bsdMarkSliceCorrupted un-decodes its macroblocks, their PIXELS stay in the frame buffer.  Concealment overwrites
+ * them at the end of the access unit — except where a later slice leaves a macroblock "decoded" without ever writing it
+ * (FJ_MB_STALE, hd_mb.c): that macroblock shows what the rolled-back slice had put there.  Here pixels are made from
+ * the finished frame job, so the rolled-back slice has to be kept: every macroblock it had decoded (the ones that
+ * stay decoded too: intra prediction inside the slice reads them) is copied into a side store, and if at the end of
+ * the picture a stale macroblock sits on such pixels the stored slices are submitted as reconstruction-only frame jobs
+ * (FjHeader.ghost) in front of the picture's own job, into the same DPB slot.  Costs nothing on intact streams. */
+static int makes_pixels(int kind)
+{
+    return kind == FJ_MB_INTER || kind == FJ_MB_I4x4 || kind == FJ_MB_I16x16 || kind == FJ_MB_IPCM;
+}
+static uint32_t rec_blocks(const FjMbRec *r)
+{
+    return r->kind == FJ_MB_IPCM ? 12u : (uint32_t)__builtin_popcount(r->coded & 0x03FFFFFFu);
+}
+typedef struct GhostMb { uint32_t addr, n_blocks; FjMbRec rec; int16_t mv[32]; } GhostMb;   /* + n_blocks * 32 bytes */
+
+static void ghost_store_slice(HostDec *d, uint32_t sid)
+{
+    const FjHeader *h = (const FjHeader *)d->job;
+    const FjMbRec *recs = (const FjMbRec *)(d->job + h->rec_off);
+    const uint32_t n = d->pic_size_mbs;
+    size_t need = sizeof(uint32_t);
+    uint32_t count = 0;
+    for (uint32_t a = 0; a < n; a++)
+        if (d->mb_slice_id[a] == sid && d->mb_decoded[a] == 1 && makes_pixels(recs[a].kind)) {
+            need += sizeof(GhostMb) + (size_t)rec_blocks(&recs[a]) * 32u;
+            count++;
+        }
+    if (!count) return;
+    /* bounded: a hostile stream can repeat a failing slice of skipped macroblocks for a few bytes each */
+    if (d->ghost_len + need > 4u * (size_t)job_capacity(n)) return;
+    if (!d->mb_ghost) d->mb_ghost = (uint8_t *)calloc(n, 1);
+    if (d->ghost_len + need > d->ghost_cap) {
+        const size_t cap = (d->ghost_len + need) * 2;
+        uint8_t *nb = (uint8_t *)realloc(d->ghost_buf, cap);
+        if (!nb) return;                              /* out of memory: the deviation is harmless, the stream is damaged */
+        d->ghost_buf = nb; d->ghost_cap = cap;
+    }
+    if (!d->mb_ghost) return;
+    uint8_t *p = d->ghost_buf + d->ghost_len;
+    memcpy(p, &count, sizeof(count)); p += sizeof(count);
+    for (uint32_t a = 0; a < n; a++)
+        if (d->mb_slice_id[a] == sid && d->mb_decoded[a] == 1 && makes_pixels(recs[a].kind)) {
+            GhostMb g;
+            g.addr = a; g.n_blocks = rec_blocks(&recs[a]); g.rec = recs[a];
+            memcpy(g.mv, d->job + h->mv_off + (size_t)a * 64u, 64);
+            memcpy(p, &g, sizeof(g)); p += sizeof(g);
+            memcpy(p, d->job + h->coef_off + (size_t)recs[a].coef_idx * 32u, (size_t)g.n_blocks * 32u);
+            p += (size_t)g.n_blocks * 32u;
+        }
+    d->ghost_len = (size_t)(p - d->ghost_buf);
+}
+
+/* one reconstruction-only frame job per stored slice, in the order in which they were decoded */
+static int ghost_submit(HostDec *d)
+{
+    const FjHeader *mh = (const FjHeader *)d->job;
+    const uint32_t n = d->pic_size_mbs, cap = job_capacity(n);
+    uint8_t *blob = (uint8_t *)malloc(cap);
+    if (!blob) return -1;
+    int rc = 0;
+    for (const uint8_t *p = d->ghost_buf, *end = d->ghost_buf + d->ghost_len; p < end && !rc;) {
+        uint32_t count, blocks = 0;
+        memcpy(&count, p, sizeof(count)); p += sizeof(count);
+        FjHeader *h = (FjHeader *)blob;
+        memset(h, 0, sizeof(*h));
+        h->magic = FJ_MAGIC; h->width_mbs = mh->width_mbs; h->height_mbs = mh->height_mbs; h->n_mbs = n;
+        h->rec_off = 128; h->mv_off = h->rec_off + n * 32u; h->coef_off = h->mv_off + n * 64u;
+        FjMbRec *recs = (FjMbRec *)(blob + h->rec_off);
+        memset(recs, 0, (size_t)n * 32u);
+        for (uint32_t a = 0; a < n; a++) recs[a].kind = FJ_MB_ABSENT;
+        memset(blob + h->mv_off, 0, (size_t)n * 64u);
+        for (uint32_t i = 0; i < count; i++) {
+            GhostMb g;
+            memcpy(&g, p, sizeof(g)); p += sizeof(g);
+            g.rec.coef_idx = blocks;
+            g.rec.dbk = 0;                           /* deblocking happens once, on the picture's own job */
+            recs[g.addr] = g.rec;
+            memcpy(blob + h->mv_off + (size_t)g.addr * 64u, g.mv, 64);
+            memcpy(blob + h->coef_off + (size_t)blocks * 32u, p, (size_t)g.n_blocks * 32u);
+            p += (size_t)g.n_blocks * 32u;
+            blocks += g.n_blocks;
+        }
+        if (fj_finalize(blob, cap, blocks)) { rc = -1; break; }
+        h->cur_slot = mh->cur_slot; h->n_slots = mh->n_slots; h->is_idr = mh->is_idr; h->pic_seq = mh->pic_seq;
+        h->ghost = 1;
+        if (d->sink.submit && d->sink.submit(d->sink.user, blob, h->total_bytes)) rc = -1;
+    }
+    free(blob);
+    return rc;
+}
+
 /* A slice whose data failed to parse: un-decode its macroblocks from the failure point back (an I slice keeps
  * everything up to max(width,10) macroblocks before the last good one, a P slice loses everything) and to its end
  * — reference h264bsdMarkSliceCorrupted, src/h264bsd_slice_data.c:298-354. */
@@ -540,13 +641,24 @@ static void mark_slice_corrupted(HostDec *d, uint32_t first_mb)
         }
         addr = i;
     }
-    if (getenv("HD_TRACE")) fprintf(stderr, "TRACE corrupt: first %u last %u start %u sid %u\n", first_mb, d->last_mb_addr, addr, sid);
+    if (hd_trace) fprintf(stderr, "TRACE corrupt: first %u last %u start %u sid %u\n", first_mb, d->last_mb_addr, addr, sid);
+    ghost_store_slice(d, sid);
+    /* The coefficient blocks of the macroblocks that become undecoded are reclaimed: they were appended in decoding
+     * order behind those of the macroblocks that stay (redundant re-decodes append nothing), so the section is cut at
+     * the first of them.  Without this a stream that repeats broken slices over the same macroblocks could grow the
+     * section past what job_capacity() reserves (27 blocks per macroblock). */
+    uint32_t cut = d->coef_blocks;
     do {
-        if (getenv("HD_TRACE")) fprintf(stderr, "TRACE   mb %u sid %u decoded %u\n", addr, d->mb_slice_id[addr], d->mb_decoded[addr]);
+        if (hd_trace) fprintf(stderr, "TRACE   mb %u sid %u decoded %u\n", addr, d->mb_slice_id[addr], d->mb_decoded[addr]);
         if (d->mb_slice_id[addr] != sid || !d->mb_decoded[addr]) break;
-        if (--d->mb_decoded[addr] == 0) recs[addr].kind = FJ_MB_ABSENT;
+        if (--d->mb_decoded[addr] == 0) {
+            if (recs[addr].kind != FJ_MB_ABSENT && recs[addr].coef_idx < cut) cut = recs[addr].coef_idx;
+            if (d->mb_ghost && makes_pixels(recs[addr].kind)) { d->mb_ghost[addr] = 1; d->ghost_dirty = 1; }
+            recs[addr].kind = FJ_MB_ABSENT;
+        }
         addr = hd_next_mb_in_group(d->slice_group_map, d->pic_size_mbs, addr);
     } while (addr);
+    d->coef_blocks = cut;
 }
 
 /* Plan the concealment of every macroblock that is still not decoded when the access unit ends — reference
@@ -567,7 +679,7 @@ static uint32_t plan_concealment(HostDec *d, int p_type)
         for (uint32_t i = 0; i < 16 && ref_slot < 0; i++) ref_slot = hd_dpb_ref_slot(&d->dpb, i);
     uint32_t first = 0;
     while (first < n && !d->mb_decoded[first]) first++;
-    if (getenv("HD_TRACE")) { fprintf(stderr, "TRACE conceal p_type %d ref %d decoded:", p_type, ref_slot); for (uint32_t a = 0; a < n; a++) fprintf(stderr, " %u", d->mb_decoded[a]); fprintf(stderr, "\n"); }
+    if (hd_trace) { fprintf(stderr, "TRACE conceal p_type %d ref %d decoded:", p_type, ref_slot); for (uint32_t a = 0; a < n; a++) fprintf(stderr, " %u", d->mb_decoded[a]); fprintf(stderr, "\n"); }
     uint32_t seq = 0, count = 0;
 
 #define CONCEAL_ONE(a_, whole_) do { \
@@ -599,6 +711,7 @@ static uint32_t plan_concealment(HostDec *d, int p_type)
             for (uint32_t a = 0; a < n; a++) CONCEAL_ONE(a, 1);
         } else {
             /* constant 128: every macroblock is an I_PCM that reads the same twelve blocks of 0x80 bytes */
+            d->coef_blocks = 0;                      /* no macroblock is left that owns a coefficient block */
             uint8_t *grey = d->job + h->coef_off + (size_t)d->coef_blocks * 32u;
             memset(grey, 128, 384);
             for (uint32_t a = 0; a < n; a++) {
@@ -741,6 +854,7 @@ int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, 
             if (hd_dpb_alloc_current(&d->dpb) < 0) ERR_RETURN;
             if (hd_job_begin(d)) return HD_MEMALLOC_ERROR;
         }
+        if (hd_trace) fprintf(stderr, "TRACE slice nal %d first_mb %u is_p %d frame_num %u start_of_picture %d redundant %u\n", nal_type, sh.first_mb, sh.is_p, sh.frame_num, start_of_picture, sh.redundant_pic_cnt);
         d->slice = sh;
         d->valid_slice_in_au = 1;
         d->cur_nal_type = (uint8_t)nal_type;
@@ -764,6 +878,7 @@ int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, 
      * deblocking (decoder.c:473-510) */
     const int is_idr = d->cur_nal_type == 5;
     if (hd_job_finish(d, is_idr)) ERR_RETURN;
+    if (d->ghost_needed && ghost_submit(d)) ERR_RETURN;
     if (d->sink.submit && d->sink.submit(d->sink.user, d->job, ((FjHeader *)d->job)->total_bytes)) {
         fprintf(stderr, "h264bsd-mi355x: frame job submission failed\n");
         ERR_RETURN;

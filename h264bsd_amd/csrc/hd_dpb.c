@@ -393,7 +393,7 @@ int hd_dpb_mark_current(Dpb *d, const SliceHdr *sh, int is_ref_pic, int is_idr, 
             if (bump_one(d)) break;
     }
     sort_positions(d);
-    if (getenv("HD_TRACE")) {
+    if (hd_trace) {
         fprintf(stderr, "TRACE dpb size %u full %u numRef %u numOut %u:", d->dpb_size, d->fullness, d->num_ref_frames, d->n_out);
         for (uint32_t i = 0; i <= d->dpb_size; i++)
             if (d->pic[i].status || d->pic[i].to_be_displayed)

@@ -43,6 +43,7 @@ typedef struct MbCtx {
     uint32_t addr, mbx, mby;
     MbInfo *cur, *A, *B, *C, *D;   /* NULL when outside the picture or another slice */
     uint16_t done;                 /* raster bit per 4x4 block of cur whose mv/ref is final */
+    uint32_t coef_start;           /* first coefficient block of this macroblock */
     int p2err;                     /* an error the reference only finds when it RECONSTRUCTS the macroblock
                                       (h264bsdDecodeMacroblock: missing reference picture, motion vector range, intra
                                       mode without its neighbours) — i.e. after the whole macroblock_layer() has been
@@ -155,8 +156,8 @@ static int resolve_ref(MbCtx *c, int quadrant, int ref_idx)
 /* error exits below report where they happened when HD_TRACE is set in the environment (debugging aid) */
 #include <stdio.h>
 #include <stdlib.h>
-#define FAIL do { if (getenv("HD_TRACE")) fprintf(stderr, "TRACE hd_mb fail at line %d\n", __LINE__); return -1; } while (0)
-#define P2ERR(c_) do { if (getenv("HD_TRACE")) fprintf(stderr, "TRACE hd_mb p2err at line %d\n", __LINE__); (c_)->p2err = 1; } while (0)
+#define FAIL do { if (hd_trace) fprintf(stderr, "TRACE hd_mb fail at line %d\n", __LINE__); return -1; } while (0)
+#define P2ERR(c_) do { if (hd_trace) fprintf(stderr, "TRACE hd_mb p2err at line %d\n", __LINE__); (c_)->p2err = 1; } while (0)
 
 static uint32_t read_te(BitReader *br, uint32_t n_active)
 {
@@ -273,8 +274,12 @@ static int parse_i4_modes(MbCtx *c)
 }
 
 /* ---------------------------------------------------------------- residual, 7.3.5.3 */
+/* The coefficient section holds job_capacity()'s 27 blocks per macroblock (+2).  A macroblock owns at most 26 live
+ * blocks and dead ones are reclaimed (decode_mb on failure, mark_slice_corrupted), so a valid stream never gets
+ * near the end; the check keeps a hostile one (slices repeated over the same macroblocks) inside the buffer. */
 static inline int16_t *next_block(HostDec *d, int16_t *coefs)
 {
+    if (d->coef_blocks >= d->coef_cap_blocks) return NULL;
     int16_t *p = coefs + 16u * d->coef_blocks;
     memset(p, 0, 32);
     return p;
@@ -290,14 +295,16 @@ static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, ui
 
     if (is_i16) {
         int16_t *blk = next_block(d, coefs);
-        n = hd_cavlc_block(br, nc_luma(c, 0), 16, blk);
+        if (!blk) FAIL;
+        n = hd_cavlc_block(br, nc_luma(c, 0), 16, blk, NULL);
         if (n < 0) FAIL;
         if (n) { coded |= FJ_CODED_LUMA_DC; d->coef_blocks++; }
     }
     for (int z = 0; z < 16; z++) {
         if (!(cbp & (1u << (z >> 2)))) { m->tc[z] = 0; continue; }
         int16_t *blk = next_block(d, coefs);
-        n = hd_cavlc_block(br, nc_luma(c, z), is_i16 ? 15 : 16, blk);
+        if (!blk) FAIL;
+        n = hd_cavlc_block(br, nc_luma(c, z), is_i16 ? 15 : 16, blk, NULL);
         if (n < 0) FAIL;
         m->tc[z] = (uint8_t)n;
         if (n) { coded |= 1u << z; d->coef_blocks++; }
@@ -305,19 +312,39 @@ static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, ui
     memset(m->tc + 16, 0, 8);
     if (cbp & 0x30) {
         int16_t *blk = next_block(d, coefs);
-        int n0 = hd_cavlc_block(br, -1, 4, blk);
+        if (!blk) FAIL;
+        int n0 = hd_cavlc_block(br, -1, 4, blk, NULL);
         if (n0 < 0) FAIL;
-        int n1 = hd_cavlc_block(br, -1, 4, blk + 4);
+        int n1 = hd_cavlc_block(br, -1, 4, blk + 4, NULL);
         if (n1 < 0) FAIL;
         if (n0 || n1) { coded |= FJ_CODED_CHROMA_DC; d->coef_blocks++; }
     }
     if (cbp & 0x20) {
         for (int k = 0; k < 8; k++) {
             int16_t *blk = next_block(d, coefs);
-            n = hd_cavlc_block(br, nc_chroma(c, k >> 2, k & 3), 15, blk);
+            int spill;
+            if (!blk) FAIL;
+            n = hd_cavlc_block(br, nc_chroma(c, k >> 2, k & 3), 15, blk, &spill);
             if (n < 0) FAIL;
             m->tc[16 + k] = (uint8_t)n;
             if (n) { coded |= 1u << (16 + k); d->coef_blocks++; }
+            if (k == 7 && spill && is_i16) {
+                /* Damaged stream: the last Cr block put a level one element past its end, which in the reference's
+                 * residual_t is level[24][0] — the first Intra16x16 DC coefficient, parsed earlier
+                 * (macroblock_layer.c:720-792; hd_cavlc_block).  With a coded DC block the level replaces its first
+                 * coefficient before the DC transform; without one (totalCoeff[24] == 0) no transform runs and the
+                 * level IS the DC of luma block 0 (macroblock_layer.c:1366-1374). */
+                int16_t *first = coefs + 16u * c->coef_start;
+                if (coded & FJ_CODED_LUMA_DC) first[0] = (int16_t)spill;
+                else {
+                    if (d->coef_blocks >= d->coef_cap_blocks) FAIL;
+                    memmove(first + 16, first, (size_t)(d->coef_blocks - c->coef_start) * 32u);
+                    memset(first, 0, 32);
+                    first[0] = (int16_t)spill;
+                    d->coef_blocks++;
+                    coded |= FJ_CODED_LUMA_DC | FJ_CODED_LUMA_DC_RAW;
+                }
+            }
         }
     }
     *coded_out = coded;
@@ -351,8 +378,8 @@ static int intra_modes_have_neighbours(const FjMbRec *rec, const MbInfo *m, int 
 }
 
 /* ---------------------------------------------------------------- one macroblock */
-static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *pps, uint32_t addr,
-                     int skipped, int *qp)
+static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *pps, uint32_t addr,
+                          int skipped, int *qp)
 {
     FjHeader *hdr = (FjHeader *)d->job;
     FjMbRec *recs = (FjMbRec *)(d->job + hdr->rec_off);
@@ -362,6 +389,7 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
     MbCtx c;
     memset(&c, 0, sizeof(c));
     c.d = d; c.br = br; c.sh = sh; c.pps = pps;
+    c.coef_start = d->coef_blocks;
     c.addr = addr; c.mbx = addr % d->width_mbs; c.mby = addr / d->width_mbs;
     MbInfo *m = c.cur = &d->mb[addr];
     const uint32_t sid = d->slice_id;
@@ -402,6 +430,7 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
 
         if (itype == 25) {                                   /* I_PCM */
             while (br->pos & 7) if (br_get1(br)) FAIL;
+            if (d->coef_blocks + 12u > d->coef_cap_blocks) FAIL;
             uint8_t *dst = (uint8_t *)(coefs + 16u * d->coef_blocks);
             for (int i = 0; i < 384; i++) dst[i] = (uint8_t)br_get(br, 8);
             if (br_overrun(br)) FAIL;
@@ -461,11 +490,32 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
             m->qp = (uint8_t)*qp;
         }
     }
-    d->mb_decoded[addr]++;
+    if (d->mb_decoded[addr] != 255) d->mb_decoded[addr]++;   /* saturates: a hostile stream cannot wrap it back to "undecoded" */
+    /* residual outside [-512,511]: the reference's first check when it reconstructs the macroblock, redundant copies
+     * included (macroblock_layer.c:1090-1094 runs before the decoded > 1 tests of the prediction) */
+    if (!c.p2err && rec.coded && rec.kind != FJ_MB_IPCM) {
+        int qi = (int)m->qp + pps->chroma_qp_index_offset;
+        qi = qi < 0 ? 0 : qi > 51 ? 51 : qi;
+        if (hd_residual_out_of_range(coefs + 16u * coef_start, rec.coded, m->qp, qpc_table[qi], rec.kind == FJ_MB_I16x16))
+            P2ERR(&c);
+    }
     if (c.p2err) {
-        if (first_decode) {            /* counted as decoded, never reconstructed: an inert, defined record */
-            memset(&recs[addr], 0, sizeof(FjMbRec));
-            recs[addr].kind = FJ_MB_ABSENT;
+        if (first_decode) {
+            /* Counted as decoded, never reconstructed.  The reference has by now stored the macroblock type, the
+             * coefficient counts and the updated QP in its mbStorage_t (macroblock_layer.c:985-1046), and if the slice
+             * roll-back does not reach this macroblock h264bsdFilterPicture filters it with them: an intra macroblock
+             * keeps a record that says so (FJ_MB_STALE).  An inter macroblock is always rolled back with its P slice. */
+            FjMbRec keep;
+            memset(&keep, 0, sizeof(keep));
+            keep.kind = FJ_MB_ABSENT;
+            if (rec.kind == FJ_MB_I4x4 || rec.kind == FJ_MB_I16x16) {
+                keep.kind = FJ_MB_STALE;
+                keep.qp_y = m->qp;
+                keep.dbk = rec.dbk; keep.alpha_off = rec.alpha_off; keep.beta_off = rec.beta_off; keep.cqp_off = rec.cqp_off;
+                keep.coef_idx = coef_start;
+                if (d->mb_ghost && d->mb_ghost[addr]) d->ghost_needed = 1;   /* it shows what a rolled-back slice left there */
+            }
+            recs[addr] = keep;
             memset(mvs[addr], 0, 64);
         }
         FAIL;
@@ -496,6 +546,16 @@ static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *p
     }
     recs[addr] = rec;
     return 0;
+}
+
+/* Coefficient blocks of a macroblock that failed are given back: nothing refers to them (no record was written, or
+ * an inert one), and a hostile stream must not be able to grow the section by repeating broken slices. */
+static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *pps, uint32_t addr, int skipped, int *qp)
+{
+    const uint32_t coef_start = d->coef_blocks;
+    const int rc = decode_mb_body(d, br, sh, pps, addr, skipped, qp);
+    if (rc) d->coef_blocks = coef_start;
+    return rc;
 }
 
 /* ---------------------------------------------------------------- slice_data(), 7.3.4 */

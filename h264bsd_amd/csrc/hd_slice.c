@@ -89,10 +89,13 @@ int hd_parse_slice_header(BitReader *br, SliceHdr *sh, const Sps *sps, const Pps
         sh->reorder_flag = (uint8_t)br_get1(br);
         if (sh->reorder_flag) {
             for (;;) {
+                /* the reference counts the terminating command as well and tests BEFORE it reads the next one
+                 * (slice_header.c:496-501): at most num_ref_idx_active commands, the end marker no later than
+                 * position num_ref_idx_active */
+                if (sh->n_reorder > sh->num_ref_idx_active) return -1;
                 uint32_t idc = br_ue(br);
                 if (br_overrun(br) || idc > 3) return -1;
                 if (idc == 3) break;
-                if (sh->n_reorder > sh->num_ref_idx_active) return -1;
                 uint32_t v = br_ue(br);
                 if (idc < 2) { if (v >= sps->max_frame_num) return -1; v += 1; }
                 sh->reorder[sh->n_reorder].idc = (uint8_t)idc;

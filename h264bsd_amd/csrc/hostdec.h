@@ -277,8 +277,16 @@ typedef struct HostDec {
     uint8_t *job; uint32_t job_cap;
     uint8_t  job_from_sink;  /* job points into memory handed out by sink.acquire (not ours to free) */
     uint32_t coef_blocks;  /* blocks written so far */
+    uint32_t coef_cap_blocks; /* blocks the coefficient section of the job can hold */
     uint32_t n_inter, n_intra;
     uint8_t  job_open;
+
+    /* "ghost" pixels (damaged streams only, see hd_core.c mark_slice_corrupted): the macroblocks of slices that were
+     * rolled back after they had been reconstructed, kept so that their pixels can be reproduced if a macroblock that is
+     * never reconstructed (FJ_MB_STALE) ends up showing them */
+    uint8_t *ghost_buf; size_t ghost_len, ghost_cap;
+    uint8_t *mb_ghost;      /* per macroblock: pixels written by a slice that was rolled back; allocated on first use */
+    uint8_t  ghost_dirty, ghost_needed;
 
     JobSink sink;
     uint8_t  sink_configured;
@@ -312,11 +320,15 @@ int  hd_dpb_mark_current(Dpb *dpb, const SliceHdr *sh, int is_ref, int is_idr, i
 void hd_dpb_flush(Dpb *dpb);
 const OutPic *hd_dpb_next_output(Dpb *dpb);
 /* hd_cavlc.c */
+extern int hd_trace;   /* HD_TRACE in the environment, read once by hd_cavlc_init() (debugging aid) */
 void hd_cavlc_init(void);
 /* Decodes one residual block.  coef[] (raster 4x4 via zig-zag, or plain order for chroma DC) must
  * be zeroed by the caller; returns total_coeff or -1 on a bitstream error.
- * max_coeff: 16, 15 (AC: scan positions 1..15) or 4 (chroma DC, nc == -1). */
-int hd_cavlc_block(BitReader *br, int nc, int max_coeff, int16_t *coef);
+ * max_coeff: 16, 15 (AC: scan positions 1..15) or 4 (chroma DC, nc == -1).
+ * *spill (may be NULL): the level a damaged 15-coefficient block places one element past its end (else 0). */
+int hd_cavlc_block(BitReader *br, int nc, int max_coeff, int16_t *coef, int *spill);
+/* hd_resid.c */
+int hd_residual_out_of_range(const int16_t *blk, uint32_t coded, int qp_y, int qp_c, int is_i16);
 /* hd_mb.c */
 uint32_t hd_next_mb_in_group(const uint32_t *map, uint32_t n, uint32_t addr);
 int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_ref_idc);

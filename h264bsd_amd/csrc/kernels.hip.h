@@ -192,6 +192,7 @@ __device__ __forceinline__ void mb_residual_compute(uint32_t coded, int qp_y, in
                 }
             const int ls = c_level_scale[qp_y % 6][0], q6 = qp_y / 6;
             dc = q6 >= 2 ? (acc * ls) << (q6 - 2) : (acc * ls + (1 << (1 - q6))) >> (2 - q6);
+            if (coded & FJ_CODED_LUMA_DC_RAW) dc = coef[4 * by + bx];   /* wave-uniform; damaged streams only (framejob.h) */
         }
         unpack_row4(rows.y, ry);
         idct_quad(ry, q, qp_y, is_i16, dc);
@@ -368,7 +369,7 @@ __device__ __forceinline__ void chroma_pred2(const uint8_t *__restrict__ p, int 
 /* concealed macroblocks are filtered as Intra4x4 (reference src/h264bsd_conceal.c:309) */
 __device__ __forceinline__ bool is_intra_kind(int k)
 {
-    return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM || k == FJ_MB_CONCEAL_I || k == FJ_MB_CONCEAL_P;
+    return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM || k == FJ_MB_CONCEAL_I || k == FJ_MB_CONCEAL_P || k == FJ_MB_STALE;
 }
 
 __device__ __forceinline__ void wave_sync()

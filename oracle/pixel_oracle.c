@@ -113,7 +113,13 @@ static void mb_residual(const FjMbRec *r, const int16_t *coef_base, int *res_y, 
     int have_dcy = 0;
     memset(res_y, 0, 256 * sizeof(int));
     memset(res_c, 0, 128 * sizeof(int));
-    if (r->coded & FJ_CODED_LUMA_DC) { oracle_luma_dc(p, r->qp_y, dcy); p += 16; have_dcy = 1; }
+    if (r->coded & FJ_CODED_LUMA_DC) {
+        /* FJ_CODED_LUMA_DC_RAW (damaged streams only): the block already holds the DC values, reference
+         * macroblock_layer.c:1366-1374 with totalCoeff[24] == 0 */
+        if (r->coded & FJ_CODED_LUMA_DC_RAW) for (int i = 0; i < 16; i++) dcy[i] = p[i];
+        else oracle_luma_dc(p, r->qp_y, dcy);
+        p += 16; have_dcy = 1;
+    }
     for (int z = 0; z < 16; z++) {
         static const int16_t zero[16] = { 0 };
         const int bx = Z_X[z], by = Z_Y[z];
@@ -494,7 +500,7 @@ int oracle_recon(const uint8_t *blob, uint8_t *const *slots)
     for (uint32_t a = 0; a < h->n_mbs; a++) {
         const FjMbRec *r = &recs[a];
         const int mbx = (int)(a % h->width_mbs), mby = (int)(a / h->width_mbs);
-        if (r->kind == FJ_MB_ABSENT) continue;
+        if (r->kind == FJ_MB_ABSENT || r->kind == FJ_MB_STALE) continue;
         if (r->kind == FJ_MB_CONCEAL_I || r->kind == FJ_MB_CONCEAL_P) { n_conceal++; continue; }
         if (r->kind == FJ_MB_IPCM) {
             const u8 *s = (const u8 *)(coefs + 16 * (size_t)r->coef_idx);
@@ -553,7 +559,7 @@ static const u8 qpc_tab[52] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
 static inline int is_intra_kind(int k)
 {
     /* concealed macroblocks are filtered as Intra4x4 (reference conceal.c:309) */
-    return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM || k == FJ_MB_CONCEAL_I || k == FJ_MB_CONCEAL_P;
+    return k == FJ_MB_I4x4 || k == FJ_MB_I16x16 || k == FJ_MB_IPCM || k == FJ_MB_CONCEAL_I || k == FJ_MB_CONCEAL_P || k == FJ_MB_STALE;
 }
 
 /* boundary strength between the 4x4 block (qx,qy) of MB q and its left (dir 0) / upper (dir 1)

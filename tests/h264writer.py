@@ -321,7 +321,7 @@ class StreamWriter:
                       idc=(0,), p_pcm=0.0, constrained_intra=0, fmo=None, idr_period=0, poc_pattern=None, reorder=False,
                       mmco=False, chroma_qp_offset=0, p_intra_in_p=0.2, p_skip=0.3, log2_max_frame_num=4,
                       num_reorder_frames=None, max_qp=28, aso=False, non_ref_every=0, gaps=0,
-                      offset_non_ref=1, redundant=False, level=40, min_qp=6, huge_levels=False)
+                      offset_non_ref=1, redundant=False, level=40, min_qp=6, huge_levels=False, overflow=0.0)
         self.c.update(cfg)
         self.rng = np.random.default_rng(self.c["seed"])
         self.sps = dict(level=self.c["level"], poc_type=self.c["poc_type"], num_ref_frames=self.c["num_ref_frames"], wmb=self.c["wmb"], hmb=self.c["hmb"],
@@ -365,6 +365,14 @@ class StreamWriter:
         if self.qp > 28:            # keep the reconstructed residual inside [-512, 511] (reference transform.c:184-188)
             amp, big = 1, 0.0
             density *= 0.5 if self.qp <= 40 else 0.15
+        if self.c["overflow"] and self.qp >= 18 and r.random() < self.c["overflow"]:
+            # one level around the size at which the dequantised coefficient alone leaves the residual range
+            # [-512, 511]: the reference then fails the macroblock (transform.c:184-188) and conceals the slice.  Levels
+            # are drawn on both sides of the limit so that near misses are exercised as well.
+            limit = 32768 // (13 << (self.qp // 6))
+            pos = int(r.integers(0, n))
+            c[pos] = min(1500, max(1, int(limit * r.uniform(0.4, 1.6)))) * (1 if r.random() < 0.5 else -1)
+            return c
         if self.c["huge_levels"] and self.qp <= 6 and r.random() < 0.5:
             # level_prefix 14 / 15 escapes and suffixLength growth (9.2.2.1): one huge level (+ a few small ones behind
             # it in scan order); at QP <= 6 a single coefficient of this size still reconstructs inside [-512, 511]

@@ -13,6 +13,25 @@ from h264bsd_amd import capi
 from oracle import pyoracle
 
 
+_libc = ctypes.CDLL(None)
+M_PERTURB = -6      # <malloc.h>: every malloc'd block is filled with ~value (glibc)
+
+
+def reference_is_deterministic(data, no_output_reordering=0):
+    """The reference never initialises its frame buffers (src/h264bsd_dpb.c:1026 ALLOCATE, no memset), and on some
+    damaged streams it outputs macroblocks it never wrote (e.g. a macroblock whose reconstruction failed but which
+    h264bsdMarkSliceCorrupted does not reach).  Such output is whatever the heap held: undefined behaviour, not a
+    parity target.  Detected by decoding twice with glibc's M_PERTURB fill set to two different bytes."""
+    outs = []
+    for fill in (0x55, 0xAA):
+        _libc.mallopt(M_PERTURB, fill)
+        try:
+            outs.append(decode_reference(data, no_output_reordering))
+        finally:
+            _libc.mallopt(M_PERTURB, 0)
+    return outs[0] == outs[1]
+
+
 def decode_reference(data, no_output_reordering=0):
     """-> (trace, [(sha1 of frame, picId, isIdr, numErrMbs)])"""
     ref = pyoracle.RefDecoder()
