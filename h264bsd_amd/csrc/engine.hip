@@ -41,6 +41,7 @@
 namespace {
 
 struct PendingJob { uint8_t *host; uint32_t bytes, cap; };
+constexpr size_t MAX_QUEUED_PICTURES = 8;    /* per decoder instance, before sink_submit starts the device on its own */
 
 struct StreamCtx {
     uint32_t wmb = 0, hmb = 0, n_slots = 0, frame_bytes = 0;
@@ -382,8 +383,19 @@ int sink_submit(void *user, const uint8_t *blob, uint32_t bytes)
         memcpy(j.host, blob, bytes);
     }
     j.bytes = bytes;
-    std::lock_guard<std::mutex> ql(u->s->qmu);
-    u->s->pending.push_back(j);
+    size_t backlog;
+    {
+        std::lock_guard<std::mutex> ql(u->s->qmu);
+        u->s->pending.push_back(j);
+        backlog = u->s->pending.size();
+    }
+    /* An application that decodes without pulling pictures (frame skipping, decoding ahead) must not pile up pinned
+     * staging buffers (worst-case sized, ~8 MB each for 1080p): past a few queued pictures the queues are enqueued on
+     * the device — asynchronously, the caller does not wait for pixels — and the buffers recycle. */
+    if (backlog >= MAX_QUEUED_PICTURES) {
+        std::lock_guard<std::mutex> lk(u->e->mu);
+        if (flush_locked(u->e, false)) return -1;
+    }
     return 0;
 }
 

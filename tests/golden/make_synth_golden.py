@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import synth                      # noqa: E402
-from synth_configs import CONFIGS, DAMAGED, DAMAGED_BUNDLED  # noqa: E402
+from synth_configs import CONFIGS, DAMAGED, DAMAGED_BUNDLED, FLIPPED, OVERFLOW  # noqa: E402
 from damage import damage  # noqa: E402
 from h264writer import StreamWriter  # noqa: E402
 
@@ -30,6 +30,18 @@ for name, (cfg, dmg) in DAMAGED.items():
     trace, pics = synth.decode_reference(data)
     out[name] = dict(stream_sha1=hashlib.sha1(data).hexdigest(), bytes=len(data), trace=trace, pics=pics)
     print(name, len(data), "bytes", len(pics), "pictures", sum(p[3] for p in pics), "concealed macroblocks")
+undefined = {}
+for name, (cfg, dmg) in list(FLIPPED.items()) + list(OVERFLOW.items()):
+    data = damage(StreamWriter(**cfg).build(), **dmg)
+    if not synth.reference_is_deterministic(data):
+        undefined[name] = "reference output changes with the heap fill byte (glibc M_PERTURB 0x55 / 0xAA): it shows memory it never wrote"
+        print(name, "SKIPPED: reference output depends on uninitialised memory")
+        continue
+    trace, pics = synth.decode_reference(data)
+    out[name] = dict(stream_sha1=hashlib.sha1(data).hexdigest(), bytes=len(data), trace=trace, pics=pics)
+    print(name, len(data), "bytes", len(pics), "pictures", sum(p[3] for p in pics), "concealed macroblocks",
+          sum(1 for t in trace if t[0] == 3), "error calls")
+json.dump(undefined, open(os.path.join(HERE, "reference_undefined.json"), "w"), indent=0, sort_keys=True)
 for name, (stream, dmg) in DAMAGED_BUNDLED.items():
     data = damage(open(os.path.join(HERE, stream + ".h264"), "rb").read(), **dmg)
     trace, pics = synth.decode_reference(data)

@@ -44,8 +44,8 @@ for _s in range(160, 200):
 
 # ---- damaged streams: (writer keywords, damage keywords).  Slice NAL units are dropped or cut
 # short; the decoder must report the same errors, conceal the same macroblocks the same way and keep the same DPB
-# state as the reference.  Streams with redundant slices or bit flips are left out on purpose: there the reference's
-# own behaviour depends on stale metadata / out-of-bounds CAVLC writes ("known deviations").
+# state as the reference.  (This first set predates the bit-flip work and keeps its golden answers: no frame_num gaps,
+# no redundant slices, no flipped bits.  FLIPPED and OVERFLOW below add them.)
 def _damaged(seed):
     cfg = random_config(seed)
     cfg["gaps"] = 0
@@ -54,6 +54,35 @@ def _damaged(seed):
 
 
 DAMAGED = {f"damaged_{_s}": _damaged(_s) for _s in range(0, 48)}
+
+# ---- bit errors INSIDE slices (round 2).  One flipped bit per hit slice NAL unit, next to dropped and truncated ones:
+# the parser must accept exactly what the reference's CAVLC accepts (src/h264bsd_cavlc.c:749-916, including the
+# 15-coefficient block that runs one element past its end), fail at the same macroblock, roll back the same
+# macroblocks (src/h264bsd_slice_data.c:298-354, with its off-by-one start) and reproduce what the frame buffer then
+# shows.  frame_num gaps stay in; redundant slices are still left out ("known deviations").
+# Some damaged streams make the reference OUTPUT memory it never initialised (a macroblock it counts as decoded but
+# never wrote, in a frame buffer used for the first time): tests/golden/make_synth_golden.py finds those by decoding
+# with two different heap fill bytes and lists them in tests/golden/reference_undefined.json; they are skipped.
+def _flipped(seed):
+    cfg = random_config(seed)
+    cfg["redundant"] = False
+    return cfg, dict(seed=seed, p_drop=0.1, p_flip=0.3, p_trunc=0.1)
+
+
+FLIPPED = {f"flipped_{_s}": _flipped(_s) for _s in range(300, 364)}
+
+
+# ---- residual outside [-512, 511]: the only decode error the reference finds after dequantisation
+# (src/h264bsd_transform.c:184-188).  The writer plants levels on both sides of the limit; the stream itself is intact.
+def _overflow(seed):
+    cfg = random_config(seed)
+    cfg["redundant"] = False
+    cfg["overflow"] = 0.02
+    cfg["max_qp"] = max(cfg["max_qp"], 40)
+    return cfg, dict(seed=seed, p_drop=0.0, p_flip=0.0, p_trunc=0.0)
+
+
+OVERFLOW = {f"overflow_{_s}": _overflow(_s) for _s in range(400, 448)}
 
 # a bundled x264 stream (one slice per picture, 40x23 macroblocks) with slices cut short: concealment at picture scale
 DAMAGED_BUNDLED = {"damaged_bundled_640x360": ("test_640x360", dict(seed=7, p_drop=0.04, p_flip=0.0, p_trunc=0.3))}

@@ -59,3 +59,54 @@ def test_damaged_streams_never_crash(tmp_path, built):
         assert out.returncode == 0, f"seed {seed}: rc={out.returncode}\n{out.stderr[-1500:]}"
         tag, n, pics, errors = out.stdout.split()[-4:]
         assert tag == "OK" and int(n) == 60 and int(errors) > 0
+
+
+REPEAT_CHILD = textwrap.dedent("""
+    import ctypes, sys
+    sys.path.insert(0, %r)
+    import h264bsd_amd
+    data = open(%r + "/tests/golden/test_640x360.h264", "rb").read()
+    starts = []
+    i = data.find(b"\\x00\\x00\\x00\\x01")
+    while i >= 0:
+        starts.append(i)
+        i = data.find(b"\\x00\\x00\\x00\\x01", i + 4)
+    starts.append(len(data))
+    worst = 0
+    for k in range(len(starts) - 1):
+        nal = data[starts[k]:starts[k + 1]]
+        if nal[4] & 31 != 1 or k < 8:
+            continue
+        for frac in (0.25, 0.5, 0.75):
+            cut = nal[: max(8, int(len(nal) * frac))]
+            d = data[:starts[k]] + cut * 400 + data[starts[k + 1]:starts[k + 3]]
+            jobs = []
+            dec = h264bsd_amd.Decoder(capture=jobs.append)
+            buf = ctypes.create_string_buffer(d, len(d))
+            base, off, stuck, guard = ctypes.addressof(buf), 0, 0, 0
+            while off < len(d) and guard < 5000:
+                guard += 1
+                r, rb = dec.decode(base + off, len(d) - off)
+                stuck = stuck + 1 if rb == 0 else 0
+                if stuck > 3:
+                    off += 1; stuck = 0
+                off += rb
+            dec.close()
+            for j in jobs:
+                h = h264bsd_amd.job_header(j)
+                assert h["n_coef_blocks"] <= 27 * h["n_mbs"] + 2, (k, frac, h["n_coef_blocks"])
+                worst = max(worst, h["n_coef_blocks"])
+        if k > 14:
+            break
+    print("OK", worst)
+""") % (ROOT, ROOT)
+
+
+def test_repeated_truncated_slices_stay_inside_the_coefficient_section(tmp_path, built):
+    """A slice NAL unit cut short and repeated 400 times: its macroblocks are decoded, rolled back and decoded again.
+    The coefficient blocks of rolled-back macroblocks are reclaimed (hd_core.c mark_slice_corrupted, hd_mb.c decode_mb)
+    and the section is bounds-checked (next_block) — round 1 overran the pinned staging buffer here."""
+    script = tmp_path / "repeat_child.py"
+    script.write_text(REPEAT_CHILD)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.split()[-2] == "OK", out.stderr[-1500:]

@@ -109,26 +109,28 @@ def _live_sweep(first, count, damaged, backend):
     from h264writer import random_config
     if not os.path.exists(pyoracle.REF_SO):
         pytest.skip("oracle/_ref not built")
-    bad = []
+    bad, undefined = [], []
     for seed in range(first, first + count):
         cfg = random_config(seed)
         if damaged:
-            cfg["gaps"], cfg["redundant"] = 0, False          # as synth_configs._damaged (known deviations)
+            cfg["redundant"] = False                          # redundant slices + damage: known deviation, DESIGN.md §2
         data = StreamWriter(**cfg).build()
         if damaged:
-            data = dmg.damage(data, seed, p_drop=0.2, p_flip=0.0, p_trunc=0.2)
+            data = dmg.damage(data, seed, p_drop=0.15, p_flip=0.25, p_trunc=0.15)
         nor = 0 if damaged else seed & 1
         if synth.decode_reference(data, nor) != synth.decode_ours(data, backend, nor):
-            bad.append(seed)
+            # not a mismatch when the reference itself shows memory it never wrote (synth.reference_is_deterministic)
+            (bad if synth.reference_is_deterministic(data, nor) else undefined).append(seed)
     assert not bad, f"seeds {bad} differ from the reference"
+    assert len(undefined) <= count // 5, f"suspiciously many streams with undefined reference output: {undefined}"
 
 
 def test_random_streams_match_live_reference(built):
     _live_sweep(91000, 40, False, "oracle")
-    _live_sweep(91500, 30, True, "oracle")
+    _live_sweep(91500, 60, True, "oracle")
 
 
 @pytest.mark.gpu
 def test_gpu_random_streams_match_live_reference(built):
     _live_sweep(92000, 120, False, "gpu")
-    _live_sweep(92500, 80, True, "gpu")
+    _live_sweep(92500, 160, True, "gpu")
