@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdCroppingParams", "h264bsdSampleAspectRatio", "h264bsdCheckValidParamSets", "h264bsdFlushBuffer",
     "h264bsdProfile", "h264bsdAlloc", "h264bsdFree", "h264bsdConvertToRGBA", "h264bsdConvertToBGRA",
     "h264bsdConvertToYCbCrA",
-    "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync",
+    "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync", "h264bsdmiDeviceErrors",
     "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads",
     "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
@@ -143,6 +143,13 @@ def lib():
 
 def device_count():
     return int(lib().h264bsdmiDeviceCount())
+
+
+def device_errors():
+    """sticky DEVERR_* bits of the engine (0 = none): tripwires of the kernels that must never fire"""
+    L = lib()
+    L.h264bsdmiDeviceErrors.restype = ctypes.c_uint
+    return int(L.h264bsdmiDeviceErrors())
 
 
 class Decoder:

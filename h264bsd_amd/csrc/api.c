@@ -21,7 +21,7 @@
 
 HostDec *hd_create(int no_output_reordering);
 void hd_destroy(HostDec *d);
-int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes);
+int hd_decode(HostDec *d, uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes);
 
 typedef struct ApiDec {
     HostDec *hd;

@@ -49,6 +49,7 @@ struct StreamCtx {
     uint8_t *d_dbk = nullptr;
     uint8_t *h_frame[FJ_MAX_SLOTS] = {};
     uint32_t *h_conv = nullptr, *d_conv = nullptr;
+    uint8_t *d_planar = nullptr;            /* a picture on its way out: tiles -> the reference's planar I420 (k_detile) */
     std::mutex qmu;                         /* guards pending / free_bufs (submit runs on the caller's threads) */
     PendingJob acquired = { nullptr, 0, 0 };   /* staging buffer the parser is currently filling (sink_acquire) */
     std::deque<PendingJob> pending;
@@ -73,9 +74,13 @@ struct Engine {
     std::vector<std::pair<StreamCtx *, PendingJob>> inflight;   /* staging buffers of enqueued, unfinished ticks */
     hipEvent_t inflight_done = nullptr;
     SideLane side;
+    /* device error word (DEVERR_* bits, kernels.hip.h): the kernels OR into d_err, poll_errors() folds it into `errors`
+     * whenever the host has waited for the device anyway */
+    uint32_t *d_err = nullptr, *h_err = nullptr;
+    uint32_t errors = 0;
 };
 
-unsigned long long *g_tail_prof = nullptr;   /* debug: per-wave cycle accounting of k_frame_tail (block 0) */
+unsigned long long *g_tail_prof = nullptr;   /* debug: per-wave cycle accounting of the per-picture kernels (block 0) */
 Engine *g_engine = nullptr;
 std::mutex g_engine_mu;
 int g_device_request = -1;
@@ -97,7 +102,10 @@ Engine *engine_get()
         hipStreamCreateWithFlags(&e->side.stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->side.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->side.join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->side.join_copy, hipEventDisableTiming) != hipSuccess) { delete e; return nullptr; }
+        hipEventCreateWithFlags(&e->side.join_copy, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void **)&e->d_err, 256) != hipSuccess || hipMemset(e->d_err, 0, 256) != hipSuccess ||
+        hipHostMalloc((void **)&e->h_err, 64, hipHostMallocDefault) != hipSuccess) { delete e; return nullptr; }
+    *e->h_err = 0;
     g_engine = e;
     return e;
 }
@@ -132,6 +140,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     d.wmb = h->width_mbs;
     d.hmb = h->height_mbs;
     d.any_deblock = h->any_deblock;
+    d.err = g_engine ? g_engine->d_err : nullptr;
     for (uint32_t k = 0; k < FJ_MAX_SLOTS; k++) d.slot[k] = k < h->n_slots ? dev_frames + (size_t)k * frame_bytes : nullptr;
     if (shape) {
         shape->n_frames++;
@@ -225,12 +234,27 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     return 0;
 }
 
+/* Fold the device error word into the engine's sticky error bits.  Called where the host waits for the stream anyway. */
+int poll_errors(Engine *e)
+{
+    HIP_TRY(hipMemcpyAsync(e->h_err, e->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const uint32_t fresh = *e->h_err & ~e->errors;
+    if (fresh) {
+        fprintf(stderr, "h264bsd-mi355x: DEVICE ERROR 0x%x:%s%s%s — pixels of the affected pictures are not trustworthy\n", fresh,
+                (fresh & DEVERR_RESIDUAL_RANGE) ? " residual outside [-512,511] reached the kernels (host check missed it)" : "",
+                (fresh & DEVERR_INTRA_SCHED) ? " k_frame_intra scheduler gave up" : "", (fresh & DEVERR_DBK_SCHED) ? " k_frame_dbk scheduler gave up" : "");
+        e->errors |= fresh;
+    }
+    return 0;
+}
+
 /* ---- lazy execution of the queued jobs of all decoder instances ---- */
 /* Recycle the pinned staging buffers of ticks whose copies have completed (all of them after wait != 0). */
 int reap_locked(Engine *e, bool wait)
 {
     if (e->inflight.empty()) return 0;
-    if (wait) HIP_TRY(hipStreamSynchronize(e->stream));
+    if (wait) { if (poll_errors(e)) return -1; }
     else if (hipEventQuery(e->inflight_done) != hipSuccess) return 0;
     for (auto &f : e->inflight) {
         std::lock_guard<std::mutex> ql(f.first->qmu);
@@ -311,7 +335,8 @@ void stream_release(StreamCtx *s)
     for (auto &p : s->h_frame) if (p) { hipHostFree(p); p = nullptr; }
     if (s->h_conv) hipHostFree(s->h_conv);
     if (s->d_conv) hipFree(s->d_conv);
-    s->d_frames = nullptr; s->h_conv = nullptr; s->d_conv = nullptr;
+    if (s->d_planar) hipFree(s->d_planar);
+    s->d_frames = nullptr; s->h_conv = nullptr; s->d_conv = nullptr; s->d_planar = nullptr;
 }
 
 int sink_configure(void *user, uint32_t wmb, uint32_t hmb, uint32_t n_slots)
@@ -406,8 +431,10 @@ uint8_t *sink_fetch(void *user, uint32_t slot)
     StreamCtx *s = u->s;
     if (slot >= s->n_slots || flush_locked(u->e)) return nullptr;
     if (!s->h_frame[slot] && hipHostMalloc((void **)&s->h_frame[slot], s->frame_bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-    if (hipMemcpyAsync(s->h_frame[slot], s->d_frames + (size_t)slot * s->frame_bytes, s->frame_bytes,
-                       hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
+    if (!s->d_planar && hipMalloc((void **)&s->d_planar, s->frame_bytes) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(h264k::k_detile, dim3(512, 1), dim3(256), 0, u->e->stream, s->d_frames + (size_t)slot * s->frame_bytes,
+                       s->d_planar, s->wmb, s->hmb, (size_t)0, (size_t)0);
+    if (hipMemcpyAsync(s->h_frame[slot], s->d_planar, s->frame_bytes, hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
     if (hipStreamSynchronize(u->e->stream) != hipSuccess) return nullptr;
     return s->h_frame[slot];
 }
@@ -423,7 +450,7 @@ uint32_t *sink_fetch_converted(void *user, uint32_t slot, int fmt)
     if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
     if (!s->h_conv && hipHostMalloc((void **)&s->h_conv, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(h264k::k_convert, dim3(1024, 1), dim3(256), 0, u->e->stream,
-                       s->d_frames + (size_t)slot * s->frame_bytes, s->d_conv, w, h, fmt, (size_t)0, (size_t)0);
+                       s->d_frames + (size_t)slot * s->frame_bytes, s->d_conv, w, h, fmt, (size_t)0, (size_t)0, 1);
     if (hipMemcpyAsync(s->h_conv, s->d_conv, bytes, hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
     if (hipStreamSynchronize(u->e->stream) != hipSuccess) return nullptr;
     return s->h_conv;
@@ -438,15 +465,20 @@ void *sink_fetch_device(void *user, uint32_t slot, int fmt, uint32_t x0, uint32_
     const uint32_t fw = s->wmb * 16, fh = s->hmb * 16;
     if (!w || !h || x0 + w > fw || y0 + h > fh) return nullptr;
     uint8_t *frame = s->d_frames + (size_t)slot * s->frame_bytes;
-    void *ret = frame;
-    if (!(fmt == 3 && x0 == 0 && y0 == 0 && w == fw && h == fh)) {          /* anything but the zero-copy case */
-        const size_t bytes = (size_t)fw * fh * 4;
-        if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
-        const uint32_t n = fmt == 3 ? w * h * 3 / 2 : w * h;
-        hipLaunchKernelGGL(h264k::k_output, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, u->e->stream,
+    void *ret;
+    /* frames are macroblock tiles in HBM: every picture that leaves is laid out by a kernel, the whole uncropped I420
+     * frame by k_detile, everything else (window, conversion) by k_output */
+    const size_t bytes = (size_t)fw * fh * 4;
+    if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
+    if (fmt == 3 && x0 == 0 && y0 == 0 && w == fw && h == fh) {
+        hipLaunchKernelGGL(h264k::k_detile, dim3(512, 1), dim3(256), 0, u->e->stream, frame, reinterpret_cast<uint8_t *>(s->d_conv),
+                           s->wmb, s->hmb, (size_t)0, (size_t)0);
+    } else {
+        const uint32_t n = fmt == 3 ? w * h * 3 / 8 : w * h / 4;
+        hipLaunchKernelGGL(h264k::k_output, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 + 1 : 2048), dim3(256), 0, u->e->stream,
                            frame, reinterpret_cast<uint8_t *>(s->d_conv), fw, fh, fmt, x0, y0, w, h);
-        ret = s->d_conv;
     }
+    ret = s->d_conv;
     if (hipStreamSynchronize(u->e->stream) != hipSuccess) return nullptr;
     if (stream) *stream = u->e->stream;
     return ret;
@@ -512,7 +544,7 @@ void eng_convert_host(int fmt, uint32_t width, uint32_t height, const uint8_t *d
     }
     if (hipMemcpyAsync(e->conv_in, data, in_b, hipMemcpyHostToDevice, e->stream) != hipSuccess) return;
     hipLaunchKernelGGL(h264k::k_convert, dim3(1024, 1), dim3(256), 0, e->stream, e->conv_in, e->conv_out, width, height, fmt,
-                       (size_t)0, (size_t)0);
+                       (size_t)0, (size_t)0, 0);
     if (hipMemcpyAsync(out, e->conv_out, out_b, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return;
     hipStreamSynchronize(e->stream);
 }
@@ -530,6 +562,15 @@ int h264bsdmiSetDevice(int device)
     if (g_engine) return g_engine->device == device ? 0 : -1;   /* engine already bound */
     g_device_request = device;
     return 0;
+}
+
+unsigned h264bsdmiDeviceErrors(void)
+{
+    Engine *e = engine_get();
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (hipSetDevice(e->device) != hipSuccess || poll_errors(e)) return 0xFFFFFFFFu;
+    return e->errors;
 }
 
 int h264bsdmiFlush(void)
@@ -559,6 +600,7 @@ struct h264bsdmi_replay {
     uint8_t *d_dbk;                   /* n_streams * n_mbs * 32 */
     FrameDesc *d_desc;                /* n_pics * n_streams */
     uint32_t *d_conv;                 /* n_streams * w*h (lazy) */
+    uint8_t *d_planar = nullptr;      /* one frame, planar (h264bsdmiReplayFetch) */
     unsigned long long *d_sums;
     std::vector<TickShape> shapes;
     std::vector<uint8_t> cur_slot;
@@ -746,6 +788,7 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     hipStreamSynchronize(r->e->stream);
     hipFree(r->d_blobs); hipFree(r->d_frames); hipFree(r->d_desc); hipFree(r->d_sums); hipFree(r->d_dbk);
     if (r->d_conv) hipFree(r->d_conv);
+    if (r->d_planar) hipFree(r->d_planar);
     for (auto &t : r->timers) for (auto &ev : t.ev) hipEventDestroy(ev);
     hipEventDestroy(r->ev_begin); hipEventDestroy(r->ev_end); if (r->gdone_any) hipEventDestroy(r->gdone_any);
     for (int g = 0; g < 8; g++) { if (r->gstream[g]) hipStreamDestroy(r->gstream[g]); if (r->gdone[g]) hipEventDestroy(r->gdone[g]); }
@@ -864,8 +907,12 @@ int h264bsdmiReplayFetch(h264bsdmi_replay *r, u32 stream, u32 slot, u8 *dst)
 {
     if (!r || stream >= r->n_streams || slot >= r->n_slots) return -1;
     HIP_TRY(hipSetDevice(r->e->device));
+    std::lock_guard<std::mutex> lk(r->e->mu);
+    if (!r->d_planar) HIP_TRY(hipMalloc((void **)&r->d_planar, r->frame_bytes));
+    hipLaunchKernelGGL(h264k::k_detile, dim3(512, 1), dim3(256), 0, r->e->stream, r->d_frames + ((size_t)stream * r->n_slots + slot) * r->frame_bytes,
+                       r->d_planar, r->wmb, r->hmb, (size_t)0, (size_t)0);
+    HIP_TRY(hipMemcpyAsync(dst, r->d_planar, r->frame_bytes, hipMemcpyDeviceToHost, r->e->stream));
     HIP_TRY(hipStreamSynchronize(r->e->stream));
-    HIP_TRY(hipMemcpy(dst, r->d_frames + ((size_t)stream * r->n_slots + slot) * r->frame_bytes, r->frame_bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -875,9 +922,9 @@ int h264bsdmiReplayChecksums(h264bsdmi_replay *r, u32 slot, unsigned long long *
     std::lock_guard<std::mutex> lk(r->e->mu);
     HIP_TRY(hipSetDevice(r->e->device));
     hipLaunchKernelGGL(h264k::k_checksum, dim3(r->n_streams), dim3(256), 0, r->e->stream,
-                       r->d_frames + (size_t)slot * r->frame_bytes, (size_t)r->n_slots * r->frame_bytes, r->frame_bytes / 4, r->d_sums);
+                       r->d_frames + (size_t)slot * r->frame_bytes, (size_t)r->n_slots * r->frame_bytes, r->wmb, r->hmb, r->d_sums);
     HIP_TRY(hipMemcpyAsync(sums, r->d_sums, sizeof(unsigned long long) * r->n_streams, hipMemcpyDeviceToHost, r->e->stream));
-    HIP_TRY(hipStreamSynchronize(r->e->stream));
+    if (poll_errors(r->e)) return -1;
     return 0;
 }
 
@@ -890,7 +937,7 @@ int h264bsdmiReplayConvert(h264bsdmi_replay *r, u32 slot, int fmt)
     if (!r->d_conv) HIP_TRY(hipMalloc((void **)&r->d_conv, (size_t)w * h * 4 * r->n_streams));
     hipLaunchKernelGGL(h264k::k_convert, dim3(256, r->n_streams), dim3(256), 0, r->e->stream,
                        r->d_frames + (size_t)slot * r->frame_bytes, r->d_conv, w, h, fmt,
-                       (size_t)r->n_slots * r->frame_bytes, (size_t)w * h);
+                       (size_t)r->n_slots * r->frame_bytes, (size_t)w * h, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }

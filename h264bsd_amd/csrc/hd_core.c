@@ -22,7 +22,7 @@ HostDec *hd_create(int no_output_reordering);
 void hd_destroy(HostDec *d);
 /* error exits of hd_decode report where they happened when HD_TRACE is set in the environment (debugging aid) */
 #define ERR_RETURN do { if (hd_trace) fprintf(stderr, "TRACE hd_decode error at line %d\n", __LINE__); return HD_ERROR; } while (0)
-int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes);
+int hd_decode(HostDec *d, uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes);
 
 HostDec *hd_create(int no_output_reordering)
 {
@@ -743,7 +743,7 @@ static uint32_t plan_concealment(HostDec *d, int p_type)
 }
 
 /* ---------------------------------------------------------------- one NAL unit */
-int hd_decode(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes)
+int hd_decode(HostDec *d, uint8_t *stream, uint32_t len, uint32_t pic_id, uint32_t *read_bytes)
 {
     int rc;
     if (d->prev_buf_not_finished && stream == d->prev_buf_ptr) {

@@ -6,9 +6,12 @@
  *  - *read_bytes = leading zeros + start code + payload + trailing zeros that do not belong to the
  *    next start code (at most three zeros are left in front of the next 0x01);
  *  - forbidden byte patterns inside a NAL unit are an error.
- * Unlike the reference the caller's buffer is NOT modified: the unescaped payload is staged in a
- * decoder-owned, zero-padded buffer (which is also what makes the "same pointer, readBytes == 0"
- * re-call protocol cheap).
+ *  - the emulation-prevention bytes are removed IN the caller's buffer as well (the reference compacts the NAL unit
+ *    in place, byte_stream.c:193-235, README.md:11: callers that feed a stream twice must keep a private copy, as
+ *    the bench harness of SURVEY §8d does), and only when the unit can contain one: a byte-stream unit in which
+ *    no 00 00 03 was seen is taken verbatim, without the forbidden-pattern checks (byte_stream.c:127-131, :190).
+ * The parser itself reads from a decoder-owned, zero-padded copy of the payload (which is also what makes the "same
+ * pointer, readBytes == 0" re-call protocol cheap).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -25,13 +28,13 @@ static int ensure_nal_cap(HostDec *d, uint32_t n)
     return 0;
 }
 
-int hd_extract_nal(HostDec *d, const uint8_t *s, uint32_t len, uint32_t *read_bytes)
+int hd_extract_nal(HostDec *d, uint8_t *s, uint32_t len, uint32_t *read_bytes)
 {
     uint32_t start = 0, end = len, consumed = len;
-    int raw_nal = 1, invalid = 0;
+    int has_emulation = 1, invalid = 0;                  /* a raw NAL unit is always unescaped (byte_stream.c:181) */
 
     if (len > 3 && s[0] == 0 && s[1] == 0 && (s[2] & 0xFE) == 0) {
-        raw_nal = 0;
+        has_emulation = 0;
         /* find the first start code prefix: >= 2 zeros followed by 0x01 */
         uint32_t i = 2, zeros = 2;
         for (;;) {
@@ -47,6 +50,7 @@ int hd_extract_nal(HostDec *d, const uint8_t *s, uint32_t len, uint32_t *read_by
         for (;;) {
             uint8_t b = s[i++];
             if (b == 0) zeros++;
+            if (b == 3 && zeros == 2) has_emulation = 1;
             if (b == 1 && zeros >= 2) {
                 end = i - zeros - 1;
                 uint32_t keep = zeros < 3 ? zeros : 3;   /* zeros owned by the next start code */
@@ -65,20 +69,27 @@ int hd_extract_nal(HostDec *d, const uint8_t *s, uint32_t len, uint32_t *read_by
     uint32_t n = end - start;
     if (ensure_nal_cap(d, n)) return -2;
     uint8_t *w = d->nal_buf;
-    const uint8_t *r = s + start;
+    uint8_t *r = s + start;
     uint32_t zeros = 0, out = 0;
-    (void)raw_nal;
-    for (uint32_t i = 0; i < n; i++) {
-        uint8_t b = r[i];
-        if (zeros == 2 && b == 3) {
-            /* emulation_prevention_three_byte must be followed by 00..03 */
-            if (i + 1 == n || r[i + 1] > 3) return -1;
-            zeros = 0;
-            continue;
+    int rc = 0;
+    if (!has_emulation) {
+        memcpy(w, r, n);
+        out = n;
+    } else {
+        for (uint32_t i = 0; i < n; i++) {
+            uint8_t b = r[i];
+            if (zeros == 2 && b == 3) {
+                /* emulation_prevention_three_byte must be followed by 00..03 */
+                if (i + 1 == n || r[i + 1] > 3) { rc = -1; break; }
+                zeros = 0;
+                continue;
+            }
+            if (zeros == 2 && b <= 2) { rc = -1; break; }   /* 000000 / 000001 / 000002 inside a NAL */
+            zeros = b ? 0 : zeros + 1;
+            w[out++] = b;
         }
-        if (zeros == 2 && b <= 2) return -1; /* 000000 / 000001 / 000002 inside a NAL */
-        zeros = b ? 0 : zeros + 1;
-        w[out++] = b;
+        if (out < n) memcpy(r, w, out);                  /* the caller's buffer, compacted as far as the reference gets */
+        if (rc) return rc;
     }
     memset(w + out, 0, 16);
     d->nal_size = out;

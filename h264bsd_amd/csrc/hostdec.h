@@ -297,7 +297,7 @@ typedef struct HostDec {
 enum { HD_RDY = 0, HD_PIC_RDY = 1, HD_HDRS_RDY = 2, HD_ERROR = 3, HD_PARAM_SET_ERROR = 4, HD_MEMALLOC_ERROR = 5 };
 
 /* hd_nal.c */
-int hd_extract_nal(HostDec *d, const uint8_t *stream, uint32_t len, uint32_t *read_bytes);
+int hd_extract_nal(HostDec *d, uint8_t *stream, uint32_t len, uint32_t *read_bytes);
 /* hd_params.c */
 int hd_parse_sps(BitReader *br, Sps *sps);
 int hd_parse_pps(BitReader *br, Pps *pps);

@@ -50,8 +50,16 @@ struct FrameDesc {
     uint32_t        n_mbs, n_levels, n_copy, n_gen, n_dbk;
     uint16_t        wmb, hmb;
     uint32_t        any_deblock;
+    uint32_t       *err;          /* device error word of the engine (DEVERR_* bits, atomicOr): must stay 0 */
     uint8_t        *slot[FJ_MAX_SLOTS];
 };
+
+/* Bits of the device error word.  None of them can be set by a frame job the host parser built: they are tripwires. */
+#define DEVERR_RESIDUAL_RANGE 1u  /* a residual sample left [-512,511]: the reference fails the macroblock there
+                                     (src/h264bsd_transform.c:184-188); the host decides this error while it parses
+                                     (hd_resid.c), so a job that reaches the kernels never contains one          */
+#define DEVERR_INTRA_SCHED    2u  /* k_frame_intra gave up waiting for a ready macroblock (scheduling bug)          */
+#define DEVERR_DBK_SCHED      4u  /* k_frame_dbk did                                                               */
 
 /* Deblocking record of one macroblock (32 bytes), written by the reconstruction of that MB:
  *   bytes 0..15  boundary strengths, one nibble per (dir, edge e, segment k): n = 16*dir + 4*e + k
@@ -59,6 +67,10 @@ struct FrameDesc {
  *   byte 28 FJ_DBK_* flags, byte 29 "any strength non-zero"
  * followed (at dbk + 32*n_mbs) by one byte per MB: 1 = at least one non-zero strength.           */
 #define DBK_REC_BYTES 32
+/* the per-macroblock flag byte behind the records */
+#define DBKF_ANY  1u   /* at least one non-zero strength: the macroblock is filtered                         */
+#define DBKF_LEFT 2u   /* its left macroblock edge has a non-zero strength: it reads and rewrites the last columns of (x-1,y) */
+#define DBKF_TOP  4u   /* its upper macroblock edge has one: it reads and rewrites the last rows of (x,y-1)                   */
 
 namespace h264k {
 
@@ -168,7 +180,8 @@ __device__ __forceinline__ void unpack_row4(int2 w, int c[4])
     c[0] = (int16_t)(w.x & 0xFFFF); c[1] = w.x >> 16; c[2] = (int16_t)(w.y & 0xFFFF); c[3] = w.y >> 16;
 }
 
-__device__ __forceinline__ void mb_residual_compute(uint32_t coded, int qp_y, int qp_c, bool is_i16, const int16_t *coef, int lane,
+/* returns true in the lanes that hold a residual sample outside [-512,511] (DEVERR_RESIDUAL_RANGE) */
+__device__ __forceinline__ bool mb_residual_compute(uint32_t coded, int qp_y, int qp_c, bool is_i16, const int16_t *coef, int lane,
                                                     const ResidRows &rows, int ry[4], int rc[4])
 {
     const int q = lane & 3;
@@ -211,12 +224,22 @@ __device__ __forceinline__ void mb_residual_compute(uint32_t coded, int qp_y, in
         unpack_row4(rows.c, rc);
         idct_quad(rc, q, qp_c, true, dc);
     }
+    /* un-processed blocks are all zero, so testing every value is exactly the reference's per-block test */
+    uint32_t over = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) over |= (uint32_t)(ry[i] + 512) | (uint32_t)(rc[i] + 512);
+    return over > 1023u;
 }
 
-__device__ __forceinline__ void mb_residual(uint32_t coded, int qp_y, int qp_c, bool is_i16, const int16_t *coef, int lane, int ry[4], int rc[4])
+__device__ __forceinline__ bool mb_residual(uint32_t coded, int qp_y, int qp_c, bool is_i16, const int16_t *coef, int lane, int ry[4], int rc[4])
 {
     const ResidRows rows = mb_residual_fetch(coded, coef, lane);
-    mb_residual_compute(coded, qp_y, qp_c, is_i16, coef, lane, rows, ry, rc);
+    return mb_residual_compute(coded, qp_y, qp_c, is_i16, coef, lane, rows, ry, rc);
+}
+__device__ __forceinline__ void report_residual_range(const FrameDesc &fd, bool bad, int lane)
+{
+    const unsigned long long m = __ballot(bad);
+    if (m != 0ull && lane == (int)__ffsll((long long)m) - 1) atomicOr(fd.err, DEVERR_RESIDUAL_RANGE);
 }
 
 /* DPB slot k of the picture's stream.  The slots of a stream are contiguous (engine.hip make_desc), so the address is
@@ -224,6 +247,34 @@ __device__ __forceinline__ void mb_residual(uint32_t coded, int qp_y, int qp_c, 
 __device__ __forceinline__ uint8_t *slot_ptr(const FrameDesc &fd, uint32_t k)
 {
     return fd.slot[0] + (size_t)k * ((size_t)fd.wmb * fd.hmb * 384u);
+}
+
+/* ------------------------------------------------------------------ frame layout in HBM: macroblock tiles
+ * A frame is its macroblocks in address order, 384 contiguous bytes each: Y[16][16] | Cb[8][8] | Cr[8][8] — three
+ * 128-byte lines per macroblock (the slots are 128-byte aligned).  Every kernel of the path works macroblock by
+ * macroblock, and what they pay for is the number of cache LINES a wavefront touches, not bytes: in the reference's
+ * planar frame (image.h:46-55) the 16 + 16 row pieces of a macroblock lie in 32 different lines, here in 3; a
+ * neighbour's last columns are 2 lines instead of 16, its last rows 1 line.  (Round 1 measured the per-CU line-request
+ * rate as the limit of k_frame_dbk — its time did not change between 4 and 16 wavefronts per picture nor with a 21 %
+ * shorter dependency chain — and 2.9 -> 4.6 TB/s for k_copy's pattern in tools/probes/layout_probe.hip.)
+ * The reference's planar I420 is produced where pictures leave the device (k_detile / k_output / k_convert). */
+constexpr int TILE = 384, T_CB = 256, T_CR = 320;
+__device__ __forceinline__ size_t luma_at(int wmb, int x, int y)
+{
+    return (size_t)((y >> 4) * wmb + (x >> 4)) * TILE + ((y & 15) << 4) + (x & 15);
+}
+__device__ __forceinline__ size_t chroma_at(int wmb, int plane, int x, int y)
+{
+    return (size_t)((y >> 3) * wmb + (x >> 3)) * TILE + T_CB + (plane << 6) + ((y & 7) << 3) + (x & 7);
+}
+/* 4 luma samples x..x+3 of row y (inside the picture): one load, or two when they straddle two tiles */
+__device__ __forceinline__ uint32_t luma4_at(const uint8_t *__restrict__ f, int wmb, int x, int y)
+{
+    const int c = x & 15;
+    const uint8_t *t = f + (size_t)((y >> 4) * wmb + (x >> 4)) * TILE + ((y & 15) << 4);
+    if (c <= 12) return load_u32_unaligned(t + c);
+    const unsigned long long v = (unsigned long long)load_u32_unaligned(t + 12) | ((unsigned long long)load_u32_unaligned(t + TILE) << 32);
+    return (uint32_t)(v >> (8 * (c - 12)));
 }
 
 /* ------------------------------------------------------------------ inter prediction */
@@ -246,25 +297,24 @@ __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { 
 /* Register window of one lane: rows y-2..y+3, columns x-2..x+9 of the reference plane (9 columns used),
  * rw[r][k] = dword k of window row r.  Filled either straight from global memory (clamp-to-edge on the
  * slow path = h264bsdFillBlock, src/h264bsd_reconstruct.c:2244) or from the wave's LDS-staged window. */
-__device__ __forceinline__ void luma_window_global(const uint8_t *__restrict__ p, int w, int h, int x, int y, uint32_t rw[6][3])
+__device__ __forceinline__ void luma_window_global(const uint8_t *__restrict__ p, int wmb, int w, int h, int x, int y, uint32_t rw[6][3])
 {
     if (x >= 2 && x + 9 < w && y >= 2 && y + 3 < h) {
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            const uint8_t *s = p + (size_t)(y - 2 + r) * w + (x - 2);
-            rw[r][0] = load_u32_unaligned(s); rw[r][1] = load_u32_unaligned(s + 4); rw[r][2] = load_u32_unaligned(s + 8);
+            rw[r][0] = luma4_at(p, wmb, x - 2, y - 2 + r); rw[r][1] = luma4_at(p, wmb, x + 2, y - 2 + r); rw[r][2] = luma4_at(p, wmb, x + 6, y - 2 + r);
         }
     } else {
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            const uint8_t *s = p + (size_t)clip3(0, h - 1, y - 2 + r) * w;
+            const int yy = clip3(0, h - 1, y - 2 + r);
             uint32_t a = 0, b = 0, c = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                a |= (uint32_t)s[clip3(0, w - 1, x - 2 + i)] << (8 * i);
-                b |= (uint32_t)s[clip3(0, w - 1, x + 2 + i)] << (8 * i);
+                a |= (uint32_t)p[luma_at(wmb, clip3(0, w - 1, x - 2 + i), yy)] << (8 * i);
+                b |= (uint32_t)p[luma_at(wmb, clip3(0, w - 1, x + 2 + i), yy)] << (8 * i);
             }
-            c = (uint32_t)s[clip3(0, w - 1, x + 6)];
+            c = (uint32_t)p[luma_at(wmb, clip3(0, w - 1, x + 6), yy)];
             rw[r][0] = a; rw[r][1] = b; rw[r][2] = c;
         }
     }
@@ -349,18 +399,15 @@ __device__ __forceinline__ void chroma_from_rows(const int a[3], const int b[3],
     out[0] = (w00 * a[0] + w10 * a[1] + w01 * b[0] + w11 * b[1] + 32) >> 6;
     out[1] = (w00 * a[1] + w10 * a[2] + w01 * b[1] + w11 * b[2] + 32) >> 6;
 }
-/* 2 chroma samples (x, x+1 ; y) straight from global memory */
-__device__ __forceinline__ void chroma_pred2(const uint8_t *__restrict__ p, int w, int h, int x, int y, int fx, int fy, int out[2])
+/* 2 chroma samples (x, x+1 ; y) of plane `plane` straight from global memory (w, h: chroma plane size) */
+__device__ __forceinline__ void chroma_pred2(const uint8_t *__restrict__ f, int wmb, int plane, int w, int h, int x, int y, int fx, int fy, int out[2])
 {
     int a[3], b[3];
-    if (x >= 0 && x + 3 < w && y >= 0 && y + 1 < h) {
-        const uint32_t r0 = load_u32_unaligned(p + (size_t)y * w + x), r1 = load_u32_unaligned(p + (size_t)(y + 1) * w + x);
-        a[0] = r0 & 255; a[1] = (r0 >> 8) & 255; a[2] = (r0 >> 16) & 255;
-        b[0] = r1 & 255; b[1] = (r1 >> 8) & 255; b[2] = (r1 >> 16) & 255;
-    } else {
-        const uint8_t *s0 = p + (size_t)clip3(0, h - 1, y) * w, *s1 = p + (size_t)clip3(0, h - 1, y + 1) * w;
+    const int y0 = clip3(0, h - 1, y), y1 = clip3(0, h - 1, y + 1);
 #pragma unroll
-        for (int i = 0; i < 3; i++) { const int xx = clip3(0, w - 1, x + i); a[i] = s0[xx]; b[i] = s1[xx]; }
+    for (int i = 0; i < 3; i++) {
+        const int xx = clip3(0, w - 1, x + i);
+        a[i] = f[chroma_at(wmb, plane, xx, y0)]; b[i] = f[chroma_at(wmb, plane, xx, y1)];
     }
     chroma_from_rows(a, b, fx, fy, out);
 }
@@ -430,7 +477,10 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
     v |= (uint32_t)__shfl_down((int)v, 2) << 8;
     v |= (uint32_t)__shfl_down((int)v, 4) << 16;
     const unsigned long long bal = __ballot(my_bs != 0);
-    const bool any = ((threadIdx.x & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal) != 0u;
+    const uint32_t bal32 = (threadIdx.x & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;     /* bit n = 16*dir + 4*e + k */
+    const bool any = bal32 != 0u;
+    /* scheduling flags of k_frame_dbk: does this macroblock touch its left / upper neighbour at all? */
+    const uint32_t sched = (any ? DBKF_ANY : 0u) | ((bal32 & 0x000Fu) ? DBKF_LEFT : 0u) | ((bal32 & 0x000F0000u) ? DBKF_TOP : 0u);
     if ((n & 7) == 0) *reinterpret_cast<uint32_t *>(out + (n >> 3) * 4) = v;
     if (n == 1) {
         const int qcq = c_qpc[clip3(0, 51, (int)q.qp_y + q.cqp_off)];
@@ -449,69 +499,59 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
         *reinterpret_cast<uint32_t *>(out + 20) = w[1];
         *reinterpret_cast<uint32_t *>(out + 24) = w[2];
         *reinterpret_cast<uint32_t *>(out + 28) = (uint32_t)q.dbk | (any ? 0x100u : 0u);
-        *any_out = any ? 1 : 0;
+        *any_out = (uint8_t)sched;
     }
 }
 
 /* ------------------------------------------------------------------ whole-sample copy macroblocks */
-/* List entries are runs of up to 8 horizontally adjacent MBs with one displacement: a 128x16 luma block
- * = 16 rows x 128 B (one cache line per row when aligned) and two 64x8 chroma blocks.  One wavefront moves one
- * entry: 16 B per lane per access — luma piece i = lane + 64 j (j = 0, 1): row i >> 3, macroblock i & 7; chroma: lane =
- * 32 plane + 4 row + (pair of macroblocks) — every load issued before the first store. */
+/* List entries are runs of up to 8 horizontally adjacent MBs with one displacement.  With macroblock tiles a run whose
+ * displacement is zero (P_Skip with zero motion: almost all of them) is ONE contiguous block of count x 384 bytes in
+ * the reference frame and in the current one: 24 x count 16-byte pieces, up to three per lane, every load issued before
+ * the first store.  Displaced (and clamped) runs gather their samples 4 at a time. */
 __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ frames)
 {
     const FrameDesc &fd = frames[blockIdx.y];
     const uint32_t ci = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ci >= fd.n_copy) return;
     const int lane = threadIdx.x & 63;
-    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
-    const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
-    const int lrow = lane >> 3, lseg = lane & 7;                /* luma: MB lseg of the run, rows lrow and lrow + 8 */
-    const int plane = lane >> 5, crow = (lane >> 2) & 7, cseg = lane & 3;     /* chroma: 16 B = 2 MBs */
+    const int wmb = fd.wmb;
     const FjCopy e = fd.copy[ci];
     const int cnt = e.count;
-    const int mbx = e.mb % wmb, mby = e.mb / wmb;
     const uint8_t *ref = slot_ptr(fd, e.slot);
-    const int x = mbx * 16 + e.dx, y = mby * 16 + e.dy;
-    uint4 vy[2], vc;
-    if (x >= 0 && x + 16 * cnt <= W && y >= 0 && y + 16 <= H) {
-        vy[0] = vy[1] = vc = make_uint4(0, 0, 0, 0);
-        if (lseg < cnt) {                                        /* only the MBs of the run */
-            __builtin_memcpy(&vy[0], ref + (size_t)(y + lrow) * W + x + 16 * lseg, 16);
-            __builtin_memcpy(&vy[1], ref + (size_t)(y + lrow + 8) * W + x + 16 * lseg, 16);
-        }
-        if (2 * cseg < cnt) __builtin_memcpy(&vc, ref + ysz + (plane ? csz : 0) + (size_t)((y >> 1) + crow) * CW + (x >> 1) + 16 * cseg, 16);
-    } else {                                                     /* clamp-to-edge, sample by sample */
-        const uint8_t *c = ref + ysz + (plane ? csz : 0) + (size_t)clip3(0, CH - 1, (y >> 1) + crow) * CW;
-        uint32_t b[4];
+    if ((e.dx | e.dy) == 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(ref + (size_t)e.mb * TILE);
+        uint4 *dst = reinterpret_cast<uint4 *>(fd.cur + (size_t)e.mb * TILE);
+        const int n16 = cnt * (TILE / 16);
+        uint4 v[3];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint8_t *s = ref + (size_t)clip3(0, H - 1, y + lrow + 8 * j) * W;
-            uint32_t a[4];
+        for (int j = 0; j < 3; j++) if (lane + 64 * j < n16) v[j] = src[lane + 64 * j];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                a[q] = 0;
+        for (int j = 0; j < 3; j++) if (lane + 64 * j < n16) dst[lane + 64 * j] = v[j];
+        return;
+    }
+    /* displaced: clamp-to-edge sample gather (h264bsdFillBlock, reconstruct.c:2244), lane = (row, 4-sample piece) */
+    const int W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
+    const int mbx = e.mb % wmb, mby = e.mb / wmb;
+    for (int m = 0; m < cnt; m++) {
+        const int x0 = (mbx + m) * 16 + e.dx, y0 = mby * 16 + e.dy;
+        uint8_t *dt = fd.cur + (size_t)(e.mb + m) * TILE;
+        {
+            const int r = lane >> 2, q = lane & 3, yy = clip3(0, H - 1, y0 + r);
+            uint32_t a = 0;
+            if (x0 >= 0 && x0 + 16 <= W) a = luma4_at(ref, wmb, x0 + 4 * q, yy);
+            else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) a[q] |= (uint32_t)s[clip3(0, W - 1, x + 16 * lseg + 4 * q + i)] << (8 * i);
+                for (int i = 0; i < 4; i++) a |= (uint32_t)ref[luma_at(wmb, clip3(0, W - 1, x0 + 4 * q + i), yy)] << (8 * i);
             }
-            vy[j] = make_uint4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<uint32_t *>(dt + r * 16 + 4 * q) = a;
         }
+        if (lane < 32) {
+            const int plane = lane >> 4, r = (lane >> 1) & 7, half = lane & 1, cy = clip3(0, CH - 1, (y0 >> 1) + r);
+            uint32_t b2 = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            b[q] = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) b[q] |= (uint32_t)c[clip3(0, CW - 1, (x >> 1) + 16 * cseg + 4 * q + i)] << (8 * i);
+            for (int i = 0; i < 4; i++) b2 |= (uint32_t)ref[chroma_at(wmb, plane, clip3(0, CW - 1, (x0 >> 1) + 4 * half + i), cy)] << (8 * i);
+            *reinterpret_cast<uint32_t *>(dt + T_CB + plane * 64 + r * 8 + 4 * half) = b2;
         }
-        vc = make_uint4(b[0], b[1], b[2], b[3]);
-    }
-    if (lseg < cnt) {
-        *reinterpret_cast<uint4 *>(fd.cur + (size_t)(mby * 16 + lrow) * W + mbx * 16 + 16 * lseg) = vy[0];
-        *reinterpret_cast<uint4 *>(fd.cur + (size_t)(mby * 16 + lrow + 8) * W + mbx * 16 + 16 * lseg) = vy[1];
-    }
-    if (2 * cseg < cnt) {
-        uint8_t *dst = fd.cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + crow) * CW + mbx * 8 + 16 * cseg;
-        if (2 * cseg + 1 < cnt) *reinterpret_cast<uint4 *>(dst) = vc;
-        else *reinterpret_cast<uint2 *>(dst) = make_uint2(vc.x, vc.y);          /* odd run length: last MB only */
     }
 }
 
@@ -525,11 +565,14 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
 struct __attribute__((packed, aligned(4))) U4a4 { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(4))) U2a4 { uint32_t x, y; };
 
-constexpr int IW_STRIDE = 36;                        /* luma window: 21 rows x 28 bytes; 9-dword stride: no bank conflicts for row-per-lane reads */
-constexpr int IC_STRIDE = 20;                        /* chroma windows: 9 rows x 16 bytes, two planes */
-constexpr int QW_STRIDE = 20;                        /* quadrant luma windows: 13 rows x 16 bytes, 5-dword stride */
-constexpr int QC_STRIDE = 12;                        /* quadrant chroma windows: 5 rows x 8 bytes, 3-dword stride, two planes */
-constexpr int INTER_WAVE_LDS = 1536;                 /* max(21 * IW_STRIDE + 2 * 9 * IC_STRIDE, 4 * 13 * QW_STRIDE + 4 * 2 * 5 * QC_STRIDE) = 1520, rounded */
+/* Reference windows are staged tile row by tile row: a window row is the 16-byte rows of the 2-3 tiles it crosses,
+ * loaded whole (aligned 16-byte / 8-byte requests) and laid side by side in LDS, so byte 0 of a staged row is the first
+ * column of the window's first tile. */
+constexpr int IW_STRIDE = 52;                        /* luma window: 21 rows x 3 tiles x 16 bytes; 13-dword stride: no bank conflicts for row-per-lane reads */
+constexpr int IC_STRIDE = 20;                        /* chroma windows: 9 rows x 2 tiles x 8 bytes, two planes */
+constexpr int QW_STRIDE = 36;                        /* quadrant luma windows: 13 rows x 2 tiles x 16 bytes, 9-dword stride */
+constexpr int QC_STRIDE = 20;                        /* quadrant chroma windows: 5 rows x 2 tiles x 8 bytes, two planes */
+constexpr int INTER_WAVE_LDS = 2688;                 /* max(21 * IW_STRIDE + 2 * 9 * IC_STRIDE = 1452, 4 * 13 * QW_STRIDE + 4 * 2 * 5 * QC_STRIDE = 2672), rounded */
 
 #ifndef INTER_OCC
 #define INTER_OCC 7      /* 72 VGPRs, 10 spilled: measured best (6: 71.5 ms, 7: 67.4, 8: 68.3, 5: 79.9 per step) */
@@ -552,7 +595,6 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
     const int16_t *mvs = fd.mvs + 32 * (size_t)mb;
     const int16_t *coef = fd.coefs + 16 * (size_t)ge.coef_idx;
     uint8_t *cur = fd.cur;
-    const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
     const bool uniform = ge.uniform == 1, quadwise = ge.uniform == 2;
     uint32_t refs = ge.slot * 0x01010101u, mv_mine = 0;
@@ -568,37 +610,40 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
         const int mvx = (int16_t)(mv0 & 0xFFFFu), mvy = (int32_t)mv0 >> 16;
         const uint8_t *ref = slot_ptr(fd, refs & 255u);
         const int xi = mbx * 16 + (mvx >> 2) - 2, yi = mby * 16 + (mvy >> 2) - 2;
-        const int xs = xi - (xi & 3);
+        const int xs = (xi >> 4) << 4;                           /* first column of the window's first tile */
         const int cxi = mbx * 8 + (mvx >> 3), cyi = mby * 8 + (mvy >> 3);
-        const int cxs = cxi - (cxi & 3);
-        /* ---- stage: luma rows yi..yi+20, bytes xs..xs+27; chroma rows cyi..cyi+8, bytes cxs..cxs+15 ----
-         * ONE 16-byte load per lane brings in both windows: lanes 0..41 = luma (row, half), lanes 42..59 = chroma
-         * (plane, row).  The second luma half starts at min(xs+16, W-16) so that it never leaves the row. */
-        const bool lfast = xs >= 0 && xs + 28 <= W && yi >= 0 && yi + 21 <= H;
-        const bool cfast = cxs >= 0 && cxs + 16 <= CW && cyi >= 0 && cyi + 9 <= CH;
-        {
-            const bool isl = lane < 42;
-            const int ci = lane - 42, cp = ci >= 9, cr = cp ? ci - 9 : ci;
-            const int lr = lane >> 1, lx = (lane & 1) ? min(xs + 16, W - 16) : xs;
-            const uint8_t *src = isl ? ref + (size_t)(yi + lr) * W + lx : ref + ysz + (cp ? csz : 0) + (size_t)(cyi + cr) * CW + cxs;
-            uint8_t *dst = isl ? lw + lr * IW_STRIDE + (lx - xs) : lc + cp * 9 * IC_STRIDE + cr * IC_STRIDE;
-            if (isl ? lfast : (cfast && lane < 60)) {
-                const U4a4 v = *reinterpret_cast<const U4a4 *>(src);
-                uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+        const int cxs = (cxi >> 3) << 3;
+        /* ---- stage: luma rows yi..yi+20 x the tiles at xs, xs+16, xs+32 (the window needs columns xi..xi+20); chroma
+         * rows cyi..cyi+8 x the tiles at cxs, cxs+8 (columns cxi..cxi+8).  One aligned 16-byte load per lane for luma
+         * (lane = 3 * row + tile: 63 lanes), one 8-byte load for chroma (lane = 18 * plane + 2 * row + tile: 36 lanes). */
+        const bool lfast = xi >= 0 && xi + 21 <= W && yi >= 0 && yi + 21 <= H;
+        const bool cfast = cxi >= 0 && cxi + 9 <= CW && cyi >= 0 && cyi + 9 <= CH;
+        if (lfast) {
+            const int lr = lane / 3, lk = lane - 3 * lr, lx = xs + 16 * lk;
+            if (lane < 63 && lx < W) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(ref + luma_at(wmb, lx, yi + lr));
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(lw + lr * IW_STRIDE + 16 * lk);
                 d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
             }
         }
+        if (cfast) {
+            const int cp = lane >= 18, rem = cp ? lane - 18 : lane, cr = rem >> 1, ck = rem & 1, cx = cxs + 8 * ck;
+            if (lane < 36 && cx < CW) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(ref + chroma_at(wmb, cp, cx, cyi + cr));
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(lc + cp * 9 * IC_STRIDE + cr * IC_STRIDE + 8 * ck);
+                d32[0] = v.x; d32[1] = v.y;
+            }
+        }
         if (!lfast) {
-            for (int d = lane; d < 21 * 28; d += 64) {
-                const int r = d / 28, c = d % 28;
-                lw[r * IW_STRIDE + c] = ref[(size_t)clip3(0, H - 1, yi + r) * W + clip3(0, W - 1, xs + c)];
+            for (int d = lane; d < 21 * 48; d += 64) {
+                const int r = d / 48, c = d % 48;
+                lw[r * IW_STRIDE + c] = ref[luma_at(wmb, clip3(0, W - 1, xs + c), clip3(0, H - 1, yi + r))];
             }
         }
         if (!cfast) {
             for (int d = lane; d < 2 * 9 * 16; d += 64) {
-                const int p = d / 144, r = (d % 144) / 16, c = d % 16;
-                lc[p * 9 * IC_STRIDE + r * IC_STRIDE + c] =
-                    ref[ysz + (p ? csz : 0) + (size_t)clip3(0, CH - 1, cyi + r) * CW + clip3(0, CW - 1, cxs + c)];
+                const int pp = d / 144, r = (d % 144) / 16, c = d % 16;
+                lc[pp * 9 * IC_STRIDE + r * IC_STRIDE + c] = ref[chroma_at(wmb, pp, clip3(0, CW - 1, cxs + c), clip3(0, CH - 1, cyi + r))];
             }
         }
         wave_sync();
@@ -633,44 +678,62 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
          * chroma windows staged in LDS with row-wide dword loads, then the same register-window arithmetic ---- */
         uint8_t *lq = lw, *cq = lw + 4 * 13 * QW_STRIDE;
         {
-            /* staging: one 16-byte luma row per lane (4 quadrants x 13 rows = lanes 0..51), then one 8-byte chroma row
-             * per lane (4 quadrants x 2 planes x 5 rows = lanes 0..39) */
-            if (lane < 52) {
-                const int q = lane / 13, r = lane % 13;
-                const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
-                const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
-                const uint8_t *ref = slot_ptr(fd, (refs >> (8 * q)) & 255u);
-                const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
-                const int xs = xi - (xi & 3);
-                uint32_t *d32 = reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + r * QW_STRIDE);
-                if (xs >= 0 && xs + 16 <= W && yi >= 0 && yi + 13 <= H) {
-                    const U4a4 v = *reinterpret_cast<const U4a4 *>(ref + (size_t)(yi + r) * W + xs);
-                    d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
-                } else {
-                    const uint8_t *rp = ref + (size_t)clip3(0, H - 1, yi + r) * W;
+            /* staging: per quadrant 13 luma rows x 2 tiles (104 aligned 16-byte loads: two per lane) and 2 planes x 5 chroma
+             * rows x 2 tiles (80 aligned 8-byte loads); a window that leaves the picture is gathered sample by sample */
 #pragma unroll
-                    for (int c = 0; c < 4; c++)
-                        d32[c] = (uint32_t)rp[clip3(0, W - 1, xs + 4 * c)] | ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 1)] << 8) |
-                                 ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 2)] << 16) | ((uint32_t)rp[clip3(0, W - 1, xs + 4 * c + 3)] << 24);
+            for (int j = 0; j < 2; j++) {
+                const int idx = lane + 64 * j;
+                if (idx < 104) {
+                    const int q = idx / 26, rem = idx - 26 * q, r = rem >> 1, k = rem & 1;
+                    const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
+                    const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
+                    const uint8_t *ref = slot_ptr(fd, (refs >> (8 * q)) & 255u);
+                    const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
+                    const int xs = ((xi >> 4) << 4) + 16 * k;
+                    uint32_t *d32 = reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + r * QW_STRIDE + 16 * k);
+                    if (xi >= 0 && xi + 13 <= W && yi >= 0 && yi + 13 <= H) {
+                        if (xs < W) {
+                            const uint4 v = *reinterpret_cast<const uint4 *>(ref + luma_at(wmb, xs, yi + r));
+                            d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
+                        }
+                    } else {
+                        const int yy = clip3(0, H - 1, yi + r);
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            uint32_t v = 0;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) v |= (uint32_t)ref[luma_at(wmb, clip3(0, W - 1, xs + 4 * c + i), yy)] << (8 * i);
+                            d32[c] = v;
+                        }
+                    }
                 }
             }
-            if (lane < 40) {
-                const int q = lane / 10, e = lane % 10, p = e >= 5, r = p ? e - 5 : e;
-                const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
-                const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
-                const uint8_t *ref = slot_ptr(fd, (refs >> (8 * q)) & 255u) + ysz + (p ? csz : 0);
-                const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
-                const int cxs = cxi - (cxi & 3);
-                uint32_t *d32 = reinterpret_cast<uint32_t *>(cq + (q * 2 + p) * 5 * QC_STRIDE + r * QC_STRIDE);
-                if (cxs >= 0 && cxs + 8 <= CW && cyi >= 0 && cyi + 5 <= CH) {
-                    const U2a4 v = *reinterpret_cast<const U2a4 *>(ref + (size_t)(cyi + r) * CW + cxs);
-                    d32[0] = v.x; d32[1] = v.y;
-                } else {
-                    const uint8_t *rp = ref + (size_t)clip3(0, CH - 1, cyi + r) * CW;
 #pragma unroll
-                    for (int c = 0; c < 2; c++)
-                        d32[c] = (uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c)] | ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 1)] << 8) |
-                                 ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 2)] << 16) | ((uint32_t)rp[clip3(0, CW - 1, cxs + 4 * c + 3)] << 24);
+            for (int j = 0; j < 2; j++) {
+                const int idx = lane + 64 * j;
+                if (idx < 80) {
+                    const int q = idx / 20, rem = idx - 20 * q, pp = rem >= 10, e2 = pp ? rem - 10 : rem, r = e2 >> 1, k = e2 & 1;
+                    const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
+                    const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
+                    const uint8_t *ref = slot_ptr(fd, (refs >> (8 * q)) & 255u);
+                    const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
+                    const int cxs = ((cxi >> 3) << 3) + 8 * k;
+                    uint32_t *d32 = reinterpret_cast<uint32_t *>(cq + (q * 2 + pp) * 5 * QC_STRIDE + r * QC_STRIDE + 8 * k);
+                    if (cxi >= 0 && cxi + 5 <= CW && cyi >= 0 && cyi + 5 <= CH) {
+                        if (cxs < CW) {
+                            const uint2 v = *reinterpret_cast<const uint2 *>(ref + chroma_at(wmb, pp, cxs, cyi + r));
+                            d32[0] = v.x; d32[1] = v.y;
+                        }
+                    } else {
+                        const int yy = clip3(0, CH - 1, cyi + r);
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            uint32_t v = 0;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) v |= (uint32_t)ref[chroma_at(wmb, pp, clip3(0, CW - 1, cxs + 4 * c + i), yy)] << (8 * i);
+                            d32[c] = v;
+                        }
+                    }
                 }
             }
         }
@@ -679,13 +742,13 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
             const int q = (by >> 1) * 2 + (bx >> 1);
             const int mvx = (int16_t)(mv_mine & 0xFFFFu), mvy = (int32_t)mv_mine >> 16;
             const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2;
-            const int o = (xi & 3) + 4 * (bx & 1), sh = 8 * (o & 3);
+            const int o = (xi & 15) + 4 * (bx & 1), sh = 8 * (o & 3);
             const uint8_t *src = lq + q * 13 * QW_STRIDE + (4 * (by & 1) + row) * QW_STRIDE + (o & ~3);
             uint32_t rw[6][3];
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 const uint32_t *qq = reinterpret_cast<const uint32_t *>(src + r * QW_STRIDE);
-                const uint32_t q0 = qq[0], q1 = qq[1], q2 = qq[2], q3 = (o & ~3) + 12 < 16 ? qq[3] : 0u;
+                const uint32_t q0 = qq[0], q1 = qq[1], q2 = qq[2], q3 = qq[3];
                 rw[r][0] = (uint32_t)(((unsigned long long)q1 << 32 | q0) >> sh);
                 rw[r][1] = (uint32_t)(((unsigned long long)q2 << 32 | q1) >> sh);
                 rw[r][2] = (uint32_t)(((unsigned long long)q3 << 32 | q2) >> sh);
@@ -698,7 +761,7 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
             const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
             const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
             const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3);
-            const uint8_t *s0 = cq + (q * 2 + plane) * 5 * QC_STRIDE + row * QC_STRIDE + (cxi & 3), *s1 = s0 + QC_STRIDE;
+            const uint8_t *s0 = cq + (q * 2 + plane) * 5 * QC_STRIDE + row * QC_STRIDE + (cxi & 7), *s1 = s0 + QC_STRIDE;
             int a[5], b[5];
 #pragma unroll
             for (int i = 0; i < 5; i++) { a[i] = s0[i]; b[i] = s1[i]; }
@@ -712,11 +775,11 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
             const uint8_t *ref = slot_ptr(fd, (refs >> (8 * ((by >> 1) * 2 + (bx >> 1)))) & 255u);
             const int x = mbx * 16 + bx * 4 + (mvx >> 2), y = mby * 16 + by * 4 + row + (mvy >> 2);
             if (((mvx | mvy) & 3) == 0 && x >= 0 && x + 3 < W && y >= 0 && y < H) {
-                const uint32_t v = load_u32_unaligned(ref + (size_t)y * W + x);
+                const uint32_t v = luma4_at(ref, wmb, x, y);
                 pl[0] = v & 255; pl[1] = (v >> 8) & 255; pl[2] = (v >> 16) & 255; pl[3] = v >> 24;
             } else {
                 uint32_t rw[6][3];
-                luma_window_global(ref, W, H, x, y, rw);
+                luma_window_global(ref, wmb, W, H, x, y, rw);
                 luma_from_window(rw, mvx & 3, mvy & 3, pl);
             }
         }
@@ -728,16 +791,16 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
                 const int cx = cx0 + 2 * pair;
                 const int lb = (cy >> 1) * 4 + (cx >> 1);             /* owning 4x4 luma block */
                 const int mvx = mvs[2 * lb], mvy = mvs[2 * lb + 1];
-                const uint8_t *ref = slot_ptr(fd, (refs >> (8 * ((cy >> 2) * 2 + (cx >> 2)))) & 255u) + ysz + (plane ? csz : 0);
-                chroma_pred2(ref, CW, CH, mbx * 8 + cx + (mvx >> 3), mby * 8 + cy + (mvy >> 3), mvx & 7, mvy & 7, pc + 2 * pair);
+                const uint8_t *ref = slot_ptr(fd, (refs >> (8 * ((cy >> 2) * 2 + (cx >> 2)))) & 255u);
+                chroma_pred2(ref, wmb, plane, CW, CH, mbx * 8 + cx + (mvx >> 3), mby * 8 + cy + (mvy >> 3), mvx & 7, mvy & 7, pc + 2 * pair);
             }
         }
     }
 
     int ry[4], rc[4];
-    mb_residual_compute(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc);
+    report_residual_range(fd, mb_residual_compute(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc), lane);
     /* ---- residual add, clip; the macroblock is gathered in LDS (the windows are dead by now) so that it leaves as
-     * whole rows: 16 luma rows of 16 bytes + 16 chroma rows of 8 bytes = 32 memory requests instead of 96 dwords ---- */
+     * its tile: 24 x 16 contiguous bytes ---- */
     wave_sync();
     *reinterpret_cast<uint32_t *>(lw + (by * 4 + row) * 16 + bx * 4) =
         pack4(clip255(pl[0] + ry[0]), clip255(pl[1] + ry[1]), clip255(pl[2] + ry[2]), clip255(pl[3] + ry[3]));
@@ -747,13 +810,9 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
             pack4(clip255(pc[0] + rc[0]), clip255(pc[1] + rc[1]), clip255(pc[2] + rc[2]), clip255(pc[3] + rc[3]));
     }
     wave_sync();
-    if (lane < 16) {
-        *reinterpret_cast<uint4 *>(cur + (size_t)(mby * 16 + lane) * W + mbx * 16) = *reinterpret_cast<const uint4 *>(lw + lane * 16);
-    } else if (lane < 32) {
-        const int plane = (lane - 16) >> 3, r = lane & 7;
-        *reinterpret_cast<uint2 *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + r) * CW + mbx * 8) =
-            *reinterpret_cast<const uint2 *>(lw + 256 + plane * 64 + r * 8);
-    }
+    /* the LDS image IS the tile (Y 16x16 | Cb 8x8 | Cr 8x8): 24 x 16 bytes, three cache lines */
+    if (lane < TILE / 16)
+        *reinterpret_cast<uint4 *>(cur + (size_t)mb * TILE + lane * 16) = *reinterpret_cast<const uint4 *>(lw + lane * 16);
 }
 
 /* ------------------------------------------------------------------ intra macroblocks */
@@ -790,20 +849,20 @@ __device__ __forceinline__ int conceal_value(int t0, int t1, int v, int bx, int 
 
 __device__ __noinline__ void conceal_mb(const FrameDesc &fd, uint32_t mb, int lane, unsigned used)
 {
-    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
-    const int mbx = mb % wmb, mby = mb / wmb;
-    uint8_t *cur = fd.cur;
-    const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
+    const int wmb = fd.wmb;
+    /* the macroblock's tile; the neighbours' tiles lie wmb tiles above / below and one tile to either side */
+    uint8_t *T = fd.cur + (size_t)mb * TILE;
+    const ptrdiff_t up = -(ptrdiff_t)wmb * TILE, down = (ptrdiff_t)wmb * TILE;
     const bool A = used & FJ_CONC_ABOVE, B = used & FJ_CONC_BELOW, L = used & FJ_CONC_LEFT, R = used & FJ_CONC_RIGHT;
     /* luma: lanes 0-15 above, 16-31 below, 32-47 left, 48-63 right, one border sample each */
     {
         const int side = lane >> 4, k = lane & 15;
-        uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
+        uint8_t *Y = T;
         int s = 0;
-        if (side == 0 && A) s = Y[-(ptrdiff_t)W + k];
-        if (side == 1 && B) s = Y[(size_t)16 * W + k];
-        if (side == 2 && L) s = Y[(size_t)k * W - 1];
-        if (side == 3 && R) s = Y[(size_t)k * W + 16];
+        if (side == 0 && A) s = T[up + 15 * 16 + k];
+        if (side == 1 && B) s = T[down + k];
+        if (side == 2 && L) s = T[-TILE + k * 16 + 15];
+        if (side == 3 && R) s = T[TILE + k * 16];
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
         const int o = __shfl_xor(s, 8);
         const int S = s + o, D = (lane & 8) ? o - s : s - o;
@@ -812,17 +871,17 @@ __device__ __noinline__ void conceal_mb(const FrameDesc &fd, uint32_t mb, int la
                        __shfl(D, 48), A, B, L, R, 0, t0, t1, v);
         const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
         const uint32_t px = (uint32_t)conceal_value(t0, t1, v, bx, by) * 0x01010101u;
-        *reinterpret_cast<uint32_t *>(Y + (size_t)(by * 4 + row) * W + bx * 4) = px;
+        *reinterpret_cast<uint32_t *>(Y + (by * 4 + row) * 16 + bx * 4) = px;
     }
     /* chroma: lane = 32*plane + 8*side + k */
     {
         const int plane = lane >> 5, side = (lane >> 3) & 3, k = lane & 7;
-        uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+        const uint8_t *P = T + T_CB + plane * 64;
         int s = 0;
-        if (side == 0 && A) s = P[-(ptrdiff_t)CW + k];
-        if (side == 1 && B) s = P[(size_t)8 * CW + k];
-        if (side == 2 && L) s = P[(size_t)k * CW - 1];
-        if (side == 3 && R) s = P[(size_t)k * CW + 8];
+        if (side == 0 && A) s = P[up + 7 * 8 + k];
+        if (side == 1 && B) s = P[down + k];
+        if (side == 2 && L) s = P[-TILE + k * 8 + 7];
+        if (side == 3 && R) s = P[TILE + k * 8];
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
         const int o = __shfl_xor(s, 4);
         const int S = s + o, D = (lane & 4) ? o - s : s - o;
@@ -834,7 +893,7 @@ __device__ __noinline__ void conceal_mb(const FrameDesc &fd, uint32_t mb, int la
         if (lane < 32) {
             /* lane -> plane (lane>>4), row y = (lane>>1)&7, half = lane&1: four samples = two 2x2 sub-block values */
             const int pl = lane >> 4, y = (lane >> 1) & 7, half = lane & 1;
-            uint8_t *Q = cur + ysz + (pl ? csz : 0) + (size_t)(mby * 8 + y) * CW + mbx * 8 + half * 4;
+            uint8_t *Q = T + T_CB + pl * 64 + y * 8 + half * 4;
             const int a0 = conceal_value(t0[pl], t1[pl], v[pl], half * 2, y >> 1);
             const int a1 = conceal_value(t0[pl], t1[pl], v[pl], half * 2 + 1, y >> 1);
             *reinterpret_cast<uint32_t *>(Q) = (uint32_t)a0 * 0x00000101u | (uint32_t)a1 * 0x01010000u;
@@ -846,22 +905,18 @@ __device__ __noinline__ void conceal_mb(const FrameDesc &fd, uint32_t mb, int la
 __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0)
 {
     const FjMbRec rec = fd.recs[mb];
-    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
-    const int mbx = mb % wmb, mby = mb / wmb;
+    const int wmb = fd.wmb;
     const int16_t *coef = fd.coefs + 16 * (size_t)rec.coef_idx;
-    uint8_t *cur = fd.cur;
-    const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
-    uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
+    /* the macroblock's tile (Y 16x16 | Cb 8x8 | Cr 8x8); neighbours: one tile to the left, wmb tiles up */
+    uint8_t *Y = fd.cur + (size_t)mb * TILE;
+    const ptrdiff_t up = -(ptrdiff_t)wmb * TILE;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
 
     if (rec.kind == FJ_MB_IPCM) {
+        /* the 384 raw samples arrive in tile order (Y raster, Cb, Cr: macroblock_layer.c:992-1022) */
         const uint8_t *s = reinterpret_cast<const uint8_t *>(coef);
-        *reinterpret_cast<uint32_t *>(Y + (size_t)(lane >> 2) * W + (lane & 3) * 4) = *reinterpret_cast<const uint32_t *>(s + 4 * lane);
-        if (lane < 32) {
-            const int plane = lane >> 4, r = (lane >> 1) & 7, half = lane & 1;
-            *reinterpret_cast<uint32_t *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + r) * CW + mbx * 8 + half * 4) =
-                *reinterpret_cast<const uint32_t *>(s + 256 + 64 * plane + 8 * r + 4 * half);
-        }
+        *reinterpret_cast<uint32_t *>(Y + 4 * lane) = *reinterpret_cast<const uint32_t *>(s + 4 * lane);
+        if (lane < 32) *reinterpret_cast<uint32_t *>(Y + 256 + 4 * lane) = *reinterpret_cast<const uint32_t *>(s + 256 + 4 * lane);
         return;
     }
 
@@ -870,30 +925,30 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
      * share the same memory round trip; written to the tiles after it */
     int nb_y = 128, nb_c = 128, nb_y_at = -1, nb_c_at = -1;
     if (lane < 21) {
-        const int c = lane;                               /* corner, 16 above, 4 above-right */
+        const int c = lane;                               /* corner, 16 above, 4 above-right: last row of the tiles above */
         const bool ok = c == 0 ? av_d : c <= 16 ? av_b : av_c;
         nb_y_at = 3 + c;
-        if (ok) nb_y = Y[-(ptrdiff_t)W + (c - 1)];
+        if (ok) nb_y = c == 0 ? Y[up - TILE + 255] : c <= 16 ? Y[up + 240 + (c - 1)] : Y[up + TILE + 240 + (c - 17)];
     } else if (lane >= 32 && lane < 48) {
-        const int r = lane - 32;
+        const int r = lane - 32;                          /* last column of the tile to the left */
         nb_y_at = (r + 1) * TS + 3;
-        if (av_a) nb_y = Y[(size_t)r * W - 1];
+        if (av_a) nb_y = Y[-TILE + r * 16 + 15];
     }
     if (lane < 18) {
         const int plane = lane / 9, c = lane % 9;
-        const uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+        const uint8_t *P = Y + T_CB + plane * 64;
         const bool ok = c == 0 ? av_d : av_b;
         nb_c_at = plane * 144 + c;
-        if (ok) nb_c = P[-(ptrdiff_t)CW + (c - 1)];
+        if (ok) nb_c = c == 0 ? P[up - TILE + 63] : P[up + 56 + (c - 1)];
     } else if (lane >= 32 && lane < 48) {
         const int plane = (lane - 32) >> 3, r = (lane - 32) & 7;
-        const uint8_t *P = cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8) * CW + mbx * 8;
+        const uint8_t *P = Y + T_CB + plane * 64;
         nb_c_at = plane * 144 + (r + 1) * 16;
-        if (av_a) nb_c = P[(size_t)r * CW - 1];
+        if (av_a) nb_c = P[-TILE + r * 8 + 7];
     }
 
     int ry[4], rc[4];
-    mb_residual(rec.coded, rec.qp_y, rec.qp_c, rec.kind == FJ_MB_I16x16, coef, lane, ry, rc);
+    report_residual_range(fd, mb_residual(rec.coded, rec.qp_y, rec.qp_c, rec.kind == FJ_MB_I16x16, coef, lane, ry, rc), lane);
 
     if (nb_y_at >= 0) tile[nb_y_at] = (uint8_t)nb_y;
     if (nb_c_at >= 0) ctile0[nb_c_at] = (uint8_t)nb_c;
@@ -926,7 +981,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
 #pragma unroll
             for (int i = 0; i < 4; i++) pr[i] = clip255((a + b * (x0 + i - 7) + c * (y - 7) + 16) >> 5);
         }
-        *reinterpret_cast<uint32_t *>(Y + (size_t)y * W + x0) =
+        *reinterpret_cast<uint32_t *>(Y + y * 16 + x0) =
             pack4(clip255(pr[0] + ry[0]), clip255(pr[1] + ry[1]), clip255(pr[2] + ry[2]), clip255(pr[3] + ry[3]));
     } else {
         /* Intra4x4.  Block (bx,by) needs the blocks left, above, above-left and above-right of it, so the
@@ -1034,7 +1089,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
             }
             wave_sync();
         }
-        *reinterpret_cast<uint32_t *>(Y + (size_t)(by * 4 + row) * W + bx * 4) =
+        *reinterpret_cast<uint32_t *>(Y + (by * 4 + row) * 16 + bx * 4) =
             *reinterpret_cast<const uint32_t *>(&tile[(by * 4 + 1 + row) * TS + 4 + bx * 4]);
     }
 
@@ -1075,7 +1130,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
 #pragma unroll
             for (int i = 0; i < 4; i++) pr[i] = clip255((a + b * (x0 + i - 3) + c * (y - 3) + 16) >> 5);
         }
-        *reinterpret_cast<uint32_t *>(cur + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + y) * CW + mbx * 8 + x0) =
+        *reinterpret_cast<uint32_t *>(Y + T_CB + plane * 64 + y * 8 + x0) =
             pack4(clip255(pr[0] + rc[0]), clip255(pr[1] + rc[1]), clip255(pr[2] + rc[2]), clip255(pr[3] + rc[3]));
     }
     wave_sync();          /* the tiles are reused by this wave's next macroblock */
@@ -1150,30 +1205,29 @@ struct DbkPrefetch { uint4 y; uint2 c; uint32_t bsb; uint4 thr; uint32_t s_ly, s
 __device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int ql, DbkPrefetch &p)
 {
     if (mb < 0) return;
-    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
+    const int wmb = fd.wmb;
     const int mbx = mb % wmb, mby = mb / wmb;
-    const uint8_t *Y = fd.cur + (size_t)(mby * 16) * W + mbx * 16;
-    p.y = *reinterpret_cast<const uint4 *>(Y + (size_t)ql * W);   /* luma row ql, one 16-byte request per lane */
-    const int plane = ql >> 3, r = ql & 7;                      /* one 8-byte chroma row */
-    const uint8_t *P = fd.cur + (size_t)W * H + (plane ? (size_t)CW * CH : 0) + (size_t)(mby * 8) * CW + mbx * 8;
-    p.c = *reinterpret_cast<const uint2 *>(P + (size_t)r * CW);
+    const uint8_t *T = fd.cur + (size_t)mb * TILE;               /* this macroblock's tile: three cache lines */
+    p.y = *reinterpret_cast<const uint4 *>(T + ql * 16);         /* luma row ql */
+    const int plane = ql >> 3, r = ql & 7;                       /* one 8-byte chroma row */
+    const uint8_t *P = T + T_CB + plane * 64;
+    p.c = *reinterpret_cast<const uint2 *>(P + r * 8);
     const uint8_t *rec = fd.dbk + (size_t)mb * DBK_REC_BYTES;
     p.bsb = rec[ql];                                            /* strengths: byte ql = nibbles 2ql, 2ql+1 */
     p.thr = *reinterpret_cast<const uint4 *>(rec + 16);
     /* The strips of the left / upper neighbour (final by now: this macroblock was only published after them).
      * Whether they are needed is in the record that is still in flight, so they are fetched unconditionally —
-     * one memory round trip per macroblock instead of two. */
+     * one memory round trip per macroblock instead of two.  Left strip: the last 4 columns of the tile to the left
+     * (2 lines); upper strip: the last 4 rows of the tile above (64 contiguous bytes). */
     p.s_ly = p.s_ty = p.s_lc = p.s_tc = 0;
     if (mbx > 0) {
-        p.s_ly = *reinterpret_cast<const uint32_t *>(Y + (size_t)ql * W - 4);
-        p.s_lc = *reinterpret_cast<const uint32_t *>(P + (size_t)r * CW - 4);
+        p.s_ly = *reinterpret_cast<const uint32_t *>(T - TILE + ql * 16 + 12);
+        p.s_lc = *reinterpret_cast<const uint32_t *>(P - TILE + r * 8 + 4);
     }
     if (mby > 0) {
-        p.s_ty = *reinterpret_cast<const uint32_t *>(Y + (ptrdiff_t)((ql >> 2) - 4) * W + 4 * (ql & 3));
-        if (ql < 8) {
-            const uint8_t *PC0 = fd.cur + (size_t)W * H + (size_t)(mby * 8) * CW + mbx * 8;
-            p.s_tc = *reinterpret_cast<const uint32_t *>(PC0 + ((ql >> 2) ? (size_t)CW * CH : 0) + (ptrdiff_t)(((ql >> 1) & 1) - 2) * CW + 4 * (ql & 1));
-        }
+        const uint8_t *U = T - (size_t)wmb * TILE;
+        p.s_ty = *reinterpret_cast<const uint32_t *>(U + (12 + (ql >> 2)) * 16 + 4 * (ql & 3));
+        if (ql < 8) p.s_tc = *reinterpret_cast<const uint32_t *>(U + T_CB + (ql >> 2) * 64 + (6 + ((ql >> 1) & 1)) * 8 + 4 * (ql & 1));
     }
 }
 
@@ -1188,12 +1242,8 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
      * global load, and these sit on the critical path of every edge */
     uint8_t *lt = w, *ct0 = w + 20 * LS, *bs_s = w + 20 * LS + 2 * 10 * CS;
     const bool act = mb >= 0;
-    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
-    const int mbx = act ? mb % wmb : 0, mby = act ? mb / wmb : 0;
-    uint8_t *cur = fd.cur;
-    const size_t ysz = (size_t)W * H, csz = (size_t)CW * CH;
-    uint8_t *Y = cur + (size_t)(mby * 16) * W + mbx * 16;
-    uint8_t *PC = cur + ysz + (size_t)(mby * 8) * CW + mbx * 8;
+    const int wmb = fd.wmb;
+    uint8_t *Y = fd.cur + (size_t)(act ? mb : 0) * TILE;          /* the macroblock's tile */
     /* lane ql holds strength byte ql: bytes 0..7 = vertical edges (0,1 = left MB edge), 8..15 = horizontal edges
      * (8,9 = top MB edge).  The neighbours are touched only if that macroblock edge has a non-zero strength. */
     const bool nz = act && p.bsb != 0;
@@ -1314,24 +1364,26 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
     if (act) {
         {
             const uint32_t *ysrc = reinterpret_cast<const uint32_t *>(&lt[(4 + ql) * LS + 4]);
-            *reinterpret_cast<uint4 *>(Y + (size_t)ql * W) = make_uint4(ysrc[0], ysrc[1], ysrc[2], ysrc[3]);
+            *reinterpret_cast<uint4 *>(Y + ql * 16) = make_uint4(ysrc[0], ysrc[1], ysrc[2], ysrc[3]);
         }
+        uint8_t *PCq = Y + T_CB + (ql >> 3) * 64;                 /* this lane's chroma plane inside the tile */
         {
             const uint32_t *csrc = reinterpret_cast<const uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS + 4]);
-            *reinterpret_cast<uint2 *>(PC + ((ql >> 3) ? csz : 0) + (size_t)(ql & 7) * CW) = make_uint2(csrc[0], csrc[1]);
+            *reinterpret_cast<uint2 *>(PCq + (ql & 7) * 8) = make_uint2(csrc[0], csrc[1]);
         }
         if (f_left) {
-            *reinterpret_cast<uint32_t *>(Y + (size_t)ql * W - 4) = *reinterpret_cast<const uint32_t *>(&lt[(4 + ql) * LS]);
-            *reinterpret_cast<uint32_t *>(PC + ((ql >> 3) ? csz : 0) + (size_t)(ql & 7) * CW - 4) =
+            *reinterpret_cast<uint32_t *>(Y - TILE + ql * 16 + 12) = *reinterpret_cast<const uint32_t *>(&lt[(4 + ql) * LS]);
+            *reinterpret_cast<uint32_t *>(PCq - TILE + (ql & 7) * 8 + 4) =
                 *reinterpret_cast<const uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS]);
         }
         if (f_top) {
+            uint8_t *U = Y - (size_t)wmb * TILE;                  /* the tile above */
             if (ql < 12) {
-                const int r = 1 + ql / 4, cw2 = ql % 4;                /* tile rows 1..3 */
-                *reinterpret_cast<uint32_t *>(Y + (ptrdiff_t)(r - 4) * W + 4 * cw2) = *reinterpret_cast<const uint32_t *>(&lt[r * LS + 4 + 4 * cw2]);
+                const int r = 1 + ql / 4, cw2 = ql % 4;                /* tile rows 1..3 = rows 13..15 of the macroblock above */
+                *reinterpret_cast<uint32_t *>(U + (12 + r) * 16 + 4 * cw2) = *reinterpret_cast<const uint32_t *>(&lt[r * LS + 4 + 4 * cw2]);
             } else {
-                const int i = ql - 12, plane = i >> 1, cw2 = i & 1;    /* chroma tile row 1 of both planes */
-                *reinterpret_cast<uint32_t *>(PC + (plane ? csz : 0) - (ptrdiff_t)CW + 4 * cw2) = *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + 1 * CS + 4 + 4 * cw2]);
+                const int i = ql - 12, plane = i >> 1, cw2 = i & 1;    /* chroma tile row 1 of both planes = row 7 above */
+                *reinterpret_cast<uint32_t *>(U + T_CB + plane * 64 + 7 * 8 + 4 * cw2) = *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + 1 * CS + 4 + 4 * cw2]);
             }
         }
     }
@@ -1345,7 +1397,10 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
  * inter-workgroup traffic inside a picture.  Occupancy comes from batching streams (256 pictures = one
  * workgroup per CU). */
 constexpr int TAIL_WAVES = 16;
-constexpr int DBK_WAVES = 6;                        /* wavefronts of k_frame_dbk: the picture's dependency critical path bounds it, and
+#ifndef DBK_WAVES_N
+#define DBK_WAVES_N 6
+#endif
+constexpr int DBK_WAVES = DBK_WAVES_N;                        /* wavefronts of k_frame_dbk: the picture's dependency critical path bounds it, and
                                                         fewer wavefronts contend less for instruction issue (measured per step: 16 waves
                                                         96 ms, 12: 94, 8: 89-91, 6: 90, 5: 87, 4: 89, 3: 102) */
 constexpr int TAIL_WORKERS = 4 * DBK_WAVES;       /* deblocking workers = quarter wavefronts */
@@ -1406,7 +1461,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
 
     volatile uint16_t *vq = queue;
     volatile uint32_t *vctr = ctr;
-    uint32_t spins = 0;                  /* safety net: a scheduling bug must end in wrong pixels, never in a hung GPU */
+    uint32_t spins = 0;                  /* safety net: a scheduling bug must end in a reported error (DEVERR_*), never in a hung GPU */
     /* debug accounting (h264bsdmiDebugTailProfile, second half of the buffer): workgroup 0, per wavefront:
      * [0] cycles with nothing ready, [1] cycles reconstructing, [2] cycles waiting for stores + release, [3] MBs */
     unsigned long long *tp = (prof && blockIdx.x == 0) ? prof + 256 + wave * 8 : nullptr;
@@ -1420,7 +1475,8 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
             else slot = 0xFFFFFFFEu;
         }
         slot = __shfl(slot, 0);
-        if (slot == 0xFFFFFFFDu || ++spins > (1u << 24)) break;
+        if (slot == 0xFFFFFFFDu) break;
+        if (++spins > (1u << 24)) { if (lane == 0) atomicOr(fd.err, DEVERR_INTRA_SCHED); break; }
         if (slot == 0xFFFFFFFEu) { __builtin_amdgcn_s_sleep(1); continue; }
         int v;
         do { v = vq[slot]; } while (v == 0xFFFF);          /* the publisher bumps the cursor, then writes the slot */
@@ -1502,10 +1558,20 @@ __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *_
         }
     }
     __syncthreads();
+    /* Dependencies at edge granularity.  A filtered macroblock waits for
+     *   (x-1,y)    only if its own left edge is active (DBKF_LEFT): otherwise it neither reads nor writes that neighbour;
+     *   (x,y-1)    only if its own upper edge is active (DBKF_TOP);
+     *   (x+1,y-1)  only if its upper edge is active AND that macroblock's left edge is: only then does (x+1,y-1)
+     *              rewrite the columns of (x,y-1) whose last rows this macroblock reads and rewrites.
+     * Every pair of macroblocks that touches a common sample is still ordered as in the reference's raster scan
+     * (deblocking.c:604-638); the longest chain of the bundled 1080p stream shrinks by 21 % (9562 -> 7512 steps). */
     for (int mb = tid; mb < n_mbs; mb += blockDim.x) {
-        if (!anyf[mb]) continue;
+        const uint32_t f = anyf[mb];
+        if (!(f & DBKF_ANY)) continue;
         const int x = mb % wmb, y = mb / wmb;
-        const int d = (x > 0 && anyf[mb - 1] ? 1 : 0) + (y > 0 && anyf[mb - wmb] ? 1 : 0) + (y > 0 && x + 1 < wmb && anyf[mb - wmb + 1] ? 1 : 0);
+        const int d = (x > 0 && (f & DBKF_LEFT) && (anyf[mb - 1] & DBKF_ANY) ? 1 : 0) +
+                      (y > 0 && (f & DBKF_TOP) && (anyf[mb - wmb] & DBKF_ANY) ? 1 : 0) +
+                      (y > 0 && x + 1 < wmb && (f & DBKF_TOP) && (anyf[mb - wmb + 1] & DBKF_LEFT) ? 1 : 0);
         dep[mb] = (uint8_t)d;
         atomicAdd(&ctr[2], 1u);
         if (d == 0) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)mb;
@@ -1517,7 +1583,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *_
     /* Pull model: a free wavefront takes up to four READY macroblocks at once (one per quarter).  Ready macroblocks
      * are therefore packed into as few wavefronts as possible — the loop is instruction-issue bound, so a step that
      * runs with one busy quarter costs as much as a full one — and a wavefront with nothing to do issues nothing. */
-    uint32_t spins = 0;                  /* safety net: a scheduling bug must end in wrong pixels, never in a hung GPU */
+    uint32_t spins = 0;                  /* safety net: a scheduling bug must end in a reported error (DEVERR_*), never in a hung GPU */
     volatile uint32_t *vctr = ctr;
     for (;;) {
         uint32_t base = 0, k = 0;
@@ -1532,7 +1598,8 @@ __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *_
             }
         }
         base = __shfl(base, 0); k = __shfl(k, 0);
-        if (k == 0xFFFFFFFFu || ++spins > (1u << 24)) break;
+        if (k == 0xFFFFFFFFu) break;
+        if (++spins > (1u << 24)) { if (lane == 0) atomicOr(fd.err, DEVERR_DBK_SCHED); break; }
         if (k == 0) { __builtin_amdgcn_s_sleep(1); continue; }
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
         int run = -1;
@@ -1555,7 +1622,13 @@ __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *_
             if (ql == 0) { if (x + 1 < wmb) dmb = run + 1; }
             else if (ql == 1) { if (y + 1 < hmb) dmb = run + wmb; }
             else { if (y + 1 < hmb && x > 0) dmb = run + wmb - 1; }
-            if (dmb >= 0 && anyf[dmb]) {
+            /* the mirror image of the dependency rule above */
+            bool waits = false;
+            if (dmb >= 0) {
+                const uint32_t fd_ = anyf[dmb], fm = anyf[run];
+                waits = ql == 0 ? (fd_ & DBKF_LEFT) != 0u : ql == 1 ? (fd_ & DBKF_TOP) != 0u : ((fd_ & DBKF_TOP) != 0u && (fm & DBKF_LEFT) != 0u);
+            }
+            if (waits) {
                 /* byte-wide counters: decrement through a 32-bit LDS atomic on the containing word */
                 uint32_t *w = reinterpret_cast<uint32_t *>(dep + (dmb & ~3));
                 const uint32_t sh = 8u * (dmb & 3);
@@ -1570,10 +1643,36 @@ __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *_
     }
 }
 
-/* ------------------------------------------------------------------ colour conversion */
-/* 4 horizontally adjacent pixels per thread; fmt 0 RGBA, 1 BGRA, 2 YCbCrA (bytes in memory order) */
+/* ------------------------------------------------------------------ pictures leaving the device */
+/* The reference's output format is planar I420, uncropped (image.h:46-55).  Frames live in HBM as macroblock tiles,
+ * so every path that hands a picture out reads tiles: k_detile (whole frame -> planar), k_output (cropped window ->
+ * planar or converted), k_convert with tiled != 0 (whole frame -> RGBA / BGRA / YCbCrA).  k_convert with tiled == 0 is
+ * the stateless h264bsdConvertTo*(), whose input is the caller's planar picture. */
+__device__ __forceinline__ uint32_t yuv_luma4(const uint8_t *__restrict__ src, int tiled, uint32_t width, uint32_t x, uint32_t y)
+{
+    return tiled ? *reinterpret_cast<const uint32_t *>(src + luma_at((int)(width >> 4), (int)x, (int)y))
+                 : *reinterpret_cast<const uint32_t *>(src + (size_t)y * width + x);
+}
+__device__ __forceinline__ uint32_t yuv_chroma2(const uint8_t *__restrict__ src, int tiled, uint32_t width, uint32_t height, int plane, uint32_t cx, uint32_t cy)
+{
+    const uint8_t *p = tiled ? src + chroma_at((int)(width >> 4), plane, (int)cx, (int)cy)
+                             : src + (size_t)width * height + (plane ? (size_t)(width >> 1) * (height >> 1) : 0) + (size_t)cy * (width >> 1) + cx;
+    return *reinterpret_cast<const uint16_t *>(p);
+}
+__device__ __forceinline__ uint32_t yuv_pixel(int fmt, int Yv, int cb, int cr)
+{
+    if (fmt == 2) return 0xFF000000u | ((uint32_t)cr << 16) | ((uint32_t)cb << 8) | (uint32_t)Yv;
+    const int c = Yv - 16, d = cb - 128, e = cr - 128;
+    const uint32_t r = clip255((298 * c + 409 * e + 128) >> 8);
+    const uint32_t g = clip255((298 * c - 100 * d - 208 * e + 128) >> 8);
+    const uint32_t b = clip255((298 * c + 516 * d + 128) >> 8);
+    return fmt == 0 ? 0xFF000000u | (b << 16) | (g << 8) | r : 0xFF000000u | (r << 16) | (g << 8) | b;
+}
+
+/* 4 horizontally adjacent pixels per thread, one 16-byte store; fmt 0 RGBA, 1 BGRA, 2 YCbCrA (bytes in memory order);
+ * integer BT.601 limited range, nearest chroma (reference src/h264bsd_decoder.c:1163-1370) */
 __global__ __launch_bounds__(256) void k_convert(const uint8_t *__restrict__ yuv, uint32_t *__restrict__ out,
-                                                 uint32_t width, uint32_t height, int fmt, size_t in_stride, size_t out_stride)
+                                                 uint32_t width, uint32_t height, int fmt, size_t in_stride, size_t out_stride, int tiled)
 {
     const uint8_t *src = yuv + blockIdx.y * in_stride;
     uint32_t *dst = out + blockIdx.y * out_stride;
@@ -1581,77 +1680,125 @@ __global__ __launch_bounds__(256) void k_convert(const uint8_t *__restrict__ yuv
     const uint32_t total = quads_per_row * height;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t y = i / quads_per_row, x = (i % quads_per_row) * 4;
-        const uint32_t yy = *reinterpret_cast<const uint32_t *>(src + (size_t)y * width + x);
-        const uint8_t *cbp = src + (size_t)width * height + (size_t)(y >> 1) * (width >> 1) + (x >> 1);
-        const uint8_t *crp = cbp + (size_t)(width >> 1) * (height >> 1);
-        const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(cbp), cr2 = *reinterpret_cast<const uint16_t *>(crp);
+        const uint32_t yy = yuv_luma4(src, tiled, width, x, y);
+        const uint32_t cb2 = yuv_chroma2(src, tiled, width, height, 0, x >> 1, y >> 1), cr2 = yuv_chroma2(src, tiled, width, height, 1, x >> 1, y >> 1);
         uint32_t px[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int Yv = (yy >> (8 * k)) & 255, cb = (cb2 >> (8 * (k >> 1))) & 255, cr = (cr2 >> (8 * (k >> 1))) & 255;
-            if (fmt == 2) px[k] = 0xFF000000u | ((uint32_t)cr << 16) | ((uint32_t)cb << 8) | (uint32_t)Yv;
-            else {
-                const int c = Yv - 16, d = cb - 128, e = cr - 128;
-                const uint32_t r = clip255((298 * c + 409 * e + 128) >> 8);
-                const uint32_t g = clip255((298 * c - 100 * d - 208 * e + 128) >> 8);
-                const uint32_t b = clip255((298 * c + 516 * d + 128) >> 8);
-                px[k] = fmt == 0 ? 0xFF000000u | (b << 16) | (g << 8) | r : 0xFF000000u | (r << 16) | (g << 8) | b;
-            }
-        }
+        for (int k = 0; k < 4; k++)
+            px[k] = yuv_pixel(fmt, (yy >> (8 * k)) & 255, (cb2 >> (8 * (k >> 1))) & 255, (cr2 >> (8 * (k >> 1))) & 255);
         *reinterpret_cast<uint4 *>(dst + (size_t)y * width + x) = make_uint4(px[0], px[1], px[2], px[3]);
     }
 }
 
-/* Device-resident output: the window (x0,y0,w,h) of a decoded frame (even offsets and sizes) either converted
- * (fmt 0..2, one pixel per lane, tightly packed w*h u32) or as a tight I420 picture (fmt 3: w*h Y, then the two
- * (w/2)*(h/2) chroma planes, one byte per lane).  Same arithmetic as k_convert. */
+/* Whole frames, tiles -> planar I420 (what h264bsdNextOutputPicture() returns): 16 bytes per thread, a luma row piece
+ * or two chroma row pieces of one tile; reads are contiguous per tile, writes 16-byte pieces of planar rows. */
+__global__ __launch_bounds__(256) void k_detile(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint32_t wmb, uint32_t hmb,
+                                                size_t in_stride, size_t out_stride)
+{
+    const uint8_t *s = src + blockIdx.y * in_stride;
+    uint8_t *d = dst + blockIdx.y * out_stride;
+    const uint32_t W = wmb * 16, CW = W >> 1;
+    const size_t ysz = (size_t)W * hmb * 16, csz = ysz >> 2;
+    const uint32_t total = wmb * hmb * (TILE / 16);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t mb = i / (TILE / 16), pc = i % (TILE / 16), mbx = mb % wmb, mby = mb / wmb;
+        const uint4 v = *reinterpret_cast<const uint4 *>(s + (size_t)i * 16);
+        if (pc < 16) *reinterpret_cast<uint4 *>(d + (size_t)(mby * 16 + pc) * W + mbx * 16) = v;
+        else {
+            const uint32_t plane = (pc - 16) >> 2, r = ((pc - 16) & 3) * 2;     /* two 8-byte chroma rows */
+            uint8_t *q = d + ysz + (plane ? csz : 0) + (size_t)(mby * 8 + r) * CW + mbx * 8;
+            *reinterpret_cast<uint2 *>(q) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2 *>(q + CW) = make_uint2(v.z, v.w);
+        }
+    }
+}
+
+/* Device-resident output: the window (x0,y0,w,h) of a decoded frame (even offsets and sizes, multiples of 4 for the
+ * window width) either converted (fmt 0..2, tightly packed w*h u32, 4 pixels per lane) or as a tight I420 picture
+ * (fmt 3: w*h Y, then the two (w/2)*(h/2) chroma planes; 4 luma samples or 2 chroma samples per lane). */
 __global__ __launch_bounds__(256) void k_output(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint32_t width,
                                                 uint32_t height, int fmt, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
 {
-    const uint8_t *cb_pl = src + (size_t)width * height;
-    const uint8_t *cr_pl = cb_pl + (size_t)(width >> 1) * (height >> 1);
-    if (fmt == 3) {
-        const uint32_t ny = w * h, nc = (w >> 1) * (h >> 1);
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ny + 2 * nc; i += gridDim.x * blockDim.x) {
-            uint8_t v;
-            if (i < ny) v = src[(size_t)(y0 + i / w) * width + x0 + i % w];
-            else {
-                const uint32_t j = (i - ny) % nc, cw = w >> 1;
-                const uint8_t *pl = i - ny < nc ? cb_pl : cr_pl;
-                v = pl[(size_t)((y0 >> 1) + j / cw) * (width >> 1) + (x0 >> 1) + j % cw];
+    const uint32_t qw = w >> 2;
+    if (w & 3u) {
+        /* window width not a multiple of 4 (cropping is in units of 2 luma samples): one sample / pixel per lane */
+        const int twmb = (int)(width >> 4);
+        if (fmt == 3) {
+            const uint32_t ny = w * h, nc = (w >> 1) * (h >> 1);
+            for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ny + 2 * nc; i += gridDim.x * blockDim.x) {
+                if (i < ny) dst[i] = src[luma_at(twmb, (int)(x0 + i % w), (int)(y0 + i / w))];
+                else {
+                    const uint32_t j = (i - ny) % nc, cw = w >> 1;
+                    dst[i] = src[chroma_at(twmb, i - ny >= nc, (int)((x0 >> 1) + j % cw), (int)((y0 >> 1) + j / cw))];
+                }
             }
-            dst[i] = v;
+        } else {
+            uint32_t *o32 = reinterpret_cast<uint32_t *>(dst);
+            for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+                const uint32_t y = y0 + i / w, x = x0 + i % w;
+                o32[i] = yuv_pixel(fmt, src[luma_at(twmb, (int)x, (int)y)], src[chroma_at(twmb, 0, (int)(x >> 1), (int)(y >> 1))],
+                                   src[chroma_at(twmb, 1, (int)(x >> 1), (int)(y >> 1))]);
+            }
         }
         return;
     }
-    uint32_t *out = reinterpret_cast<uint32_t *>(dst);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
-        const uint32_t y = y0 + i / w, x = x0 + i % w;
-        const int Yv = src[(size_t)y * width + x];
-        const int cb = cb_pl[(size_t)(y >> 1) * (width >> 1) + (x >> 1)], cr = cr_pl[(size_t)(y >> 1) * (width >> 1) + (x >> 1)];
-        uint32_t px;
-        if (fmt == 2) px = 0xFF000000u | ((uint32_t)cr << 16) | ((uint32_t)cb << 8) | (uint32_t)Yv;
-        else {
-            const int c = Yv - 16, d = cb - 128, e = cr - 128;
-            const uint32_t r = clip255((298 * c + 409 * e + 128) >> 8);
-            const uint32_t g = clip255((298 * c - 100 * d - 208 * e + 128) >> 8);
-            const uint32_t b = clip255((298 * c + 516 * d + 128) >> 8);
-            px = fmt == 0 ? 0xFF000000u | (b << 16) | (g << 8) | r : 0xFF000000u | (r << 16) | (g << 8) | b;
+    if (fmt == 3) {
+        const uint32_t ny4 = qw * h, cw = w >> 1, nc2 = (cw >> 1) * (h >> 1);
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ny4 + 2 * nc2; i += gridDim.x * blockDim.x) {
+            if (i < ny4) {
+                const uint32_t y = i / qw, x = (i % qw) * 4;
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) v |= (uint32_t)src[luma_at((int)(width >> 4), (int)(x0 + x + k), (int)(y0 + y))] << (8 * k);
+                *reinterpret_cast<uint32_t *>(dst + (size_t)y * w + x) = v;
+            } else {
+                const uint32_t j = i - ny4, plane = j >= nc2, jj = plane ? j - nc2 : j, y = jj / (cw >> 1), x = (jj % (cw >> 1)) * 2;
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 2; k++) v |= (uint32_t)src[chroma_at((int)(width >> 4), (int)plane, (int)((x0 >> 1) + x + k), (int)((y0 >> 1) + y))] << (8 * k);
+                *reinterpret_cast<uint16_t *>(dst + (size_t)w * h + (plane ? (size_t)cw * (h >> 1) : 0) + (size_t)y * cw + x) = (uint16_t)v;
+            }
         }
-        out[i] = px;
+        return;
+    }
+    (void)height;
+    uint32_t *out = reinterpret_cast<uint32_t *>(dst);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < qw * h; i += gridDim.x * blockDim.x) {
+        const uint32_t y = y0 + i / qw, x = x0 + (i % qw) * 4;
+        uint32_t px[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int Yv = src[luma_at((int)(width >> 4), (int)(x + k), (int)y)];
+            const int cb = src[chroma_at((int)(width >> 4), 0, (int)((x + k) >> 1), (int)(y >> 1))];
+            const int cr = src[chroma_at((int)(width >> 4), 1, (int)((x + k) >> 1), (int)(y >> 1))];
+            px[k] = yuv_pixel(fmt, Yv, cb, cr);
+        }
+        *reinterpret_cast<uint4 *>(out + (size_t)(i / qw) * w + (i % qw) * 4) = make_uint4(px[0], px[1], px[2], px[3]);
     }
 }
 
 /* ------------------------------------------------------------------ on-device verification */
-/* sum over 32-bit words w[i] of (w[i] ^ i*0x9E3779B1) * (2i+1)  (mod 2^64); one block per frame */
-__global__ __launch_bounds__(256) void k_checksum(const uint8_t *__restrict__ base, size_t stride, uint32_t words,
+/* sum over the 32-bit words w[i] of the PLANAR picture of (w[i] ^ i*0x9E3779B1) * (2i+1)  (mod 2^64); one block per
+ * frame.  The frame is stored as tiles: every 4-byte piece of a tile is one word of the planar picture, whose index i
+ * follows from the macroblock position — the value is the one the golden files hold for the reference's output. */
+__global__ __launch_bounds__(256) void k_checksum(const uint8_t *__restrict__ base, size_t stride, uint32_t wmb, uint32_t hmb,
                                                   unsigned long long *__restrict__ out)
 {
     __shared__ unsigned long long part[256];
     const uint32_t *w = reinterpret_cast<const uint32_t *>(base + blockIdx.x * stride);
+    const uint32_t words = wmb * hmb * (TILE / 4), W4 = wmb * 4, CW4 = wmb * 2;
+    const uint32_t ywords = W4 * hmb * 16, cwords = ywords >> 2;
     unsigned long long acc = 0;
-    for (uint32_t i = threadIdx.x; i < words; i += 256)
-        acc += (unsigned long long)(w[i] ^ (i * 0x9E3779B1u)) * (unsigned long long)(2u * i + 1u);
+    for (uint32_t t = threadIdx.x; t < words; t += 256) {
+        const uint32_t mb = t / (TILE / 4), k = t % (TILE / 4), mbx = mb % wmb, mby = mb / wmb;
+        uint32_t i;
+        if (k < 64) i = (mby * 16 + (k >> 2)) * W4 + mbx * 4 + (k & 3);
+        else {
+            const uint32_t kk = k - 64, plane = kk >> 4, r = (kk & 15) >> 1, half = kk & 1;
+            i = ywords + plane * cwords + (mby * 8 + r) * CW4 + mbx * 2 + half;
+        }
+        acc += (unsigned long long)(w[t] ^ (i * 0x9E3779B1u)) * (unsigned long long)(2u * i + 1u);
+    }
     part[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {

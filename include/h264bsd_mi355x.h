@@ -79,6 +79,10 @@ int  h264bsdmiSetDevice(int device);
 /* Run every queued frame job of every decoder instance of this process now (they are otherwise run
  * lazily, when the first picture is pulled).  Returns 0 on success. */
 int  h264bsdmiFlush(void);
+/* Sticky device error bits (0 = none): 1 a residual outside [-512,511] reached the kernels (the host parser finds this
+ * decode error while it parses, so the kernels' check is a tripwire), 2 / 4 the intra / deblocking scheduler of a
+ * picture gave up.  Any bit means that pixels were produced that cannot be trusted; the library also says so on stderr. */
+unsigned h264bsdmiDeviceErrors(void);
 /* Like h264bsdmiFlush() but returns as soon as the copies and kernels are enqueued, so that parsing the next
  * pictures overlaps the reconstruction of these.  Any call that needs pixels (h264bsdNextOutputPicture*,
  * h264bsdmiFlush) waits for the outstanding work first. */

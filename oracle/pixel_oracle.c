@@ -699,3 +699,31 @@ void oracle_convert(int fmt, uint32_t width, uint32_t height, const uint8_t *dat
             out[(size_t)y * width + x] = v;
         }
 }
+
+/* Boundary strengths of a picture, for analysis tools: out[32 * mb + 16 * dir + 4 * e + k] (dir 0 = vertical edges),
+ * 0 where the edge is not filtered at all (GetMbFilteringFlags). */
+int oracle_strengths(const uint8_t *blob, uint8_t *out)
+{
+    if (check_blob(blob)) return -1;
+    const FjHeader *h = (const FjHeader *)blob;
+    const FjMbRec *recs = (const FjMbRec *)(blob + h->rec_off);
+    const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(blob + h->mv_off);
+    memset(out, 0, (size_t)h->n_mbs * 32u);
+    for (uint32_t a = 0; a < h->n_mbs; a++) {
+        const FjMbRec *q = &recs[a];
+        if (q->kind == FJ_MB_ABSENT || !q->dbk) continue;
+        for (int dir = 0; dir < 2; dir++)
+            for (int e = 0; e < 4; e++) {
+                const int mb_edge = e == 0;
+                if (mb_edge && !(q->dbk & (dir ? FJ_DBK_TOP : FJ_DBK_LEFT))) continue;
+                if (!mb_edge && !(q->dbk & FJ_DBK_INNER)) continue;
+                const uint32_t pa = mb_edge ? (dir ? a - h->width_mbs : a - 1) : a;
+                for (int k = 0; k < 4; k++) {
+                    const int qx = dir ? k : e, qy = dir ? e : k;
+                    const int px = dir ? k : (mb_edge ? 3 : e - 1), py = dir ? (mb_edge ? 3 : e - 1) : k;
+                    out[32 * a + 16 * dir + 4 * e + k] = (uint8_t)bs_of(q, mvs[a], &recs[pa], mvs[pa], qx, qy, px, py, mb_edge);
+                }
+            }
+    }
+    return 0;
+}

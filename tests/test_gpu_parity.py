@@ -154,3 +154,19 @@ def test_stateless_convert_api_random_frames(built):
         yuv = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
         for fmt in range(3):
             assert np.array_equal(built.convert(fmt, w, h, yuv), pyoracle.oracle_convert(fmt, w, h, yuv))
+
+
+def test_config4_at_full_size_256_streams(built, captured, golden):
+    """BASELINE.json config 4 exactly as the bench runs it — 256 concurrent copies of test_1920x1080.h264, all 73
+    pictures, private frame jobs and DPBs per stream (22 GB of HBM) — outside bench.py: after every tick the
+    device-computed checksum of the picture it produced is compared, for all 256 streams, with the reference's."""
+    name = "test_1920x1080"
+    jobs, _, _ = captured(name)
+    rep = built.Replay(jobs, n_streams=256)
+    g = golden[name]
+    for i, job in enumerate(jobs):
+        rep.run(i, 1)
+        sums = rep.checksums(pyoracle.blob_header(job)["cur_slot"])
+        assert sums.shape == (256,) and (sums == np.uint64(g["frame_checksum64"][i])).all(), f"picture {i}"
+    assert built.device_errors() == 0
+    rep.close()

@@ -2,11 +2,12 @@
 
 This is what pins the oracle (and the parser) before any kernel is trusted: golden.json was produced by
 the compiled reference (tests/golden/make_golden.py)."""
+import os
 import hashlib
 
 import pytest
 
-from conftest import STREAMS
+from conftest import STREAMS, stream_bytes
 from oracle import pyoracle
 
 
@@ -133,3 +134,46 @@ def test_frame_job_schedules_are_consistent(pic, captured):
     assert ((run_cnt >= 1) & (run_cnt <= 8)).all() and ((run_mb % w) + run_cnt <= w).all()
     # deblocking index: exactly the MBs not marked trivially strength-free
     assert sorted(dbk.tolist()) == np.nonzero(rec[:, 21] == 0)[0].tolist()
+
+
+def test_input_buffer_is_unescaped_in_place_like_the_reference(built):
+    """The reference removes the emulation-prevention bytes of every NAL unit it extracts IN the caller's buffer
+    (src/h264bsd_byte_stream.c:193-235, README.md:11).  A drop-in has to leave the buffer in the same state."""
+    import ctypes
+    import hashlib
+    from oracle import pyoracle
+    from h264bsd_amd import capi
+    from h264writer import StreamWriter
+    from synth_configs import CONFIGS
+    if not os.path.exists(pyoracle.REF_SO):
+        pytest.skip("oracle/_ref not built")
+    streams = [stream_bytes("test_640x360"), StreamWriter(**CONFIGS["ipcm"]).build(), StreamWriter(**CONFIGS["high_qp"]).build()]
+    n_changed = 0
+    for data in streams:
+        lib = pyoracle.RefDecoder().lib
+        rbuf = ctypes.create_string_buffer(data, len(data))
+        dec = lib.h264bsdAlloc()
+        assert lib.h264bsdInit(dec, 0) == 0
+        off, rb = 0, ctypes.c_uint32(0)
+        a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        while off < len(data):
+            r = lib.h264bsdDecode(dec, ctypes.addressof(rbuf) + off, len(data) - off, 0, ctypes.byref(rb))
+            off += rb.value
+            if r == 1:
+                while lib.h264bsdNextOutputPicture(dec, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)):
+                    pass
+        lib.h264bsdShutdown(dec)
+        lib.h264bsdFree(dec)
+        obuf = ctypes.create_string_buffer(data, len(data))
+        ours = capi.Decoder(0, capture=lambda blob: None)
+        off = 0
+        while off < len(data):
+            r, n = ours.decode(ctypes.addressof(obuf) + off, len(data) - off, 0)
+            off += n
+            if r == 1:
+                while ours.next_output_info() is not None:
+                    pass
+        ours.close()
+        assert hashlib.sha1(obuf.raw).hexdigest() == hashlib.sha1(rbuf.raw).hexdigest()
+        n_changed += obuf.raw != data
+    assert n_changed >= 1, "none of the streams contains an emulation-prevention byte: the test checks nothing"
