@@ -38,8 +38,54 @@ HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s
 STREAM = "test_1920x1080"
 
 
-def cpu_baseline(data, seconds=12.0):
-    """Reference decoder (oracle/_ref) on ONE host core, decode-only loop, fresh input copy per pass."""
+def _cpu_worker(core, seconds):
+    """child process of cpu_baseline_all_cores: the compiled reference on ONE pinned core, decode-only loop with a fresh
+    copy of the input per pass (it is unescaped in place); prints pictures and seconds."""
+    from oracle import pyoracle
+    os.sched_setaffinity(0, {core})
+    data = open(os.path.join(ROOT, "tests", "golden", STREAM + ".h264"), "rb").read()
+    ref = pyoracle.RefDecoder()
+    ref.decode_stream(data)                                   # warm-up pass (page faults, caches)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        n += ref.decode_stream(data)[1]
+    print(n, time.perf_counter() - t0, flush=True)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_all_cores(seconds=8.0):
+    """SURVEY.md §8d / posix/Rakefile:7: one pinned process per host core, all at once (the reference has no threads of
+    its own; independent streams are how a host scales it)."""
+    import subprocess
+    cores = sorted(os.sched_getaffinity(0))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(c), str(seconds)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for c in cores]
+    pics = fps = 0.0
+    ok = 0
+    for p in procs:
+        out, _ = p.communicate(timeout=seconds * 6 + 120)
+        try:
+            n, dt = out.split()[-2:]
+            pics += float(n); fps += float(n) / float(dt); ok += 1
+        except (ValueError, IndexError):
+            pass
+    if not ok:
+        return None
+    return dict(value=fps * 8160, unit="macroblocks/s", fps=fps, cores=ok, cpu=cpu_model(),
+                sample=f"{ok} pinned processes (one per host core), each looping over {STREAM}.h264 for {seconds:.0f} s: {int(pics)} pictures")
+
+
+def cpu_baseline(data, seconds=10.0):
+    """Reference decoder (oracle/_ref) on ONE host core, decode-only loop, fresh input copy per pass; plus all cores."""
     from oracle import pyoracle
     try:
         ref = pyoracle.RefDecoder()
@@ -60,11 +106,49 @@ def cpu_baseline(data, seconds=12.0):
         n_pics += run()
         passes += 1
     dt = time.perf_counter() - t0
-    return dict(value=n_pics * 8160 / dt, unit="macroblocks/s", fps=n_pics / dt, cores=1, kind=kind,
-                sample=f"{passes} full passes of {STREAM}.h264 ({n_pics} pictures, {dt:.1f} s) on 1 of {os.cpu_count()} host cores")
+    out = dict(value=n_pics * 8160 / dt, unit="macroblocks/s", fps=n_pics / dt, cores=1, kind=kind, cpu=cpu_model(),
+               note="whole decoder (entropy decoding included) on the host; `value` of this bench is the pixel path only, "
+                    "from frame jobs already parsed — like for like is `end_to_end` below",
+               sample=f"{passes} full passes of {STREAM}.h264 ({n_pics} pictures, {dt:.1f} s) on 1 of {os.cpu_count()} host cores")
+    if kind == "reference":
+        out["all_cores"] = cpu_baseline_all_cores()
+    return out
+
+
+def end_to_end(data, streams, threads, laps=2):
+    """the drop-in C API end to end — host parse on the library's parser threads
+    (h264bsdmiDecodePictureBatch), frame jobs built in pinned memory, one H2D copy per picture, kernels; pictures stay in
+    HBM (no D2H).  Round k+1 is parsed while round k reconstructs (h264bsdmiFlushAsync)."""
+    import h264bsd_amd as h
+    L = h.lib()
+    decs = [h.Decoder() for _ in range(streams)]
+    threads = L.h264bsdmiSetParserThreads(threads)
+    drv = h.BatchDriver(decs, [data * (laps + 1)] * streams)
+    timed, t0 = 0, None
+    for pic in range(73 * (laps + 1)):
+        if pic == 73:                                         # first lap: untimed (pinned staging buffers are allocated)
+            assert L.h264bsdmiFlush() == 0
+            t0 = time.perf_counter()
+        assert len(drv.step()) == streams
+        assert L.h264bsdmiFlushAsync() == 0
+        timed += pic >= 73
+    assert L.h264bsdmiFlush() == 0
+    dt = time.perf_counter() - t0
+    jobs, _, _ = h.capture_stream(data)
+    h2d = sum(len(j) for j in jobs) * streams * laps
+    for d in decs:
+        d.close()
+    pics = streams * timed
+    return dict(value=pics * 8160 / dt, unit="macroblocks/s", fps=pics / dt, streams=streams, parser_threads=int(threads),
+                host_cores=os.cpu_count(), h2d_bytes_per_picture=h2d / pics, d2h_bytes_per_picture=0,
+                device_errors=h.device_errors(),
+                sample=f"{streams} decoder instances x {timed} pictures through h264bsdDecode-equivalent batch calls, PCIe inclusive, "
+                       f"{dt:.1f} s; pictures left in HBM")
 
 
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-worker":
+        return _cpu_worker(int(sys.argv[2]), float(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -76,6 +160,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-desync", action="store_true", help="skip the fully desynchronised variants (reported next to the lock-step value)")
     ap.add_argument("--no-staggered", action="store_true", help="skip the staggered-start variant (reported next to the lock-step value)")
+    ap.add_argument("--no-argb", action="store_true", help="skip the config-3 variant (colour conversion of every picture inside the timed region)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end leg through the drop-in C API (host parse + H2D + kernels)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,19 +255,58 @@ def main():
         verify(n_pics - 1)                                     # the final pictures, after the timed region
         job_bytes = rep.job_bytes
         rep.close()
+        local = elapsed
         if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        return elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown
+        return elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local
 
-    elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown = run_variant(0)
+    elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local_elapsed = run_variant(0)
     staggered = None
     if not args.no_staggered and args.streams > 1:
         idr = [i for i, h in enumerate(heads) if h["is_idr"] and i > 0]
         if idr:
-            st_elapsed, _, _, st_dev_ms, _, _, st_breakdown = run_variant(idr[0])
+            st_elapsed, _, _, st_dev_ms, _, _, st_breakdown, _ = run_variant(idr[0])
             staggered = dict(odd_stream_offset=idr[0], elapsed=st_elapsed, breakdown=st_breakdown, dev_ms=st_dev_ms)
+
+    # ---- BASELINE.json config 3: the same lock-step work with the colour conversion of every produced picture inside
+    # the timed region (k_convert, BGRA = the reference's "ARGB" word, h264bsdConvertToBGRA semantics): +1024 B written
+    # per macroblock.  The converted pictures 0, 1 and 72 of one stream are checked against the reference's own
+    # conversion (golden.json convert_sha256) in an untimed pass first.
+    argb = None
+    if not args.no_argb:
+        import hashlib
+        rep = h264bsd_amd.Replay(jobs, n_streams=args.streams)
+        w_px, h_px = info["width_mbs"] * 16, info["height_mbs"] * 16
+        for i in range(n_pics):
+            rep.run(i, 1)
+            if str(i) in golden["convert_sha256"]:
+                rep.convert(heads[i]["cur_slot"], h264bsd_amd.FMT_BGRA)
+                got = rep.fetch_converted(args.streams - 1, w_px * h_px)
+                if hashlib.sha256(got.tobytes()).hexdigest() != golden["convert_sha256"][str(i)][h264bsd_amd.FMT_BGRA]:
+                    raise SystemExit(f"rank {rank}: BGRA conversion of picture {i} differs from the reference")
+        rep.set_convert(h264bsd_amd.FMT_BGRA)
+        rep.run(); rep.sync()
+        barrier()
+        t0 = time.perf_counter()
+        conv_ms, conv_n, a_dev_ms = 0.0, 0, 0.0
+        for _ in range(args.steps):
+            rep.run()
+            a_dev_ms += rep.timings()["total_ms"]
+            ms, n = rep.convert_timings()
+            conv_ms += ms; conv_n += n
+        barrier()
+        a_elapsed = time.perf_counter() - t0
+        sums = rep.checksums(heads[-1]["cur_slot"])
+        if not (sums == golden_sums[-1]).all():
+            raise SystemExit(f"rank {rank}: ARGB variant: final pictures are not bit-exact")
+        rep.close()
+        if dist is not None:
+            tt = torch.tensor([a_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            a_elapsed = float(tt.item())
+        argb = dict(elapsed=a_elapsed, conv_ms=conv_ms, conv_n=conv_n, dev_ms=a_dev_ms)
 
     # ---- streams that are not in step at all: stream s starts at picture s * n_pics / n_streams.  Every tick then
     # holds I pictures AND the heaviest P pictures of the stream, and a tick lasts as long as its slowest picture:
@@ -235,6 +360,14 @@ def main():
         copy_gbs = 10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9      # read + write
         del src, dst
 
+    # per-GPU values (config 5 asks for them next to the node total): every rank's own elapsed time of the timed steps
+    per_gpu = None
+    if dist is not None:
+        mine = torch.tensor([local_elapsed], dtype=torch.float64, device="cuda")
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_gpu = [n_pics * args.streams * n_mbs * args.steps / float(v.item()) for v in allv]
+
     if rank == 0:
         pics_per_step = n_pics * args.streams * world
         mbs = pics_per_step * n_mbs * args.steps
@@ -252,11 +385,22 @@ def main():
         units_per_launch = n_mbs * n_pics * args.streams * args.steps / launches
         achieved = alg_per_mb * units_per_launch / (avg_launch_us * 1e-6) / 1e9       # GB/s
         path_gbs = alg_bytes_stream * args.streams * args.steps / (dev_total_ms * 1e-3) / 1e9
-        traffic = None
-        try:   # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes (profiles/)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"][dom]
-            traffic = (tj.get("fetch_bytes_per_launch_calibrated", tj["fetch_bytes_per_launch"]) +
-                       tj.get("write_bytes_per_launch_calibrated", tj["write_bytes_per_launch"]))
+        # HBM bytes per launch of the dominant kernel: PMC counters need rocprofv3 (separate --pmc passes,
+        # tools/refresh_profiles.sh), so they cannot be collected inside this run; the committed table is only used
+        # while it belongs to the kernels that just ran (sha256 of the kernel sources), otherwise traffic is null
+        traffic, traffic_note = None, "no traffic table in profiles/"
+        try:
+            import hashlib
+            tfile = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            src_sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "h264bsd_amd", "csrc", f), "rb").read()
+                                              for f in ("kernels.hip.h", "framejob.h"))).hexdigest()
+            if tfile.get("kernel_source_sha256") != src_sha:
+                traffic_note = "profiles/r02_traffic.json was measured with other kernel sources: stale, not reported (rerun tools/refresh_profiles.sh)"
+            else:
+                tj = tfile["kernels"][dom]
+                traffic = (tj.get("fetch_bytes_per_launch_calibrated", tj["fetch_bytes_per_launch"]) +
+                           tj.get("write_bytes_per_launch_calibrated", tj["write_bytes_per_launch"]))
+                traffic_note = "profiles/r02_traffic.json: FETCH_SIZE + WRITE_SIZE of this kernel, separate rocprofv3 --pmc passes of this command, calibrated on k_copy's known byte count"
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -270,7 +414,7 @@ def main():
                                    "inter+intra reconstruction + in-loop deblocking, bit-exact vs reference verified on device",
                        "streams_per_gpu": args.streams, "pictures_per_step": pics_per_step, "parallelism": f"streams/{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "alg_bytes_per_launch": alg_per_mb * units_per_launch,
                          "alg_bytes_per_mb": alg_per_mb, "mbs_per_launch": units_per_launch,
                          "avg_launch_us": avg_launch_us, "launches": launches,
@@ -289,8 +433,25 @@ def main():
                                 "odd_stream_offset_pictures": staggered["odd_stream_offset"],
                                 "device_ms_per_step": dict({k: staggered["breakdown"][k][0] for k in kernels},
                                                            total=staggered["dev_ms"] / args.steps)}
+        if argb is not None:
+            # config 3: algorithmic bytes per macroblock + 1024 (32-bit pixels written); k_convert's own roofline:
+            # 384 B read + 1024 B written per macroblock, every launch covers one picture of every stream
+            a_launches = max(argb["conv_n"], 1)
+            conv_us = argb["conv_ms"] * 1e3 / a_launches
+            conv_bytes = (384 + 1024) * n_mbs * args.streams
+            out["argb"] = {"value": mbs / argb["elapsed"], "unit": "macroblocks/s", "fps": pics_per_step * args.steps / argb["elapsed"],
+                           "ms_per_step": argb["elapsed"] * 1e3 / args.steps, "format": "BGRA (the reference's ARGB word, h264bsdConvertToBGRA)",
+                           "alg_bytes_per_mb": alg_per_mb + 1024,
+                           "whole_path_GBs": (alg_bytes_stream + 1024 * n_mbs * n_pics) * args.streams * args.steps / (argb["dev_ms"] * 1e-3) / 1e9,
+                           "k_convert": {"avg_launch_us": conv_us, "launches": argb["conv_n"], "alg_bytes_per_launch": conv_bytes,
+                                         "achieved_GBs": conv_bytes / (conv_us * 1e-6) / 1e9, "frac": conv_bytes / (conv_us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
+        if per_gpu is not None:
+            out["per_gpu"] = {"value": per_gpu, "unit": "macroblocks/s", "note": "lock-step variant, each rank's own clock over the timed steps"}
         if desync is not None:
             out["desynchronised"] = desync
+        if world == 1 and not args.no_end_to_end:
+            out["end_to_end"] = end_to_end(data, min(args.streams, 256), min(64, os.cpu_count() or 1))
+        out["device_errors"] = h264bsd_amd.device_errors()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data)
         print(json.dumps(out), flush=True)

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads",
     "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
-    "h264bsdmiReplayTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
+    "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
 ]
 
 class DevicePicture(ctypes.Structure):
@@ -420,6 +420,17 @@ class Replay:
         if self._L.h264bsdmiReplayChecksums(self._h, slot, out.ctypes.data) != 0:
             raise RuntimeError("h264bsdmiReplayChecksums failed")
         return out
+
+    def set_convert(self, fmt):
+        """fmt 0..2: every tick of run() is followed by the colour conversion of the produced pictures; -1: off"""
+        if self._L.h264bsdmiReplaySetConvert(self._h, fmt) != 0:
+            raise RuntimeError("h264bsdmiReplaySetConvert failed")
+
+    def convert_timings(self):
+        ms, n = ctypes.c_float(0), ctypes.c_uint32(0)
+        if self._L.h264bsdmiReplayConvertTimings(self._h, ctypes.byref(ms), ctypes.byref(n)) != 0:
+            raise RuntimeError("h264bsdmiReplayConvertTimings failed")
+        return ms.value, n.value
 
     def convert(self, slot, fmt):
         if self._L.h264bsdmiReplayConvert(self._h, slot, fmt) != 0:

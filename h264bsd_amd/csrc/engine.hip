@@ -621,6 +621,9 @@ struct h264bsdmi_replay {
     hipStream_t lanes[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     uint32_t n_lanes = 0;
     std::vector<uint32_t> offsets;    /* first picture of every stream */
+    /* config 3 ("ARGB conversion on-GPU"): colour conversion of every produced picture inside the run, timed */
+    int convert_fmt = -1;
+    std::vector<hipEvent_t> cev;      /* 2 per tick */
 };
 
 h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams)
@@ -793,6 +796,7 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     hipEventDestroy(r->ev_begin); hipEventDestroy(r->ev_end); if (r->gdone_any) hipEventDestroy(r->gdone_any);
     for (int g = 0; g < 8; g++) { if (r->gstream[g]) hipStreamDestroy(r->gstream[g]); if (r->gdone[g]) hipEventDestroy(r->gdone[g]); }
     for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
+    for (auto &ev : r->cev) hipEventDestroy(ev);
     for (auto &st : r->lanes) if (st) hipStreamDestroy(st);
     delete r;
 }
@@ -822,6 +826,15 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
         for (u32 i = first; i < first + count; i++) {
             r->timers[i].on = true; r->timers[i].mask = r->timed_mask;
             if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr)) return -1;
+            if (r->convert_fmt >= 0) {
+                /* the picture every stream has just produced, converted where it lies (tiles -> packed 32-bit pixels) */
+                const uint32_t w = r->wmb * 16, h = r->hmb * 16;
+                HIP_TRY(hipEventRecord(r->cev[2 * i], r->e->stream));
+                hipLaunchKernelGGL(h264k::k_convert, dim3(256, r->n_streams), dim3(256), 0, r->e->stream,
+                                   r->d_frames + (size_t)r->cur_slot[i] * r->frame_bytes, r->d_conv, w, h, r->convert_fmt,
+                                   (size_t)r->n_slots * r->frame_bytes, (size_t)w * h, 1);
+                HIP_TRY(hipEventRecord(r->cev[2 * i + 1], r->e->stream));
+            }
         }
     } else {
         /* stream groups on separate HIP streams: the latency-bound per-picture tail of one group overlaps
@@ -949,6 +962,36 @@ int h264bsdmiReplayFetchConverted(h264bsdmi_replay *r, u32 stream, u32 *dst)
     HIP_TRY(hipStreamSynchronize(r->e->stream));
     const size_t n = (size_t)r->wmb * 16 * r->hmb * 16;
     HIP_TRY(hipMemcpy(dst, r->d_conv + (size_t)stream * n, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* fmt 0..2: every h264bsdmiReplayRun() tick (lock-step sets, one group) is followed by the colour conversion of the
+ * pictures it produced, inside the timed region; fmt < 0: off.  h264bsdmiReplayConvertTimings: k_convert time of the last run. */
+int h264bsdmiReplaySetConvert(h264bsdmi_replay *r, int fmt)
+{
+    if (!r || fmt > 2 || !r->sched.empty()) return -1;
+    std::lock_guard<std::mutex> lk(r->e->mu);
+    HIP_TRY(hipSetDevice(r->e->device));
+    if (fmt >= 0) {
+        const size_t n = (size_t)r->wmb * 16 * r->hmb * 16;
+        if (!r->d_conv) HIP_TRY(hipMalloc((void **)&r->d_conv, n * 4 * r->n_streams));
+        while (r->cev.size() < 2 * (size_t)r->n_pics) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); r->cev.push_back(ev); }
+    }
+    r->convert_fmt = fmt;
+    return 0;
+}
+
+int h264bsdmiReplayConvertTimings(h264bsdmi_replay *r, float *ms, u32 *launches)
+{
+    if (!r || r->convert_fmt < 0) return -1;
+    HIP_TRY(hipSetDevice(r->e->device));
+    HIP_TRY(hipStreamSynchronize(r->e->stream));
+    *ms = 0.f; *launches = 0;
+    for (u32 i = r->timed_first; i < r->timed_first + r->timed_count; i++) {
+        float t;
+        HIP_TRY(hipEventElapsedTime(&t, r->cev[2 * i], r->cev[2 * i + 1]));
+        *ms += t; (*launches)++;
+    }
     return 0;
 }
 

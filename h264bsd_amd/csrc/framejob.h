@@ -118,11 +118,15 @@ typedef struct FjHeader {
 /* An inter macroblock with no coefficients whose 16 motion vectors are equal and whole-sample for
  * luma AND chroma (mv multiple of 8 quarter-samples; 66 % of the inter MBs of the bundled 1080p
  * stream, almost all of them P_Skip with mv 0): reconstruction is a 384-byte copy. */
-#define FJ_COPY_RUN 8         /* longest run of a copy-list entry: 8 MBs = one 128-byte line per luma row */
+#ifndef FJ_COPY_RUN
+#define FJ_COPY_RUN 8         /* longest run of a copy-list entry.  Frames are stored as macroblock tiles (384 contiguous bytes
+                                 per macroblock, address order), so a run with zero displacement is ONE contiguous block of
+                                 count x 384 bytes in both frames — also across the end of a macroblock row */
+#endif
 typedef struct FjCopy {
     uint16_t mb;              /* address of the first macroblock of the run                   */
     uint8_t  slot;            /* reference DPB slot                                           */
-    uint8_t  count;           /* 1..FJ_COPY_RUN horizontally adjacent MBs with the same slot and mv */
+    uint8_t  count;           /* 1..FJ_COPY_RUN MBs with consecutive addresses, the same slot and mv (a displaced run stays inside one row) */
     int16_t  dx, dy;          /* displacement in luma samples (even)                          */
 } FjCopy;                     /* 8 bytes */
 

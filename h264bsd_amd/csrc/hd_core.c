@@ -219,10 +219,11 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
             }
         }
         if (cls[a] & 2) {
-            /* copy list: runs of up to FJ_COPY_RUN horizontally adjacent copy MBs with equal reference and mv */
+            /* copy list: runs of up to FJ_COPY_RUN copy MBs with consecutive addresses, equal reference and mv; a run whose
+             * displacement is zero may continue into the next row (tiles are contiguous in address order) */
             const int16_t *m0 = mvs[a][0];
             FjCopy *last = n_copy ? &copy_tmp[n_copy - 1] : NULL;
-            if (last && last->count < FJ_COPY_RUN && (uint32_t)last->mb + last->count == a && a % w != 0 &&
+            if (last && last->count < FJ_COPY_RUN && (uint32_t)last->mb + last->count == a && (a % w != 0 || (m0[0] | m0[1]) == 0) &&
                 last->slot == r->ref_slot[0] && last->dx == (m0[0] >> 2) && last->dy == (m0[1] >> 2)) {
                 last->count++;
             } else {

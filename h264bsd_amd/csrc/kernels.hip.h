@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
 /* ------------------------------------------------------------------ whole-sample copy macroblocks */
 /* List entries are runs of up to 8 horizontally adjacent MBs with one displacement.  With macroblock tiles a run whose
  * displacement is zero (P_Skip with zero motion: almost all of them) is ONE contiguous block of count x 384 bytes in
- * the reference frame and in the current one: 24 x count 16-byte pieces, up to three per lane, every load issued before
+ * the reference frame and in the current one: 24 x count 16-byte pieces, up to six per lane, every load issued before
  * the first store.  Displaced (and clamped) runs gather their samples 4 at a time. */
 __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ frames)
 {
@@ -522,11 +522,12 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
         const uint4 *src = reinterpret_cast<const uint4 *>(ref + (size_t)e.mb * TILE);
         uint4 *dst = reinterpret_cast<uint4 *>(fd.cur + (size_t)e.mb * TILE);
         const int n16 = cnt * (TILE / 16);
-        uint4 v[3];
+        constexpr int PIECES = (FJ_COPY_RUN * (TILE / 16) + 63) / 64;
+        uint4 v[PIECES];
 #pragma unroll
-        for (int j = 0; j < 3; j++) if (lane + 64 * j < n16) v[j] = src[lane + 64 * j];
+        for (int j = 0; j < PIECES; j++) if (lane + 64 * j < n16) v[j] = src[lane + 64 * j];
 #pragma unroll
-        for (int j = 0; j < 3; j++) if (lane + 64 * j < n16) dst[lane + 64 * j] = v[j];
+        for (int j = 0; j < PIECES; j++) if (lane + 64 * j < n16) dst[lane + 64 * j] = v[j];
         return;
     }
     /* displaced: clamp-to-edge sample gather (h264bsdFillBlock, reconstruct.c:2244), lane = (row, 4-sample piece) */
@@ -575,7 +576,7 @@ constexpr int QC_STRIDE = 20;                        /* quadrant chroma windows:
 constexpr int INTER_WAVE_LDS = 2688;                 /* max(21 * IW_STRIDE + 2 * 9 * IC_STRIDE = 1452, 4 * 13 * QW_STRIDE + 4 * 2 * 5 * QC_STRIDE = 2672), rounded */
 
 #ifndef INTER_OCC
-#define INTER_OCC 7      /* 72 VGPRs, 10 spilled: measured best (6: 71.5 ms, 7: 67.4, 8: 68.3, 5: 79.9 per step) */
+#define INTER_OCC 8      /* macroblock-tile layout: 8 waves per SIMD (64 VGPRs, more spills) beat 7 / 6 / 5: 50.4 vs 54.4 / 58.9 / 59.2 ms per step — the kernel hides latency with wavefronts */
 #endif
 __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
@@ -1398,11 +1399,12 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
  * workgroup per CU). */
 constexpr int TAIL_WAVES = 16;
 #ifndef DBK_WAVES_N
-#define DBK_WAVES_N 6
+#define DBK_WAVES_N 12
 #endif
-constexpr int DBK_WAVES = DBK_WAVES_N;                        /* wavefronts of k_frame_dbk: the picture's dependency critical path bounds it, and
-                                                        fewer wavefronts contend less for instruction issue (measured per step: 16 waves
-                                                        96 ms, 12: 94, 8: 89-91, 6: 90, 5: 87, 4: 89, 3: 102) */
+constexpr int DBK_WAVES = DBK_WAVES_N;              /* wavefronts of k_frame_dbk.  With planar frames the per-CU cache-line request rate
+                                                        bounded a picture and the count did not matter (4..16 wavefronts: 85-90 ms per
+                                                        step); with macroblock tiles it does: 4: 72.9, 6: 62.5, 8: 56.8, 12: 54.9 ms, 16: 67.6
+                                                        (a 1024-thread workgroup caps the kernel at 128 VGPRs: spills) */
 constexpr int TAIL_WORKERS = 4 * DBK_WAVES;       /* deblocking workers = quarter wavefronts */
 
 /* Intra (and concealed) macroblocks of one picture, dataflow-scheduled inside one workgroup.  A macroblock of the

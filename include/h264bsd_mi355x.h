@@ -139,6 +139,11 @@ int  h264bsdmiReplaySetStages(h264bsdmi_replay *r, unsigned mask);
  * default 31 = all).  Every event is a barrier packet between two kernels; the bench times all five kernels in
  * its warm-up steps and only the dominant one in the timed steps. */
 int  h264bsdmiReplaySetTimedKernels(h264bsdmi_replay *r, unsigned mask);
+/* BASELINE.json config 3 ("ARGB conversion on-GPU"): fmt 0 RGBA, 1 BGRA (= the ARGB word), 2 YCbCrA: every tick of
+ * h264bsdmiReplayRun() is followed, inside the timed region, by the colour conversion of the pictures it produced
+ * (k_convert, 1024 B written per macroblock); fmt < 0 switches it off.  ConvertTimings: HIP-event time of those launches. */
+int  h264bsdmiReplaySetConvert(h264bsdmi_replay *r, int fmt);
+int  h264bsdmiReplayConvertTimings(h264bsdmi_replay *r, float *ms, u32 *launches);
 /* Debug hook: cycle accounting of k_frame_tail's deblocking loop for workgroup 0 of every launch between
  * enable=1 and enable=0 (which copies out[16 waves][8]: cycles in {choose MB, filter, extra rounds, wait for
  * own memory traffic, #filtered, barrier wait}). */

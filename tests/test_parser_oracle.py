@@ -131,7 +131,10 @@ def test_frame_job_schedules_are_consistent(pic, captured):
     run_cnt = copy[:, 3].astype(int)
     covered = np.concatenate([np.arange(m, m + c) for m, c in zip(run_mb, run_cnt)] + [gen.astype(int)]) if len(inter) else np.array([], int)
     assert sorted(covered.tolist()) == inter.tolist()
-    assert ((run_cnt >= 1) & (run_cnt <= 8)).all() and ((run_mb % w) + run_cnt <= w).all()
+    # runs are at most FJ_COPY_RUN (8) macroblocks; only a run with zero displacement may continue into the next row
+    # (tiles are contiguous in address order), a displaced one stays inside its row
+    displaced = (copy[:, 4:8].view(np.int16).reshape(-1, 2) != 0).any(1) if len(copy) else np.zeros(0, bool)
+    assert ((run_cnt >= 1) & (run_cnt <= 8)).all() and (((run_mb % w) + run_cnt <= w) | ~displaced).all()
     # deblocking index: exactly the MBs not marked trivially strength-free
     assert sorted(dbk.tolist()) == np.nonzero(rec[:, 21] == 0)[0].tolist()
 
