@@ -310,7 +310,8 @@ def main():
 
     # ---- streams that are not in step at all: stream s starts at picture s * n_pics / n_streams.  Every tick then
     # holds I pictures AND the heaviest P pictures of the stream, and a tick lasts as long as its slowest picture:
-    # (a) common ticks, (b) mostly-intra pictures on 4 extra HIP streams ("heavy lanes"), rejoining 4 ticks later.
+    # (a) common ticks, (b) mostly-intra pictures on 4 extra HIP streams ("heavy lanes"), rejoining 4 ticks later,
+    # (c) the same with the streams split into 2 groups that run their own ticks on their own HIP streams.
     # Verified at the end of laps 2 and N (a lap = every stream n_pics pictures; the last picture of stream s is
     # picture offsets[s] - 1, so the 256 streams together cover every picture index).
     desync = None
@@ -318,8 +319,8 @@ def main():
         offsets = [(st * n_pics) // args.streams for st in range(args.streams)]
         slots = sorted(set(h["cur_slot"] for h in heads))
         desync = {"offsets": "stream s starts at picture floor(s * n_pics / n_streams)"}
-        for key, lanes, delay in (("common_ticks", 0, 0), ("heavy_lanes", 4, 4)):
-            rep = h264bsd_amd.Replay(jobs, n_streams=args.streams, offsets=offsets, heavy_lanes=lanes, heavy_delay=delay)
+        for key, lanes, delay, groups in (("common_ticks", 0, 0, 1), ("heavy_lanes", 4, 4, 1), ("heavy_lanes_2_groups", 4, 4, 2)):
+            rep = h264bsd_amd.Replay(jobs, n_streams=args.streams, offsets=offsets, heavy_lanes=lanes, heavy_delay=delay, groups=groups)
 
             def verify_lap():
                 sums = {sl: rep.checksums(sl) for sl in slots}
@@ -343,7 +344,7 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = float(tt.item())
             desync[key] = {"value": n_pics * args.streams * world * n_mbs * args.steps / dt, "unit": "macroblocks/s",
-                           "ms_per_step": dt * 1e3 / args.steps, "lanes": lanes, "rejoin_after_ticks": delay}
+                           "ms_per_step": dt * 1e3 / args.steps, "lanes": lanes, "rejoin_after_ticks": delay, "stream_groups": groups}
 
     # on-box ceiling of a plain device-to-device copy (report the fraction of both peaks)
     copy_gbs = None

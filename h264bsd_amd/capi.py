@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdConvertToYCbCrA",
     "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync", "h264bsdmiDeviceErrors",
     "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads",
-    "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
+    "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayCreateSched", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
 ]
@@ -121,6 +121,8 @@ def lib():
     L.h264bsdmiReplayCreateStaggered.restype = vp
     L.h264bsdmiReplayCreateDesync.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32, P32, u32, u32]
     L.h264bsdmiReplayCreateDesync.restype = vp
+    L.h264bsdmiReplayCreateSched.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32, P32, u32, u32, u32]
+    L.h264bsdmiReplayCreateSched.restype = vp
     L.h264bsdmiReplayDestroy.argtypes = [vp]
     L.h264bsdmiReplayDestroy.restype = None
     L.h264bsdmiReplayRun.argtypes = [vp, u32, u32]
@@ -130,6 +132,9 @@ def lib():
     L.h264bsdmiReplayConvert.argtypes = [vp, u32, ctypes.c_int]
     L.h264bsdmiReplayFetchConverted.argtypes = [vp, u32, vp]
     L.h264bsdmiReplayTimings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), P32]
+    L.h264bsdmiReplaySetConvert.argtypes = [vp, ctypes.c_int]
+    L.h264bsdmiReplayConvertTimings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), P32]
+    L.h264bsdmiDeviceErrors.restype = ctypes.c_uint
     L.h264bsdmiReplaySetStages.argtypes = [vp, ctypes.c_uint]
     L.h264bsdmiReplaySetTimedKernels.argtypes = [vp, ctypes.c_uint]
     L.h264bsdmiReplaySetGroups.argtypes = [vp, u32]
@@ -372,10 +377,11 @@ def convert(fmt, width, height, yuv):
 class Replay:
     """HBM-resident replay set: n_streams private copies of one captured stream (kernels only)."""
 
-    def __init__(self, jobs, n_streams, odd_offset=0, offsets=None, heavy_lanes=0, heavy_delay=4):
+    def __init__(self, jobs, n_streams, odd_offset=0, offsets=None, heavy_lanes=0, heavy_delay=4, groups=1):
         """odd_offset: odd-numbered streams run picture (k + odd_offset) % n_pics in tick k ("staggered").
         offsets: first picture of every stream (desynchronised streams); heavy_lanes > 0: mostly intra-coded pictures
-        run on extra HIP streams and rejoin heavy_delay ticks later (run() then always runs one whole lap)."""
+        run on extra HIP streams and rejoin heavy_delay ticks later (run() then always runs one whole lap); groups > 1
+        (with heavy_lanes > 0): the streams are split into groups that run their own ticks on their own HIP streams."""
         L = lib()
         self._L = L
         self._keep = [ctypes.create_string_buffer(j, len(j)) for j in jobs]
@@ -387,7 +393,7 @@ class Replay:
             offsets = [odd_offset if s & 1 else 0 for s in range(n_streams)]
         self.offsets = [int(o) for o in offsets]
         offs = (ctypes.c_uint32 * n_streams)(*self.offsets)
-        self._h = L.h264bsdmiReplayCreateDesync(ptrs, sizes, len(jobs), n_streams, offs, heavy_lanes, heavy_delay)
+        self._h = L.h264bsdmiReplayCreateSched(ptrs, sizes, len(jobs), n_streams, offs, heavy_lanes, heavy_delay, groups)
         if not self._h:
             raise RuntimeError("h264bsdmiReplayCreate failed (no HIP device or out of memory)")
         self.frame_bytes = int(L.h264bsdmiReplayFrameBytes(self._h))

@@ -615,16 +615,21 @@ struct h264bsdmi_replay {
     bool overlap_dbk = true;
     unsigned timed_mask = 31u;
     /* desynchronised sets with heavy lanes (h264bsdmiReplayCreateDesync, lanes > 0): a static launch schedule */
-    struct Launch { size_t first; TickShape shape; int lane; int wait_ev; int record_ev; };
+    struct Launch { size_t first; TickShape shape; int lane; std::vector<int> waits; int record_ev; bool light; };
     std::vector<Launch> sched;
     std::vector<hipEvent_t> sched_ev;
-    hipStream_t lanes[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    uint32_t n_lanes = 0;
+    static constexpr int MAX_LANES = 24;  /* lanes 0..n_light-1: one per stream group (light pictures), then the heavy lanes */
+    hipStream_t lanes[MAX_LANES] = {};
+    SideLane lane_side[MAX_LANES];        /* k_dbk next to the reconstruction kernels, per light lane */
+    uint32_t n_lanes = 0, n_light = 0;
     std::vector<uint32_t> offsets;    /* first picture of every stream */
     /* config 3 ("ARGB conversion on-GPU"): colour conversion of every produced picture inside the run, timed */
     int convert_fmt = -1;
     std::vector<hipEvent_t> cev;      /* 2 per tick */
 };
+
+h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
+                                             const u32 *offsets, u32 heavy_lanes, u32 heavy_delay, u32 groups);
 
 h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams)
 {
@@ -644,15 +649,26 @@ h264bsdmi_replay *h264bsdmiReplayCreateStaggered(const u8 *const *blobs, const u
 
 /* Streams that are NOT in step: stream s starts at picture offsets[s] (nullptr = all 0) and runs n_pics pictures,
  * wrapping around (picture 0 must be an IDR picture).  heavy_lanes == 0: tick i holds picture (i + offsets[s]) mod
- * n_pics of every stream — a tick then lasts as long as its slowest picture.  heavy_lanes > 0: pictures that are
- * mostly intra-coded ("heavy", more than a quarter of their macroblocks) leave the common tick and run on one of
- * heavy_lanes extra HIP streams; their stream of pictures rejoins the common ticks heavy_delay ticks later (an event
- * makes the common tick wait if the heavy picture is not finished by then).  A static schedule: what a scheduler that
- * keeps light pictures from waiting for heavy ones achieves. */
+ * n_pics of every stream — a tick then lasts as long as its slowest picture.  heavy_lanes > 0: a static schedule of
+ * what a scheduler achieves that keeps light pictures from waiting for heavy ones:
+ *   - the streams are split into `groups` groups (stream s -> group s % groups), every group runs its own ticks on its
+ *     own HIP stream ("light lane"): a group's tick lasts as long as ITS slowest picture, and the workgroups of the
+ *     other groups fill the compute units it leaves idle (tail kernels are one workgroup per picture);
+ *   - pictures that are mostly intra-coded ("heavy", more than a quarter of their macroblocks) leave their group's
+ *     tick and run on one of heavy_lanes extra HIP streams; their stream of pictures rejoins its group heavy_delay
+ *     ticks later (an event makes the group's tick wait if the heavy picture is not finished by then). */
 h264bsdmi_replay *h264bsdmiReplayCreateDesync(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
                                               const u32 *offsets, u32 heavy_lanes, u32 heavy_delay)
 {
-    if (heavy_lanes > 8) return nullptr;
+    return h264bsdmiReplayCreateSched(blobs, bytes, n_pics, n_streams, offsets, heavy_lanes, heavy_delay, 1);
+}
+
+h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
+                                             const u32 *offsets, u32 heavy_lanes, u32 heavy_delay, u32 groups)
+{
+    if (groups < 1) groups = 1;
+    if (groups > 16 || groups > n_streams) return nullptr;
+    if (heavy_lanes + groups > (u32)h264bsdmi_replay::MAX_LANES) return nullptr;
     for (u32 s = 0; offsets && s < n_streams; s++) if (offsets[s] >= n_pics) return nullptr;
     Engine *e = engine_get();
     if (!e || !n_pics || !n_streams) {
@@ -711,49 +727,68 @@ h264bsdmi_replay *h264bsdmiReplayCreateDesync(const u8 *const *blobs, const u32 
                 r->shapes[i] = shape;
             }
         } else {
-            /* static schedule: common ticks on the engine stream, heavy pictures round-robin on the lanes */
+            /* static schedule: every group's light ticks on its own lane, heavy pictures round-robin on the heavy lanes */
             std::vector<u32> done(n_streams, 0), ready_at(n_streams, 0);
+            std::vector<int> last_ev(n_streams, -1);     /* event of the heavy launch a stream's previous picture ran in */
             size_t n_desc = 0;
             u32 left = n_streams, heavy_count = 0;
-            std::vector<std::pair<u32, int>> rejoin;      /* (tick, event of the heavy launch) */
-            auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[p]); return h->n_intra * 4u > h->n_mbs; };
+            const char *thr_env = getenv("H264BSDMI_HEAVY_INTRA");    /* experiment hook: absolute intra-macroblock count that makes a picture heavy */
+            const u32 thr_abs = thr_env ? (u32)atoi(thr_env) : 0xFFFFFFFFu;
+            auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[p]); return h->n_intra * 4u > h->n_mbs || h->n_intra > thr_abs; };
+            auto new_event = [&]() { r->sched_ev.push_back(nullptr); return (int)r->sched_ev.size() - 1; };
             for (u32 t = 0; left && t < 16u * n_pics; t++) {
-                h264bsdmi_replay::Launch light{ n_desc, TickShape(), -1, -1, -1 }, heavy{ 0, TickShape(), 0, -1, -1 };
-                std::vector<u32> hs;
-                for (u32 s = 0; s < n_streams; s++) {
-                    if (done[s] >= n_pics || ready_at[s] > t) continue;
-                    const u32 p = (r->offsets[s] + done[s]) % n_pics;
-                    if (is_heavy(p)) hs.push_back(s);
-                    else { desc_of(descs[n_desc++], s, p, &light.shape); if (++done[s] == n_pics) left--; }
-                }
-                for (auto &rj : rejoin) if (rj.first == t) { light.wait_ev = rj.second; }    /* at most one heavy launch per tick */
-                const bool have_light = light.shape.n_frames != 0;
-                if (have_light || light.wait_ev >= 0) {
-                    if (!hs.empty()) { light.record_ev = (int)r->sched_ev.size(); r->sched_ev.push_back(nullptr); }
-                    r->sched.push_back(light);
-                }
-                if (!hs.empty()) {
-                    heavy.first = n_desc;
-                    heavy.lane = (int)(heavy_count++ % heavy_lanes);
-                    heavy.wait_ev = (have_light || light.wait_ev >= 0) ? r->sched.back().record_ev : -1;
-                    for (u32 s : hs) {
-                        desc_of(descs[n_desc++], s, (r->offsets[s] + done[s]) % n_pics, &heavy.shape);
+                for (u32 g = 0; g < groups; g++) {
+                    h264bsdmi_replay::Launch light{ n_desc, TickShape(), (int)g, {}, -1, true };
+                    std::vector<u32> hs;
+                    for (u32 s = g; s < n_streams; s += groups) {
+                        if (done[s] >= n_pics || ready_at[s] > t) continue;
+                        const u32 p = (r->offsets[s] + done[s]) % n_pics;
+                        if (is_heavy(p)) { hs.push_back(s); continue; }
+                        if (last_ev[s] >= 0) {               /* rejoining after a heavy picture */
+                            if (std::find(light.waits.begin(), light.waits.end(), last_ev[s]) == light.waits.end()) light.waits.push_back(last_ev[s]);
+                            last_ev[s] = -1;
+                        }
+                        desc_of(descs[n_desc++], s, p, &light.shape);
                         if (++done[s] == n_pics) left--;
-                        ready_at[s] = t + 1 + heavy_delay;
                     }
-                    heavy.record_ev = (int)r->sched_ev.size(); r->sched_ev.push_back(nullptr);
-                    rejoin.emplace_back(t + 1 + heavy_delay, heavy.record_ev);
-                    r->sched.push_back(heavy);
+                    const bool have_light = light.shape.n_frames != 0;
+                    if (have_light) {
+                        if (!hs.empty()) light.record_ev = new_event();
+                        r->sched.push_back(light);
+                    }
+                    if (!hs.empty()) {
+                        h264bsdmi_replay::Launch heavy{ n_desc, TickShape(), (int)(groups + heavy_count++ % heavy_lanes), {}, -1, false };
+                        /* the previous pictures of these streams ran in the group's light launches up to this tick, or in
+                         * an earlier heavy launch */
+                        if (have_light) heavy.waits.push_back(r->sched.back().record_ev);
+                        else heavy.waits.push_back(-2 - (int)g);                  /* "everything enqueued on light lane g so far" */
+                        for (u32 s : hs) {
+                            if (last_ev[s] >= 0 && std::find(heavy.waits.begin(), heavy.waits.end(), last_ev[s]) == heavy.waits.end()) heavy.waits.push_back(last_ev[s]);
+                            desc_of(descs[n_desc++], s, (r->offsets[s] + done[s]) % n_pics, &heavy.shape);
+                            if (++done[s] == n_pics) left--;
+                            ready_at[s] = t + 1 + heavy_delay;
+                        }
+                        heavy.record_ev = new_event();
+                        for (u32 s : hs) last_ev[s] = heavy.record_ev;
+                        r->sched.push_back(heavy);
+                    }
                 }
             }
             if (left || n_desc != descs.size()) ok = false;
-            r->n_lanes = heavy_lanes;
+            r->n_light = groups;
+            r->n_lanes = groups + heavy_lanes;
             /* the heavy pictures' workgroups need a whole compute unit each: highest priority (measured: no
              * difference on this runtime, kept because it states the intent) */
             int prio_least = 0, prio_greatest = 0;
             if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
-            for (u32 k = 0; ok && k < heavy_lanes; k++)
-                ok = hipStreamCreateWithPriority(&r->lanes[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
+            for (u32 k = 0; ok && k < r->n_lanes; k++) {
+                if (k < groups) {
+                    ok = hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking) == hipSuccess &&
+                         hipStreamCreateWithFlags(&r->lane_side[k].stream, hipStreamNonBlocking) == hipSuccess &&
+                         hipEventCreateWithFlags(&r->lane_side[k].fork, hipEventDisableTiming) == hipSuccess &&
+                         hipEventCreateWithFlags(&r->lane_side[k].join, hipEventDisableTiming) == hipSuccess;
+                } else ok = hipStreamCreateWithPriority(&r->lanes[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
+            }
             for (auto &ev : r->sched_ev) if (ok) ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
         }
         if (ok) ok = hipMemcpyAsync(r->d_desc, descs.data(), descs.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream) == hipSuccess &&
@@ -798,6 +833,7 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
     for (auto &ev : r->cev) hipEventDestroy(ev);
     for (auto &st : r->lanes) if (st) hipStreamDestroy(st);
+    for (auto &sl : r->lane_side) { if (sl.stream) hipStreamDestroy(sl.stream); if (sl.fork) hipEventDestroy(sl.fork); if (sl.join) hipEventDestroy(sl.join); }
     delete r;
 }
 
@@ -810,18 +846,27 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
     for (auto &l : r->launches) l = 0;
     HIP_TRY(hipEventRecord(r->ev_begin, r->e->stream));
     if (!r->sched.empty()) {
-        /* desynchronised set with heavy lanes: one whole lap of the static schedule (first / count are ignored) */
+        /* desynchronised set with lanes: one whole lap of the static schedule (first / count are ignored) */
         r->timed_count = 0;
+        for (u32 k = 0; k < r->n_lanes; k++) HIP_TRY(hipStreamWaitEvent(r->lanes[k], r->ev_begin, 0));   /* the previous lap is complete */
+        std::vector<hipEvent_t> lane_mark(r->n_light, nullptr);
         for (const auto &l : r->sched) {
-            hipStream_t st = l.lane < 0 ? r->e->stream : r->lanes[l.lane];
-            if (l.wait_ev >= 0) HIP_TRY(hipStreamWaitEvent(st, r->sched_ev[l.wait_ev], 0));
-            else if (l.lane >= 0) { HIP_TRY(hipEventRecord(r->gdone_any, r->e->stream)); HIP_TRY(hipStreamWaitEvent(st, r->gdone_any, 0)); }
+            hipStream_t st = r->lanes[l.lane];
+            for (int w : l.waits) {
+                if (w >= 0) HIP_TRY(hipStreamWaitEvent(st, r->sched_ev[w], 0));
+                else {                                   /* -2 - g: everything enqueued on light lane g so far */
+                    HIP_TRY(hipEventRecord(r->gdone_any, r->lanes[-2 - w]));
+                    HIP_TRY(hipStreamWaitEvent(st, r->gdone_any, 0));
+                }
+            }
             if (l.shape.n_frames && launch_tick(st, r->d_desc + l.first, l.shape, nullptr, r->launches, r->stages,
-                                                (l.lane < 0 && r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr)) return -1;
+                                                (l.light && r->overlap_dbk && !(r->stages & 8u)) ? &r->lane_side[l.lane] : nullptr)) return -1;
             if (l.record_ev >= 0) HIP_TRY(hipEventRecord(r->sched_ev[l.record_ev], st));
         }
-        for (const auto &l : r->sched)                      /* the lap ends when every lane has drained */
-            if (l.lane >= 0) HIP_TRY(hipStreamWaitEvent(r->e->stream, r->sched_ev[l.record_ev], 0));
+        for (u32 k = 0; k < r->n_lanes; k++) {               /* the lap ends when every lane has drained */
+            HIP_TRY(hipEventRecord(r->gdone_any, r->lanes[k]));
+            HIP_TRY(hipStreamWaitEvent(r->e->stream, r->gdone_any, 0));
+        }
     } else if (r->n_groups <= 1) {
         for (u32 i = first; i < first + count; i++) {
             r->timers[i].on = true; r->timers[i].mask = r->timed_mask;

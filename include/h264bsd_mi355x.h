@@ -108,6 +108,11 @@ h264bsdmi_replay *h264bsdmiReplayCreateStaggered(const u8 *const *blobs, const u
  * always runs one whole lap (every stream n_pics pictures) and h264bsdmiReplayTimings() reports only the total. */
 h264bsdmi_replay *h264bsdmiReplayCreateDesync(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
                                               const u32 *offsets, u32 heavy_lanes, u32 heavy_delay);
+/* The same with the streams split into `groups` groups (stream s -> group s % groups) that run their own ticks on their
+ * own HIP streams (plus the heavy lanes): a group's tick lasts as long as its own slowest picture and the other groups'
+ * workgroups fill the compute units it leaves idle.  groups == 1 is h264bsdmiReplayCreateDesync. */
+h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
+                                             const u32 *offsets, u32 heavy_lanes, u32 heavy_delay, u32 groups);
 void h264bsdmiReplayDestroy(h264bsdmi_replay *r);
 /* Enqueue ticks [first, first+count) on the engine stream; asynchronous.  0 = ok. */
 int  h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count);

@@ -213,3 +213,69 @@ def test_concurrent_application_threads(built, golden):
         t.join(timeout=300)
     assert not any(t.is_alive() for t in threads), "a decoder thread is stuck"
     assert not errors, errors
+
+
+def test_72_different_streams_through_the_batch_api(built, golden):
+    """many DIFFERENT streams at once through the product's own scheduling — 72 decoder
+    instances (60 writer streams of different picture sizes, lengths, slice structures and IDR phases, the three
+    bundled streams, 9 of them started late so that their I pictures fall into other instances' P ticks), advanced
+    picture by picture with h264bsdmiDecodePictureBatch on the parser threads, reconstruction enqueued with
+    h264bsdmiFlushAsync.  Every output picture of every instance is compared with the reference's answer: per-frame
+    SHA-256 for the bundled streams, (hash, picId, isIdr, numErrMbs) from synth_golden.json for the writer streams."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from h264writer import StreamWriter
+    from synth_configs import CONFIGS
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth_golden.json")))
+    names = [n for n in CONFIGS if n != "max_frame_size_4096x2304"][:60]
+    streams, want, kind = [], [], []
+    for n in names:
+        data = StreamWriter(**CONFIGS[n]).build()
+        assert hashlib.sha1(data).hexdigest() == gold[n]["stream_sha1"]
+        streams.append(data); want.append([tuple(p) for p in gold[n]["pics"]]); kind.append("synth")
+    for n in ["test_640x360", "test_1920x1080", "test_1920x1080_fullRange"] * 4:
+        streams.append(stream_bytes(n)); want.append(golden[n]["frame_sha256"]); kind.append("bundled")
+    N = len(streams)
+    assert N == 72
+    L = built.lib()
+    L.h264bsdmiSetParserThreads(8)
+    decs = [built.Decoder() for _ in range(N)]
+    drv = built.BatchDriver(decs, streams)
+    start_round = [0] * 63 + [5 * (k + 1) for k in range(9)]            # the last 9 instances join later
+    got = [[] for _ in range(N)]
+
+    def pull(k):
+        while True:
+            pic = decs[k].next_output_picture()
+            if pic is None:
+                return
+            frame, pid, idr, nerr = pic
+            if kind[k] == "bundled":
+                got[k].append(hashlib.sha256(frame.tobytes()).hexdigest())
+            else:
+                got[k].append((hashlib.sha1(frame.tobytes()).hexdigest(), pid, idr, nerr))
+
+    rounds = 0
+    held = {k: (drv.size[k]) for k in range(N) if start_round[k]}     # parked: pretend they have no data yet
+    for k in held:
+        drv.size[k] = 0
+    while True:
+        for k in list(held):
+            if rounds >= start_round[k]:
+                drv.size[k] = held.pop(k)
+        ready = drv.step()
+        if not ready and not held:
+            break
+        assert L.h264bsdmiFlushAsync() == 0
+        rounds += 1
+        for k in ready:
+            pull(k)
+    for k in range(N):
+        decs[k].flush_buffer()
+        pull(k)
+        assert got[k] == want[k], f"instance {k} ({kind[k]}) differs from the reference"
+    assert built.device_errors() == 0
+    for d in decs:
+        d.close()

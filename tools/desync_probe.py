@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Desynchronised streams (every stream at its own picture index): lap time of the common-tick schedule and of the
 heavy-lane schedules, verified against the golden checksums at the end of a lap.
-usage: desync_probe.py [streams] [K,D ...]"""
+usage: desync_probe.py [streams] [K,D[,G] ...]   K heavy lanes, D rejoin delay in ticks, G stream groups"""
 import sys, os, json, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,9 +14,11 @@ heads = [h.job_header(j) for j in jobs]
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 P = len(jobs)
 offsets = [(s * P) // S for s in range(S)]
-cfgs = [(0, 0)] + [tuple(int(x) for x in a.split(",")) for a in sys.argv[2:]]
-for K, D in cfgs:
-    rep = h.Replay(jobs, n_streams=S, offsets=offsets, heavy_lanes=K, heavy_delay=D)
+cfgs = [(0, 0, 1)] + [tuple(int(x) for x in a.split(",")) for a in sys.argv[2:]]
+for cfg in cfgs:
+    K, D = cfg[0], cfg[1]
+    G = cfg[2] if len(cfg) > 2 else 1
+    rep = h.Replay(jobs, n_streams=S, offsets=offsets, heavy_lanes=K, heavy_delay=D, groups=G)
     def verify():
         bad = 0
         sums = {slot: rep.checksums(slot) for slot in set(hd["cur_slot"] for hd in heads)}
@@ -31,5 +33,5 @@ for K, D in cfgs:
         rep.run(); t.append(rep.timings()["total_ms"])
     b3 = verify()
     ms = sum(t) / len(t)
-    print(f"lanes {K} delay {D}: {ms:.1f} ms per lap = {S * P * heads[0]['n_mbs'] / ms / 1e3:.1f} M MB/s; mismatching streams after lap 1/2/5: {b1}/{b2}/{b3}")
+    print(f"lanes {K} delay {D} groups {G}: {ms:.1f} ms per lap = {S * P * heads[0]['n_mbs'] / ms / 1e3:.1f} M MB/s; mismatching streams after lap 1/2/5: {b1}/{b2}/{b3}")
     rep.close()
