@@ -22,7 +22,7 @@ for l in body.splitlines():
     if m:
         kern.setdefault(m.group(1), {})["fetch_bytes_per_launch" if m.group(2) == "FETCH_SIZE" else "write_bytes_per_launch"] = float(m.group(3)) * 1024
 # Calibration on a known byte count in our own access pattern (MI355X_MICROARCH.md, HBM section): k_copy moves exactly
-# 384 bytes in and 384 bytes out per copied macroblock, in the same 16-byte-per-lane row pieces the other kernels use.
+# 384 bytes in and 384 bytes out per copied macroblock, as contiguous 16-byte-per-lane pieces of macroblock tiles.
 sys.path.insert(0, root)
 import h264bsd_amd
 jobs, _, _ = h264bsd_amd.capture_stream(open(os.path.join(root, "tests", "golden", "test_1920x1080.h264"), "rb").read())
@@ -35,6 +35,8 @@ cal = {"fetch": copy_alg / kern["k_copy"]["fetch_bytes_per_launch"], "write": co
 for k in kern.values():
     k["fetch_bytes_per_launch_calibrated"] = k["fetch_bytes_per_launch"] * cal["fetch"]
     k["write_bytes_per_launch_calibrated"] = k["write_bytes_per_launch"] * cal["write"]
-json.dump({"source": f"profiles/{tag}_pmc_summary.txt (separate rocprofv3 --pmc passes)", "calibration": cal, "kernels": kern},
+import hashlib
+src_sha = hashlib.sha256(b"".join(open(os.path.join(root, "h264bsd_amd", "csrc", f), "rb").read() for f in ("kernels.hip.h", "framejob.h"))).hexdigest()
+json.dump({"source": f"profiles/{tag}_pmc_summary.txt (separate rocprofv3 --pmc passes)", "kernel_source_sha256": src_sha, "calibration": cal, "kernels": kern},
           open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 print(line[:300]); print(json.dumps(kern)[:600])
