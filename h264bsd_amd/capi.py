@@ -11,12 +11,14 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "lib", "libh264bsd_mi355x.so")
+LIB_PATH = os.path.join(HERE, "lib", "libh264bsd_mi355x.so")                  # the product: what a C application links
+BENCH_LIB_PATH = os.path.join(HERE, "lib", "libh264bsd_mi355x_bench.so")      # same objects + the harness exports; what
+                                                                              # this mirror loads (Replay, job tools)
 
 (H264BSD_RDY, H264BSD_PIC_RDY, H264BSD_HDRS_RDY, H264BSD_ERROR, H264BSD_PARAM_SET_ERROR,
  H264BSD_MEMALLOC_ERROR) = range(6)
 
-# every symbol include/*.h declares (checked by tests/test_abi.py)
+# every symbol include/*.h declares (checked by tests/test_abi.py); PRODUCT_SYMBOLS: those of the product library
 EXPORTED_SYMBOLS = [
     "h264bsdInit", "h264bsdDecode", "h264bsdShutdown", "h264bsdNextOutputPicture",
     "h264bsdNextOutputPictureRGBA", "h264bsdNextOutputPictureBGRA", "h264bsdNextOutputPictureYCbCrA",
@@ -77,10 +79,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(BENCH_LIB_PATH):
         build()
     _share_torch_hip_runtime()
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(BENCH_LIB_PATH)
     vp, u32, u8p = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p
     L.h264bsdAlloc.restype = vp
     L.h264bsdFree.argtypes = [vp]

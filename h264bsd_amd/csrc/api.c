@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
-#include "../../include/h264bsd_mi355x.h"
+#include "../../include/h264bsd_mi355x_bench.h"
 #include "hostdec.h"
 #include "engine.h"
 

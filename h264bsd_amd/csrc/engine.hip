@@ -1,16 +1,16 @@
 /*
- * engine.hip — host side of the HIP engine: device context, per-decoder DPB in HBM, lazy batched
- * execution of queued frame jobs ("ticks"), and the HBM-resident replay sets used by bench.py and the
- * parity tests.
+ * engine.hip — host side of the HIP engine: device context, per-decoder DPB in HBM (macroblock tiles,
+ * kernels.hip.h), lazy batched execution of queued frame jobs ("ticks"), and the HBM-resident replay sets used by
+ * bench.py and the kernel tests (exported by the bench library only, include/h264bsd_mi355x_bench.h).
  *
- * Execution model.  A tick holds at most one picture per stream (pictures of one stream depend on
- * each other through the DPB; pictures of different streams never do).  A tick of N pictures is TWO
- * launches on one HIP stream:
- *     k_recon_inter  grid (ceil(MBs/4), N) x 256 threads — every inter MB of every picture, one wave each
- *     k_frame_tail   grid (N) x 1024 threads             — one workgroup per picture: intra levels, then
- *                                                          the deblocking wavefront, synchronised by
- *                                                          __syncthreads() only
- * Occupancy of the second launch comes from batching streams: 256 pictures = one workgroup per CU.
+ * Execution model.  A tick holds at most one picture per stream (pictures of one stream depend on each other
+ * through the DPB; pictures of different streams never do).  A tick of N pictures is FIVE launches (launch_tick):
+ *     k_copy         grid (runs/4, N)   x 256  whole-sample copy macroblocks, one run of <= 8 tiles per wavefront
+ *     k_recon_inter  grid (n_gen/4, N)  x 256  every other inter macroblock, one wavefront each
+ *     k_dbk          grid (n_dbk/8, N)  x 256  boundary strengths from metadata; on a second HIP stream, next to the two above
+ *     k_frame_intra  grid (N)           x 1024 one workgroup per picture: intra macroblocks, dataflow-scheduled in LDS
+ *     k_frame_dbk    grid (N)           x 768  one workgroup per picture: in-loop filter, dataflow-scheduled in LDS
+ * Occupancy of the two per-picture kernels comes from batching streams: 256 pictures = one workgroup per CU.
  *
  * This replaces, for the pixels, what the reference does synchronously inside h264bsdDecode
  * (src/h264bsd_slice_data.c:185 -> h264bsdDecodeMacroblock, src/h264bsd_decoder.c:475 ->
@@ -26,7 +26,7 @@
 #include <algorithm>
 #include "kernels.hip.h"
 #include "engine.h"
-#include "../../include/h264bsd_mi355x.h"
+#include "../../include/h264bsd_mi355x_bench.h"
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \

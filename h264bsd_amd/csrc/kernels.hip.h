@@ -1,30 +1,34 @@
 /*
  * kernels.hip.h — hand-written gfx950 (CDNA4, wave64) kernels of the macroblock reconstruction path.
  *
- *   k_copy        : inter macroblocks that are whole-sample copies without residual (host-built list,
- *                   66 % of the inter MBs of the 1080p stream): 4 macroblocks per wavefront, 8 loads in
- *                   flight per lane, nothing but data movement.
+ * Frames live in HBM as MACROBLOCK TILES: 384 contiguous bytes per macroblock (Y 16x16 | Cb 8x8 | Cr 8x8), tiles in
+ * macroblock address order — see "frame layout in HBM" below.  Planar I420 exists only where pictures leave the device.
+ *
+ *   k_copy        : inter macroblocks that are whole-sample copies without residual (host-built list of runs of up to
+ *                   8 tiles; 61 % of the macroblocks of the 1080p stream): a zero-displacement run is one contiguous
+ *                   block of count x 384 bytes, 16 bytes per lane per access, every load before the first store.
  *                       reference: the P_Skip / integer-mv path of src/h264bsd_inter_prediction.c:361-482,
  *                                  h264bsdFillBlock src/h264bsd_reconstruct.c:2244, src/h264bsd_image.c:81
- *   k_recon_inter : every other inter macroblock, one wavefront each (4 per 256-thread workgroup),
- *                   list-driven.  6-tap luma / bilinear chroma motion compensation straight from the
- *                   reference frames (register windows, unaligned dword loads, clamp-to-edge slow path),
- *                   dequant + 4x4 inverse transform with quad-wide shuffles, residual add, u32 stores.
+ *   k_recon_inter : every other inter macroblock, one wavefront each (4 per 256-thread workgroup), list-driven.
+ *                   Reference windows staged in LDS tile row by tile row (aligned 16-byte loads), 6-tap luma on packed
+ *                   sample pairs / bilinear chroma, dequant + 4x4 inverse transform with DPP quad transposes, residual
+ *                   add; the macroblock leaves as its tile (24 x 16 bytes).
  *                       reference: src/h264bsd_reconstruct.c, src/h264bsd_inter_prediction.c:361-482,
  *                                  src/h264bsd_transform.c, src/h264bsd_image.c:172
- *   k_dbk         : boundary strengths + threshold indices of every macroblock (metadata only, two MBs
- *                   per wavefront) -> 32-byte deblocking records + one "needs filtering" byte per MB.
+ *   k_dbk         : boundary strengths + threshold indices of every macroblock the host could not prove strength-free
+ *                   (metadata only, two MBs per wavefront) -> 32-byte deblocking records + one flag byte per MB
+ *                   (DBKF_*: filtered at all / touches the left / the upper neighbour).
  *                       reference: src/h264bsd_deblocking.c:1187-1541
- *   k_frame_tail  : ONE 1024-thread workgroup per picture (a picture never leaves its CU): first the
- *                   intra macroblocks, dependency level by level, then the in-loop deblocking filter,
- *                   anti-diagonal (x+2y=d) by anti-diagonal.  Waves of the workgroup take the MBs of a
- *                   level/diagonal; the only synchronisation is __syncthreads() between levels — no
- *                   kernel boundary, no inter-workgroup traffic.  Per-wave LDS tiles: 16x16 block +
- *                   neighbour row/column for intra, 20x20 luma + 2x(10x12) chroma for deblocking.
- *                       reference: src/h264bsd_intra_prediction.c, src/h264bsd_deblocking.c:575-1745
- *   k_convert     : YUV420 -> RGBA / BGRA / YCbCrA, 4 pixels per lane, 16-byte stores.
- *                       reference: src/h264bsd_decoder.c:1163-1370
- *   k_checksum    : position-weighted 64-bit checksum of a frame (on-device verification).
+ *   k_frame_intra : ONE workgroup per picture (a picture never leaves its CU): intra and concealed macroblocks,
+ *                   dataflow-scheduled in LDS (dependency counters + ready queue, a free wavefront takes one ready MB).
+ *                       reference: src/h264bsd_intra_prediction.c, src/h264bsd_conceal.c
+ *   k_frame_dbk   : ONE workgroup per picture: the in-loop filter, dataflow-scheduled in LDS at macroblock-EDGE
+ *                   granularity (a macroblock waits only for the neighbours whose samples it really shares), quarter-
+ *                   wavefront workers, packed 16-bit arithmetic.
+ *                       reference: src/h264bsd_deblocking.c:575-1745
+ *   k_convert / k_output / k_detile : YUV420 -> RGBA / BGRA / YCbCrA, cropped windows, tiles -> planar I420.
+ *                       reference: src/h264bsd_decoder.c:1163-1370, :970-1001
+ *   k_checksum    : position-weighted 64-bit checksum of a frame in planar order (on-device verification).
  *
  * Everything is integer arithmetic on u8 samples / i16 levels / i32 intermediates: there is no dense
  * contraction on this path, hence no MFMA.

@@ -2,15 +2,16 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
 from conftest import ROOT
 
 
-def _declared_symbols():
+def _declared_symbols(headers):
     names = set()
-    for hdr in ("h264bsd_decoder.h", "h264bsd_mi355x.h"):
+    for hdr in headers:
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(h264bsd\w+)\s*\(", text))
@@ -18,12 +19,21 @@ def _declared_symbols():
     return names
 
 
+def _exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if " T " in line}
+
+
 def test_library_exports_every_declared_symbol(built):
-    lib = built.lib()
-    declared = _declared_symbols()
-    assert declared == set(built.EXPORTED_SYMBOLS)
-    for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} is declared in include/ but not exported"
+    """the product library exports exactly the reference's API + the device extensions (no harness entry points); the
+    bench library exports the harness of include/h264bsd_mi355x_bench.h on top"""
+    product = _declared_symbols(("h264bsd_decoder.h", "h264bsd_mi355x.h"))
+    everything = product | _declared_symbols(("h264bsd_mi355x_bench.h",))
+    assert everything == set(built.EXPORTED_SYMBOLS)
+    built.lib()
+    assert _exported(built.LIB_PATH) == product
+    assert _exported(built.capi.BENCH_LIB_PATH) == everything
+    assert not any("Replay" in n or "Debug" in n for n in product)
 
 
 def test_storage_t_keeps_reference_size():
