@@ -175,12 +175,21 @@ def main():
 
     if not torch.cuda.is_available() or h264bsd_amd.device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: the product has no CPU pixel path")
-    torch.cuda.set_device(local_rank)
-    h264bsd_amd.lib().h264bsdmiSetDevice(local_rank)
+    # one process per GPU.  When there are fewer GPUs than ranks (the 2-ranks-on-one-GPU smoke test of the N > 1 path)
+    # the ranks share devices and the three scalar reductions go over gloo: RCCL cannot put two ranks on one device.
+    n_dev = torch.cuda.device_count()
+    device = local_rank % n_dev
+    torch.cuda.set_device(device)
+    assert h264bsd_amd.lib().h264bsdmiSetDevice(device) == 0
     dist = None
+    red_dev = "cuda"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if n_dev >= world:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
+            red_dev = "cpu"
 
     def barrier():
         if dist is not None:
@@ -257,7 +266,7 @@ def main():
         rep.close()
         local = elapsed
         if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         return elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local
@@ -303,7 +312,7 @@ def main():
             raise SystemExit(f"rank {rank}: ARGB variant: final pictures are not bit-exact")
         rep.close()
         if dist is not None:
-            tt = torch.tensor([a_elapsed], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([a_elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             a_elapsed = float(tt.item())
         argb = dict(elapsed=a_elapsed, conv_ms=conv_ms, conv_n=conv_n, dev_ms=a_dev_ms)
@@ -340,7 +349,7 @@ def main():
             verify_lap()
             rep.close()
             if dist is not None:
-                tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = float(tt.item())
             desync[key] = {"value": n_pics * args.streams * world * n_mbs * args.steps / dt, "unit": "macroblocks/s",
@@ -364,7 +373,7 @@ def main():
     # per-GPU values (config 5 asks for them next to the node total): every rank's own elapsed time of the timed steps
     per_gpu = None
     if dist is not None:
-        mine = torch.tensor([local_elapsed], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([local_elapsed], dtype=torch.float64, device=red_dev)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         per_gpu = [n_pics * args.streams * n_mbs * args.steps / float(v.item()) for v in allv]

@@ -260,7 +260,12 @@ u32 h264bsdmiDecodePicture(storage_t *s, u8 *buf, u32 len, u32 picId, u32 *consu
 }
 
 /* A small persistent pool: workers sleep on a condition variable, a batch is an index range handed out by an atomic
- * counter (pictures differ a lot in parse time: I pictures cost several times a P picture). */
+ * counter (pictures differ a lot in parse time: I pictures cost several times a P picture).
+ * One process may drive several GPUs (h264bsdmiSetDevice per thread): the workers are then split into one group per
+ * device in use, a worker first takes the pictures of decoder instances that live on ITS device, and (H264BSDMI_PIN=2,
+ * the default) is pinned to the CPUs of that device's NUMA node (eng_device_cpus: /sys/bus/pci/devices/<gpu>/
+ * local_cpulist), so that the frame job it builds in pinned staging memory and the parser state it touches sit next to
+ * the GPU they feed.  H264BSDMI_PIN=1: spread over all CPUs; 0: no pinning. */
 typedef struct Batch {
     u32 n;
     storage_t *const *dec;
@@ -269,6 +274,8 @@ typedef struct Batch {
     u32 *status, *consumed, *n_errors;
     atomic_uchar *taken;                    /* one flag per item */
     int active;                             /* pool threads currently inside this batch (guarded by g_pool.mu) */
+    signed char *item_dev;                  /* device of every item's decoder instance (-1: capture mode) */
+    int devs[16], n_devs;                   /* the devices in use in this batch */
 } Batch;
 
 static struct {
@@ -282,34 +289,59 @@ static struct {
 } g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, { 0 }, 0, 0, 0, 0, 0, NULL,
              PTHREAD_MUTEX_INITIALIZER };
 
-/* Worker `me` of `nw` takes the items i = me, me+nw, ... first (so that a stream is normally parsed by the same
- * thread — and from the same NUMA node — every round) and then helps with whatever is left. */
 static void batch_run_item(Batch *b, u32 i)
 {
     b->status[i] = h264bsdmiDecodePicture(b->dec[i], b->buf[i], b->len[i], b->pic_id ? b->pic_id[i] : 0,
                                           &b->consumed[i], b->n_errors ? &b->n_errors[i] : NULL);
 }
 
+/* Worker `me` of `nw`: group g = me % n_devs serves device devs[g].  It takes the items of its device i = k, k + gs,
+ * ... (k = its index in the group, gs = group size) first — so that a stream is normally parsed by the same thread,
+ * from the same NUMA node, every round — then whatever else is left anywhere. */
 static void batch_work(Batch *b, u32 me, u32 nw)
 {
-    for (u32 i = me; i < b->n; i += nw)
-        if (!atomic_exchange(&b->taken[i], 1)) batch_run_item(b, i);
-    for (u32 i = 0; i < b->n; i++)
-        if (!atomic_load(&b->taken[i]) && !atomic_exchange(&b->taken[i], 1)) batch_run_item(b, i);
+    const u32 nd = b->n_devs > 0 ? (u32)b->n_devs : 1u;
+    const u32 g = me % nd, k = me / nd, gs = (nw - g + nd - 1) / nd;
+    const int my_dev = b->n_devs > 0 ? b->devs[g] : -1;
+    u32 seen = 0;
+    for (u32 i = 0; i < b->n; i++) {
+        if (b->n_devs > 0 && b->item_dev[i] != my_dev) continue;
+        if (seen++ % gs == k && !atomic_exchange(&b->taken[i], 1)) batch_run_item(b, i);
+    }
+    for (int pass = 0; pass < 2; pass++)        /* leftovers: own device first */
+        for (u32 i = 0; i < b->n; i++) {
+            if (pass == 0 && b->n_devs > 0 && b->item_dev[i] != my_dev) continue;
+            if (!atomic_load(&b->taken[i]) && !atomic_exchange(&b->taken[i], 1)) batch_run_item(b, i);
+        }
 }
 
-static void *pool_main(void *arg)
+static void pin_worker(u32 me, int device, int *pinned_to)
 {
-    const u32 me = (u32)(size_t)arg;        /* 1.. ; the caller's thread is worker 0 */
-    if (g_pool.pin) {
-        /* spread the workers over the CPUs (worker k -> CPU k * ncpu / nthreads): first-touch then places each
-         * stream's parser state on the node of the thread that owns it */
+    if (g_pool.pin == 1 && *pinned_to != -2) {
+        /* spread the workers over the CPUs (worker k -> CPU k * ncpu / nthreads) */
         const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
         cpu_set_t set;
         CPU_ZERO(&set);
         CPU_SET((int)(((long)me * ncpu) / (g_pool.want > 0 ? g_pool.want : 1)) % (int)ncpu, &set);
         pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+        *pinned_to = -2;
+    } else if (g_pool.pin == 2 && device >= 0 && *pinned_to != device) {
+        int cpus[1024];
+        const int n = eng_device_cpus(device, cpus, 1024);
+        if (n > 0) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            for (int i = 0; i < n; i++) if (cpus[i] < CPU_SETSIZE) CPU_SET(cpus[i], &set);
+            pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+        }
+        *pinned_to = device;
     }
+}
+
+static void *pool_main(void *arg)
+{
+    const u32 me = (u32)(size_t)arg;        /* 1.. ; the caller's thread is worker 0 (never pinned: it is the application's) */
+    int pinned_to = -1;
     unsigned seen = 0;
     pthread_mutex_lock(&g_pool.mu);
     for (;;) {
@@ -320,6 +352,7 @@ static void *pool_main(void *arg)
         b->active++;
         const u32 nw = (u32)g_pool.n_threads;
         pthread_mutex_unlock(&g_pool.mu);
+        pin_worker(me, b->n_devs > 0 ? b->devs[me % (u32)b->n_devs] : -1, &pinned_to);
         batch_work(b, me, nw);
         pthread_mutex_lock(&g_pool.mu);
         if (--b->active == 0) pthread_cond_broadcast(&g_pool.idle);
@@ -342,7 +375,7 @@ int h264bsdmiSetParserThreads(int n)
     if (n < 1) n = pool_default_threads();
     if (n > 64) n = 64;
     g_pool.want = n;
-    g_pool.pin = getenv("H264BSDMI_PIN") ? atoi(getenv("H264BSDMI_PIN")) : 0;
+    g_pool.pin = getenv("H264BSDMI_PIN") ? atoi(getenv("H264BSDMI_PIN")) : 2;
     /* the caller's thread works too: n threads in total = n-1 pool threads (threads are only ever added) */
     while (g_pool.started < n - 1) {
         if (pthread_create(&g_pool.th[g_pool.started], NULL, pool_main, (void *)(size_t)(g_pool.started + 1))) break;
@@ -363,8 +396,17 @@ int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *dec, u8 *const *buf, co
     pthread_mutex_lock(&g_pool.api_mu);
     if (!g_pool.n_threads) h264bsdmiSetParserThreads(0);
     atomic_uchar *taken = (atomic_uchar *)calloc(n, sizeof(atomic_uchar));
-    if (!taken) { pthread_mutex_unlock(&g_pool.api_mu); return -1; }
-    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, taken, 0 };
+    signed char *item_dev = (signed char *)malloc(n);
+    if (!taken || !item_dev) { free(taken); free(item_dev); pthread_mutex_unlock(&g_pool.api_mu); return -1; }
+    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, taken, 0, item_dev, { 0 }, 0 };
+    for (u32 i = 0; i < n; i++) {
+        const ApiDec *a = dec_of(dec[i]);
+        const int dv = a && a->hd ? eng_sink_device(&a->hd->sink) : -1;
+        item_dev[i] = (signed char)dv;
+        int known = dv < 0;
+        for (int k = 0; k < b.n_devs && !known; k++) known = b.devs[k] == dv;
+        if (!known && b.n_devs < 16) b.devs[b.n_devs++] = dv;
+    }
     pthread_mutex_lock(&g_pool.mu);
     g_pool.batch = &b;
     g_pool.generation++;
@@ -377,6 +419,7 @@ int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *dec, u8 *const *buf, co
     while (b.active) pthread_cond_wait(&g_pool.idle, &g_pool.mu);
     pthread_mutex_unlock(&g_pool.mu);
     free(taken);
+    free(item_dev);
     pthread_mutex_unlock(&g_pool.api_mu);
     return 0;
 }

@@ -78,22 +78,38 @@ struct Engine {
      * whenever the host has waited for the device anyway */
     uint32_t *d_err = nullptr, *h_err = nullptr;
     uint32_t errors = 0;
+    unsigned long long *tail_prof = nullptr;   /* debug: per-wave cycle accounting of the per-picture kernels (block 0) */
 };
 
-unsigned long long *g_tail_prof = nullptr;   /* debug: per-wave cycle accounting of the per-picture kernels (block 0) */
-Engine *g_engine = nullptr;
+/* One engine per HIP device, created on first use.  A decoder instance (or replay set) lives on the device that is
+ * current for the thread that initialises it: h264bsdmiSetDevice() sets it for the calling thread (and, the first time,
+ * the process default); one process can therefore drive several GPUs, and the usual one-process-per-GPU launch just
+ * calls it once. */
+constexpr int MAX_DEVICES = 16;
+Engine *g_engines[MAX_DEVICES] = {};
 std::mutex g_engine_mu;
-int g_device_request = -1;
+int g_default_device = -1;
+thread_local int tl_device = -1;
 
-Engine *engine_get()
+int current_device()
 {
+    if (tl_device >= 0) return tl_device;
+    if (g_default_device >= 0) return g_default_device;
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d;
+}
+
+Engine *engine_get(int device = -1)
+{
+    if (device < 0) device = current_device();
+    if (device >= MAX_DEVICES) return nullptr;
     std::lock_guard<std::mutex> lk(g_engine_mu);
-    if (g_engine) return g_engine;
+    if (g_engines[device]) return g_engines[device];
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return nullptr;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n) return nullptr;
     Engine *e = new Engine();
-    if (g_device_request >= 0) e->device = g_device_request;
-    else if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
+    e->device = device;
     if (hipSetDevice(e->device) != hipSuccess) { delete e; return nullptr; }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return nullptr; }
     if (hipEventCreateWithFlags(&e->desc_ev[0], hipEventDisableTiming) != hipSuccess ||
@@ -106,7 +122,7 @@ Engine *engine_get()
         hipMalloc((void **)&e->d_err, 256) != hipSuccess || hipMemset(e->d_err, 0, 256) != hipSuccess ||
         hipHostMalloc((void **)&e->h_err, 64, hipHostMallocDefault) != hipSuccess) { delete e; return nullptr; }
     *e->h_err = 0;
-    g_engine = e;
+    g_engines[device] = e;
     return e;
 }
 
@@ -119,7 +135,7 @@ struct TickShape {
 
 /* descriptor of one picture: device addresses of the sections of its (device-resident) frame job */
 void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, uint8_t *dev_frames, uint32_t frame_bytes,
-               uint8_t *dev_dbk, TickShape *shape)
+               uint8_t *dev_dbk, TickShape *shape, uint32_t *dev_err)
 {
     const FjHeader *h = reinterpret_cast<const FjHeader *>(host_blob);
     d.recs = reinterpret_cast<const FjMbRec *>(dev_blob + h->rec_off);
@@ -140,7 +156,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     d.wmb = h->width_mbs;
     d.hmb = h->height_mbs;
     d.any_deblock = h->any_deblock;
-    d.err = g_engine ? g_engine->d_err : nullptr;
+    d.err = dev_err;
     for (uint32_t k = 0; k < FJ_MAX_SLOTS; k++) d.slot[k] = k < h->n_slots ? dev_frames + (size_t)k * frame_bytes : nullptr;
     if (shape) {
         shape->n_frames++;
@@ -159,7 +175,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
 struct TickTimers { hipEvent_t ev[6]; hipEvent_t sev[3] = { nullptr, nullptr, nullptr }; bool on = false; unsigned mask = 31u; };   /* mask bit k: kernel k of KERNELS is timed */   /* boundaries of the 5 kernels of a tick; sev = k_copy, k_dbk on the side stream */
 
 int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5],
-                unsigned stages = 7u, const SideLane *side = nullptr)
+                unsigned stages = 7u, const SideLane *side = nullptr, unsigned long long *prof = nullptr)
 {
     const bool timed = tt && tt->on;
     const unsigned tmask = timed ? tt->mask : 0u;
@@ -208,7 +224,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
             HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_intra, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_enabled = lds;
         }
-        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, g_tail_prof);
+        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof);
         if (launches) launches[3]++;
     }
     if (EV_NEEDED(4)) HIP_TRY(hipEventRecord(tt->ev[4], st));
@@ -225,7 +241,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
             HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_dbk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_enabled = lds;
         }
-        hipLaunchKernelGGL(h264k::k_frame_dbk, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, g_tail_prof);
+        hipLaunchKernelGGL(h264k::k_frame_dbk, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof);
         if (launches) launches[4]++;
     }
     if (EV_NEEDED(5)) HIP_TRY(hipEventRecord(tt->ev[5], st));
@@ -304,7 +320,7 @@ int flush_locked(Engine *e, bool wait = true)
             PendingJob j;
             { std::lock_guard<std::mutex> ql(s->qmu); j = s->pending.front(); s->pending.pop_front(); }
             HIP_TRY(hipMemcpyAsync(e->d_arena + off, j.host, j.bytes, hipMemcpyHostToDevice, e->stream));
-            make_desc(descs[i], j.host, e->d_arena + off, s->d_frames, s->frame_bytes, s->d_dbk, &shape);
+            make_desc(descs[i], j.host, e->d_arena + off, s->d_frames, s->frame_bytes, s->d_dbk, &shape, e->d_err);
             off += (j.bytes + 255u) & ~255u;
             e->inflight.emplace_back(s, j);
         }
@@ -556,38 +572,83 @@ int h264bsdmiDeviceCount(void)
     return n;
 }
 
+/* Decoder instances and replay sets created by the calling thread from now on live on `device`; the first call also
+ * sets the process default (threads that never call it).  Existing instances stay where they are. */
 int h264bsdmiSetDevice(int device)
 {
+    int n = 0;
+    if (device < 0 || device >= MAX_DEVICES || hipGetDeviceCount(&n) != hipSuccess || device >= n) return -1;
+    tl_device = device;
     std::lock_guard<std::mutex> lk(g_engine_mu);
-    if (g_engine) return g_engine->device == device ? 0 : -1;   /* engine already bound */
-    g_device_request = device;
+    if (g_default_device < 0) g_default_device = device;
     return 0;
+}
+
+/* the device (and with it the NUMA node: eng_device_cpus) a decoder instance lives on */
+int eng_sink_device(const JobSink *sink)
+{
+    if (!sink || !sink->user || sink->submit != sink_submit) return -1;      /* capture-mode instances have another sink */
+    return static_cast<const SinkUser *>(sink->user)->e->device;
+}
+
+/* CPUs close to a device: /sys/bus/pci/devices/<bus id>/local_cpulist ("0-63,128-191"), for pinning parser threads to
+ * the NUMA node of the GPU their streams feed.  Returns the number of CPUs written to cpus[]. */
+int eng_device_cpus(int device, int *cpus, int max)
+{
+    char bus[64], path[160], line[4096];
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return 0;
+    for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;
+    int n = 0;
+    if (fgets(line, sizeof(line), f)) {
+        for (char *p = line; *p && n < max;) {
+            char *end;
+            long a = strtol(p, &end, 10), b = a;
+            if (end == p) break;
+            if (*end == '-') { p = end + 1; b = strtol(p, &end, 10); }
+            for (long c = a; c <= b && n < max; c++) cpus[n++] = (int)c;
+            p = *end == ',' ? end + 1 : end;
+            if (*end != ',' ) break;
+        }
+    }
+    fclose(f);
+    return n;
 }
 
 unsigned h264bsdmiDeviceErrors(void)
 {
-    Engine *e = engine_get();
-    if (!e) return 0;
-    std::lock_guard<std::mutex> lk(e->mu);
-    if (hipSetDevice(e->device) != hipSuccess || poll_errors(e)) return 0xFFFFFFFFu;
-    return e->errors;
+    unsigned all = 0;
+    for (int d = 0; d < MAX_DEVICES; d++) {
+        Engine *e;
+        { std::lock_guard<std::mutex> lk(g_engine_mu); e = g_engines[d]; }
+        if (!e) continue;
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (hipSetDevice(e->device) != hipSuccess || poll_errors(e)) return 0xFFFFFFFFu;
+        all |= e->errors;
+    }
+    return all;
 }
 
-int h264bsdmiFlush(void)
+static int flush_all(bool wait)
 {
-    Engine *e = engine_get();
-    if (!e) return -1;
-    std::lock_guard<std::mutex> lk(e->mu);
-    return flush_locked(e);
+    int rc = 0, any = 0;
+    for (int d = 0; d < MAX_DEVICES; d++) {
+        Engine *e;
+        { std::lock_guard<std::mutex> lk(g_engine_mu); e = g_engines[d]; }
+        if (!e) continue;
+        any = 1;
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (flush_locked(e, wait)) rc = -1;
+    }
+    if (!any && !engine_get()) return -1;
+    return rc;
 }
 
-int h264bsdmiFlushAsync(void)
-{
-    Engine *e = engine_get();
-    if (!e) return -1;
-    std::lock_guard<std::mutex> lk(e->mu);
-    return flush_locked(e, false);
-}
+int h264bsdmiFlush(void) { return flush_all(true); }
+
+int h264bsdmiFlushAsync(void) { return flush_all(false); }
 
 /* ------------------------------------------------------------------ replay sets */
 struct h264bsdmi_replay {
@@ -706,7 +767,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
         if (h->width_mbs != r->wmb || h->height_mbs != r->hmb || h->n_slots != r->n_slots) ok = false;
         TickShape s;
         FrameDesc tmp;
-        make_desc(tmp, blobs[i], nullptr, nullptr, 0, nullptr, &s);
+        make_desc(tmp, blobs[i], nullptr, nullptr, 0, nullptr, &s, nullptr);
         s.n_frames = n_streams;
         r->shapes.push_back(s);
         r->cur_slot.push_back(h->cur_slot);
@@ -718,7 +779,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
         std::vector<FrameDesc> descs((size_t)n_pics * n_streams);
         auto desc_of = [&](FrameDesc &d, u32 s, u32 p, TickShape *shape) {
             make_desc(d, blobs[p], r->d_blobs + (size_t)s * total + offs[p], r->d_frames + (size_t)s * frames_per_stream,
-                      r->frame_bytes, r->d_dbk + (size_t)s * dbk_stride, shape);
+                      r->frame_bytes, r->d_dbk + (size_t)s * dbk_stride, shape, e->d_err);
         };
         if (!heavy_lanes) {
             for (u32 i = 0; i < n_pics; i++) {
@@ -870,7 +931,7 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
     } else if (r->n_groups <= 1) {
         for (u32 i = first; i < first + count; i++) {
             r->timers[i].on = true; r->timers[i].mask = r->timed_mask;
-            if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr)) return -1;
+            if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr, r->e->tail_prof)) return -1;
             if (r->convert_fmt >= 0) {
                 /* the picture every stream has just produced, converted where it lies (tiles -> packed 32-bit pixels) */
                 const uint32_t w = r->wmb * 16, h = r->hmb * 16;
@@ -1063,12 +1124,12 @@ int h264bsdmiDebugTailProfile(int enable, unsigned long long *out)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     if (enable) {
-        if (!g_tail_prof) HIP_TRY(hipMalloc((void **)&g_tail_prof, (16 * 16 + 16 * 8) * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(g_tail_prof, 0, (16 * 16 + 16 * 8) * sizeof(unsigned long long)));
-    } else if (g_tail_prof) {
-        if (out) HIP_TRY(hipMemcpy(out, g_tail_prof, (16 * 16 + 16 * 8) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipFree(g_tail_prof));
-        g_tail_prof = nullptr;
+        if (!e->tail_prof) HIP_TRY(hipMalloc((void **)&e->tail_prof, (16 * 16 + 16 * 8) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(e->tail_prof, 0, (16 * 16 + 16 * 8) * sizeof(unsigned long long)));
+    } else if (e->tail_prof) {
+        if (out) HIP_TRY(hipMemcpy(out, e->tail_prof, (16 * 16 + 16 * 8) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(e->tail_prof));
+        e->tail_prof = nullptr;
     }
     return 0;
 }
@@ -1076,4 +1137,4 @@ int h264bsdmiDebugTailProfile(int enable, unsigned long long *out)
 unsigned long long h264bsdmiReplayJobBytes(h264bsdmi_replay *r) { return r ? r->job_bytes : 0; }
 u32 h264bsdmiReplayFrameBytes(h264bsdmi_replay *r) { return r ? r->frame_bytes : 0; }
 
-} // extern "C"
+} /* extern "C" */

@@ -53,3 +53,26 @@ def test_two_ranks_shard_streams_over_gloo(tmp_path, built):
     res = json.loads(line)
     assert res["world"] == 2 and res["pics"] == 4 * 73          # every rank decoded its own 2 streams
     assert res["distinct_job_streams"] == 1                        # identical copies -> identical frame jobs
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_gpu_bench_two_ranks_on_one_box(built):
+    """the N > 1 path of bench.py before an 8-GPU node runs it: two ranks under torch.distributed.run (on one GPU they
+    share the device and reduce over gloo; on a multi-GPU box each takes its own device over RCCL), 32 streams each,
+    verified on device; the line must carry the node total AND the per-GPU values"""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--streams", "32", "--steps", "1", "--warmup", "0", "--ramp-seconds", "0",
+                          "--no-staggered", "--no-desync", "--no-argb"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["config"]["pictures_per_step"] == 2 * 32 * 73
+    assert len(res["per_gpu"]["value"]) == 2 and all(v > 0 for v in res["per_gpu"]["value"])
+    assert abs(res["value"] - 2 * 32 * 73 * 8160 * 1000 / res["ms_per_step"]) < 1e-3 * res["value"]
+    assert res["device_errors"] == 0 and "cpu_baseline" not in res
