@@ -215,10 +215,10 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
     if (s.max_levels && (stages & 2u)) {
         const uint32_t n = s.max_mbs;
-        const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64;
-        if (arrays + 1024 > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_intra\n", n); return -1; }
-        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::TAIL_WAVES, (LDS_BUDGET - arrays) / 1024);   /* 16: throughput-bound (12 waves: +11 %, 8: +41 %) */
-        const size_t lds = (size_t)waves * 1024 + arrays;
+        const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64 + h264k::I4TAB_BYTES;
+        if (arrays + h264k::INTRA_WAVE_LDS > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_intra\n", n); return -1; }
+        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::TAIL_WAVES, (LDS_BUDGET - arrays) / h264k::INTRA_WAVE_LDS);
+        const size_t lds = (size_t)waves * h264k::INTRA_WAVE_LDS + arrays;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
             HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_intra, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

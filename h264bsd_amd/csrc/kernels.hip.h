@@ -821,10 +821,6 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
 }
 
 /* ------------------------------------------------------------------ intra macroblocks */
-/* Intra4x4 sample (x,y) of mode `mode`; T(k) k=-1..7 and L(k) k=-1..3 read the LDS tile */
-#define I4_T(k) ((int)tile[(by4) * TS + 4 + (bx4) + ((k) > 3 && !has_tr ? 3 : (k))])
-#define I4_L(k) ((int)tile[((by4) + 1 + (k)) * TS + 3 + (bx4)])
-
 constexpr int TS = 32;   /* intra luma tile: row 0 = row above, rows 1..16 = MB; byte 3 = left column / corner,
                             bytes 4..19 = MB columns (dword aligned), bytes 20..23 of row 0 = above-right */
 
@@ -906,8 +902,91 @@ __device__ __noinline__ void conceal_mb(const FrameDesc &fd, uint32_t mb, int la
     }
 }
 
-/* one intra macroblock by one wavefront; tile = 17*TS bytes, ctile = 2 x 9*16 bytes (wave-private LDS) */
-__device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0)
+/* ---- Intra4x4 prediction, table-driven ----
+ * Every sample of the eight directional modes is (a + 2b + c + 2) >> 2 or (a + b + 1) >> 1 over three of the block's
+ * 13 neighbour samples n[0] = corner, n[1..8] = above 0..7 (above-right replaced by above[3] when it is not available),
+ * n[9..12] = left 0..3 (8.3.1.2.1-9; reference Intra4x4*Prediction, src/h264bsd_intra_prediction.c:1493-1830).  The table
+ * holds, per (mode, row, sample): a byte selector for v_perm_b32 (the three neighbours out of n[0..7] resp. n[8..12]), the
+ * byte mask that picks between the two, the weights (1,2,1 / 1,1,0) for v_dot4_u32_u8 and the shift (= the rounding
+ * term): five instructions per sample, ONE instruction stream for all lanes whatever their modes are (a switch over the
+ * modes executes every mode that occurs among the active lanes — up to eight when four macroblocks are predicted
+ * together).  DC (mode 2) is the only special case. */
+__constant__ uint4 c_i4tab[36][4] = {
+    { { 0x0C010101u, 0x00000000u, 0x00010201u, 2u }, { 0x0C020202u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030303u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040404u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C010101u, 0x00000000u, 0x00010201u, 2u }, { 0x0C020202u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030303u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040404u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C010101u, 0x00000000u, 0x00010201u, 2u }, { 0x0C020202u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030303u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040404u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C010101u, 0x00000000u, 0x00010201u, 2u }, { 0x0C020202u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030303u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040404u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C010101u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C010101u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C010101u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C010101u, 0x00FFFFFFu, 0x00010201u, 2u } },
+    { { 0x0C020202u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020202u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020202u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020202u, 0x00FFFFFFu, 0x00010201u, 2u } },
+    { { 0x0C030303u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030303u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030303u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030303u, 0x00FFFFFFu, 0x00010201u, 2u } },
+    { { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u } },
+    { { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C030201u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040302u, 0x00000000u, 0x00010201u, 2u }, { 0x0C050403u, 0x00000000u, 0x00010201u, 2u }, { 0x0C060504u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C040302u, 0x00000000u, 0x00010201u, 2u }, { 0x0C050403u, 0x00000000u, 0x00010201u, 2u }, { 0x0C060504u, 0x00000000u, 0x00010201u, 2u }, { 0x0C070605u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C050403u, 0x00000000u, 0x00010201u, 2u }, { 0x0C060504u, 0x00000000u, 0x00010201u, 2u }, { 0x0C070605u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000706u, 0x00FF0000u, 0x00010201u, 2u } },
+    { { 0x0C060504u, 0x00000000u, 0x00010201u, 2u }, { 0x0C070605u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000706u, 0x00FF0000u, 0x00010201u, 2u }, { 0x0C000007u, 0x00FFFF00u, 0x00010201u, 2u } },
+    { { 0x0C010001u, 0x00FF0000u, 0x00010201u, 2u }, { 0x0C020100u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030201u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040302u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C020100u, 0x00FFFF00u, 0x00010201u, 2u }, { 0x0C010001u, 0x00FF0000u, 0x00010201u, 2u }, { 0x0C020100u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030201u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C030201u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020100u, 0x00FFFF00u, 0x00010201u, 2u }, { 0x0C010001u, 0x00FF0000u, 0x00010201u, 2u }, { 0x0C020100u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C040302u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030201u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020100u, 0x00FFFF00u, 0x00010201u, 2u }, { 0x0C010001u, 0x00FF0000u, 0x00010201u, 2u } },
+    { { 0x0C010100u, 0x00000000u, 0x00000101u, 1u }, { 0x0C020201u, 0x00000000u, 0x00000101u, 1u }, { 0x0C030302u, 0x00000000u, 0x00000101u, 1u }, { 0x0C040403u, 0x00000000u, 0x00000101u, 1u } },
+    { { 0x0C010001u, 0x000000FFu, 0x00010201u, 2u }, { 0x0C020100u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030201u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040302u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C000102u, 0x0000FFFFu, 0x00010201u, 2u }, { 0x0C010100u, 0x00000000u, 0x00000101u, 1u }, { 0x0C020201u, 0x00000000u, 0x00000101u, 1u }, { 0x0C030302u, 0x00000000u, 0x00000101u, 1u } },
+    { { 0x0C010203u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C010001u, 0x000000FFu, 0x00010201u, 2u }, { 0x0C020100u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030201u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C010100u, 0x00FFFF00u, 0x00000101u, 1u }, { 0x0C010001u, 0x000000FFu, 0x00010201u, 2u }, { 0x0C000102u, 0x00000000u, 0x00010201u, 2u }, { 0x0C010203u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C020201u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C020100u, 0x00FFFF00u, 0x00010201u, 2u }, { 0x0C010100u, 0x00FFFF00u, 0x00000101u, 1u }, { 0x0C010001u, 0x000000FFu, 0x00010201u, 2u } },
+    { { 0x0C030302u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C030201u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020201u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C020100u, 0x00FFFF00u, 0x00010201u, 2u } },
+    { { 0x0C040403u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C040302u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030302u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C030201u, 0x00FFFFFFu, 0x00010201u, 2u } },
+    { { 0x0C020201u, 0x00000000u, 0x00000101u, 1u }, { 0x0C030302u, 0x00000000u, 0x00000101u, 1u }, { 0x0C040403u, 0x00000000u, 0x00000101u, 1u }, { 0x0C050504u, 0x00000000u, 0x00000101u, 1u } },
+    { { 0x0C030201u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040302u, 0x00000000u, 0x00010201u, 2u }, { 0x0C050403u, 0x00000000u, 0x00010201u, 2u }, { 0x0C060504u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C030302u, 0x00000000u, 0x00000101u, 1u }, { 0x0C040403u, 0x00000000u, 0x00000101u, 1u }, { 0x0C050504u, 0x00000000u, 0x00000101u, 1u }, { 0x0C060605u, 0x00000000u, 0x00000101u, 1u } },
+    { { 0x0C040302u, 0x00000000u, 0x00010201u, 2u }, { 0x0C050403u, 0x00000000u, 0x00010201u, 2u }, { 0x0C060504u, 0x00000000u, 0x00010201u, 2u }, { 0x0C070605u, 0x00000000u, 0x00010201u, 2u } },
+    { { 0x0C020201u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C030201u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030302u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C040302u, 0x00FFFFFFu, 0x00010201u, 2u } },
+    { { 0x0C030302u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C040302u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040403u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C040403u, 0x00FFFFFFu, 0x00010201u, 2u } },
+    { { 0x0C040403u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C040403u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u } },
+    { { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u } },
+};
+constexpr int I4TAB_BYTES = 36 * 4 * 16;
+
+/* One row (4 samples) of the Intra4x4 prediction of the block at (bx4, by4) of the macroblock whose LDS tile is `tile`.
+ * i4tab: the table above in LDS.  Lanes without a block pass any valid mode and ignore the result. */
+__device__ __forceinline__ void intra4_row(const uint8_t *tile, int bx4, int by4, int y, int mode, bool has_left, bool has_top, bool has_tr,
+                                           const uint4 *i4tab, int vv[4])
+{
+    /* the 13 neighbour samples in seven INDEPENDENT LDS reads: corner | above 0..7 | left 0..3 */
+    const uint8_t *trow = &tile[by4 * TS + bx4];
+    const uint32_t w0 = *reinterpret_cast<const uint32_t *>(trow), w1 = *reinterpret_cast<const uint32_t *>(trow + 4),
+                   w2 = *reinterpret_cast<const uint32_t *>(trow + 8);
+    const uint32_t l0 = tile[(by4 + 1) * TS + 3 + bx4], l1 = tile[(by4 + 2) * TS + 3 + bx4],
+                   l2 = tile[(by4 + 3) * TS + 3 + bx4], l3 = tile[(by4 + 4) * TS + 3 + bx4];
+    const uint4 *ent = i4tab + ((mode & 15) * 4 + y) * 4;
+    const uint32_t tr = has_tr ? w2 : (w1 >> 24) * 0x01010101u;
+    const uint32_t N0 = (w0 >> 24) | (w1 << 8), N1 = (w1 >> 24) | (tr << 8);          /* n[0..3], n[4..7] */
+    const uint32_t N2 = (tr >> 24) | (l0 << 8) | (l1 << 16) | (l2 << 24), N3 = l3;      /* n[8..11], n[12] */
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const uint4 e = ent[x];                          /* selector | mask | weights | shift */
+        const uint32_t lo = perm(N1, N0, e.x), hi = perm(N3, N2, e.x);
+        const uint32_t v = (hi & e.y) | (lo & ~e.y);
+        vv[x] = (int)(__builtin_amdgcn_udot4(v, e.z, e.w, false) >> e.w);
+    }
+    if (__ballot(mode == 2) != 0ull) {
+        const int st = (int)((w1 & 255u) + ((w1 >> 8) & 255u) + ((w1 >> 16) & 255u) + (w1 >> 24)), sl = (int)(l0 + l1 + l2 + l3);
+        const int dc = (has_top && has_left) ? (st + sl + 4) >> 3 : has_left ? (sl + 2) >> 2 : has_top ? (st + 2) >> 2 : 128;
+        if (mode == 2) vv[0] = vv[1] = vv[2] = vv[3] = dc;
+    }
+}
+
+/* Bytes of the LDS luma tile that the macroblock's samples never use carry what the joint Intra4x4 pass needs to know
+ * about a macroblock prepared earlier (intra_mb with res_defer): byte 0 = availability flags, bytes 24..31 = the 16 modes */
+/* one intra macroblock by one wavefront; tile = 17*TS bytes, ctile = 2 x 9*16 bytes (wave-private LDS).
+ * res_defer != nullptr: an Intra4x4 macroblock is only PREPARED — neighbours in the tile, residual (16 x 16 int16) in
+ * res_defer, chroma done — and its luma prediction is left to intra4_joint(); other kinds are done completely. */
+__device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0,
+                                         const uint4 *i4tab, int16_t *res_defer = nullptr)
 {
     const FjMbRec rec = fd.recs[mb];
     const int wmb = fd.wmb;
@@ -996,6 +1075,12 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
          * written to the picture once at the end. */
         uint64_t i4modes;
         __builtin_memcpy(&i4modes, rec.i4mode, 8);
+        if (res_defer) {
+            /* joint pass later: residual rows and the per-macroblock facts go to LDS */
+            *reinterpret_cast<uint2 *>(res_defer + (by * 4 + row) * 16 + bx * 4) =
+                make_uint2((uint32_t)(ry[0] & 0xFFFF) | ((uint32_t)ry[1] << 16), (uint32_t)(ry[2] & 0xFFFF) | ((uint32_t)ry[3] << 16));
+            if (lane == 0) { tile[0] = rec.avail; *reinterpret_cast<uint2 *>(&tile[24]) = make_uint2((uint32_t)i4modes, (uint32_t)(i4modes >> 32)); }
+        } else {
         const int z = z_of(bx, by);
         const int mode = (int)((i4modes >> (4 * z)) & 15u);
         const int bx4 = bx * 4, by4 = by * 4, y = row;
@@ -1005,87 +1090,8 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
         else has_tr = bx < 3 && z_of(bx + 1, by - 1) < z;
         for (int d = 0; d < 10; d++) {
             if (bx + 2 * by == d) {
-                /* the 13 neighbour samples of the block in seven INDEPENDENT LDS reads (one latency instead of a chain
-                 * of byte reads inside the mode switch): corner | top 0..7 (64-bit, above-right replaced when it is
-                 * not available) | left 0..3 (32-bit); elements are cut out with shifts */
-                const uint8_t *trow = &tile[by4 * TS + bx4];
-                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(trow), w1 = *reinterpret_cast<const uint32_t *>(trow + 4),
-                               w2 = *reinterpret_cast<const uint32_t *>(trow + 8);
-                const uint32_t l0 = tile[(by4 + 1) * TS + 3 + bx4], l1 = tile[(by4 + 2) * TS + 3 + bx4],
-                               l2 = tile[(by4 + 3) * TS + 3 + bx4], l3 = tile[(by4 + 4) * TS + 3 + bx4];
-                const int CN = (int)(w0 >> 24);
-                const unsigned long long TW = (unsigned long long)w1 | ((unsigned long long)(has_tr ? w2 : (w1 >> 24) * 0x01010101u) << 32);
-                const uint32_t LW = l0 | (l1 << 8) | (l2 << 16) | (l3 << 24);
-#undef I4_T
-#undef I4_L
-#define I4_T(k) (((k) < 0) ? CN : (int)((TW >> (8 * (k))) & 255u))
-#define I4_L(k) (((k) < 0) ? CN : (int)((LW >> (8 * (k))) & 255u))
-                /* At most two blocks are active in a step, so at most two of the nine modes occur: every mode sits behind
-                 * a wave-uniform test (a plain switch over the lane's mode executes all nine bodies under predication) */
-                int vv[4] = { 0, 0, 0, 0 };
-#define I4_MODE(m) if (__ballot(mode == (m)) != 0ull) if (mode == (m))
-#define I4_EACH_X _Pragma("unroll") for (int x = 0; x < 4; x++)
-                I4_MODE(0) { I4_EACH_X vv[x] = I4_T(x); }
-                I4_MODE(1) { I4_EACH_X vv[x] = I4_L(y); }
-                I4_MODE(2) {
-                    int v;
-                    if (has_top && has_left) v = (I4_T(0) + I4_T(1) + I4_T(2) + I4_T(3) + I4_L(0) + I4_L(1) + I4_L(2) + I4_L(3) + 4) >> 3;
-                    else if (has_left) v = (I4_L(0) + I4_L(1) + I4_L(2) + I4_L(3) + 2) >> 2;
-                    else if (has_top) v = (I4_T(0) + I4_T(1) + I4_T(2) + I4_T(3) + 2) >> 2;
-                    else v = 128;
-                    I4_EACH_X vv[x] = v;
-                }
-                I4_MODE(3) {
-                    I4_EACH_X vv[x] = (x == 3 && y == 3) ? (I4_T(6) + 3 * I4_T(7) + 2) >> 2 : (I4_T(x + y) + 2 * I4_T(x + y + 1) + I4_T(x + y + 2) + 2) >> 2;
-                }
-                I4_MODE(4) {
-                    I4_EACH_X {
-                        int v;
-                        if (x > y) v = (I4_T(x - y - 2) + 2 * I4_T(x - y - 1) + I4_T(x - y) + 2) >> 2;
-                        else if (x < y) v = (I4_L(y - x - 2) + 2 * I4_L(y - x - 1) + I4_L(y - x) + 2) >> 2;
-                        else v = (I4_T(0) + 2 * I4_T(-1) + I4_L(0) + 2) >> 2;
-                        vv[x] = v;
-                    }
-                }
-                I4_MODE(5) {
-                    I4_EACH_X {
-                        const int zz = 2 * x - y;
-                        int v;
-                        if (zz >= 0 && !(zz & 1)) v = (I4_T(x - (y >> 1) - 1) + I4_T(x - (y >> 1)) + 1) >> 1;
-                        else if (zz >= 0) v = (I4_T(x - (y >> 1) - 2) + 2 * I4_T(x - (y >> 1) - 1) + I4_T(x - (y >> 1)) + 2) >> 2;
-                        else if (zz == -1) v = (I4_L(0) + 2 * I4_T(-1) + I4_T(0) + 2) >> 2;
-                        else v = (I4_L(y - 1) + 2 * I4_L(y - 2) + I4_L(y - 3) + 2) >> 2;
-                        vv[x] = v;
-                    }
-                }
-                I4_MODE(6) {
-                    I4_EACH_X {
-                        const int zz = 2 * y - x;
-                        int v;
-                        if (zz >= 0 && !(zz & 1)) v = (I4_L(y - (x >> 1) - 1) + I4_L(y - (x >> 1)) + 1) >> 1;
-                        else if (zz >= 0) v = (I4_L(y - (x >> 1) - 2) + 2 * I4_L(y - (x >> 1) - 1) + I4_L(y - (x >> 1)) + 2) >> 2;
-                        else if (zz == -1) v = (I4_L(0) + 2 * I4_T(-1) + I4_T(0) + 2) >> 2;
-                        else v = (I4_T(x - 1) + 2 * I4_T(x - 2) + I4_T(x - 3) + 2) >> 2;
-                        vv[x] = v;
-                    }
-                }
-                I4_MODE(7) {
-                    I4_EACH_X vv[x] = !(y & 1) ? (I4_T(x + (y >> 1)) + I4_T(x + (y >> 1) + 1) + 1) >> 1
-                                                : (I4_T(x + (y >> 1)) + 2 * I4_T(x + (y >> 1) + 1) + I4_T(x + (y >> 1) + 2) + 2) >> 2;
-                }
-                I4_MODE(8) {
-                    I4_EACH_X {
-                        const int zz = x + 2 * y;
-                        int v;
-                        if (zz > 5) v = I4_L(3);
-                        else if (zz == 5) v = (I4_L(2) + 3 * I4_L(3) + 2) >> 2;
-                        else if (!(zz & 1)) v = (I4_L(y + (x >> 1)) + I4_L(y + (x >> 1) + 1) + 1) >> 1;
-                        else v = (I4_L(y + (x >> 1)) + 2 * I4_L(y + (x >> 1) + 1) + I4_L(y + (x >> 1) + 2) + 2) >> 2;
-                        vv[x] = v;
-                    }
-                }
-#undef I4_MODE
-#undef I4_EACH_X
+                int vv[4];
+                intra4_row(tile, bx4, by4, y, mode, has_left, has_top, has_tr, i4tab, vv);
                 int pr[4];
 #pragma unroll
                 for (int x = 0; x < 4; x++) pr[x] = clip255(vv[x] + ry[x]);
@@ -1096,6 +1102,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
         }
         *reinterpret_cast<uint32_t *>(Y + (by * 4 + row) * 16 + bx * 4) =
             *reinterpret_cast<const uint32_t *>(&tile[(by * 4 + 1 + row) * TS + 4 + bx * 4]);
+        }
     }
 
     /* chroma: lanes 0..31, lane = 4*k + row */
@@ -1142,6 +1149,51 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
 }
 #undef I4_T
 #undef I4_L
+
+/* Joint luma pass of up to FOUR prepared Intra4x4 macroblocks by one wavefront: 16 lanes per macroblock (group g =
+ * lane >> 4, tile and residual of slot g).  Inside a macroblock the blocks with bx + 2*by == d are independent (10 steps
+ * for 16 blocks), at most two per step: lanes 4a + y (a = 0, 1; y = row) of the group predict row y of the a-th of them —
+ * 8 of 16 lanes busy, 32 of 64 with four macroblocks, against 8 of 64 when a wavefront walks one macroblock alone.  The
+ * prediction is table-driven (intra4_row), so four macroblocks' worth of different modes cost one instruction stream.
+ * my_mb < 0: the group has no macroblock.  Afterwards lane s of a group stores row s of the finished macroblock. */
+constexpr int INTRA_SLOT = 1024;                     /* LDS per prepared macroblock: luma tile 17 x TS + chroma tiles 2 x 144 */
+constexpr int INTRA_WAVE_LDS = 4 * INTRA_SLOT + 4 * 512;   /* four slots + four residual blocks of 16 x 16 int16 */
+__device__ __forceinline__ void intra4_joint(const FrameDesc &fd, int my_mb, int lane, uint8_t *wave_lds, const uint4 *i4tab)
+{
+    const int g = lane >> 4, sub = lane & 15, a = sub >> 2, y = sub & 3;
+    uint8_t *tile = wave_lds + g * INTRA_SLOT;
+    const int16_t *res = reinterpret_cast<const int16_t *>(wave_lds + 4 * INTRA_SLOT + g * 512);
+    const bool on = my_mb >= 0;
+    const uint32_t avail = on ? tile[0] : 0u;
+    const uint2 mw = on ? *reinterpret_cast<const uint2 *>(&tile[24]) : make_uint2(0u, 0u);
+    const unsigned long long i4modes = (unsigned long long)mw.x | ((unsigned long long)mw.y << 32);
+    const bool av_a = avail & FJ_AVAIL_A, av_b = avail & FJ_AVAIL_B, av_c = avail & FJ_AVAIL_C;
+    for (int d = 0; d < 10; d++) {
+        const int by = min(3, d >> 1) - a, bx = d - 2 * by;
+        const bool act = on && a < 2 && by >= 0 && bx >= 0 && bx <= 3;
+        if (__ballot(act) != 0ull) {
+            const int cbx = act ? bx : 0, cby = act ? by : 0;
+            const int z = z_of(cbx, cby);
+            const int mode = act ? (int)((i4modes >> (4 * z)) & 15u) : 0;
+            const bool has_left = cbx > 0 || av_a, has_top = cby > 0 || av_b;
+            const bool has_tr = cby == 0 ? (cbx < 3 ? av_b : av_c) : (cbx < 3 && z_of(cbx + 1, cby - 1) < z);
+            int vv[4];
+            intra4_row(tile, cbx * 4, cby * 4, y, mode, has_left, has_top, has_tr, i4tab, vv);
+            if (act) {
+                const uint2 rr = *reinterpret_cast<const uint2 *>(res + (cby * 4 + y) * 16 + cbx * 4);
+                const int r0 = (int16_t)(rr.x & 0xFFFFu), r1 = (int32_t)rr.x >> 16, r2 = (int16_t)(rr.y & 0xFFFFu), r3 = (int32_t)rr.y >> 16;
+                *reinterpret_cast<uint32_t *>(&tile[(cby * 4 + 1 + y) * TS + 4 + cbx * 4]) =
+                    pack4(clip255(vv[0] + r0), clip255(vv[1] + r1), clip255(vv[2] + r2), clip255(vv[3] + r3));
+            }
+        }
+        wave_sync();
+    }
+    if (on) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tile[(sub + 1) * TS + 4]);
+        *reinterpret_cast<uint4 *>(fd.cur + (size_t)my_mb * TILE + sub * 16) = make_uint4(src[0], src[1], src[2], src[3]);
+    }
+    wave_sync();
+}
 
 /* ------------------------------------------------------------------ deblocking */
 struct EdgeThr { int alpha, beta, ia; };
@@ -1426,15 +1478,17 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
     const uint32_t total = fd.lvl[fd.n_levels];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
-    uint8_t *my = lds + wave * 1024;
-    uint8_t *need = lds + (blockDim.x >> 6) * 1024;      /* the host launches fewer wavefronts when n_mbs leaves less LDS */
+    uint8_t *my = lds + wave * INTRA_WAVE_LDS;
+    uint8_t *need = lds + (blockDim.x >> 6) * INTRA_WAVE_LDS;      /* the host launches fewer wavefronts when n_mbs leaves less LDS */
     uint8_t *dep = need + ((n_mbs + 15) & ~15);
     uint16_t *queue = reinterpret_cast<uint16_t *>(dep + ((n_mbs + 15) & ~15));
     uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + ((n_mbs + 7) & ~7));   /* [0] head, [1] tail */
+    uint4 *i4tab = reinterpret_cast<uint4 *>(ctr + 4);
 
     for (int i = tid; i < (n_mbs + 3) / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dep)[i] = 0xFFFFFFFFu;
     for (int i = tid; i < (n_mbs + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
     if (tid < 4) ctr[tid] = 0;
+    if (tid < 144) i4tab[tid] = c_i4tab[tid >> 2][tid & 3];
     __syncthreads();
     for (uint32_t i = tid; i < total; i += blockDim.x) {
         const uint32_t mb = fd.idx[i];
@@ -1472,38 +1526,61 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
      * [0] cycles with nothing ready, [1] cycles reconstructing, [2] cycles waiting for stores + release, [3] MBs */
     unsigned long long *tp = (prof && blockIdx.x == 0) ? prof + 256 + wave * 8 : nullptr;
     unsigned long long t_idle = 0, t_work = 0, t_rel = 0, n_done = 0, t_mark = tp ? __builtin_readcyclecounter() : 0ull;
+    /* Pull model: a free wavefront takes up to FOUR ready macroblocks at once.  Each is prepared by the whole wavefront
+     * in turn (neighbours, residual, chroma; Intra16x16 / I_PCM / concealed macroblocks completely); the luma of the
+     * Intra4x4 ones among them — 10 dependent steps with at most two blocks each — is then predicted jointly, one quarter
+     * of the wavefront per macroblock (intra4_joint).  A lone ready macroblock takes the single-macroblock path. */
     for (;;) {
-        uint32_t slot = 0xFFFFFFFFu;
+        uint32_t base = 0, k = 0;
         if (lane == 0) {
             const uint32_t h = vctr[0], t = vctr[1];
-            if (t > h) { if (atomicCAS(&ctr[0], h, h + 1) == h) slot = h; else slot = 0xFFFFFFFEu; }
-            else if (h >= total) slot = 0xFFFFFFFDu;
-            else slot = 0xFFFFFFFEu;
+            if (t > h) {
+                /* several at once only when there is more ready work than wavefronts: with few ready macroblocks (P
+                 * pictures) one per wavefront finishes them sooner than one wavefront preparing four in turn */
+                const uint32_t share = (t - h) / (blockDim.x >> 6);
+                k = share < 1u ? 1u : share > 4u ? 4u : share;
+                if (atomicCAS(&ctr[0], h, h + k) != h) k = 0;       /* lost the race: look again */
+                base = h;
+            } else if (h >= total) k = 0xFFFFFFFFu;                /* everything has been claimed */
         }
-        slot = __shfl(slot, 0);
-        if (slot == 0xFFFFFFFDu) break;
+        base = __shfl(base, 0); k = __shfl(k, 0);
+        if (k == 0xFFFFFFFFu) break;
         if (++spins > (1u << 24)) { if (lane == 0) atomicOr(fd.err, DEVERR_INTRA_SCHED); break; }
-        if (slot == 0xFFFFFFFEu) { __builtin_amdgcn_s_sleep(1); continue; }
-        int v;
-        do { v = vq[slot]; } while (v == 0xFFFF);          /* the publisher bumps the cursor, then writes the slot */
-        const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(v);
+        if (k == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+        /* lane j < k fetches queue slot base + j (the publisher bumps the cursor, then writes the slot) */
+        int v = 0;
+        if ((uint32_t)lane < k) do { v = vq[base + lane]; } while (v == 0xFFFF);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
-        /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
-        const uint32_t head = *reinterpret_cast<const uint32_t *>(&fd.recs[mb]);     /* kind, qp_y, qp_c, avail */
-        if ((head & 255u) == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
-        else intra_mb(fd, mb, lane, my, my + 17 * TS);
-        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done++; }
-        /* release: stores done -> the neighbours that wait for this macroblock */
+        int joint_mb = -1;                                          /* per 16-lane group: its Intra4x4 macroblock, if any */
+        for (uint32_t j = 0; j < k; j++) {
+            const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(v, (int)j));
+            const uint32_t head = *reinterpret_cast<const uint32_t *>(&fd.recs[mb]);     /* kind, qp_y, qp_c, avail */
+            const uint32_t kind = head & 255u;
+            uint8_t *slot = my + j * INTRA_SLOT;
+            /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
+            if (kind == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
+            else if (kind == FJ_MB_I4x4 && k > 1) {
+                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512));
+                if ((uint32_t)(lane >> 4) == j) joint_mb = (int)mb;
+            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab);
+        }
+        if (__ballot(joint_mb >= 0) != 0ull) intra4_joint(fd, joint_mb, lane, my, i4tab);
+        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += k; }
+        /* release: stores done -> the neighbours that wait for these macroblocks (lanes 16j + b: neighbour b of macroblock j) */
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane < 8) {
-            const int s = neighbour((int)mb, lane);
-            if (s >= 0 && dep[s] != 0xFF && ((need[s] >> (lane ^ 4)) & 1u)) {
-                uint32_t *w = reinterpret_cast<uint32_t *>(dep + (s & ~3));
-                const uint32_t sh = 8u * (s & 3);
-                const uint32_t old = atomicSub(w, 1u << sh);
-                if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)s;
+        {
+            const int j = lane >> 4, b = lane & 15;
+            const int mbj = __shfl(v, j);
+            if ((uint32_t)j < k && b < 8) {
+                const int s = neighbour(mbj, b);
+                if (s >= 0 && dep[s] != 0xFF && ((need[s] >> (b ^ 4)) & 1u)) {
+                    uint32_t *w = reinterpret_cast<uint32_t *>(dep + (s & ~3));
+                    const uint32_t sh = 8u * (s & 3);
+                    const uint32_t old = atomicSub(w, 1u << sh);
+                    if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)s;
+                }
             }
         }
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_rel += t - t_mark; t_mark = t; }
