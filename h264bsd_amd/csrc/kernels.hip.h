@@ -986,9 +986,17 @@ __device__ __forceinline__ void intra4_row(const uint8_t *tile, int bx4, int by4
  * res_defer != nullptr: an Intra4x4 macroblock is only PREPARED — neighbours in the tile, residual (16 x 16 int16) in
  * res_defer, chroma done — and its luma prediction is left to intra4_joint(); other kinds are done completely. */
 __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0,
-                                         const uint4 *i4tab, int16_t *res_defer = nullptr)
+                                         const uint4 *i4tab, const uint32_t *rec_lds, int16_t *res_defer = nullptr)
 {
-    const FjMbRec rec = fd.recs[mb];
+    /* the record was fetched together with those of the other macroblocks this wavefront claimed (one round trip for all
+     * of them) and parked in LDS; it is wave-uniform: back into scalar registers */
+    FjMbRec rec;
+    {
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_lds[i]);
+        __builtin_memcpy(&rec, w, 32);
+    }
     const int wmb = fd.wmb;
     const int16_t *coef = fd.coefs + 16 * (size_t)rec.coef_idx;
     /* the macroblock's tile (Y 16x16 | Cb 8x8 | Cr 8x8); neighbours: one tile to the left, wmb tiles up */
@@ -1157,7 +1165,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
  * prediction is table-driven (intra4_row), so four macroblocks' worth of different modes cost one instruction stream.
  * my_mb < 0: the group has no macroblock.  Afterwards lane s of a group stores row s of the finished macroblock. */
 constexpr int INTRA_SLOT = 1024;                     /* LDS per prepared macroblock: luma tile 17 x TS + chroma tiles 2 x 144 */
-constexpr int INTRA_WAVE_LDS = 4 * INTRA_SLOT + 4 * 512;   /* four slots + four residual blocks of 16 x 16 int16 */
+constexpr int INTRA_WAVE_LDS = 4 * INTRA_SLOT + 4 * 512 + 128;   /* four slots + four residual blocks of 16 x 16 int16 + four records */
 __device__ __forceinline__ void intra4_joint(const FrameDesc &fd, int my_mb, int lane, uint8_t *wave_lds, const uint4 *i4tab)
 {
     const int g = lane >> 4, sub = lane & 15, a = sub >> 2, y = sub & 3;
@@ -1553,17 +1561,25 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
         int joint_mb = -1;                                          /* per 16-lane group: its Intra4x4 macroblock, if any */
+        /* the records of all claimed macroblocks in ONE vector load (lane 8j + w: dword w of record j), parked in LDS:
+         * one memory round trip per group instead of one per macroblock in front of the neighbour / coefficient loads */
+        uint32_t *rec_lds = reinterpret_cast<uint32_t *>(my + 4 * INTRA_SLOT + 4 * 512);
+        if ((uint32_t)lane < 8u * k) {
+            const int mbj = __shfl(v, lane >> 3);
+            rec_lds[lane] = reinterpret_cast<const uint32_t *>(&fd.recs[mbj])[lane & 7];
+        }
+        wave_sync();
         for (uint32_t j = 0; j < k; j++) {
             const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(v, (int)j));
-            const uint32_t head = *reinterpret_cast<const uint32_t *>(&fd.recs[mb]);     /* kind, qp_y, qp_c, avail */
+            const uint32_t head = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_lds[8 * j]);     /* kind, qp_y, qp_c, avail */
             const uint32_t kind = head & 255u;
             uint8_t *slot = my + j * INTRA_SLOT;
             /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
             if (kind == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
             else if (kind == FJ_MB_I4x4 && k > 1) {
-                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512));
+                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512));
                 if ((uint32_t)(lane >> 4) == j) joint_mb = (int)mb;
-            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab);
+            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j);
         }
         if (__ballot(joint_mb >= 0) != 0ull) intra4_joint(fd, joint_mb, lane, my, i4tab);
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += k; }
