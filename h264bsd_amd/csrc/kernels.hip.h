@@ -985,23 +985,58 @@ __device__ __forceinline__ void intra4_row(const uint8_t *tile, int bx4, int by4
 /* one intra macroblock by one wavefront; tile = 17*TS bytes, ctile = 2 x 9*16 bytes (wave-private LDS).
  * res_defer != nullptr: an Intra4x4 macroblock is only PREPARED — neighbours in the tile, residual (16 x 16 int16) in
  * res_defer, chroma done — and its luma prediction is left to intra4_joint(); other kinds are done completely. */
-__device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0,
-                                         const uint4 *i4tab, const uint32_t *rec_lds, int16_t *res_defer = nullptr)
+struct IntraLoads { int nb_y, nb_c; ResidRows rows; };
+
+__device__ __forceinline__ FjMbRec rec_from_lds(const uint32_t *rec_lds)
 {
     /* the record was fetched together with those of the other macroblocks this wavefront claimed (one round trip for all
      * of them) and parked in LDS; it is wave-uniform: back into scalar registers */
     FjMbRec rec;
-    {
-        uint32_t w[8];
+    uint32_t w[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_lds[i]);
-        __builtin_memcpy(&rec, w, 32);
+    for (int i = 0; i < 8; i++) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_lds[i]);
+    __builtin_memcpy(&rec, w, 32);
+    return rec;
+}
+
+/* The global loads of one intra macroblock — neighbour samples of the un-deblocked current picture and the coefficient
+ * rows — issued one macroblock AHEAD of their use (k_frame_intra: while the previous macroblock of the group is being
+ * reconstructed), so that the round trip hides behind that work. */
+__device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, const uint32_t *rec_lds, int lane, IntraLoads &L)
+{
+    const FjMbRec rec = rec_from_lds(rec_lds);
+    L.nb_y = L.nb_c = 128;
+    L.rows.y = L.rows.c = L.rows.cdc = make_int2(0, 0);
+    if (rec.kind == FJ_MB_IPCM || rec.kind == FJ_MB_CONCEAL_I) return;
+    const uint8_t *Y = fd.cur + (size_t)mb * TILE;       /* neighbours: one tile to the left, wmb tiles up */
+    const ptrdiff_t up = -(ptrdiff_t)fd.wmb * TILE;
+    const bool av_a = rec.avail & FJ_AVAIL_A, av_b = rec.avail & FJ_AVAIL_B, av_c = rec.avail & FJ_AVAIL_C, av_d = rec.avail & FJ_AVAIL_D;
+    if (lane < 21) {
+        const int c = lane;                               /* corner, 16 above, 4 above-right: last row of the tiles above */
+        const bool ok = c == 0 ? av_d : c <= 16 ? av_b : av_c;
+        if (ok) L.nb_y = c == 0 ? Y[up - TILE + 255] : c <= 16 ? Y[up + 240 + (c - 1)] : Y[up + TILE + 240 + (c - 17)];
+    } else if (lane >= 32 && lane < 48) {
+        if (av_a) L.nb_y = Y[-TILE + (lane - 32) * 16 + 15];   /* last column of the tile to the left */
     }
-    const int wmb = fd.wmb;
+    if (lane < 18) {
+        const int plane = lane / 9, c = lane % 9;
+        const uint8_t *P = Y + T_CB + plane * 64;
+        const bool ok = c == 0 ? av_d : av_b;
+        if (ok) L.nb_c = c == 0 ? P[up - TILE + 63] : P[up + 56 + (c - 1)];
+    } else if (lane >= 32 && lane < 48) {
+        const int plane = (lane - 32) >> 3, r = (lane - 32) & 7;
+        if (av_a) L.nb_c = (Y + T_CB + plane * 64)[-TILE + r * 8 + 7];
+    }
+    L.rows = mb_residual_fetch(rec.coded, fd.coefs + 16 * (size_t)rec.coef_idx, lane);
+}
+
+__device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0,
+                                         const uint4 *i4tab, const uint32_t *rec_lds, const IntraLoads &L, int16_t *res_defer = nullptr)
+{
+    const FjMbRec rec = rec_from_lds(rec_lds);
     const int16_t *coef = fd.coefs + 16 * (size_t)rec.coef_idx;
-    /* the macroblock's tile (Y 16x16 | Cb 8x8 | Cr 8x8); neighbours: one tile to the left, wmb tiles up */
+    /* the macroblock's tile (Y 16x16 | Cb 8x8 | Cr 8x8) */
     uint8_t *Y = fd.cur + (size_t)mb * TILE;
-    const ptrdiff_t up = -(ptrdiff_t)wmb * TILE;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
 
     if (rec.kind == FJ_MB_IPCM) {
@@ -1012,35 +1047,14 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
         return;
     }
 
-    const bool av_a = rec.avail & FJ_AVAIL_A, av_b = rec.avail & FJ_AVAIL_B, av_c = rec.avail & FJ_AVAIL_C, av_d = rec.avail & FJ_AVAIL_D;
-    /* neighbour samples (un-deblocked current picture): requested BEFORE the residual, whose coefficient loads then
-     * share the same memory round trip; written to the tiles after it */
-    int nb_y = 128, nb_c = 128, nb_y_at = -1, nb_c_at = -1;
-    if (lane < 21) {
-        const int c = lane;                               /* corner, 16 above, 4 above-right: last row of the tiles above */
-        const bool ok = c == 0 ? av_d : c <= 16 ? av_b : av_c;
-        nb_y_at = 3 + c;
-        if (ok) nb_y = c == 0 ? Y[up - TILE + 255] : c <= 16 ? Y[up + 240 + (c - 1)] : Y[up + TILE + 240 + (c - 17)];
-    } else if (lane >= 32 && lane < 48) {
-        const int r = lane - 32;                          /* last column of the tile to the left */
-        nb_y_at = (r + 1) * TS + 3;
-        if (av_a) nb_y = Y[-TILE + r * 16 + 15];
-    }
-    if (lane < 18) {
-        const int plane = lane / 9, c = lane % 9;
-        const uint8_t *P = Y + T_CB + plane * 64;
-        const bool ok = c == 0 ? av_d : av_b;
-        nb_c_at = plane * 144 + c;
-        if (ok) nb_c = c == 0 ? P[up - TILE + 63] : P[up + 56 + (c - 1)];
-    } else if (lane >= 32 && lane < 48) {
-        const int plane = (lane - 32) >> 3, r = (lane - 32) & 7;
-        const uint8_t *P = Y + T_CB + plane * 64;
-        nb_c_at = plane * 144 + (r + 1) * 16;
-        if (av_a) nb_c = P[-TILE + r * 8 + 7];
-    }
+    const bool av_a = rec.avail & FJ_AVAIL_A, av_b = rec.avail & FJ_AVAIL_B, av_c = rec.avail & FJ_AVAIL_C;
+    /* where the prefetched neighbour samples (intra_issue) go in the tiles */
+    const int nb_y_at = lane < 21 ? 3 + lane : (lane >= 32 && lane < 48) ? (lane - 32 + 1) * TS + 3 : -1;
+    const int nb_c_at = lane < 18 ? (lane / 9) * 144 + lane % 9 : (lane >= 32 && lane < 48) ? ((lane - 32) >> 3) * 144 + (((lane - 32) & 7) + 1) * 16 : -1;
+    const int nb_y = L.nb_y, nb_c = L.nb_c;
 
     int ry[4], rc[4];
-    report_residual_range(fd, mb_residual(rec.coded, rec.qp_y, rec.qp_c, rec.kind == FJ_MB_I16x16, coef, lane, ry, rc), lane);
+    report_residual_range(fd, mb_residual_compute(rec.coded, rec.qp_y, rec.qp_c, rec.kind == FJ_MB_I16x16, coef, lane, L.rows, ry, rc), lane);
 
     if (nb_y_at >= 0) tile[nb_y_at] = (uint8_t)nb_y;
     if (nb_c_at >= 0) ctile0[nb_c_at] = (uint8_t)nb_c;
@@ -1569,17 +1583,22 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
             rec_lds[lane] = reinterpret_cast<const uint32_t *>(&fd.recs[mbj])[lane & 7];
         }
         wave_sync();
+        /* software pipeline over the group: the loads of macroblock j + 1 are in flight while macroblock j is reconstructed */
+        IntraLoads cur_loads, next_loads;
+        intra_issue(fd, (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(v, 0)), rec_lds, lane, cur_loads);
         for (uint32_t j = 0; j < k; j++) {
             const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(v, (int)j));
             const uint32_t head = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_lds[8 * j]);     /* kind, qp_y, qp_c, avail */
             const uint32_t kind = head & 255u;
             uint8_t *slot = my + j * INTRA_SLOT;
+            if (j + 1 < k) intra_issue(fd, (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(v, (int)j + 1)), rec_lds + 8 * (j + 1), lane, next_loads);
             /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
             if (kind == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
             else if (kind == FJ_MB_I4x4 && k > 1) {
-                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512));
+                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512));
                 if ((uint32_t)(lane >> 4) == j) joint_mb = (int)mb;
-            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j);
+            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads);
+            if (j + 1 < k) cur_loads = next_loads;
         }
         if (__ballot(joint_mb >= 0) != 0ull) intra4_joint(fd, joint_mb, lane, my, i4tab);
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += k; }
