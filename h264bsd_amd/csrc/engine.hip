@@ -189,14 +189,14 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
         if ((tmask & 4u) && tt->sev[1]) HIP_TRY(hipEventRecord(tt->sev[1], side->stream));
         if (do_dbk) {
-            hipLaunchKernelGGL(h264k::k_dbk, dim3((s.max_dbk + 7) / 8, s.n_frames), dim3(256), 0, side->stream, d_desc);
+            hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 7) / 8, DBK_WGS), s.n_frames), dim3(256), 0, side->stream, d_desc);
             if (launches) launches[2]++;
         }
         if ((tmask & 4u) && tt->sev[2]) HIP_TRY(hipEventRecord(tt->sev[2], side->stream));
         HIP_TRY(hipEventRecord(side->join, side->stream));
     }
     if (do_copy) {
-        hipLaunchKernelGGL(h264k::k_copy, dim3((s.max_copy + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);   /* one run per wavefront */
+        hipLaunchKernelGGL(h264k::k_copy, dim3(std::min<uint32_t>((s.max_copy + 3) / 4, COPY_WGS), s.n_frames), dim3(256), 0, st, d_desc);   /* COPY_WGS workgroups per picture walk its run list */
         if (launches) launches[0]++;
     }
     if (EV_NEEDED(1)) HIP_TRY(hipEventRecord(tt->ev[1], st));
@@ -206,7 +206,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     }
     if (EV_NEEDED(2)) HIP_TRY(hipEventRecord(tt->ev[2], st));
     if (do_dbk && !aside) {
-        hipLaunchKernelGGL(h264k::k_dbk, dim3((s.max_dbk + 7) / 8, s.n_frames), dim3(256), 0, st, d_desc);
+        hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 7) / 8, DBK_WGS), s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[2]++;
     }
     if (EV_NEEDED(3)) HIP_TRY(hipEventRecord(tt->ev[3], st));

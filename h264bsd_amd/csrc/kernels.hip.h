@@ -434,29 +434,45 @@ __device__ __forceinline__ void wave_sync()
 /* Boundary strengths (8.7.2.1) + threshold indices from metadata only; one macroblock per 32 lanes.
  * reference: GetBoundaryStrengths / GetLumaEdgeThresholds / GetChromaEdgeThresholds,
  * src/h264bsd_deblocking.c:1187-1541 */
+#ifndef DBK_WGS
+#define DBK_WGS 32           /* workgroups per picture: each walks the picture's index list with stride 8 * DBK_WGS */
+#endif
 __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frames)
 {
     const FrameDesc &fd = frames[blockIdx.y];
-    const uint32_t di = blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (di >= fd.n_dbk) return;
-    const uint32_t mb = fd.dbki[di];
     const int n = threadIdx.x & 31;
+    const int wmb = fd.wmb;
+    const uint32_t n_dbk = fd.n_dbk;
+    /* A fixed number of workgroups per picture walks the index list with a stride; the next index is requested while
+     * the current macroblock is worked on, and everything a macroblock needs — its record, the records of its left and
+     * upper neighbours, the motion vectors on both sides of the lane's edge — is requested TOGETHER, whether the flags in
+     * the record (still in flight) will want it or not: two dependent memory round trips per macroblock instead of four. */
+    uint32_t di = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (di >= n_dbk) return;
+    uint32_t mb = fd.dbki[di];
+  for (;;) {
+    const uint32_t ndi = di + 8u * gridDim.x;
+    uint32_t nmb = mb;
+    if (ndi < n_dbk) nmb = fd.dbki[ndi];
+    const uint32_t mbl = mb % (uint32_t)wmb ? mb - 1 : mb, mbt = mb >= (uint32_t)wmb ? mb - wmb : mb;    /* in-picture stand-ins */
     const FjMbRec q = fd.recs[mb];
+    const FjMbRec pl = fd.recs[mbl], pt = fd.recs[mbt];
+    const int dir = n >> 4, e = (n >> 2) & 3, k = n & 3;
+    const int qx = dir ? k : e, qy = dir ? e : k;
+    const int px = dir ? k : (e ? e - 1 : 3), py = dir ? (e ? e - 1 : 3) : k;
+    const uint32_t pmb = e ? mb : (dir ? mbt : mbl);
+    const uint32_t mva = *reinterpret_cast<const uint32_t *>(fd.mvs + 32 * (size_t)mb + 2 * (4 * qy + qx));
+    const uint32_t mvb = *reinterpret_cast<const uint32_t *>(fd.mvs + 32 * (size_t)pmb + 2 * (4 * py + px));
     uint8_t *out = fd.dbk + (size_t)mb * DBK_REC_BYTES;
     uint8_t *any_out = fd.dbk + (size_t)fd.n_mbs * DBK_REC_BYTES + mb;
     if (!q.dbk || q.kind == FJ_MB_ABSENT) {
         if (n == 0) { *reinterpret_cast<uint32_t *>(out + 28) = 0; *any_out = 0; }
-        return;
-    }
-    const int wmb = fd.wmb;
+    } else {
     const bool f_left = q.dbk & FJ_DBK_LEFT, f_top = q.dbk & FJ_DBK_TOP;
-    const FjMbRec pl = fd.recs[f_left ? mb - 1 : mb], pt = fd.recs[f_top ? mb - wmb : mb];
     int my_bs = 0;
     {
-        const int dir = n >> 4, e = (n >> 2) & 3, k = n & 3;
         const bool edge_on = e ? true : (dir ? f_top : f_left);
         if (edge_on) {
-            const uint32_t pmb = e ? mb : (dir ? mb - wmb : mb - 1);
             const int p_kind = e ? q.kind : (dir ? pt.kind : pl.kind);
             const uint32_t p_coded = e ? q.coded : (dir ? pt.coded : pl.coded);
             uint32_t qrefs, prefs, t0, t1;
@@ -464,14 +480,12 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
             __builtin_memcpy(&t0, pl.ref_slot, 4);
             __builtin_memcpy(&t1, pt.ref_slot, 4);
             prefs = e ? qrefs : (dir ? t1 : t0);
-            const int qx = dir ? k : e, qy = dir ? e : k;
-            const int px = dir ? k : (e ? e - 1 : 3), py = dir ? (e ? e - 1 : 3) : k;
             if (is_intra_kind(q.kind) || is_intra_kind(p_kind)) my_bs = e ? 3 : 4;
             else if (((q.coded >> z_of(qx, qy)) & 1) || ((p_coded >> z_of(px, py)) & 1)) my_bs = 2;
             else if (((qrefs >> (8 * ((qy >> 1) * 2 + (qx >> 1)))) & 255u) != ((prefs >> (8 * ((py >> 1) * 2 + (px >> 1)))) & 255u)) my_bs = 1;
             else {
-                const int16_t *a = fd.mvs + 32 * (size_t)mb + 2 * (4 * qy + qx), *b = fd.mvs + 32 * (size_t)pmb + 2 * (4 * py + px);
-                my_bs = (abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4) ? 1 : 0;
+                const int ax = (int16_t)(mva & 0xFFFFu), ay = (int32_t)mva >> 16, bx2 = (int16_t)(mvb & 0xFFFFu), by2 = (int32_t)mvb >> 16;
+                my_bs = (abs(ax - bx2) >= 4 || abs(ay - by2) >= 4) ? 1 : 0;
             }
         }
     }
@@ -505,6 +519,10 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
         *reinterpret_cast<uint32_t *>(out + 28) = (uint32_t)q.dbk | (any ? 0x100u : 0u);
         *any_out = (uint8_t)sched;
     }
+    }
+    if (ndi >= n_dbk) return;
+    di = ndi; mb = nmb;
+  }
 }
 
 /* ------------------------------------------------------------------ whole-sample copy macroblocks */
@@ -512,14 +530,25 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
  * displacement is zero (P_Skip with zero motion: almost all of them) is ONE contiguous block of count x 384 bytes in
  * the reference frame and in the current one: 24 x count 16-byte pieces, up to six per lane, every load issued before
  * the first store.  Displaced (and clamped) runs gather their samples 4 at a time. */
+#ifndef COPY_WGS
+#define COPY_WGS 32          /* workgroups per picture: each walks the picture's run list with stride 4 * COPY_WGS */
+#endif
 __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ frames)
 {
     const FrameDesc &fd = frames[blockIdx.y];
-    const uint32_t ci = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ci >= fd.n_copy) return;
     const int lane = threadIdx.x & 63;
     const int wmb = fd.wmb;
-    const FjCopy e = fd.copy[ci];
+    const uint32_t n_copy = fd.n_copy;
+    /* a fixed number of workgroups per picture, every wavefront walks the run list with a stride: no workgroup is
+     * launched for nothing (the grid used to be sized by the longest list of the tick), and the next list entry is
+     * requested while the current run moves */
+    uint32_t ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ci >= n_copy) return;
+    FjCopy e = fd.copy[ci];
+  for (;;) {
+    const uint32_t nci = ci + 4u * gridDim.x;
+    FjCopy ne = e;
+    if (nci < n_copy) ne = fd.copy[nci];
     const int cnt = e.count;
     const uint8_t *ref = slot_ptr(fd, e.slot);
     if ((e.dx | e.dy) == 0) {
@@ -532,8 +561,7 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
         for (int j = 0; j < PIECES; j++) if (lane + 64 * j < n16) v[j] = src[lane + 64 * j];
 #pragma unroll
         for (int j = 0; j < PIECES; j++) if (lane + 64 * j < n16) dst[lane + 64 * j] = v[j];
-        return;
-    }
+    } else {
     /* displaced: clamp-to-edge sample gather (h264bsdFillBlock, reconstruct.c:2244), lane = (row, 4-sample piece) */
     const int W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mbx = e.mb % wmb, mby = e.mb / wmb;
@@ -558,6 +586,10 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
             *reinterpret_cast<uint32_t *>(dt + T_CB + plane * 64 + r * 8 + 4 * half) = b2;
         }
     }
+    }
+    if (nci >= n_copy) return;
+    ci = nci; e = ne;
+  }
 }
 
 /* ------------------------------------------------------------------ inter macroblocks */
