@@ -129,7 +129,7 @@ Engine *engine_get(int device = -1)
 /* ---- launch of one tick ---- */
 struct TickShape {
     uint32_t n_frames = 0, max_mbs = 0;
-    uint32_t max_copy = 0, max_gen = 0, max_dbk = 0, max_levels = 0, max_w = 0, max_h = 0;
+    uint32_t max_copy = 0, max_gen = 0, max_gen_uni = 0, max_gen_rest = 0, max_dbk = 0, max_levels = 0, max_w = 0, max_h = 0;
     bool any_tail = false, any_deblock = false;
 };
 
@@ -147,6 +147,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     d.gen = reinterpret_cast<const FjGen *>(dev_blob + h->gen_off);
     d.n_copy = h->n_copy;
     d.n_gen = h->n_gen;
+    d.n_gen_uni = h->n_gen_uniform;
     d.dbki = reinterpret_cast<const uint16_t *>(dev_blob + h->dbk_off);
     d.n_dbk = h->n_dbk;
     d.dbk = dev_dbk;
@@ -163,6 +164,8 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
         shape->max_mbs = std::max(shape->max_mbs, h->n_mbs);
         shape->max_copy = std::max(shape->max_copy, h->n_copy);
         shape->max_gen = std::max(shape->max_gen, h->n_gen);
+        shape->max_gen_uni = std::max(shape->max_gen_uni, h->n_gen_uniform);
+        shape->max_gen_rest = std::max(shape->max_gen_rest, h->n_gen - h->n_gen_uniform);
         shape->max_dbk = std::max(shape->max_dbk, h->n_dbk);
         shape->any_deblock |= h->any_deblock != 0;
         shape->max_levels = std::max(shape->max_levels, h->n_intra_levels);
@@ -201,7 +204,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     }
     if (EV_NEEDED(1)) HIP_TRY(hipEventRecord(tt->ev[1], st));
     if ((stages & 1u) && s.max_gen) {
-        hipLaunchKernelGGL(h264k::k_recon_inter, dim3((s.max_gen + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
+        if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_inter<0>, dim3((s.max_gen_uni + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
+        if (s.max_gen_rest) hipLaunchKernelGGL(h264k::k_recon_inter<1>, dim3((s.max_gen_rest + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[1]++;
     }
     if (EV_NEEDED(2)) HIP_TRY(hipEventRecord(tt->ev[2], st));

@@ -110,9 +110,11 @@ typedef struct FjHeader {
     uint32_t n_gen;
     uint32_t dbk_off;         /* uint16 dbk_idx[n_dbk]: MBs whose boundary strengths are not trivially all zero */
     uint32_t n_dbk;
+    uint32_t n_gen_uniform;   /* the first n_gen_uniform entries of the general-inter list have ONE motion vector and
+                                 reference for the whole macroblock (FjGen.uniform == 1), the rest are partitioned */
     uint32_t ghost;           /* 1: pre-pass of the picture that follows in the same slot (pixels of a rolled-back slice that a
                                  FJ_MB_STALE macroblock of that picture shows): reconstruction only, not a picture of its own */
-    uint32_t reserved[10];
+    uint32_t reserved[9];
 } FjHeader;                   /* 128 bytes */
 
 /* An inter macroblock with no coefficients whose 16 motion vectors are equal and whole-sample for

@@ -52,6 +52,7 @@ struct FrameDesc {
     uint8_t        *dbk;          /* per-stream scratch: n_mbs x 32-byte deblocking records, then n_mbs "any" bytes */
     uint8_t        *cur;          /* slot that receives the picture */
     uint32_t        n_mbs, n_levels, n_copy, n_gen, n_dbk;
+    uint32_t        n_gen_uni;    /* the first n_gen_uni entries of gen have one motion vector for the whole macroblock */
     uint16_t        wmb, hmb;
     uint32_t        any_deblock;
     uint32_t       *err;          /* device error word of the engine (DEVERR_* bits, atomicOr): must stay 0 */
@@ -614,14 +615,18 @@ constexpr int INTER_WAVE_LDS = 2688;                 /* max(21 * IW_STRIDE + 2 *
 #ifndef INTER_OCC
 #define INTER_OCC 8      /* macroblock-tile layout: 8 waves per SIMD (64 VGPRs, more spills) beat 7 / 6 / 5: 50.4 vs 54.4 / 58.9 / 59.2 ms per step — the kernel hides latency with wavefronts */
 #endif
+/* Two instantiations share the list: PATH 0 reconstructs the entries with one motion vector per macroblock (82 % of
+ * them), PATH 1 the partitioned ones.  Compiled separately, each gets the registers its own path needs — the common
+ * case no longer pays (in spills at 8 waves per SIMD) for the per-lane window code of the rare one. */
+template <int PATH>
 __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * INTER_WAVE_LDS];
     const FrameDesc &fd = frames[blockIdx.y];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform: the list entry, the record and
                                                                                  everything derived live in scalar registers */
-    const uint32_t gi = blockIdx.x * 4 + wave;
-    if (gi >= fd.n_gen) return;
+    const uint32_t gi = (PATH == 0 ? 0u : fd.n_gen_uni) + blockIdx.x * 4 + wave;
+    if (gi >= (PATH == 0 ? fd.n_gen_uni : fd.n_gen)) return;
     const FjGen ge = fd.gen[gi];
     const uint32_t mb = ge.mb;
     const FjMbRec rec = fd.recs[mb];                  /* only the QPs are needed from it (in flight meanwhile) */
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc 
     const int16_t *coef = fd.coefs + 16 * (size_t)ge.coef_idx;
     uint8_t *cur = fd.cur;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
-    const bool uniform = ge.uniform == 1, quadwise = ge.uniform == 2;
+    const bool uniform = PATH == 0, quadwise = PATH == 1 && ge.uniform == 2;
     uint32_t refs = ge.slot * 0x01010101u, mv_mine = 0;
     const uint32_t mv0 = (uint32_t)(uint16_t)ge.mvx | ((uint32_t)(uint16_t)ge.mvy << 16);
     if (!uniform) {
