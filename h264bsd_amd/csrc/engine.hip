@@ -177,6 +177,15 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
 
 struct TickTimers { hipEvent_t ev[6]; hipEvent_t sev[3] = { nullptr, nullptr, nullptr }; bool on = false; unsigned mask = 31u; };   /* mask bit k: kernel k of KERNELS is timed */   /* boundaries of the 5 kernels of a tick; sev = k_copy, k_dbk on the side stream */
 
+/* Experiment hook (tools/desync_probe.py): fewer wavefronts per workgroup in the two per-picture kernels, so that several
+ * pictures share a compute unit.  Never above the compiled launch bounds. */
+static uint32_t env_waves(const char *name, uint32_t compiled)
+{
+    const char *v = getenv(name);
+    const int n = v ? atoi(v) : 0;
+    return n > 0 && (uint32_t)n < compiled ? (uint32_t)n : compiled;
+}
+
 int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5],
                 unsigned stages = 7u, const SideLane *side = nullptr, unsigned long long *prof = nullptr)
 {
@@ -221,7 +230,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         const uint32_t n = s.max_mbs;
         const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64 + h264k::I4TAB_BYTES;
         if (arrays + h264k::INTRA_WAVE_LDS > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_intra\n", n); return -1; }
-        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::TAIL_WAVES, (LDS_BUDGET - arrays) / h264k::INTRA_WAVE_LDS);
+        static const uint32_t want = env_waves("H264BSDMI_INTRA_WAVES", h264k::TAIL_WAVES);
+        const uint32_t waves = (uint32_t)std::min<size_t>(want, (LDS_BUDGET - arrays) / h264k::INTRA_WAVE_LDS);
         const size_t lds = (size_t)waves * h264k::INTRA_WAVE_LDS + arrays;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
@@ -238,7 +248,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 16 + 384 + 64;
         const size_t per_wave = 4 * (size_t)h264k::WORKER_LDS;
         if (arrays + per_wave > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_dbk\n", n); return -1; }
-        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::DBK_WAVES, (LDS_BUDGET - arrays) / per_wave);
+        static const uint32_t want = env_waves("H264BSDMI_DBK_WAVES", h264k::DBK_WAVES);
+        const uint32_t waves = (uint32_t)std::min<size_t>(want, (LDS_BUDGET - arrays) / per_wave);
         const size_t lds = (size_t)waves * per_wave + arrays;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
@@ -683,7 +694,7 @@ struct h264bsdmi_replay {
     struct Launch { size_t first; TickShape shape; int lane; std::vector<int> waits; int record_ev; bool light; };
     std::vector<Launch> sched;
     std::vector<hipEvent_t> sched_ev;
-    static constexpr int MAX_LANES = 24;  /* lanes 0..n_light-1: one per stream group (light pictures), then the heavy lanes */
+    static constexpr int MAX_LANES = 72;  /* lanes 0..n_light-1: one per stream group (light pictures), then the heavy lanes */
     hipStream_t lanes[MAX_LANES] = {};
     SideLane lane_side[MAX_LANES];        /* k_dbk next to the reconstruction kernels, per light lane */
     uint32_t n_lanes = 0, n_light = 0;
@@ -802,13 +813,17 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
             auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[p]); return h->n_intra * 4u > h->n_mbs || h->n_intra > thr_abs; };
             auto new_event = [&]() { r->sched_ev.push_back(nullptr); return (int)r->sched_ev.size() - 1; };
             for (u32 t = 0; left && t < 16u * n_pics; t++) {
+                /* one heavy launch per round for the heavy pictures of all groups: it waits for the light launch of
+                 * every group it takes a stream from (the previous picture of that stream ran there or earlier) */
+                std::vector<u32> hs;
+                std::vector<int> hwaits;
                 for (u32 g = 0; g < groups; g++) {
                     h264bsdmi_replay::Launch light{ n_desc, TickShape(), (int)g, {}, -1, true };
-                    std::vector<u32> hs;
+                    bool group_has_heavy = false;
                     for (u32 s = g; s < n_streams; s += groups) {
                         if (done[s] >= n_pics || ready_at[s] > t) continue;
                         const u32 p = (r->offsets[s] + done[s]) % n_pics;
-                        if (is_heavy(p)) { hs.push_back(s); continue; }
+                        if (is_heavy(p)) { hs.push_back(s); group_has_heavy = true; continue; }
                         if (last_ev[s] >= 0) {               /* rejoining after a heavy picture */
                             if (std::find(light.waits.begin(), light.waits.end(), last_ev[s]) == light.waits.end()) light.waits.push_back(last_ev[s]);
                             last_ev[s] = -1;
@@ -818,25 +833,21 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
                     }
                     const bool have_light = light.shape.n_frames != 0;
                     if (have_light) {
-                        if (!hs.empty()) light.record_ev = new_event();
+                        if (group_has_heavy) { light.record_ev = new_event(); hwaits.push_back(light.record_ev); }
                         r->sched.push_back(light);
+                    } else if (group_has_heavy) hwaits.push_back(-2 - (int)g);      /* "everything enqueued on light lane g so far" */
+                }
+                if (!hs.empty()) {
+                    h264bsdmi_replay::Launch heavy{ n_desc, TickShape(), (int)(groups + heavy_count++ % heavy_lanes), hwaits, -1, false };
+                    for (u32 s : hs) {
+                        if (last_ev[s] >= 0 && std::find(heavy.waits.begin(), heavy.waits.end(), last_ev[s]) == heavy.waits.end()) heavy.waits.push_back(last_ev[s]);
+                        desc_of(descs[n_desc++], s, (r->offsets[s] + done[s]) % n_pics, &heavy.shape);
+                        if (++done[s] == n_pics) left--;
+                        ready_at[s] = t + 1 + heavy_delay;
                     }
-                    if (!hs.empty()) {
-                        h264bsdmi_replay::Launch heavy{ n_desc, TickShape(), (int)(groups + heavy_count++ % heavy_lanes), {}, -1, false };
-                        /* the previous pictures of these streams ran in the group's light launches up to this tick, or in
-                         * an earlier heavy launch */
-                        if (have_light) heavy.waits.push_back(r->sched.back().record_ev);
-                        else heavy.waits.push_back(-2 - (int)g);                  /* "everything enqueued on light lane g so far" */
-                        for (u32 s : hs) {
-                            if (last_ev[s] >= 0 && std::find(heavy.waits.begin(), heavy.waits.end(), last_ev[s]) == heavy.waits.end()) heavy.waits.push_back(last_ev[s]);
-                            desc_of(descs[n_desc++], s, (r->offsets[s] + done[s]) % n_pics, &heavy.shape);
-                            if (++done[s] == n_pics) left--;
-                            ready_at[s] = t + 1 + heavy_delay;
-                        }
-                        heavy.record_ev = new_event();
-                        for (u32 s : hs) last_ev[s] = heavy.record_ev;
-                        r->sched.push_back(heavy);
-                    }
+                    heavy.record_ev = new_event();
+                    for (u32 s : hs) last_ev[s] = heavy.record_ev;
+                    r->sched.push_back(heavy);
                 }
             }
             if (left || n_desc != descs.size()) ok = false;
@@ -848,8 +859,9 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
             if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
             for (u32 k = 0; ok && k < r->n_lanes; k++) {
                 if (k < groups) {
-                    ok = hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking) == hipSuccess &&
-                         hipStreamCreateWithFlags(&r->lane_side[k].stream, hipStreamNonBlocking) == hipSuccess &&
+                    ok = hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking) == hipSuccess;
+                    if (ok && !getenv("H264BSDMI_NO_SIDE_LANES"))        /* experiment hook: k_dbk in line instead of next to the reconstruction kernels */
+                        ok = hipStreamCreateWithFlags(&r->lane_side[k].stream, hipStreamNonBlocking) == hipSuccess &&
                          hipEventCreateWithFlags(&r->lane_side[k].fork, hipEventDisableTiming) == hipSuccess &&
                          hipEventCreateWithFlags(&r->lane_side[k].join, hipEventDisableTiming) == hipSuccess;
                 } else ok = hipStreamCreateWithPriority(&r->lanes[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
@@ -925,7 +937,7 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
                 }
             }
             if (l.shape.n_frames && launch_tick(st, r->d_desc + l.first, l.shape, nullptr, r->launches, r->stages,
-                                                (l.light && r->overlap_dbk && !(r->stages & 8u)) ? &r->lane_side[l.lane] : nullptr)) return -1;
+                                                (l.light && r->overlap_dbk && !(r->stages & 8u) && r->lane_side[l.lane].stream) ? &r->lane_side[l.lane] : nullptr)) return -1;
             if (l.record_ev >= 0) HIP_TRY(hipEventRecord(r->sched_ev[l.record_ev], st));
         }
         for (u32 k = 0; k < r->n_lanes; k++) {               /* the lap ends when every lane has drained */

@@ -618,8 +618,11 @@ constexpr int INTER_WAVE_LDS = 2688;                 /* max(21 * IW_STRIDE + 2 *
 /* Two instantiations share the list: PATH 0 reconstructs the entries with one motion vector per macroblock (82 % of
  * them), PATH 1 the partitioned ones.  Compiled separately, each gets the registers its own path needs — the common
  * case no longer pays (in spills at 8 waves per SIMD) for the per-lane window code of the rare one. */
+#ifndef INTER_OCC_PART
+#define INTER_OCC_PART INTER_OCC
+#endif
 template <int PATH>
-__global__ __launch_bounds__(256, INTER_OCC) void k_recon_inter(const FrameDesc *__restrict__ frames)
+__global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * INTER_WAVE_LDS];
     const FrameDesc &fd = frames[blockIdx.y];
@@ -1512,7 +1515,10 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
  * the macroblocks of a dependency level, __syncthreads() separates levels: no kernel boundary and no
  * inter-workgroup traffic inside a picture.  Occupancy comes from batching streams (256 pictures = one
  * workgroup per CU). */
-constexpr int TAIL_WAVES = 16;
+#ifndef TAIL_WAVES_N
+#define TAIL_WAVES_N 12
+#endif
+constexpr int TAIL_WAVES = TAIL_WAVES_N;
 #ifndef DBK_WAVES_N
 #define DBK_WAVES_N 12
 #endif
@@ -1547,7 +1553,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
     for (int i = tid; i < (n_mbs + 3) / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dep)[i] = 0xFFFFFFFFu;
     for (int i = tid; i < (n_mbs + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
     if (tid < 4) ctr[tid] = 0;
-    if (tid < 144) i4tab[tid] = c_i4tab[tid >> 2][tid & 3];
+    for (int i = tid; i < 144; i += blockDim.x) i4tab[i] = c_i4tab[i >> 2][i & 3];      /* (huge pictures run with as few as 2 wavefronts) */
     __syncthreads();
     for (uint32_t i = tid; i < total; i += blockDim.x) {
         const uint32_t mb = fd.idx[i];

@@ -14,7 +14,7 @@ heads = [h.job_header(j) for j in jobs]
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 P = len(jobs)
 offsets = [(s * P) // S for s in range(S)]
-cfgs = [(0, 0, 1)] + [tuple(int(x) for x in a.split(",")) for a in sys.argv[2:]]
+cfgs = ([] if os.environ.get("NOBASE") else [(0, 0, 1)]) + [tuple(int(x) for x in a.split(",")) for a in sys.argv[2:]]
 for cfg in cfgs:
     K, D = cfg[0], cfg[1]
     G = cfg[2] if len(cfg) > 2 else 1

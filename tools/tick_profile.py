@@ -24,7 +24,7 @@ for lap in range(2):
                 tot[k] += t[k][0] or 0.0
 print("tick n_intra n_dbk n_copy n_gen | " + " ".join(K) + " | total")
 for r in rows:
-    if r[0] < 6 or r[0] in (39, 40, 41, 42) or r[0] % 10 == 0:
+    if os.environ.get("ALL") or r[0] < 6 or r[0] in (39, 40, 41, 42) or r[0] % 10 == 0:
         print(r[0], r[1], r[2], r[3], r[4], "|", " ".join(f"{v:.3f}" for v in r[5]), "|", f"{r[6]:.3f}")
 print("sum", {k: round(v, 1) for k, v in tot.items()})
 rep.close()
