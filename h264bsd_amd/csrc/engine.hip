@@ -54,6 +54,11 @@ struct StreamCtx {
     PendingJob acquired = { nullptr, 0, 0 };   /* staging buffer the parser is currently filling (sink_acquire) */
     std::deque<PendingJob> pending;
     std::vector<PendingJob> free_bufs;      /* recycled pinned staging buffers */
+    /* lane scheduling (flush_locked): the light lane this instance belongs to, where its latest picture was launched
+     * (lane index, launch number on that lane) and the first round of the current flush that may take its next one */
+    int group = 0, last_lane = -1;
+    unsigned long long last_launch = 0;
+    unsigned ready_round = 0;
 };
 
 /* k_dbk (boundary strengths) needs only the frame job, not pixels: it runs on a second HIP stream next to the
@@ -61,16 +66,41 @@ struct StreamCtx {
  * Putting k_copy there as well was tried and lost (it competes with k_recon_inter for the memory system). */
 struct SideLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join_copy = nullptr; };
 
+/* A lane = one HIP stream that runs ticks one after the other, with its own device arena for the frame jobs of a tick
+ * and its own descriptor staging.  Light lanes: one per stream group (decoder instances are dealt round-robin to the
+ * groups), so that the per-picture kernels of one group — which last as long as the slowest picture of the tick —
+ * overlap with the work of the other groups.  Heavy lanes: pictures that are mostly intra coded take 3-4 times as long
+ * as the others in the per-picture kernels; they leave their group's tick and run on one of these, and the instance
+ * rejoins its group HEAVY_DELAY rounds later if it has that many pictures queued.  Order inside one instance is kept by
+ * events: every launch records ring[launch number % RING] on its lane, and a picture whose predecessor ran on another
+ * lane makes its lane wait for that event (a recycled ring slot stands for a later launch of the same lane, which only
+ * waits longer).  Measured on the replay sets: 256 desynchronised 1080p streams, 304 M MB/s with common
+ * ticks, 550 M with heavy lanes, 660 M with 8 groups + 4 heavy lanes; more than ~12 busy HIP streams fall off a cliff
+ * on this runtime (tools/probes/queue_probe.hip), and the runtime's default of 4 hardware queues serialises lanes:
+ * the library asks for 16 (GPU_MAX_HW_QUEUES) when it is loaded before the HIP runtime starts. */
+struct Lane {
+    hipStream_t st = nullptr;
+    bool owns_stream = false;
+    uint8_t *d_arena = nullptr; size_t arena_cap = 0;      /* device copies of the blobs of one tick */
+    FrameDesc *d_desc = nullptr, *h_desc = nullptr; size_t desc_cap = 0;    /* h_desc: pinned staging, 2 halves */
+    int flip = 0; unsigned ticks = 0;
+    hipEvent_t desc_ev[2] = { nullptr, nullptr };
+    static constexpr unsigned RING = 64;
+    hipEvent_t ring[RING] = {};
+    unsigned long long launches = 0;
+    hipEvent_t tail = nullptr;
+    const SideLane *side = nullptr;
+};
+constexpr unsigned HEAVY_DELAY = 4;
+
 struct Engine {
     std::mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
+    std::vector<Lane> lanes;                 /* [0, n_light) light lanes, then n_heavy heavy lanes */
+    unsigned n_light = 1, n_heavy = 0, heavy_rr = 0, group_rr = 0;
     std::vector<StreamCtx *> streams;
-    uint8_t *d_arena = nullptr; size_t arena_cap = 0;      /* device copies of the blobs of one tick */
-    FrameDesc *d_desc = nullptr; size_t desc_cap = 0;
     uint8_t *conv_in = nullptr; uint32_t *conv_out = nullptr; size_t conv_cap = 0; /* eng_convert_host scratch */
-    FrameDesc *h_desc = nullptr; int h_desc_flip = 0; unsigned desc_ticks = 0;    /* pinned descriptor staging, 2 halves */
-    hipEvent_t desc_ev[2] = { nullptr, nullptr };
     std::vector<std::pair<StreamCtx *, PendingJob>> inflight;   /* staging buffers of enqueued, unfinished ticks */
     hipEvent_t inflight_done = nullptr;
     SideLane side;
@@ -100,6 +130,39 @@ int current_device()
     return d;
 }
 
+/* The HIP runtime maps streams onto 4 hardware queues unless told otherwise, and it reads the setting when it starts
+ * (first HIP call of the process): lanes that share a queue run one after the other.  Ask for 16 unless the
+ * application has chosen a value itself.  When the application has started the runtime before this library is loaded
+ * this comes too late; set GPU_MAX_HW_QUEUES=16 in the environment then. */
+__attribute__((constructor)) static void lib_init() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
+/* Lane configuration: H264BSDMI_LANES="<groups>,<heavy lanes>".  Default 4,2 when the runtime was given enough hardware
+ * queues for them (GPU_MAX_HW_QUEUES >= 8, see lib_init below), else one lane = the engine's own stream. */
+static int lanes_create(Engine *e)
+{
+    unsigned g = 1, k = 0;
+    const char *hwq = getenv("GPU_MAX_HW_QUEUES");
+    if (hwq && atoi(hwq) >= 8) { g = 4; k = 2; }
+    if (const char *cfg = getenv("H264BSDMI_LANES")) {
+        unsigned a = 0, b = 0;
+        if (sscanf(cfg, "%u,%u", &a, &b) >= 1 && a >= 1 && a <= 8 && b <= 4) { g = a; k = b; }
+        else fprintf(stderr, "h264bsd-mi355x: H264BSDMI_LANES=%s ignored (expected <groups 1-8>,<heavy lanes 0-4>)\n", cfg);
+    }
+    std::vector<Lane> lanes(g + k);                        /* (handed to the engine only when complete) */
+    for (unsigned i = 0; i < g + k; i++) {
+        Lane &l = lanes[i];
+        if (g == 1 && i == 0) { l.st = e->stream; l.side = &e->side; }      /* the single-lane engine: k_dbk next to the reconstruction kernels */
+        else { HIP_TRY(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking)); l.owns_stream = true; }
+        HIP_TRY(hipEventCreateWithFlags(&l.desc_ev[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&l.desc_ev[1], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&l.tail, hipEventDisableTiming));
+        for (auto &ev : l.ring) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    e->n_light = g; e->n_heavy = k;
+    e->lanes.swap(lanes);
+    return 0;
+}
+
 Engine *engine_get(int device = -1)
 {
     if (device < 0) device = current_device();
@@ -112,9 +175,7 @@ Engine *engine_get(int device = -1)
     e->device = device;
     if (hipSetDevice(e->device) != hipSuccess) { delete e; return nullptr; }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return nullptr; }
-    if (hipEventCreateWithFlags(&e->desc_ev[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->desc_ev[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->inflight_done, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&e->inflight_done, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&e->side.stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->side.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->side.join, hipEventDisableTiming) != hipSuccess ||
@@ -177,15 +238,6 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
 
 struct TickTimers { hipEvent_t ev[6]; hipEvent_t sev[3] = { nullptr, nullptr, nullptr }; bool on = false; unsigned mask = 31u; };   /* mask bit k: kernel k of KERNELS is timed */   /* boundaries of the 5 kernels of a tick; sev = k_copy, k_dbk on the side stream */
 
-/* Experiment hook (tools/desync_probe.py): fewer wavefronts per workgroup in the two per-picture kernels, so that several
- * pictures share a compute unit.  Never above the compiled launch bounds. */
-static uint32_t env_waves(const char *name, uint32_t compiled)
-{
-    const char *v = getenv(name);
-    const int n = v ? atoi(v) : 0;
-    return n > 0 && (uint32_t)n < compiled ? (uint32_t)n : compiled;
-}
-
 int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5],
                 unsigned stages = 7u, const SideLane *side = nullptr, unsigned long long *prof = nullptr)
 {
@@ -230,8 +282,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         const uint32_t n = s.max_mbs;
         const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64 + h264k::I4TAB_BYTES;
         if (arrays + h264k::INTRA_WAVE_LDS > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_intra\n", n); return -1; }
-        static const uint32_t want = env_waves("H264BSDMI_INTRA_WAVES", h264k::TAIL_WAVES);
-        const uint32_t waves = (uint32_t)std::min<size_t>(want, (LDS_BUDGET - arrays) / h264k::INTRA_WAVE_LDS);
+        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::TAIL_WAVES, (LDS_BUDGET - arrays) / h264k::INTRA_WAVE_LDS);
         const size_t lds = (size_t)waves * h264k::INTRA_WAVE_LDS + arrays;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
@@ -248,8 +299,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 16 + 384 + 64;
         const size_t per_wave = 4 * (size_t)h264k::WORKER_LDS;
         if (arrays + per_wave > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_dbk\n", n); return -1; }
-        static const uint32_t want = env_waves("H264BSDMI_DBK_WAVES", h264k::DBK_WAVES);
-        const uint32_t waves = (uint32_t)std::min<size_t>(want, (LDS_BUDGET - arrays) / per_wave);
+        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::DBK_WAVES, (LDS_BUDGET - arrays) / per_wave);
         const size_t lds = (size_t)waves * per_wave + arrays;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
@@ -295,56 +345,107 @@ int reap_locked(Engine *e, bool wait)
     return 0;
 }
 
-/* Enqueue one tick per round of pending jobs (at most one picture per stream and tick).  wait: block until the
- * pixels exist; otherwise return once everything is enqueued (the staging buffers stay owned by `inflight`). */
+/* One tick on one lane: the front jobs of `part` (popped here) are copied to the lane's arena and launched. */
+static int lane_launch(Engine *e, unsigned lane_idx, const std::vector<StreamCtx *> &part)
+{
+    Lane &l = e->lanes[lane_idx];
+    size_t bytes = 0;
+    for (StreamCtx *s : part) {
+        std::lock_guard<std::mutex> ql(s->qmu);
+        bytes += (s->pending.front().bytes + 255u) & ~255u;
+    }
+    if (bytes > l.arena_cap) {
+        HIP_TRY(hipStreamSynchronize(l.st));               /* earlier ticks may still read the old arena */
+        if (l.d_arena) HIP_TRY(hipFree(l.d_arena));
+        l.arena_cap = bytes + bytes / 4;
+        HIP_TRY(hipMalloc((void **)&l.d_arena, l.arena_cap));
+    }
+    if (part.size() > l.desc_cap) {
+        HIP_TRY(hipStreamSynchronize(l.st));
+        if (l.d_desc) HIP_TRY(hipFree(l.d_desc));
+        if (l.h_desc) HIP_TRY(hipHostFree(l.h_desc));
+        l.desc_cap = part.size() * 2;
+        HIP_TRY(hipMalloc((void **)&l.d_desc, l.desc_cap * sizeof(FrameDesc)));
+        HIP_TRY(hipHostMalloc((void **)&l.h_desc, 2 * l.desc_cap * sizeof(FrameDesc), hipHostMallocDefault));
+        l.flip = 0; l.ticks = 0;
+    }
+    /* descriptors are staged in pinned memory (two halves, alternating) so that the copy can be asynchronous;
+     * before reusing a half, the tick that used it two ticks ago must have consumed it */
+    if (l.ticks >= 2) HIP_TRY(hipEventSynchronize(l.desc_ev[l.flip]));
+    FrameDesc *descs = l.h_desc + (size_t)l.flip * l.desc_cap;
+    TickShape shape;
+    size_t off = 0;
+    std::vector<std::pair<int, unsigned long long>> waited;
+    for (size_t i = 0; i < part.size(); i++) {
+        StreamCtx *s = part[i];
+        PendingJob j;
+        { std::lock_guard<std::mutex> ql(s->qmu); j = s->pending.front(); s->pending.pop_front(); }
+        if (s->last_lane >= 0 && (unsigned)s->last_lane != lane_idx) {     /* its previous picture ran on another lane */
+            const std::pair<int, unsigned long long> key(s->last_lane, s->last_launch);
+            if (std::find(waited.begin(), waited.end(), key) == waited.end()) {
+                HIP_TRY(hipStreamWaitEvent(l.st, e->lanes[s->last_lane].ring[s->last_launch % Lane::RING], 0));
+                waited.push_back(key);
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(l.d_arena + off, j.host, j.bytes, hipMemcpyHostToDevice, l.st));
+        make_desc(descs[i], j.host, l.d_arena + off, s->d_frames, s->frame_bytes, s->d_dbk, &shape, e->d_err);
+        off += (j.bytes + 255u) & ~255u;
+        e->inflight.emplace_back(s, j);
+        s->last_lane = (int)lane_idx; s->last_launch = l.launches;
+    }
+    HIP_TRY(hipMemcpyAsync(l.d_desc, descs, part.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, l.st));
+    HIP_TRY(hipEventRecord(l.desc_ev[l.flip], l.st));
+    l.flip ^= 1;
+    l.ticks++;
+    if (launch_tick(l.st, l.d_desc, shape, nullptr, nullptr, 7u, l.side)) return -1;
+    HIP_TRY(hipEventRecord(l.ring[l.launches % Lane::RING], l.st));
+    l.launches++;
+    return 0;
+}
+
+/* Enqueue the pending jobs, round by round: a round takes at most one picture per instance; the light pictures of a
+ * group form one tick on the group's lane, the heavy pictures of all groups one tick on a heavy lane (Lane, above).
+ * wait: block until the pixels exist; otherwise return once everything is enqueued (the staging buffers stay owned by
+ * `inflight`). */
 int flush_locked(Engine *e, bool wait = true)
 {
     HIP_TRY(hipSetDevice(e->device));
     if (reap_locked(e, false)) return -1;
-    for (;;) {
-        std::vector<StreamCtx *> part;
-        size_t bytes = 0;
+    if (e->lanes.empty() && lanes_create(e)) return -1;      /* on first use: a process that only runs replay sets keeps its HIP streams for those */
+    const bool multi = e->lanes.size() > 1;
+    bool started = false;
+    std::vector<std::vector<StreamCtx *>> part(e->n_light);
+    std::vector<StreamCtx *> heavy;
+    for (unsigned round = 0;; round++) {
+        bool any_pending = false;
+        for (auto &p : part) p.clear();
+        heavy.clear();
         for (StreamCtx *s : e->streams) {
             std::lock_guard<std::mutex> ql(s->qmu);
-            if (!s->pending.empty()) { part.push_back(s); bytes += (s->pending.front().bytes + 255u) & ~255u; }
+            if (s->pending.empty()) continue;
+            any_pending = true;
+            if (s->ready_round > round) continue;
+            const FjHeader *h = reinterpret_cast<const FjHeader *>(s->pending.front().host);
+            if (e->n_heavy && h->n_intra * 4u > h->n_mbs) heavy.push_back(s);
+            else part[(unsigned)s->group % e->n_light].push_back(s);
         }
-        if (part.empty()) break;
-        if (bytes > e->arena_cap) {
-            HIP_TRY(hipStreamSynchronize(e->stream));          /* earlier ticks may still read the old arena */
-            if (e->d_arena) HIP_TRY(hipFree(e->d_arena));
-            e->arena_cap = bytes + bytes / 4;
-            HIP_TRY(hipMalloc((void **)&e->d_arena, e->arena_cap));
+        if (!any_pending) break;
+        started = true;
+        for (unsigned g = 0; g < e->n_light; g++)
+            if (!part[g].empty() && lane_launch(e, g, part[g])) return -1;
+        if (!heavy.empty()) {
+            if (lane_launch(e, e->n_light + e->heavy_rr++ % e->n_heavy, heavy)) return -1;
+            for (StreamCtx *s : heavy) s->ready_round = round + 1 + HEAVY_DELAY;
         }
-        if (part.size() > e->desc_cap) {
-            HIP_TRY(hipStreamSynchronize(e->stream));
-            if (e->d_desc) HIP_TRY(hipFree(e->d_desc));
-            if (e->h_desc) HIP_TRY(hipHostFree(e->h_desc));
-            e->desc_cap = part.size() * 2;
-            HIP_TRY(hipMalloc((void **)&e->d_desc, e->desc_cap * sizeof(FrameDesc)));
-            HIP_TRY(hipHostMalloc((void **)&e->h_desc, 2 * e->desc_cap * sizeof(FrameDesc), hipHostMallocDefault));
-            e->h_desc_flip = 0;
-        }
-        /* descriptors are staged in pinned memory (two halves, alternating) so that the copy can be asynchronous;
-         * before reusing a half, the tick that used it two ticks ago must have consumed it */
-        if (e->desc_ticks >= 2) HIP_TRY(hipEventSynchronize(e->desc_ev[e->h_desc_flip]));
-        FrameDesc *descs = e->h_desc + (size_t)e->h_desc_flip * e->desc_cap;
-        TickShape shape;
-        size_t off = 0;
-        for (size_t i = 0; i < part.size(); i++) {
-            StreamCtx *s = part[i];
-            PendingJob j;
-            { std::lock_guard<std::mutex> ql(s->qmu); j = s->pending.front(); s->pending.pop_front(); }
-            HIP_TRY(hipMemcpyAsync(e->d_arena + off, j.host, j.bytes, hipMemcpyHostToDevice, e->stream));
-            make_desc(descs[i], j.host, e->d_arena + off, s->d_frames, s->frame_bytes, s->d_dbk, &shape, e->d_err);
-            off += (j.bytes + 255u) & ~255u;
-            e->inflight.emplace_back(s, j);
-        }
-        HIP_TRY(hipMemcpyAsync(e->d_desc, descs, part.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipEventRecord(e->desc_ev[e->h_desc_flip], e->stream));
-        e->h_desc_flip ^= 1;
-        e->desc_ticks++;
-        if (launch_tick(e->stream, e->d_desc, shape, nullptr, nullptr, 7u, &e->side)) return -1;
     }
+    for (StreamCtx *s : e->streams) s->ready_round = 0;          /* rounds count from the start of a flush */
+    /* Lanes never wait for the engine's own stream: everything that stream does to frame buffers (clearing them in
+     * sink_configure, laying pictures out for the application) is complete when the call that enqueued it returns. */
+    if (started && multi)
+        for (auto &l : e->lanes) {                               /* the engine's stream continues behind all lanes */
+            HIP_TRY(hipEventRecord(l.tail, l.st));
+            HIP_TRY(hipStreamWaitEvent(e->stream, l.tail, 0));
+        }
     if (!e->inflight.empty()) HIP_TRY(hipEventRecord(e->inflight_done, e->stream));
     return wait ? reap_locked(e, true) : 0;
 }
@@ -384,6 +485,8 @@ int sink_configure(void *user, uint32_t wmb, uint32_t hmb, uint32_t n_slots)
     HIP_TRY(hipMemsetAsync(u->s->d_frames, 0, total, u->e->stream));
     HIP_TRY(hipMalloc((void **)&u->s->d_dbk, (size_t)wmb * hmb * (DBK_REC_BYTES + 1) + 64));
     HIP_TRY(hipMemsetAsync(u->s->d_dbk, 0, (size_t)wmb * hmb * (DBK_REC_BYTES + 1) + 64, u->e->stream));
+    HIP_TRY(hipStreamSynchronize(u->e->stream));           /* the lanes do not order themselves behind this stream */
+    u->s->last_lane = -1;
     return 0;
 }
 
@@ -543,6 +646,7 @@ int eng_attach(JobSink *sink)
     SinkUser *u = new SinkUser{ e, new StreamCtx() };
     {
         std::lock_guard<std::mutex> lk(e->mu);
+        u->s->group = (int)e->group_rr++;             /* taken modulo the number of light lanes */
         e->streams.push_back(u->s);
     }
     sink->user = u;
@@ -808,9 +912,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
             std::vector<int> last_ev(n_streams, -1);     /* event of the heavy launch a stream's previous picture ran in */
             size_t n_desc = 0;
             u32 left = n_streams, heavy_count = 0;
-            const char *thr_env = getenv("H264BSDMI_HEAVY_INTRA");    /* experiment hook: absolute intra-macroblock count that makes a picture heavy */
-            const u32 thr_abs = thr_env ? (u32)atoi(thr_env) : 0xFFFFFFFFu;
-            auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[p]); return h->n_intra * 4u > h->n_mbs || h->n_intra > thr_abs; };
+            auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[p]); return h->n_intra * 4u > h->n_mbs; };
             auto new_event = [&]() { r->sched_ev.push_back(nullptr); return (int)r->sched_ev.size() - 1; };
             for (u32 t = 0; left && t < 16u * n_pics; t++) {
                 /* one heavy launch per round for the heavy pictures of all groups: it waits for the light launch of
@@ -860,7 +962,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
             for (u32 k = 0; ok && k < r->n_lanes; k++) {
                 if (k < groups) {
                     ok = hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking) == hipSuccess;
-                    if (ok && !getenv("H264BSDMI_NO_SIDE_LANES"))        /* experiment hook: k_dbk in line instead of next to the reconstruction kernels */
+                    if (ok && groups <= 2)        /* with more groups the other groups are the overlap, and busy HIP streams are scarce (Lane, above) */
                         ok = hipStreamCreateWithFlags(&r->lane_side[k].stream, hipStreamNonBlocking) == hipSuccess &&
                          hipEventCreateWithFlags(&r->lane_side[k].fork, hipEventDisableTiming) == hipSuccess &&
                          hipEventCreateWithFlags(&r->lane_side[k].join, hipEventDisableTiming) == hipSuccess;
