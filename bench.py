@@ -30,6 +30,10 @@ import os
 import sys
 import time
 
+# The HIP runtime maps streams onto 4 hardware queues unless told otherwise, and reads the setting when it starts;
+# the stream groups / heavy lanes measured below need more (the library asks for the same when it is loaded first).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -158,6 +162,7 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=4.0, help="untimed load before the warm-up steps (device clock ramp)")
     ap.add_argument("--time-all-kernels", action="store_true", help="bracket all five kernels with events in the timed steps too (A/B of the event overhead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-groups-variant", action="store_true", help="skip the lock-step measurement with 4 stream groups")
     ap.add_argument("--no-desync", action="store_true", help="skip the fully desynchronised variants (reported next to the lock-step value)")
     ap.add_argument("--no-staggered", action="store_true", help="skip the staggered-start variant (reported next to the lock-step value)")
     ap.add_argument("--no-argb", action="store_true", help="skip the config-3 variant (colour conversion of every picture inside the timed region)")
@@ -210,6 +215,7 @@ def main():
         the same picture index: two all-IDR ticks per step, the worst case); otherwise odd streams start at the
         second IDR (SURVEY.md §8d config 4 "staggered").  Returns (elapsed s, kernel ms, launches, device ms, job bytes)."""
         rep = h264bsd_amd.Replay(jobs, n_streams=args.streams, odd_offset=odd_offset)   # jobs + DPBs resident in HBM
+        extra = {}
 
         def verify(i):
             # picture i of the even streams and picture (i + odd_offset) % n of the odd streams
@@ -262,6 +268,19 @@ def main():
             dom = max(kernels, key=lambda k: k_ms[k])
             breakdown = {k: (k_ms[k] / args.steps, k_n[k] // args.steps) for k in kernels}
         verify(n_pics - 1)                                     # the final pictures, after the timed region
+        # the same lock-step work with the streams split into 4 groups that run their ticks on their own HIP streams
+        # (the per-picture kernels of one group overlap with the other groups' work); reported next to `value`
+        if odd_offset == 0 and args.groups == 1 and args.streams >= 8 and not args.no_groups_variant:
+            rep.set_groups(4)
+            rep.run(); rep.sync()
+            barrier()
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                rep.run()
+                rep.timings()
+            barrier()
+            extra["groups4_elapsed"] = time.perf_counter() - tg
+            verify(n_pics - 1)
         job_bytes = rep.job_bytes
         rep.close()
         local = elapsed
@@ -269,14 +288,14 @@ def main():
             tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        return elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local
+        return elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local, extra
 
-    elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local_elapsed = run_variant(0)
+    elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local_elapsed, lock_extra = run_variant(0)
     staggered = None
     if not args.no_staggered and args.streams > 1:
         idr = [i for i, h in enumerate(heads) if h["is_idr"] and i > 0]
         if idr:
-            st_elapsed, _, _, st_dev_ms, _, _, st_breakdown, _ = run_variant(idr[0])
+            st_elapsed, _, _, st_dev_ms, _, _, st_breakdown, _, _ = run_variant(idr[0])
             staggered = dict(odd_stream_offset=idr[0], elapsed=st_elapsed, breakdown=st_breakdown, dev_ms=st_dev_ms)
 
     # ---- BASELINE.json config 3: the same lock-step work with the colour conversion of every produced picture inside
@@ -320,7 +339,8 @@ def main():
     # ---- streams that are not in step at all: stream s starts at picture s * n_pics / n_streams.  Every tick then
     # holds I pictures AND the heaviest P pictures of the stream, and a tick lasts as long as its slowest picture:
     # (a) common ticks, (b) mostly-intra pictures on 4 extra HIP streams ("heavy lanes"), rejoining 4 ticks later,
-    # (c) the same with the streams split into 2 groups that run their own ticks on their own HIP streams.
+    # (c) 3 heavy lanes and the streams split into 9 groups that run their own ticks on their own HIP streams (12 busy
+    # HIP streams: more fall off a cliff on this runtime, tools/probes/queue_probe.hip).
     # Verified at the end of laps 2 and N (a lap = every stream n_pics pictures; the last picture of stream s is
     # picture offsets[s] - 1, so the 256 streams together cover every picture index).
     desync = None
@@ -328,7 +348,7 @@ def main():
         offsets = [(st * n_pics) // args.streams for st in range(args.streams)]
         slots = sorted(set(h["cur_slot"] for h in heads))
         desync = {"offsets": "stream s starts at picture floor(s * n_pics / n_streams)"}
-        for key, lanes, delay, groups in (("common_ticks", 0, 0, 1), ("heavy_lanes", 4, 4, 1), ("heavy_lanes_2_groups", 4, 4, 2)):
+        for key, lanes, delay, groups in (("common_ticks", 0, 0, 1), ("heavy_lanes", 4, 4, 1), ("heavy_lanes_9_groups", 3, 4, 9)):
             rep = h264bsd_amd.Replay(jobs, n_streams=args.streams, offsets=offsets, heavy_lanes=lanes, heavy_delay=delay, groups=groups)
 
             def verify_lap():
@@ -435,6 +455,11 @@ def main():
                                                     note="per-kernel: last untimed warm-up pass (all kernels bracketed by events); total: timed steps"),
                          "launches_per_step": {k: k_n[k] // args.steps for k in kernels}},
         }
+        if "groups4_elapsed" in lock_extra:
+            ge = lock_extra["groups4_elapsed"]
+            out["lock_step_4_stream_groups"] = {"value": n_pics * args.streams * n_mbs * args.steps / ge, "unit": "macroblocks/s",
+                                                "ms_per_step": ge * 1e3 / args.steps,
+                                                "note": "rank 0's own clock; same work as `value`, streams split into 4 groups on 4 HIP streams"}
         if staggered is not None:
             # same work per step, odd streams start at the second IDR: I pictures never fill a whole tick
             out["staggered"] = {"value": mbs / staggered["elapsed"], "unit": "macroblocks/s",

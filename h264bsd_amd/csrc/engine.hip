@@ -92,6 +92,10 @@ struct Lane {
     const SideLane *side = nullptr;
 };
 constexpr unsigned HEAVY_DELAY = 4;
+/* Under lane scheduling a k_frame_dbk workgroup shares its compute unit with the other lanes' kernels: 8 wavefronts
+ * hold less of the register file than the 12 that are best when a tick has the GPU to itself (desynchronised replay
+ * with 9 groups: 763 vs 734 M MB/s; lock-step, single lane: 12 wavefronts 54.9 ms per step, 8: 56.8). */
+constexpr uint32_t LANE_DBK_WAVES = 8;
 
 struct Engine {
     std::mutex mu;
@@ -192,6 +196,7 @@ struct TickShape {
     uint32_t n_frames = 0, max_mbs = 0;
     uint32_t max_copy = 0, max_gen = 0, max_gen_uni = 0, max_gen_rest = 0, max_dbk = 0, max_levels = 0, max_w = 0, max_h = 0;
     bool any_tail = false, any_deblock = false;
+    uint32_t dbk_waves = 0;          /* wavefronts per workgroup of k_frame_dbk; 0 = the compiled maximum (launch_tick) */
 };
 
 /* descriptor of one picture: device addresses of the sections of its (device-resident) frame job */
@@ -299,7 +304,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 16 + 384 + 64;
         const size_t per_wave = 4 * (size_t)h264k::WORKER_LDS;
         if (arrays + per_wave > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_dbk\n", n); return -1; }
-        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::DBK_WAVES, (LDS_BUDGET - arrays) / per_wave);
+        const uint32_t waves = (uint32_t)std::min<size_t>(s.dbk_waves ? std::min<uint32_t>(s.dbk_waves, h264k::DBK_WAVES) : h264k::DBK_WAVES, (LDS_BUDGET - arrays) / per_wave);
         const size_t lds = (size_t)waves * per_wave + arrays;
         static size_t lds_enabled = 0;
         if (lds > lds_enabled) {
@@ -397,6 +402,7 @@ static int lane_launch(Engine *e, unsigned lane_idx, const std::vector<StreamCtx
     HIP_TRY(hipEventRecord(l.desc_ev[l.flip], l.st));
     l.flip ^= 1;
     l.ticks++;
+    if (e->lanes.size() > 1) shape.dbk_waves = LANE_DBK_WAVES;
     if (launch_tick(l.st, l.d_desc, shape, nullptr, nullptr, 7u, l.side)) return -1;
     HIP_TRY(hipEventRecord(l.ring[l.launches % Lane::RING], l.st));
     l.launches++;
@@ -913,16 +919,50 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
             size_t n_desc = 0;
             u32 left = n_streams, heavy_count = 0;
             auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[p]); return h->n_intra * 4u > h->n_mbs; };
+            /* Cost-affine groups: a group's tick lasts as long as its slowest picture, so streams whose next pictures cost
+             * about the same belong together.  Every REGROUP rounds the streams are sorted by the estimated per-picture
+             * kernel time of their next REGROUP pictures (from the job headers: intra and filtered macroblock counts) and
+             * dealt to the groups in that order; a stream that changes groups makes its new lane wait for the event its
+             * old lane recorded after the last round before the regrouping. */
+#ifndef REGROUP_ROUNDS
+#define REGROUP_ROUNDS 32      /* measured: 4: 681, 8: 664, 16: 699, 32: 709-733 M MB/s (8-9 groups); every regrouping costs cross-lane waits */
+#endif
+            constexpr u32 REGROUP = REGROUP_ROUNDS;
+            std::vector<std::vector<u32>> members(groups);
+            std::vector<u32> group_of(n_streams, 0);
+            std::vector<int> pre_regroup_ev(groups, -1);
+            auto upcoming_cost = [&](u32 s) {
+                uint64_t c = 0;
+                for (u32 i = 0; i < REGROUP && done[s] + i < n_pics; i++) {
+                    const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[(r->offsets[s] + done[s] + i) % n_pics]);
+                    c += 11u * h->n_intra + 4u * h->n_dbk;          /* ~0.55 us per intra macroblock, ~0.2 us per filtered one */
+                }
+                return c;
+            };
             auto new_event = [&]() { r->sched_ev.push_back(nullptr); return (int)r->sched_ev.size() - 1; };
             for (u32 t = 0; left && t < 16u * n_pics; t++) {
                 /* one heavy launch per round for the heavy pictures of all groups: it waits for the light launch of
                  * every group it takes a stream from (the previous picture of that stream ran there or earlier) */
                 std::vector<u32> hs;
                 std::vector<int> hwaits;
+                if (t % REGROUP == 0) {
+                    std::vector<std::pair<uint64_t, u32>> order;
+                    for (u32 s = 0; s < n_streams; s++) if (done[s] < n_pics) order.emplace_back(upcoming_cost(s), s);
+                    std::sort(order.begin(), order.end());
+                    for (auto &m : members) m.clear();
+                    for (size_t i = 0; i < order.size(); i++) {
+                        const u32 s = order[i].second, g = (u32)(i * groups / order.size());
+                        if (t && g != group_of[s] && last_ev[s] < 0) last_ev[s] = pre_regroup_ev[group_of[s]];
+                        group_of[s] = g;
+                        members[g].push_back(s);
+                    }
+                    for (auto &m : members) std::sort(m.begin(), m.end());
+                }
+                const bool before_regroup = (t + 1) % REGROUP == 0;
                 for (u32 g = 0; g < groups; g++) {
                     h264bsdmi_replay::Launch light{ n_desc, TickShape(), (int)g, {}, -1, true };
                     bool group_has_heavy = false;
-                    for (u32 s = g; s < n_streams; s += groups) {
+                    for (u32 s : members[g]) {
                         if (done[s] >= n_pics || ready_at[s] > t) continue;
                         const u32 p = (r->offsets[s] + done[s]) % n_pics;
                         if (is_heavy(p)) { hs.push_back(s); group_has_heavy = true; continue; }
@@ -935,9 +975,18 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
                     }
                     const bool have_light = light.shape.n_frames != 0;
                     if (have_light) {
-                        if (group_has_heavy) { light.record_ev = new_event(); hwaits.push_back(light.record_ev); }
+                        if (group_has_heavy || before_regroup) light.record_ev = new_event();
+                        if (group_has_heavy) hwaits.push_back(light.record_ev);
+                        if (before_regroup) pre_regroup_ev[g] = light.record_ev;
+                        light.shape.dbk_waves = LANE_DBK_WAVES;
                         r->sched.push_back(light);
-                    } else if (group_has_heavy) hwaits.push_back(-2 - (int)g);      /* "everything enqueued on light lane g so far" */
+                    } else {
+                        if (group_has_heavy) hwaits.push_back(-2 - (int)g);        /* "everything enqueued on light lane g so far" */
+                        if (before_regroup) {                                      /* an empty launch: only the event */
+                            light.record_ev = pre_regroup_ev[g] = new_event();
+                            r->sched.push_back(light);
+                        }
+                    }
                 }
                 if (!hs.empty()) {
                     h264bsdmi_replay::Launch heavy{ n_desc, TickShape(), (int)(groups + heavy_count++ % heavy_lanes), hwaits, -1, false };

@@ -28,10 +28,10 @@ for cfg in cfgs:
         return bad
     rep.run(); rep.sync(); b1 = verify()
     rep.run(); rep.sync(); b2 = verify()
-    t = []
+    t, th = [], []
     for _ in range(3):
-        rep.run(); t.append(rep.timings()["total_ms"])
+        h0 = time.perf_counter(); rep.run(); th.append((time.perf_counter() - h0) * 1e3); t.append(rep.timings()["total_ms"])
     b3 = verify()
     ms = sum(t) / len(t)
-    print(f"lanes {K} delay {D} groups {G}: {ms:.1f} ms per lap = {S * P * heads[0]['n_mbs'] / ms / 1e3:.1f} M MB/s; mismatching streams after lap 1/2/5: {b1}/{b2}/{b3}")
+    print(f"lanes {K} delay {D} groups {G}: host enqueue {sum(th) / len(th):.1f} ms, {ms:.1f} ms per lap = {S * P * heads[0]['n_mbs'] / ms / 1e3:.1f} M MB/s; mismatching streams after lap 1/2/5: {b1}/{b2}/{b3}")
     rep.close()
