@@ -263,11 +263,6 @@ def main():
             dev_total_ms += t["total_ms"]
         barrier()
         elapsed = time.perf_counter() - t0
-        rep.set_timed_kernels(31)
-        if dom is None:
-            dom = max(kernels, key=lambda k: k_ms[k])
-            breakdown = {k: (k_ms[k] / args.steps, k_n[k] // args.steps) for k in kernels}
-        verify(n_pics - 1)                                     # the final pictures, after the timed region
         # the same lock-step work with the streams split into 4 groups that run their ticks on their own HIP streams
         # (the per-picture kernels of one group overlap with the other groups' work); reported next to `value`
         if odd_offset == 0 and args.groups == 1 and args.streams >= 8 and not args.no_groups_variant:
@@ -280,7 +275,12 @@ def main():
                 rep.timings()
             barrier()
             extra["groups4_elapsed"] = time.perf_counter() - tg
-            verify(n_pics - 1)
+            rep.set_groups(1)
+        rep.set_timed_kernels(31)
+        if dom is None:
+            dom = max(kernels, key=lambda k: k_ms[k])
+            breakdown = {k: (k_ms[k] / args.steps, k_n[k] // args.steps) for k in kernels}
+        verify(n_pics - 1)                                     # the final pictures, after the timed region
         job_bytes = rep.job_bytes
         rep.close()
         local = elapsed

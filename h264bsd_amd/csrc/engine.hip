@@ -4,13 +4,16 @@
  * bench.py and the kernel tests (exported by the bench library only, include/h264bsd_mi355x_bench.h).
  *
  * Execution model.  A tick holds at most one picture per stream (pictures of one stream depend on each other
- * through the DPB; pictures of different streams never do).  A tick of N pictures is FIVE launches (launch_tick):
- *     k_copy         grid (runs/4, N)   x 256  whole-sample copy macroblocks, one run of <= 8 tiles per wavefront
- *     k_recon_inter  grid (n_gen/4, N)  x 256  every other inter macroblock, one wavefront each
- *     k_dbk          grid (n_dbk/8, N)  x 256  boundary strengths from metadata; on a second HIP stream, next to the two above
- *     k_frame_intra  grid (N)           x 1024 one workgroup per picture: intra macroblocks, dataflow-scheduled in LDS
- *     k_frame_dbk    grid (N)           x 768  one workgroup per picture: in-loop filter, dataflow-scheduled in LDS
+ * through the DPB; pictures of different streams never do).  A tick of N pictures is SIX launches (launch_tick):
+ *     k_copy            grid (32, N)          x 256  whole-sample copy macroblocks, one run of <= 8 tiles per wavefront
+ *     k_recon_inter<0>  grid (n_uni/4, N)     x 256  inter macroblocks with one motion vector, one wavefront each
+ *     k_recon_inter<1>  grid (n_part/4, N)    x 256  partitioned inter macroblocks
+ *     k_dbk             grid (32, N)          x 256  boundary strengths from metadata; on a second HIP stream, next to the three above
+ *     k_frame_intra     grid (N)              x 768  one workgroup per picture: intra macroblocks, dataflow-scheduled in LDS
+ *     k_frame_dbk       grid (N)              x 768  one workgroup per picture: in-loop filter, dataflow-scheduled in LDS
  * Occupancy of the two per-picture kernels comes from batching streams: 256 pictures = one workgroup per CU.
+ * Which pictures share a tick, and on which HIP stream a tick runs, is the lane scheduler's business (Lane, flush_locked;
+ * for the replay sets h264bsdmiReplayCreateSched).
  *
  * This replaces, for the pixels, what the reference does synchronously inside h264bsdDecode
  * (src/h264bsd_slice_data.c:185 -> h264bsdDecodeMacroblock, src/h264bsd_decoder.c:475 ->

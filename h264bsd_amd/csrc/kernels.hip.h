@@ -1511,10 +1511,10 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
 #undef DTICK
 }
 
-/* ONE 1024-thread workgroup per picture (a picture never leaves its CU); the waves of the workgroup take
- * the macroblocks of a dependency level, __syncthreads() separates levels: no kernel boundary and no
- * inter-workgroup traffic inside a picture.  Occupancy comes from batching streams (256 pictures = one
- * workgroup per CU). */
+/* ONE workgroup per picture in the two kernels below (a picture never leaves its CU): dependencies inside a picture
+ * are tracked in LDS, no kernel boundary and no inter-workgroup traffic inside a picture.  Occupancy comes from
+ * batching streams (256 pictures = one workgroup per CU).  k_frame_intra: 12 wavefronts = 162 VGPRs without spills
+ * (16 wavefronts cap the kernel at 128 VGPRs: 33 spilled, 20.8 vs 19.3 ms per step; 8: 22.2 ms). */
 #ifndef TAIL_WAVES_N
 #define TAIL_WAVES_N 12
 #endif
@@ -1534,7 +1534,8 @@ constexpr int TAIL_WORKERS = 4 * DBK_WAVES;       /* deblocking workers = quarte
  * scheduled), need[mb] = the mask, a ready queue with claim / publish cursors.  A free wavefront takes ONE ready
  * macroblock, reconstructs it (intra_mb / conceal_mb), waits for its stores and then releases the neighbours that
  * wait for it.  No level barriers: the picture's time is its dependency critical path, not levels x slowest wave.
- * Dynamic LDS: 16 x 1 KB tiles | need[n_mbs] | dep[n_mbs] | queue[n_mbs] u16 | counters. */
+ * Dynamic LDS: per wavefront INTRA_WAVE_LDS (4 macroblock slots + deferred residuals + records) | need[n_mbs] | dep[n_mbs] |
+ * queue[n_mbs] u16 | counters | Intra4x4 table. */
 __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames, unsigned long long *prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];

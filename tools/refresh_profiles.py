@@ -18,9 +18,12 @@ body = open(os.path.join(src, "pmc_FETCH_SIZE.txt")).read() + open(os.path.join(
 open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w").write(head + body)
 kern = {}
 for l in body.splitlines():
-    m = re.match(r"h264k::(\w+)\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+total=\S+ per_dispatch=(\S+)", l)
+    m = re.match(r"(?:void )?h264k::(\w+)(<\d>)?\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+total=\S+ per_dispatch=(\S+)", l)
     if m:
-        kern.setdefault(m.group(1), {})["fetch_bytes_per_launch" if m.group(2) == "FETCH_SIZE" else "write_bytes_per_launch"] = float(m.group(3)) * 1024
+        # k_recon_inter<0> and <1> are the two halves of one tick's inter reconstruction: their bytes add up
+        k = kern.setdefault(m.group(1), {})
+        key = "fetch_bytes_per_launch" if m.group(3) == "FETCH_SIZE" else "write_bytes_per_launch"
+        k[key] = k.get(key, 0.0) + float(m.group(4)) * 1024
 # Calibration on a known byte count in our own access pattern (MI355X_MICROARCH.md, HBM section): k_copy moves exactly
 # 384 bytes in and 384 bytes out per copied macroblock, as contiguous 16-byte-per-lane pieces of macroblock tiles.
 sys.path.insert(0, root)
