@@ -422,8 +422,8 @@ def main():
         try:
             import hashlib
             tfile = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            src_sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "h264bsd_amd", "csrc", f), "rb").read()
-                                              for f in ("kernels.hip.h", "framejob.h"))).hexdigest()
+            from h264bsd_amd.srchash import kernel_source_sha256
+            src_sha = kernel_source_sha256(ROOT)
             if tfile.get("kernel_source_sha256") != src_sha:
                 traffic_note = "profiles/r02_traffic.json was measured with other kernel sources: stale, not reported (rerun tools/refresh_profiles.sh)"
             else:

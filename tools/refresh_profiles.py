@@ -38,8 +38,8 @@ cal = {"fetch": copy_alg / kern["k_copy"]["fetch_bytes_per_launch"], "write": co
 for k in kern.values():
     k["fetch_bytes_per_launch_calibrated"] = k["fetch_bytes_per_launch"] * cal["fetch"]
     k["write_bytes_per_launch_calibrated"] = k["write_bytes_per_launch"] * cal["write"]
-import hashlib
-src_sha = hashlib.sha256(b"".join(open(os.path.join(root, "h264bsd_amd", "csrc", f), "rb").read() for f in ("kernels.hip.h", "framejob.h"))).hexdigest()
+from h264bsd_amd.srchash import kernel_source_sha256
+src_sha = kernel_source_sha256(root)
 json.dump({"source": f"profiles/{tag}_pmc_summary.txt (separate rocprofv3 --pmc passes)", "kernel_source_sha256": src_sha, "calibration": cal, "kernels": kern},
           open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 print(line[:300]); print(json.dumps(kern)[:600])
