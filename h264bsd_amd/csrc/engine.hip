@@ -95,6 +95,10 @@ struct Lane {
     const SideLane *side = nullptr;
 };
 constexpr unsigned HEAVY_DELAY = 4;
+#ifndef CONVERT_WGS_N
+#define CONVERT_WGS_N 512       /* 64: 808, 128: 744, 256: 703, 512: 680 us per tick of 256 pictures */
+#endif
+constexpr unsigned CONVERT_WGS = CONVERT_WGS_N;      /* workgroups per picture of k_convert_tiles in batched launches */
 /* Under lane scheduling a k_frame_dbk workgroup shares its compute unit with the other lanes' kernels: 8 wavefronts
  * hold less of the register file than the 12 that are best when a tick has the GPU to itself (desynchronised replay
  * with 9 groups: 763 vs 734 M MB/s; lock-step, single lane: 12 wavefronts 54.9 ms per step, 8: 56.8). */
@@ -592,8 +596,8 @@ uint32_t *sink_fetch_converted(void *user, uint32_t slot, int fmt)
     const size_t bytes = (size_t)w * h * 4;
     if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
     if (!s->h_conv && hipHostMalloc((void **)&s->h_conv, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(h264k::k_convert, dim3(1024, 1), dim3(256), 0, u->e->stream,
-                       s->d_frames + (size_t)slot * s->frame_bytes, s->d_conv, w, h, fmt, (size_t)0, (size_t)0, 1);
+    hipLaunchKernelGGL(h264k::k_convert_tiles, dim3(1024, 1), dim3(256), 0, u->e->stream,
+                       s->d_frames + (size_t)slot * s->frame_bytes, s->d_conv, s->wmb, s->hmb, fmt, (size_t)0, (size_t)0);
     if (hipMemcpyAsync(s->h_conv, s->d_conv, bytes, hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
     if (hipStreamSynchronize(u->e->stream) != hipSuccess) return nullptr;
     return s->h_conv;
@@ -1106,9 +1110,9 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
                 /* the picture every stream has just produced, converted where it lies (tiles -> packed 32-bit pixels) */
                 const uint32_t w = r->wmb * 16, h = r->hmb * 16;
                 HIP_TRY(hipEventRecord(r->cev[2 * i], r->e->stream));
-                hipLaunchKernelGGL(h264k::k_convert, dim3(256, r->n_streams), dim3(256), 0, r->e->stream,
-                                   r->d_frames + (size_t)r->cur_slot[i] * r->frame_bytes, r->d_conv, w, h, r->convert_fmt,
-                                   (size_t)r->n_slots * r->frame_bytes, (size_t)w * h, 1);
+                hipLaunchKernelGGL(h264k::k_convert_tiles, dim3(CONVERT_WGS, r->n_streams), dim3(256), 0, r->e->stream,
+                                   r->d_frames + (size_t)r->cur_slot[i] * r->frame_bytes, r->d_conv, r->wmb, r->hmb, r->convert_fmt,
+                                   (size_t)r->n_slots * r->frame_bytes, (size_t)w * h);
                 HIP_TRY(hipEventRecord(r->cev[2 * i + 1], r->e->stream));
             }
         }
@@ -1224,9 +1228,9 @@ int h264bsdmiReplayConvert(h264bsdmi_replay *r, u32 slot, int fmt)
     HIP_TRY(hipSetDevice(r->e->device));
     const uint32_t w = r->wmb * 16, h = r->hmb * 16;
     if (!r->d_conv) HIP_TRY(hipMalloc((void **)&r->d_conv, (size_t)w * h * 4 * r->n_streams));
-    hipLaunchKernelGGL(h264k::k_convert, dim3(256, r->n_streams), dim3(256), 0, r->e->stream,
-                       r->d_frames + (size_t)slot * r->frame_bytes, r->d_conv, w, h, fmt,
-                       (size_t)r->n_slots * r->frame_bytes, (size_t)w * h, 1);
+    hipLaunchKernelGGL(h264k::k_convert_tiles, dim3(CONVERT_WGS, r->n_streams), dim3(256), 0, r->e->stream,
+                       r->d_frames + (size_t)slot * r->frame_bytes, r->d_conv, r->wmb, r->hmb, fmt,
+                       (size_t)r->n_slots * r->frame_bytes, (size_t)w * h);
     HIP_TRY(hipGetLastError());
     return 0;
 }
