@@ -532,7 +532,11 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
  * the reference frame and in the current one: 24 x count 16-byte pieces, up to six per lane, every load issued before
  * the first store.  Displaced (and clamped) runs gather their samples 4 at a time. */
 #ifndef COPY_WGS
-#define COPY_WGS 32          /* workgroups per picture: each walks the picture's run list with stride 4 * COPY_WGS */
+#define COPY_WGS 16          /* workgroups per picture: each walks the picture's run list with stride 4 * COPY_WGS.  k_dbk runs next to
+                                k_copy and k_recon_inter, and the three together are bound by instruction issue: with 8 / 16 / 24 / 32 / 48
+                                workgroups k_copy takes 14.3 / 18.4 / 21.3 / 25.7 / 28.1 ms per step (5.0 TB/s with 8) and k_recon_inter
+                                52.3 / 48.3 / 45.3 / 41.8 / 40.7: the sum stays at 66.6-68.8, the step at 139.6-141.8 ms.  Two runs per
+                                loop trip (all loads of both before the first store) lost: 37.4 ms */
 #endif
 __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ frames)
 {
