@@ -338,8 +338,8 @@ def job_header(blob):
     """Decode the FjHeader of a frame job (h264bsd_amd/csrc/framejob.h)."""
     import struct
     (magic, total, wmb, hmb, n_mbs, cur, is_idr, n_slots, any_dbk, rec_off, mv_off, lvl_off, idx_off, coef_off,
-     n_intra, n_levels, n_coef, n_inter, pic_seq, copy_off, n_copy, gen_off, n_gen, dbk_off, n_dbk) = \
-        struct.unpack_from("<IIHHIBBBBIIIIIIIIIIIIIIII", blob, 0)
+     n_intra, n_levels, n_coef, n_inter, pic_seq, copy_off, n_copy, gen_off, n_gen, dbk_off, n_dbk, n_gen_uniform, ghost,
+     dbk_only) = struct.unpack_from("<IIHHIBBBBIIIIIIIIIIIIIIIIIII", blob, 0)
     if magic != 0x314A4648:
         raise ValueError("not a frame job")
     # FjCopy entries are 8 bytes {u16 mb, u8 slot, u8 count, i16 dx, i16 dy}: macroblocks moved by k_copy
@@ -348,7 +348,8 @@ def job_header(blob):
                 n_slots=n_slots, any_deblock=any_dbk, rec_off=rec_off, mv_off=mv_off, lvl_off=lvl_off,
                 idx_off=idx_off, coef_off=coef_off, n_intra=n_intra, n_intra_levels=n_levels,
                 n_coef_blocks=n_coef, n_inter=n_inter, pic_seq=pic_seq, copy_off=copy_off, n_copy=n_copy,
-                gen_off=gen_off, n_gen=n_gen, dbk_off=dbk_off, n_dbk=n_dbk, n_copy_mbs=n_copy_mbs)
+                gen_off=gen_off, n_gen=n_gen, dbk_off=dbk_off, n_dbk=n_dbk, n_copy_mbs=n_copy_mbs,
+                n_gen_uniform=n_gen_uniform, ghost=ghost, dbk_only=dbk_only)
 
 
 def capture_stream(data):

@@ -60,6 +60,16 @@
 #define FJ_AVAIL_D 8  /* above-left */
 
 /* FjMbRec.dbk bits — reference GetMbFilteringFlags, src/h264bsd_deblocking.c:289-320 */
+#define FJ_PRED_PHASE2 0x80u  /* in a deblock-only job (FjHeader.dbk_only): this macroblock is nevertheless reconstructed, on top of
+                                 the pixels of the job before — it replaced pixels that other macroblocks had already predicted
+                                 from (concealment of, or a later slice over, a macroblock that a failed redundant slice un-decoded) */
+#define FJ_PRED_PARTS_SHIFT 4  /* inter macroblocks, pred bits 4-5: where the macroblock TYPE allows motion to differ inside it — the
+                                 deblocking filter compares motion vectors / references only there (reference
+                                 deblocking.c:1266-1345) */
+#define FJ_PARTS_8x8   0      /* P_8x8, P_8x8ref0: every inner edge */
+#define FJ_PARTS_16x16 1      /* P_L0_16x16, P_Skip: none           */
+#define FJ_PARTS_16x8  2      /* the middle horizontal edge         */
+#define FJ_PARTS_8x16  3      /* the middle vertical edge           */
 #define FJ_DBK_LEFT  1
 #define FJ_DBK_TOP   2
 #define FJ_DBK_INNER 4
@@ -114,7 +124,10 @@ typedef struct FjHeader {
                                  reference for the whole macroblock (FjGen.uniform == 1), the rest are partitioned */
     uint32_t ghost;           /* 1: pre-pass of the picture that follows in the same slot (pixels of a rolled-back slice that a
                                  FJ_MB_STALE macroblock of that picture shows): reconstruction only, not a picture of its own */
-    uint32_t reserved[9];
+    uint32_t dbk_only;        /* 1: the pixels of this picture were reconstructed by the job before it (a ghost job with the records
+                                 they were made from); this job only deblocks, with the records the reference ends up with
+                                 (macroblocks re-decoded by a redundant slice: it keeps the first pixels, the last metadata) */
+    uint32_t reserved[8];
 } FjHeader;                   /* 128 bytes */
 
 /* An inter macroblock with no coefficients whose 16 motion vectors are equal and whole-sample for
@@ -151,7 +164,8 @@ typedef struct FjMbRec {
     uint8_t  qp_c;            /* QPc of THIS macroblock (chroma dequant)                      */
     uint8_t  avail;
     uint8_t  pred;            /* bits0-1 Intra16x16 mode (0 V,1 H,2 DC,3 plane);
-                                 bits2-3 intra chroma mode (0 DC,1 H,2 V,3 plane)             */
+                                 bits2-3 intra chroma mode (0 DC,1 H,2 V,3 plane);
+                                 inter: bits4-5 FJ_PARTS_*;  bit7 FJ_PRED_PHASE2               */
     uint8_t  dbk;
     int8_t   alpha_off;       /* FilterOffsetA = 2*slice_alpha_c0_offset_div2                 */
     int8_t   beta_off;

@@ -45,9 +45,12 @@ void hd_destroy(HostDec *d)
     free(d->mb);
     free(d->mb_decoded);
     free(d->mb_slice_id);
+    free(d->mb_rec_sid);
     free(d->slice_group_map);
     free(d->ghost_buf);
     free(d->mb_ghost);
+    free(d->redo);
+    free(d->mb_redone);
     free(d->nal_buf);
     if (!d->job_from_sink) free(d->job);
     free(d->conv_buf);
@@ -141,13 +144,17 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
 
     /* ---- one raster pass: intra dependency levels + FJ_NEED masks, classification of the inter macroblocks, copy
      * runs, general-inter entries, deblocking index ---- */
+    const int recon_all = !h->dbk_only;       /* a deblock-only job reconstructs only its FJ_PRED_PHASE2 macroblocks */
+#define RECON(r_) (recon_all || ((r_)->pred & FJ_PRED_PHASE2))
     for (uint32_t a = 0; a < n; a++) {
         FjMbRec *r = &recs[a];
+        const int recon = RECON(r);
         any_dbk |= r->dbk;
         cls[a] = 0;
         if (r->kind == FJ_MB_ABSENT || r->kind == FJ_MB_STALE) n_absent++;
-        else if (r->kind == FJ_MB_CONCEAL_I) n_conceal++;
+        else if (r->kind == FJ_MB_CONCEAL_I) n_conceal += (uint32_t)recon;
         else if (in_intra_schedule(r->kind)) {
+            if (!recon) goto deblock_index;
             const uint32_t x = a % w, y = a / w;
             int lvl = -1;
             /* which neighbouring macroblocks does the prediction of this one actually read? (8.3.1.2, 8.3.3, 8.3.4) */
@@ -175,7 +182,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
             }
             need &= r->avail;             /* an unavailable neighbour is never read (its samples are replaced by 128) */
 #define DEP(cond, idx) do { if (cond) { const FjMbRec *q = &recs[idx]; \
-            if (in_intra_schedule(q->kind) && (int)q->intra_level > lvl) lvl = q->intra_level; } } while (0)
+            if (in_intra_schedule(q->kind) && RECON(q) && (int)q->intra_level > lvl) lvl = q->intra_level; } } while (0)
             DEP(x > 0 && (need & FJ_AVAIL_A), a - 1);
             DEP(y > 0 && (need & FJ_AVAIL_B), a - w);
             DEP(y > 0 && x + 1 < w && (need & FJ_AVAIL_C), a - w + 1);
@@ -202,7 +209,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
             for (int k = 1; same_mv && k < 16; k++) same_mv = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
             const int uni = same_mv && r->coded == 0;
             cls[a] = (uint8_t)(uni ? (((m0[0] | m0[1]) & 7) == 0 ? 3 : 1) : 0);
-            if (!(cls[a] & 2)) {
+            if (recon && !(cls[a] & 2)) {
                 FjGen *gi = &gen_tmp[n_gen++];
                 int quad = 0;
                 if (!same_mv) {                               /* one motion vector per 8x8 quadrant (16x8, 8x16, 8x8 partitions)? */
@@ -218,7 +225,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
                 gi->mvx = m0[0]; gi->mvy = m0[1]; gi->coef_idx = r->coef_idx; gi->coded = r->coded;
             }
         }
-        if (cls[a] & 2) {
+        if (recon && (cls[a] & 2)) {
             /* copy list: runs of up to FJ_COPY_RUN copy MBs with consecutive addresses, equal reference and mv; a run whose
              * displacement is zero may continue into the next row (tiles are contiguous in address order) */
             const int16_t *m0 = mvs[a][0];
@@ -232,6 +239,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
                 n_copy++;
             }
         }
+deblock_index:
         {
             /* deblocking: a uniform MB whose filtered left/top neighbours are uniform too, with the same reference and
              * mv components closer than 4 quarter samples, has all-zero strengths (8.7.2.1) — never visited again */
@@ -257,7 +265,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
         uint32_t *ord = (uint32_t *)malloc(n_conceal * sizeof(uint32_t));
         if (!ord) return -1;
         uint32_t k = 0;
-        for (uint32_t a = 0; a < n; a++) if (recs[a].kind == FJ_MB_CONCEAL_I) ord[k++] = a;
+        for (uint32_t a = 0; a < n; a++) if (recs[a].kind == FJ_MB_CONCEAL_I && RECON(&recs[a])) ord[k++] = a;
         for (uint32_t i = 1; i < k; i++) {              /* insertion sort by sequence number */
             const uint32_t v = ord[i];
             uint32_t j = i;
@@ -269,7 +277,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
             FjMbRec *r = &recs[a];
             int lvl = -1;
 #define DEP(cond, idx) do { if (cond) { const FjMbRec *q = &recs[idx]; \
-            if (in_intra_schedule(q->kind) && (int)q->intra_level > lvl) lvl = q->intra_level; } } while (0)
+            if (in_intra_schedule(q->kind) && RECON(q) && (int)q->intra_level > lvl) lvl = q->intra_level; } } while (0)
             DEP((r->avail & FJ_CONC_LEFT) && x > 0, a - 1);
             DEP((r->avail & FJ_CONC_RIGHT) && x + 1 < w, a + 1);
             DEP((r->avail & FJ_CONC_ABOVE) && a >= w, a - w);
@@ -318,7 +326,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
             for (uint32_t i = 0; i < n_intra; i++) idx[hist[recs[ilist[i]].intra_level]++] = ilist[i];
         } else {
             for (uint32_t a = 0; a < n; a++)
-                if (in_intra_schedule(recs[a].kind)) idx[hist[recs[a].intra_level]++] = (uint16_t)a;
+                if (in_intra_schedule(recs[a].kind) && RECON(&recs[a])) idx[hist[recs[a].intra_level]++] = (uint16_t)a;
         }
     }
     {   /* zero the alignment gaps so that a frame job is a pure function of the bitstream */
@@ -335,19 +343,24 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
     return 0;
 }
 
+/* safety net: after concealment every macroblock is decoded, but never leave uninitialised records */
+static void fill_undecoded(HostDec *d)
+{
+    FjHeader *h = (FjHeader *)d->job;
+    if (d->num_decoded_mbs == d->pic_size_mbs) return;
+    FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
+    for (uint32_t a = 0; a < d->pic_size_mbs; a++)
+        if (!d->mb_decoded[a]) {
+            memset(&recs[a], 0, sizeof(FjMbRec));
+            recs[a].kind = FJ_MB_ABSENT;
+            memset(d->job + h->mv_off + (size_t)a * 64u, 0, 64);
+        }
+}
+
 int hd_job_finish(HostDec *d, int is_idr)
 {
     FjHeader *h = (FjHeader *)d->job;
-    if (d->num_decoded_mbs != d->pic_size_mbs) {
-        /* safety net: after concealment every macroblock is decoded, but never leave uninitialised records */
-        FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
-        for (uint32_t a = 0; a < d->pic_size_mbs; a++)
-            if (!d->mb_decoded[a]) {
-                memset(&recs[a], 0, sizeof(FjMbRec));
-                recs[a].kind = FJ_MB_ABSENT;
-                memset(d->job + h->mv_off + (size_t)a * 64u, 0, 64);
-            }
-    }
+    fill_undecoded(d);
     if (fj_finalize(d->job, d->job_cap, d->coef_blocks)) return -1;
     h->cur_slot = (uint8_t)hd_dpb_cur_slot(&d->dpb);
     h->n_slots = (uint8_t)d->dpb.n_slots;
@@ -405,11 +418,14 @@ static int activate_param_sets(HostDec *d, uint32_t pps_id, int is_idr)
         d->mb = (MbInfo *)calloc(d->pic_size_mbs, sizeof(MbInfo));
         free(d->mb_decoded);
         free(d->mb_slice_id);
+        free(d->mb_rec_sid);
         free(d->mb_ghost); d->mb_ghost = NULL; d->ghost_dirty = 0; d->ghost_len = 0;
+        free(d->mb_redone); d->mb_redone = NULL; d->n_redo = 0;
         d->mb_decoded = (uint8_t *)calloc(d->pic_size_mbs, 1);
         d->mb_slice_id = (uint32_t *)calloc(d->pic_size_mbs, sizeof(uint32_t));
+        d->mb_rec_sid = (uint32_t *)calloc(d->pic_size_mbs, sizeof(uint32_t));
         d->slice_group_map = (uint32_t *)calloc(d->pic_size_mbs, sizeof(uint32_t));
-        if (!d->mb || !d->slice_group_map || !d->mb_decoded || !d->mb_slice_id) return -2;
+        if (!d->mb || !d->slice_group_map || !d->mb_decoded || !d->mb_slice_id || !d->mb_rec_sid) return -2;
         for (uint32_t i = 0; i < d->pic_size_mbs; i++) d->mb[i].kind = FJ_MB_ABSENT;
         const Sps *s = d->active_sps;
         int no_reorder = d->no_reordering_app || s->poc_type == 2 ||
@@ -500,9 +516,13 @@ static void reset_picture_state(HostDec *d)
     d->slice_id = 0;
     memset(d->mb_decoded, 0, d->pic_size_mbs);
     memset(d->mb_slice_id, 0, (size_t)d->pic_size_mbs * sizeof(uint32_t));
+    memset(d->mb_rec_sid, 0, (size_t)d->pic_size_mbs * sizeof(uint32_t));
     if (d->ghost_dirty && d->mb_ghost) memset(d->mb_ghost, 0, d->pic_size_mbs);
     d->ghost_dirty = d->ghost_needed = 0;
     d->ghost_len = 0;
+    if (d->n_redo && d->mb_redone) memset(d->mb_redone, 0, d->pic_size_mbs);
+    d->n_redo = 0;
+    d->slice_ids_rewritten = 0;
 }
 
 /* ---------------------------------------------------------------- parameter set storage */
@@ -632,6 +652,73 @@ static int ghost_submit(HostDec *d)
     return rc;
 }
 
+/* ---- macroblocks decoded twice (redundant slices in a damaged picture; hostdec.h, RedoMb) ---- */
+int hd_redo_keep_first(HostDec *d, uint32_t addr, const FjMbRec *rec, const int16_t *mv)
+{
+    if (!d->mb_redone && !(d->mb_redone = (uint8_t *)calloc(d->pic_size_mbs, 1))) return -1;
+    if (d->mb_redone[addr]) return 0;                      /* decoded a third time: the FIRST decode made the pixels */
+    if (d->n_redo == d->redo_cap) {
+        const uint32_t cap = d->redo_cap ? 2 * d->redo_cap : 64;
+        struct RedoMb *nb = (struct RedoMb *)realloc(d->redo, (size_t)cap * sizeof(*nb));
+        if (!nb) return -1;
+        d->redo = nb; d->redo_cap = cap;
+    }
+    struct RedoMb *r = &d->redo[d->n_redo++];
+    r->addr = addr; r->rec = *rec;
+    memcpy(r->mv, mv, 64);
+    d->mb_redone[addr] = 1;
+    return 0;
+}
+
+/* End of a picture with such macroblocks: returns a malloc'ed reconstruction-only job — the picture's records with the
+ * first decodes put back, no deblocking — and turns the picture's own job into a deblock-only one.  Both still have to
+ * be finalized. */
+/* A redundant slice restamps the slice id of every macroblock it starts on (slice_data.c:140, before the macroblock is
+ * parsed), also when it then fails and is rolled back.  The reference decides "slice boundary" for
+ * disable_deblocking_filter_idc 2 when it filters (deblocking.c:236-275), from the ids as they are then: the edge flags
+ * that were derived while parsing are derived again from the final ids. */
+static void restamp_slice_edges(HostDec *d)
+{
+    FjHeader *h = (FjHeader *)d->job;
+    const uint32_t n = d->pic_size_mbs, w = d->width_mbs;
+    FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
+    for (uint32_t a = 0; a < n; a++) {
+        if (!d->mb_rec_sid[a] || !(recs[a].dbk & FJ_DBK_INNER) || d->mb[a].dbk_idc != 2 ||
+            recs[a].kind == FJ_MB_CONCEAL_P || recs[a].kind == FJ_MB_CONCEAL_I) continue;     /* (concealed: filtered everywhere, conceal.c:305-313) */
+        if (a % w) recs[a].dbk = (uint8_t)((recs[a].dbk & ~FJ_DBK_LEFT) | (d->mb_slice_id[a - 1] == d->mb_slice_id[a] ? FJ_DBK_LEFT : 0));
+        if (a >= w) recs[a].dbk = (uint8_t)((recs[a].dbk & ~FJ_DBK_TOP) | (d->mb_slice_id[a - w] == d->mb_slice_id[a] ? FJ_DBK_TOP : 0));
+    }
+}
+
+static uint8_t *redo_split(HostDec *d)
+{
+    FjHeader *h = (FjHeader *)d->job;
+    const uint32_t n = d->pic_size_mbs;
+    const size_t used = (size_t)h->coef_off + (size_t)d->coef_blocks * 32u;
+    uint8_t *blob = (uint8_t *)malloc(d->job_cap);
+    if (!blob) return NULL;
+    memcpy(blob, d->job, used);
+    FjHeader *gh = (FjHeader *)blob;
+    FjMbRec *grecs = (FjMbRec *)(blob + gh->rec_off);
+    for (uint32_t i = 0; i < d->n_redo; i++) {
+        const struct RedoMb *r = &d->redo[i];
+        grecs[r->addr] = r->rec;
+        memcpy(blob + gh->mv_off + (size_t)r->addr * 64u, r->mv, 64);
+    }
+    /* concealment comes after everything that was decoded (conceal.c works on the finished picture): all of it moves
+     * to the second job, where a synthesised macroblock finds its neighbours as the reference does */
+    FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
+    for (uint32_t a = 0; a < n; a++)
+        if (recs[a].kind == FJ_MB_CONCEAL_P || recs[a].kind == FJ_MB_CONCEAL_I) {
+            recs[a].pred |= FJ_PRED_PHASE2;
+            if (!d->mb_redone || !d->mb_redone[a]) grecs[a].kind = FJ_MB_ABSENT;
+        }
+    for (uint32_t a = 0; a < n; a++) grecs[a].dbk = 0;          /* deblocking happens once, in the picture's own job */
+    gh->ghost = 1;
+    h->dbk_only = 1;
+    return blob;
+}
+
 /* A slice whose data failed to parse: un-decode its macroblocks from the failure point back (an I slice keeps
  * everything up to max(width,10) macroblocks before the last good one, a P slice loses everything) and to its end
  * — reference h264bsdMarkSliceCorrupted, src/h264bsd_slice_data.c:298-354. */
@@ -659,11 +746,15 @@ static void mark_slice_corrupted(HostDec *d, uint32_t first_mb)
     do {
         if (hd_trace) fprintf(stderr, "TRACE   mb %u sid %u decoded %u\n", addr, d->mb_slice_id[addr], d->mb_decoded[addr]);
         if (d->mb_slice_id[addr] != sid || !d->mb_decoded[addr]) break;
-        if (--d->mb_decoded[addr] == 0) {
+        if (--d->mb_decoded[addr] == 0 && d->mb_rec_sid[addr] == sid) {
             if (recs[addr].kind != FJ_MB_ABSENT && recs[addr].coef_idx < cut) cut = recs[addr].coef_idx;
             if (d->mb_ghost && makes_pixels(recs[addr].kind)) { d->mb_ghost[addr] = 1; d->ghost_dirty = 1; }
             recs[addr].kind = FJ_MB_ABSENT;
+            d->mb_rec_sid[addr] = 0;
         }
+        /* (else, counter at 0 but the record is an earlier slice's: a redundant slice stamped the macroblock and failed
+         * before it decoded it — slice_data.c:140 / :322-333.  The macroblock counts as not decoded from here on, but the
+         * pixels the earlier slice made stay in the picture unless concealment or a later slice replaces them.) */
         addr = hd_next_mb_in_group(d->slice_group_map, d->pic_size_mbs, addr);
     } while (addr);
     d->coef_blocks = cut;
@@ -693,8 +784,13 @@ static uint32_t plan_concealment(HostDec *d, int p_type)
 #define CONCEAL_ONE(a_, whole_) do { \
         const uint32_t a__ = (a_); \
         FjMbRec *r = &recs[a__]; \
+        /* pixels of an earlier slice under a macroblock that a failed redundant slice un-decoded: other macroblocks may \
+         * have predicted from them; they are reconstructed first, the concealment replaces them afterwards (RedoMb) */ \
+        const int over__ = d->mb_rec_sid[a__] && makes_pixels(r->kind) && !hd_redo_keep_first(d, a__, r, &mvs[a__][0][0]); \
         memset(r, 0, sizeof(*r)); \
         memset(mvs[a__], 0, 64); \
+        if (over__) r->pred = FJ_PRED_PHASE2; \
+        d->mb_rec_sid[a__] = 0; \
         r->qp_y = 40; r->qp_c = 36;          /* QPc of QP 40 with chroma_qp_index_offset 0 */ \
         r->dbk = (whole_) ? 0 : (uint8_t)(FJ_DBK_INNER | ((a__ % w) ? FJ_DBK_LEFT : 0) | (a__ >= w ? FJ_DBK_TOP : 0)); \
         r->coef_idx = seq++; \
@@ -862,7 +958,7 @@ int hd_decode(HostDec *d, uint8_t *stream, uint32_t len, uint32_t pic_id, uint32
             if (hd_dpb_alloc_current(&d->dpb) < 0) ERR_RETURN;
             if (hd_job_begin(d)) return HD_MEMALLOC_ERROR;
         }
-        if (hd_trace) fprintf(stderr, "TRACE slice nal %d first_mb %u is_p %d frame_num %u start_of_picture %d redundant %u\n", nal_type, sh.first_mb, sh.is_p, sh.frame_num, start_of_picture, sh.redundant_pic_cnt);
+        if (hd_trace) fprintf(stderr, "TRACE slice nal %d picid %u first_mb %u is_p %d frame_num %u start_of_picture %d redundant %u\n", nal_type, pic_id, sh.first_mb, sh.is_p, sh.frame_num, start_of_picture, sh.redundant_pic_cnt);
         d->slice = sh;
         d->valid_slice_in_au = 1;
         d->cur_nal_type = (uint8_t)nal_type;
@@ -885,8 +981,21 @@ int hd_decode(HostDec *d, uint8_t *stream, uint32_t len, uint32_t pic_id, uint32
     /* picture complete: queue the frame job, then do the bookkeeping the reference does after
      * deblocking (decoder.c:473-510) */
     const int is_idr = d->cur_nal_type == 5;
-    if (hd_job_finish(d, is_idr)) ERR_RETURN;
-    if (d->ghost_needed && ghost_submit(d)) ERR_RETURN;
+    uint8_t *first_decodes = NULL;
+    fill_undecoded(d);
+    if (d->slice_ids_rewritten) restamp_slice_edges(d);
+    if (d->n_redo && !(first_decodes = redo_split(d))) ERR_RETURN;
+    if (hd_job_finish(d, is_idr)) { free(first_decodes); ERR_RETURN; }
+    if (d->ghost_needed && ghost_submit(d)) { free(first_decodes); ERR_RETURN; }
+    if (first_decodes) {
+        FjHeader *gh = (FjHeader *)first_decodes;
+        const FjHeader *mh = (const FjHeader *)d->job;
+        int rc = fj_finalize(first_decodes, d->job_cap, mh->n_coef_blocks);
+        gh->cur_slot = mh->cur_slot; gh->n_slots = mh->n_slots; gh->is_idr = mh->is_idr; gh->pic_seq = mh->pic_seq;
+        if (!rc && d->sink.submit && d->sink.submit(d->sink.user, first_decodes, gh->total_bytes)) rc = -1;
+        free(first_decodes);
+        if (rc) ERR_RETURN;
+    }
     if (d->sink.submit && d->sink.submit(d->sink.user, d->job, ((FjHeader *)d->job)->total_bytes)) {
         fprintf(stderr, "h264bsd-mi355x: frame job submission failed\n");
         ERR_RETURN;

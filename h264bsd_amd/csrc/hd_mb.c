@@ -43,6 +43,9 @@ typedef struct MbCtx {
     uint32_t addr, mbx, mby;
     MbInfo *cur, *A, *B, *C, *D;   /* NULL when outside the picture or another slice */
     uint16_t done;                 /* raster bit per 4x4 block of cur whose mv/ref is final */
+    uint16_t ok_blocks;            /* ... and was final before the first reconstruction-time error (p2err): the reference
+                                      writes motion vectors and references partition by partition and stops at the first
+                                      one that fails (inter_prediction.c:520-565 and the partitioned variants) */
     uint32_t coef_start;           /* first coefficient block of this macroblock */
     int p2err;                     /* an error the reference only finds when it RECONSTRUCTS the macroblock
                                       (h264bsdDecodeMacroblock: missing reference picture, motion vector range, intra
@@ -138,6 +141,7 @@ static int set_partition(MbCtx *c, int x, int y, int w, int h, int ref, const in
             c->cur->mv[z][0] = mv[0];
             c->cur->mv[z][1] = mv[1];
             c->done |= (uint16_t)(1u << (4 * yy + xx));
+            if (!c->p2err) c->ok_blocks |= (uint16_t)(1u << (4 * yy + xx));
         }
     (void)ref;
     return 0;
@@ -406,6 +410,7 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
     rec.cqp_off = (int8_t)pps->chroma_qp_index_offset;
     rec.alpha_off = (int8_t)sh->alpha_off;
     rec.beta_off = (int8_t)sh->beta_off;
+    m->dbk_idc = (uint8_t)sh->disable_deblocking_filter_idc;
     if (sh->disable_deblocking_filter_idc != 1) {
         rec.dbk = FJ_DBK_INNER;
         if (c.mbx && (sh->disable_deblocking_filter_idc != 2 || c.A)) rec.dbk |= FJ_DBK_LEFT;
@@ -419,6 +424,7 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
         memset(m->tc, 0, sizeof(m->tc));
         m->qp = (uint8_t)*qp;
         rec.kind = FJ_MB_INTER;
+        rec.pred = FJ_PARTS_16x16 << FJ_PRED_PARTS_SHIFT;
     } else {
         uint32_t t = br_ue(br);
         if (br_overrun(br)) FAIL;
@@ -446,6 +452,7 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
                 m->kind = FJ_MB_INTER;
                 if (parse_inter(&c, ptype)) FAIL;
                 rec.kind = FJ_MB_INTER;
+                rec.pred = (uint8_t)((ptype == 0 ? FJ_PARTS_16x16 : ptype == 1 ? FJ_PARTS_16x8 : ptype == 2 ? FJ_PARTS_8x16 : FJ_PARTS_8x8) << FJ_PRED_PARTS_SHIFT);
             } else {
                 /* intra: availability of the four neighbours for prediction */
                 const int cip = pps->constrained_intra_pred;
@@ -496,11 +503,13 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
     if (!c.p2err && rec.coded && rec.kind != FJ_MB_IPCM) {
         int qi = (int)m->qp + pps->chroma_qp_index_offset;
         qi = qi < 0 ? 0 : qi > 51 ? 51 : qi;
-        if (hd_residual_out_of_range(coefs + 16u * coef_start, rec.coded, m->qp, qpc_table[qi], rec.kind == FJ_MB_I16x16))
+        if (hd_residual_out_of_range(coefs + 16u * coef_start, rec.coded, m->qp, qpc_table[qi], rec.kind == FJ_MB_I16x16)) {
             P2ERR(&c);
+            c.ok_blocks = 0;          /* the residual is processed before the prediction: no motion vector was written */
+        }
     }
-    if (c.p2err) {
-        if (first_decode) {
+    if (c.p2err && first_decode) {
+        {
             /* Counted as decoded, never reconstructed.  The reference has by now stored the macroblock type, the
              * coefficient counts and the updated QP in its mbStorage_t (macroblock_layer.c:985-1046), and if the slice
              * roll-back does not reach this macroblock h264bsdFilterPicture filters it with them: an intra macroblock
@@ -515,15 +524,31 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
                 keep.coef_idx = coef_start;
                 if (d->mb_ghost && d->mb_ghost[addr]) d->ghost_needed = 1;   /* it shows what a rolled-back slice left there */
             }
-            recs[addr] = keep;
-            memset(mvs[addr], 0, 64);
+            /* (a macroblock that a failed redundant slice left "not decoded" with an earlier slice's pixels under it:
+             * those pixels stay, this record only speaks for the deblocking filter — RedoMb) */
+            if (d->mb_rec_sid[addr] && keep.kind == FJ_MB_STALE && hd_redo_keep_first(d, addr, &recs[addr], &mvs[addr][0][0])) FAIL;
+            if (!(d->mb_rec_sid[addr] && keep.kind == FJ_MB_ABSENT)) {
+                recs[addr] = keep;
+                memset(mvs[addr], 0, 64);
+                d->mb_rec_sid[addr] = sid;
+            }
         }
         FAIL;
     }
 
-    if (!first_decode) {          /* redundant re-decode: keep the primary's record and pixels */
+    if (first_decode && d->mb_rec_sid[addr] && recs[addr].kind != FJ_MB_ABSENT && recs[addr].kind != FJ_MB_STALE) {
+        /* A macroblock that a failed redundant slice un-decoded (hd_core.c, mark_slice_corrupted) is decoded anew: the
+         * reference writes it again, over pixels that other macroblocks may have predicted from.  Those are reconstructed
+         * first (RedoMb), this decode on top of them. */
+        if (!hd_redo_keep_first(d, addr, &recs[addr], &mvs[addr][0][0])) rec.pred |= FJ_PRED_PHASE2;
+    }
+    if (!first_decode) {
+        /* Decoded again by a redundant slice: the pixels of the first decode stay (its record is set aside for the
+         * reconstruction), everything the deblocking filter looks at becomes what this decode says (hostdec.h, RedoMb).
+         * The coefficients of this decode are never used: only their positions (rec.coded) matter. */
         d->coef_blocks = coef_start;
-        return 0;
+        if (hd_redo_keep_first(d, addr, &recs[addr], &mvs[addr][0][0])) return 0;     /* out of memory: first metadata stays */
+        rec.coef_idx = 0;
     }
     rec.qp_y = m->qp;
     {
@@ -534,17 +559,30 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
     if (rec.kind == FJ_MB_INTER) {
         memcpy(rec.ref_slot, m->ref_slot, 4);
         int16_t (*dst)[2] = mvs[addr];
+        /* a redundant decode that failed while it reconstructed: the partitions from the failing one on keep what the
+         * macroblock had before (only reachable with !first_decode, see the p2err exit above) */
+        const uint16_t keep_old = c.p2err ? (uint16_t)~c.ok_blocks : 0;
+        const int old_inter = recs[addr].kind == FJ_MB_INTER;
+        for (int q = 0; q < 4; q++) {
+            const uint16_t quad = (uint16_t)(0x33u << (2 * (q & 1) + 8 * (q >> 1)));
+            if ((keep_old & quad) == quad) rec.ref_slot[q] = old_inter ? recs[addr].ref_slot[q] : 0;
+        }
         for (int z = 0; z < 16; z++) {
             const int r = 4 * Z_Y[z] + Z_X[z];
+            if (keep_old & (1u << r)) { if (!old_inter) dst[r][0] = dst[r][1] = 0; continue; }
             dst[r][0] = m->mv[z][0];
             dst[r][1] = m->mv[z][1];
         }
-        d->n_inter++;
+        d->n_inter += (uint32_t)first_decode;
     } else {
         memset(mvs[addr], 0, 64);      /* the sections are not pre-zeroed: keep the job a pure function of the stream */
-        d->n_intra++;
+        d->n_intra += (uint32_t)first_decode;
     }
     recs[addr] = rec;
+    d->mb_rec_sid[addr] = sid;
+    /* (a redundant decode that fails while it reconstructs has by then replaced the macroblock's type, coefficient
+     * counts and QP in the reference's mbStorage_t, macroblock_layer.c:985-1046: the record above says the same) */
+    if (c.p2err) FAIL;
     return 0;
 }
 
@@ -575,10 +613,22 @@ int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_
     int qp = pps->pic_init_qp + sh->slice_qp_delta;
     d->slice_id++;
     d->last_mb_addr = 0;
+    if (sh->redundant_pic_cnt) d->slice_ids_rewritten = 1;
 
     do {
         if (!sh->redundant_pic_cnt && d->mb_decoded[addr]) FAIL;
         d->mb_slice_id[addr] = d->slice_id;
+        if (d->mb_decoded[addr]) {
+            /* a redundant slice over a decoded macroblock: the slice-level parameters the deblocking filter uses are
+             * restamped before the macroblock is parsed (SetMbParams, slice_data.c:53-66,140), so they change even when
+             * the parse then fails; edge flags across slice boundaries are settled at the end of the picture */
+            FjMbRec *r = (FjMbRec *)(d->job + ((const FjHeader *)d->job)->rec_off) + addr;
+            r->alpha_off = (int8_t)sh->alpha_off; r->beta_off = (int8_t)sh->beta_off;
+            r->cqp_off = (int8_t)pps->chroma_qp_index_offset;
+            r->dbk = (uint8_t)(sh->disable_deblocking_filter_idc == 1 ? 0 :
+                               FJ_DBK_INNER | (addr % d->width_mbs ? FJ_DBK_LEFT : 0) | (addr >= d->width_mbs ? FJ_DBK_TOP : 0));
+            d->mb[addr].dbk_idc = (uint8_t)sh->disable_deblocking_filter_idc;
+        }
         if (sh->is_p && !prev_skipped) {
             skip_run = br_ue(br);
             if (br_overrun(br) || skip_run > d->pic_size_mbs - addr) FAIL;

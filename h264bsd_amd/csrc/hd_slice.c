@@ -114,7 +114,10 @@ int hd_parse_slice_header(BitReader *br, SliceHdr *sh, const Sps *sps, const Pps
             sh->adaptive_marking = (uint8_t)br_get1(br);
             if (sh->adaptive_marking) {
                 uint32_t n4 = 0, n5 = 0, n6 = 0, n123 = 0;
-                for (;;) {
+                for (uint32_t i = 0;; i++) {
+                    /* the count is checked before every operation is read, the terminating 0 included
+                     * (slice_header.c:618-624) */
+                    if (i > 2u * sps->num_ref_frames + 2u) return -1;
                     uint32_t op = br_ue(br);
                     if (br_overrun(br) || op > 6) return -1;
                     if (op == 0) break;
@@ -124,7 +127,7 @@ int hd_parse_slice_header(BitReader *br, SliceHdr *sh, const Sps *sps, const Pps
                     if (op == 1 || op == 3) c->a = br_ue(br) + 1;          /* difference_of_pic_nums */
                     if (op == 2) c->a = br_ue(br);                        /* long_term_pic_num */
                     if (op == 3 || op == 6) c->b = br_ue(br);             /* long_term_frame_idx */
-                    if (op == 4) c->a = br_ue(br);                        /* max_long_term_frame_idx_plus1 */
+                    if (op == 4) { c->a = br_ue(br); if (c->a > sps->num_ref_frames) return -1; }   /* max_long_term_frame_idx_plus1, in [0, num_ref_frames] (slice_header.c:668-673) */
                     if (op == 4) n4++;
                     if (op == 5) n5++;
                     if (op == 6) n6++;

@@ -170,7 +170,7 @@ typedef struct MbInfo {
     uint8_t  kind;          /* FJ_MB_* of the last decode of this MB                             */
     uint8_t  mb_type;       /* reference numbering: 0 P_Skip, 1..5 P, 6 I4x4, 7..30 I16x16, 31 PCM */
     uint8_t  qp;
-    uint8_t  pad_;
+    uint8_t  dbk_idc;       /* disable_deblocking_filter_idc of the slice of the last decode      */
     uint8_t  tc[24];        /* total_coeff per 4x4 block, H.264 block order (luma 0-15, Cb, Cr)   */
     int8_t   i4mode[16];    /* Intra4x4PredMode, H.264 block order                                */
     int8_t   ref_idx[4];
@@ -252,6 +252,7 @@ typedef struct HostDec {
      * reset touches 5 bytes per macroblock instead of a cache line (the parser is memory-bound at scale) */
     uint8_t  *mb_decoded;   /* times decoded in the current picture                                 */
     uint32_t *mb_slice_id;  /* slice that last touched the macroblock; 0 = none in this picture       */
+    uint32_t *mb_rec_sid;   /* slice whose decode wrote the macroblock's record in the job; 0 = none  */
     uint32_t num_decoded_mbs, slice_id;
     uint32_t last_mb_addr;
 
@@ -287,6 +288,16 @@ typedef struct HostDec {
     uint8_t *ghost_buf; size_t ghost_len, ghost_cap;
     uint8_t *mb_ghost;      /* per macroblock: pixels written by a slice that was rolled back; allocated on first use */
     uint8_t  ghost_dirty, ghost_needed;
+
+    /* macroblocks decoded again by a redundant slice (only possible while the primary picture is incomplete, i.e. in
+     * damaged streams): the reference keeps the pixels of the first decode and the metadata of the last one
+     * (macroblock_layer.c:985-1046 run again, the writes are skipped: :1006, :1110, intra_prediction.c:526,
+     * inter_prediction.c:468).  The first decode's record and motion vectors are kept here; at the end of the picture
+     * they go into a reconstruction-only job, and the picture's own job only deblocks (FjHeader.dbk_only). */
+    struct RedoMb { uint32_t addr; FjMbRec rec; int16_t mv[32]; } *redo;
+    uint32_t n_redo, redo_cap;
+    uint8_t *mb_redone;     /* per macroblock, allocated on first use */
+    uint8_t  slice_ids_rewritten;   /* a redundant slice ran over macroblocks of this picture (it restamps their slice id even when it fails) */
 
     JobSink sink;
     uint8_t  sink_configured;
@@ -332,6 +343,8 @@ int hd_residual_out_of_range(const int16_t *blk, uint32_t coded, int qp_y, int q
 /* hd_mb.c */
 uint32_t hd_next_mb_in_group(const uint32_t *map, uint32_t n, uint32_t addr);
 int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_ref_idc);
+/* hd_core.c: set the first decode's record of a macroblock aside before a redundant slice's decode replaces it (0 = ok) */
+int hd_redo_keep_first(HostDec *d, uint32_t addr, const FjMbRec *rec, const int16_t *mv);
 /* hd_api.c helpers used across files */
 int  hd_job_begin(HostDec *d);
 int  hd_job_finish(HostDec *d, int is_idr);

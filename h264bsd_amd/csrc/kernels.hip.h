@@ -475,6 +475,7 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
         const bool edge_on = e ? true : (dir ? f_top : f_left);
         if (edge_on) {
             const int p_kind = e ? q.kind : (dir ? pt.kind : pl.kind);
+            const int parts = (q.pred >> FJ_PRED_PARTS_SHIFT) & 3;
             const uint32_t p_coded = e ? q.coded : (dir ? pt.coded : pl.coded);
             uint32_t qrefs, prefs, t0, t1;
             __builtin_memcpy(&qrefs, q.ref_slot, 4);
@@ -483,6 +484,9 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
             prefs = e ? qrefs : (dir ? t1 : t0);
             if (is_intra_kind(q.kind) || is_intra_kind(p_kind)) my_bs = e ? 3 : 4;
             else if (((q.coded >> z_of(qx, qy)) & 1) || ((p_coded >> z_of(px, py)) & 1)) my_bs = 2;
+            /* inside a macroblock motion is compared only across the partition boundaries its type has (FJ_PARTS_*,
+             * reference deblocking.c:1266-1345) */
+            else if (e && (parts == FJ_PARTS_16x16 || (parts == FJ_PARTS_16x8 && !(dir == 1 && e == 2)) || (parts == FJ_PARTS_8x16 && !(dir == 0 && e == 2)))) my_bs = 0;
             else if (((qrefs >> (8 * ((qy >> 1) * 2 + (qx >> 1)))) & 255u) != ((prefs >> (8 * ((py >> 1) * 2 + (px >> 1)))) & 255u)) my_bs = 1;
             else {
                 const int ax = (int16_t)(mva & 0xFFFFu), ay = (int32_t)mva >> 16, bx2 = (int16_t)(mvb & 0xFFFFu), by2 = (int32_t)mvb >> 16;

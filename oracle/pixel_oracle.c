@@ -501,6 +501,7 @@ int oracle_recon(const uint8_t *blob, uint8_t *const *slots)
         const FjMbRec *r = &recs[a];
         const int mbx = (int)(a % h->width_mbs), mby = (int)(a / h->width_mbs);
         if (r->kind == FJ_MB_ABSENT || r->kind == FJ_MB_STALE) continue;
+        if (h->dbk_only && !(r->pred & FJ_PRED_PHASE2)) continue;     /* its pixels were made by the job before this one (FjHeader.dbk_only) */
         if (r->kind == FJ_MB_CONCEAL_I || r->kind == FJ_MB_CONCEAL_P) { n_conceal++; continue; }
         if (r->kind == FJ_MB_IPCM) {
             const u8 *s = (const u8 *)(coefs + 16 * (size_t)r->coef_idx);
@@ -528,6 +529,7 @@ int oracle_recon(const uint8_t *blob, uint8_t *const *slots)
         for (uint32_t a = 0; a < h->n_mbs; a++) {
             const FjMbRec *r = &recs[a];
             if (r->kind != FJ_MB_CONCEAL_I && r->kind != FJ_MB_CONCEAL_P) continue;
+            if (h->dbk_only && !(r->pred & FJ_PRED_PHASE2)) continue;
             if (r->coef_idx >= h->n_mbs || ord[r->coef_idx] != 0xFFFFFFFFu) { free(ord); return -1; }
             ord[r->coef_idx] = a;
         }
@@ -569,6 +571,14 @@ static int bs_of(const FjMbRec *q, const int16_t (*qmv)[2], const FjMbRec *p, co
 {
     if (is_intra_kind(q->kind) || is_intra_kind(p->kind)) return mb_edge ? 4 : 3;
     if (((q->coded >> z_of(qx, qy)) & 1) || ((p->coded >> z_of(px, py)) & 1)) return 2;
+    if (!mb_edge) {
+        /* inside a macroblock the reference compares motion only across the partition boundaries its TYPE has
+         * (deblocking.c:1266-1345): none for 16x16 / P_Skip, the middle horizontal edge for 16x8, the middle vertical one
+         * for 8x16.  The same thing as comparing everywhere unless the type and the vectors disagree, which happens
+         * when a redundant decode changed the type and then failed before it wrote its vectors (FJ_PRED_PARTS) */
+        const int parts = (q->pred >> FJ_PRED_PARTS_SHIFT) & 3, hor = qx == px, mid = hor ? qy == 2 : qx == 2;
+        if (parts == FJ_PARTS_16x16 || (parts == FJ_PARTS_16x8 && !(hor && mid)) || (parts == FJ_PARTS_8x16 && !(!hor && mid))) return 0;
+    }
     if (q->ref_slot[(qy >> 1) * 2 + (qx >> 1)] != p->ref_slot[(py >> 1) * 2 + (px >> 1)]) return 1;
     const int16_t *a = qmv[4 * qy + qx], *b = pmv[4 * py + px];
     if (iabs(a[0] - b[0]) >= 4 || iabs(a[1] - b[1]) >= 4) return 1;

@@ -84,5 +84,21 @@ def _overflow(seed):
 
 OVERFLOW = {f"overflow_{_s}": _overflow(_s) for _s in range(400, 448)}
 
+# ---- redundant slices in damaged pictures (round 2).  The reference decodes a redundant slice only while the primary
+# picture is incomplete, keeps the PIXELS of the first decode of a macroblock and the METADATA of the last one
+# (src/h264bsd_macroblock_layer.c:985-1046, the writes skipped at :1006 / :1110), restamps slice ids and slice-level
+# filter parameters before it parses a macroblock (src/h264bsd_slice_data.c:140), and a redundant slice that fails
+# un-decodes macroblocks the primary slice had decoded (:298-354).  Seeds whose random configuration has redundant slices;
+# the last third also carries flipped bits.
+def _redundant(seed, flip):
+    cfg = random_config(seed)
+    cfg["gaps"] = 0
+    assert cfg["redundant"]
+    return cfg, dict(seed=seed, p_drop=0.2, p_flip=flip, p_trunc=0.2)
+
+
+_RED_SEEDS = [_s for _s in range(500, 900) if random_config(_s)["redundant"]][:48]
+REDUNDANT = {f"redundant_{_s}": _redundant(_s, 0.3 if _i >= 32 else 0.0) for _i, _s in enumerate(_RED_SEEDS)}
+
 # a bundled x264 stream (one slice per picture, 40x23 macroblocks) with slices cut short: concealment at picture scale
 DAMAGED_BUNDLED = {"damaged_bundled_640x360": ("test_640x360", dict(seed=7, p_drop=0.04, p_flip=0.0, p_trunc=0.3))}

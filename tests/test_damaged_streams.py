@@ -18,13 +18,13 @@ import pytest
 import synth
 from damage import damage
 from h264writer import StreamWriter
-from synth_configs import DAMAGED, DAMAGED_BUNDLED, FLIPPED, OVERFLOW
+from synth_configs import DAMAGED, DAMAGED_BUNDLED, FLIPPED, OVERFLOW, REDUNDANT
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth_golden.json")))
 # streams on which the reference's own output is undefined (it shows memory it never wrote; found by
 # tests/golden/make_synth_golden.py with two heap fill bytes): nothing to be bit-exact with
 UNDEFINED = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_undefined.json")))
-ALL = {**DAMAGED, **FLIPPED, **OVERFLOW}
+ALL = {**DAMAGED, **FLIPPED, **OVERFLOW, **REDUNDANT}
 NAMES = [n for n in list(ALL) + list(DAMAGED_BUNDLED) if n not in UNDEFINED]
 _streams = {}
 
@@ -67,6 +67,29 @@ def test_the_bit_error_and_residual_range_sets_are_not_empty_shells():
     # h264bsdProcessBlock range check (transform.c:184-188), each concealed macroblock its consequence
     assert sum(1 for n in overflow for t in GOLD[n]["trace"] if t[0] == 3) > 100
     assert sum(p[3] for n in overflow for p in GOLD[n]["pics"]) > 300
+
+
+def test_the_redundant_slice_set_reaches_the_second_decodes(built):
+    """The set must really contain macroblocks that are decoded twice: pictures that the parser splits into a
+    reconstruction-only job and a deblock-only job (FjHeader.ghost / dbk_only)."""
+    import ctypes
+    import h264bsd_amd
+    from h264bsd_amd import capi
+    split = 0
+    for name in [n for n in REDUNDANT if n not in UNDEFINED][:16]:
+        jobs = []
+        dec = capi.Decoder(0, capture=lambda b: jobs.append(h264bsd_amd.job_header(bytes(b))))
+        data = stream_of(name)
+        buf = ctypes.create_string_buffer(data, len(data))
+        base, off, stall, pid = ctypes.addressof(buf), 0, 0, 0
+        while off < len(data) and stall <= 3:
+            r, rb = dec.decode(base + off, len(data) - off, pid)
+            off += rb
+            pid += r == 1
+            stall = stall + 1 if rb == 0 else 0
+        dec.close()
+        split += sum(1 for j in jobs if j["dbk_only"])
+    assert split >= 20
 
 
 @pytest.mark.parametrize("name", NAMES)
