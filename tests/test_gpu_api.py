@@ -279,3 +279,23 @@ def test_72_different_streams_through_the_batch_api(built, golden):
     assert built.device_errors() == 0
     for d in decs:
         d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", ["1,0", "2,1", "8,4"])
+def test_lane_configurations_of_the_product_engine(lanes):
+    """The engine's lane scheduler (stream groups + heavy lanes on their own HIP streams, per-instance ordering by
+    events, engine.hip: Lane / flush_locked) in other shapes than the default 4,2: the 72-different-streams test and the
+    damaged / redundant-slice fixtures (ghost and deblock-only jobs that must stay in order across lanes) in a fresh
+    process with H264BSDMI_LANES set."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, H264BSDMI_LANES=lanes, GPU_MAX_HW_QUEUES="16")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "tests/test_gpu_api.py::test_72_different_streams_through_the_batch_api",
+                        "tests/test_gpu_api.py::test_many_instances_round_robin_are_batched_and_exact",
+                        "tests/test_damaged_streams.py", "-k", "not lane_configurations and (batch_api or round_robin or redundant_5 or flipped_30)"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
