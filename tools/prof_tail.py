@@ -8,7 +8,7 @@ L = h.lib()
 jobs, _, _ = h.capture_stream(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "test_1920x1080.h264"), "rb").read())
 rep = h.Replay(jobs, n_streams=256)
 done = 0
-for tick in (0, 10, 20, 41):
+for tick in (0, 9, 22, 28, 41, 60):
     if tick > done:
         rep.run(done, tick - done); rep.sync()
     L.h264bsdmiDebugTailProfile(1, None)

@@ -42,4 +42,12 @@ from h264bsd_amd.srchash import kernel_source_sha256
 src_sha = kernel_source_sha256(root)
 json.dump({"source": f"profiles/{tag}_pmc_summary.txt (separate rocprofv3 --pmc passes)", "kernel_source_sha256": src_sha, "calibration": cal, "kernels": kern},
           open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+# the bench line was printed before the PMC passes of this session existed: fill its traffic field from them
+bl = json.loads(line)
+dom = bl["roofline"]["kernel"]
+if bl["roofline"].get("traffic") is None and dom in kern:
+    bl["roofline"]["traffic"] = kern[dom]["fetch_bytes_per_launch_calibrated"] + kern[dom]["write_bytes_per_launch_calibrated"]
+    bl["roofline"]["traffic_source"] = (f"profiles/{tag}_traffic.json: FETCH_SIZE + WRITE_SIZE of this kernel, separate rocprofv3 --pmc passes run "
+                                        "right after this line on the same box (filled in by tools/refresh_profiles.py), calibrated on k_copy's known byte count")
+    open(os.path.join(dst, f"{tag}_bench_line.json"), "w").write(json.dumps(bl) + "\n")
 print(line[:300]); print(json.dumps(kern)[:600])
