@@ -66,6 +66,21 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota():
+    """CPUs the container may use at once (cgroup v2 cpu.max / v1 cfs quota), None when unlimited or unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline_all_cores(seconds=8.0):
     """SURVEY.md §8d / posix/Rakefile:7: one pinned process per host core, all at once (the reference has no threads of
     its own; independent streams are how a host scales it)."""
@@ -84,8 +99,11 @@ def cpu_baseline_all_cores(seconds=8.0):
             pass
     if not ok:
         return None
-    return dict(value=fps * 8160, unit="macroblocks/s", fps=fps, cores=ok, cpu=cpu_model(),
-                sample=f"{ok} pinned processes (one per host core), each looping over {STREAM}.h264 for {seconds:.0f} s: {int(pics)} pictures")
+    quota = cpu_quota()
+    return dict(value=fps * 8160, unit="macroblocks/s", fps=fps, cores=ok, cpu_quota=quota, cpu=cpu_model(),
+                sample=f"{ok} pinned processes (one per hardware thread the process may run on), each looping over {STREAM}.h264 for "
+                       f"{seconds:.0f} s: {int(pics)} pictures" +
+                       (f"; the container's CPU quota is {quota:g} CPUs, so this is what {quota:g} CPUs of this host deliver, not {ok}" if quota and quota < ok else ""))
 
 
 def cpu_baseline(data, seconds=10.0):
@@ -144,7 +162,7 @@ def end_to_end(data, streams, threads, laps=2):
         d.close()
     pics = streams * timed
     return dict(value=pics * 8160 / dt, unit="macroblocks/s", fps=pics / dt, streams=streams, parser_threads=int(threads),
-                host_cores=os.cpu_count(), h2d_bytes_per_picture=h2d / pics, d2h_bytes_per_picture=0,
+                host_cores=os.cpu_count(), cpu_quota=cpu_quota(), h2d_bytes_per_picture=h2d / pics, d2h_bytes_per_picture=0,
                 device_errors=h.device_errors(),
                 sample=f"{streams} decoder instances x {timed} pictures through h264bsdDecode-equivalent batch calls, PCIe inclusive, "
                        f"{dt:.1f} s; pictures left in HBM")
@@ -485,7 +503,7 @@ def main():
         if desync is not None:
             out["desynchronised"] = desync
         if world == 1 and not args.no_end_to_end:
-            out["end_to_end"] = end_to_end(data, min(args.streams, 256), min(64, os.cpu_count() or 1))
+            out["end_to_end"] = end_to_end(data, min(args.streams, 256), 0)      # 0: the library's default (usable CPUs, at most 64)
         out["device_errors"] = h264bsd_amd.device_errors()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data)

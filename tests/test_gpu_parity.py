@@ -107,17 +107,19 @@ def test_staggered_streams_mix_pictures_in_one_tick(built, captured, golden):
         rep.close()
 
 
-@pytest.mark.parametrize("lanes,delay", [(0, 0), (2, 2), (3, 5)])
-def test_desynchronised_streams(lanes, delay, built, captured, golden):
+@pytest.mark.parametrize("lanes,delay,groups,S", [(0, 0, 1, 11), (2, 2, 1, 11), (3, 5, 1, 11), (2, 3, 4, 37), (3, 4, 9, 40)])
+def test_desynchronised_streams(lanes, delay, groups, S, built, captured, golden):
     """every stream at its own picture index (so every tick mixes I pictures and P pictures), with and without
-    heavy lanes; after each lap stream s has just finished picture offsets[s] - 1"""
+    heavy lanes and stream groups (the lane scheduler of h264bsdmiReplayCreateSched: one heavy launch per round, the
+    streams regrouped by estimated cost every 32 rounds, ordering across lanes by events); after each lap stream s has
+    just finished picture offsets[s] - 1"""
     name = "test_640x360"
     jobs, _, _ = captured(name)
     g = golden[name]["frame_checksum64"]
     heads = [pyoracle.blob_header(j) for j in jobs]
-    n, S = len(jobs), 11
+    n = len(jobs)
     offsets = [(s * n) // S for s in range(S)]
-    rep = built.Replay(jobs, n_streams=S, offsets=offsets, heavy_lanes=lanes, heavy_delay=delay)
+    rep = built.Replay(jobs, n_streams=S, offsets=offsets, heavy_lanes=lanes, heavy_delay=delay, groups=groups)
     try:
         for lap in range(3):
             rep.run()
