@@ -64,6 +64,23 @@ int hd_residual_out_of_range(const int16_t *blk, uint32_t coded, int qp_y, int q
 {
     int32_t ydc[16];
     const int has_ldc = (coded & FJ_CODED_LUMA_DC) != 0;
+    if (!has_ldc) {
+        /* One pass over the whole macroblock before any per-block work (all macroblocks but Intra16x16): the sum of
+         * the magnitudes of ALL its levels bounds the sum of any one block, so the per-block bound holds for every
+         * block at once when it holds for the totals.  Almost every coded macroblock leaves here. */
+        const uint32_t n_luma = (uint32_t)__builtin_popcount(coded & 0xFFFFu), n_cac = (uint32_t)__builtin_popcount((coded >> 16) & 0xFFu);
+        const int16_t *p = blk;
+        uint32_t sum_l = 0, sum_d = 0, sum_c = 0;
+        for (uint32_t i = 0; i < 16u * n_luma; i++) sum_l += (uint32_t)abs(p[i]);
+        p += 16u * n_luma;
+        if (coded & FJ_CODED_CHROMA_DC) { for (int i = 0; i < 8; i++) sum_d += (uint32_t)abs(p[i]); p += 16; }
+        for (uint32_t i = 0; i < 16u * n_cac; i++) sum_c += (uint32_t)abs(p[i]);
+        const uint64_t bound_l = (uint64_t)sum_l * ((uint32_t)level_scale[qp_y % 6][2] << (qp_y / 6));
+        const int q6c = qp_c / 6;
+        const uint64_t dc_max = ((uint64_t)sum_d * level_scale[qp_c % 6][0]) << (q6c >= 1 ? q6c - 1 : 0);   /* |every chroma DC| after 8.5.11 */
+        const uint64_t bound_c = (uint64_t)sum_c * ((uint32_t)level_scale[qp_c % 6][2] << q6c) + dc_max;
+        if (bound_l <= 32735u && bound_c <= 32735u) return 0;
+    }
     if (has_ldc) {
         if (coded & FJ_CODED_LUMA_DC_RAW) {
             for (int i = 0; i < 16; i++) ydc[i] = blk[i];
