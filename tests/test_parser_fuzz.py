@@ -2,6 +2,8 @@
 in a crash or a hang.  Runs in a child process so that a memory fault shows up as a failed test instead of killing
 pytest.  (tests/fuzz_asan/ is the same idea under ASan/UBSan, with every frame job also rendered by the oracle.)"""
 import subprocess
+
+import pytest
 import sys
 import textwrap
 
@@ -110,3 +112,21 @@ def test_repeated_truncated_slices_stay_inside_the_coefficient_section(tmp_path,
     script.write_text(REPEAT_CHILD)
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.split()[-2] == "OK", out.stderr[-1500:]
+
+
+def test_sanitizer_harness_builds_and_runs(tmp_path):
+    """tests/fuzz_asan/run.sh compiles the host parser + oracle with AddressSanitizer and UBSan and feeds them mutated
+    streams; the harness had silently stopped linking once (a new engine entry point without a stub), so a short run is
+    part of the suite: it must build, finish, and report no sanitizer finding."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = subprocess.run(["bash", os.path.join(root, "tests", "fuzz_asan", "run.sh"),
+                        os.path.join(root, "tests", "golden", "test_640x360.h264"), "40", "3"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "cases 40" in r.stdout and "ERROR: AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout.replace("left shift of negative", "")
