@@ -135,6 +135,16 @@ static int set_partition(MbCtx *c, int x, int y, int w, int h, int ref, const in
 {
     /* horizontal [-2048, 2047.75], vertical [-512, 511.75] luma samples */
     if ((uint32_t)(mv[0] + 8192) >= 16384u || (uint32_t)(mv[1] + 2048) >= 4096u) return -1;
+    if (w == 4 && h == 4) {                                  /* the whole macroblock (P_Skip, 16x16): most inter macroblocks */
+        uint32_t one;
+        memcpy(&one, mv, 4);
+        const uint64_t two = (uint64_t)one << 32 | one;
+        uint64_t *dst = (uint64_t *)(void *)c->cur->mv;
+        for (int i = 0; i < 8; i++) dst[i] = two;
+        c->done = 0xFFFF;
+        if (!c->p2err) c->ok_blocks = 0xFFFF;
+        return 0;
+    }
     for (int yy = y; yy < y + h; yy++)
         for (int xx = x; xx < x + w; xx++) {
             const int z = z_of(xx, yy);
@@ -144,6 +154,17 @@ static int set_partition(MbCtx *c, int x, int y, int w, int h, int ref, const in
             if (!c->p2err) c->ok_blocks |= (uint16_t)(1u << (4 * yy + xx));
         }
     (void)ref;
+    return 0;
+}
+
+/* the same reference for all four quadrants (P_Skip, 16x16): one DPB lookup */
+static int resolve_ref_all(MbCtx *c, int ref_idx)
+{
+    if (ref_idx < 0) return -1;
+    const int slot = hd_dpb_ref_slot(&c->d->dpb, (uint32_t)ref_idx);
+    if (slot < 0) return -1;
+    memset(c->cur->ref_idx, ref_idx, 4);
+    memset(c->cur->ref_slot, slot, 4);
     return 0;
 }
 
@@ -193,7 +214,7 @@ static int parse_inter(MbCtx *c, int p_type)
             if (p_type == 2) { x = 2 * i; w = 2; shape = 3 + i; }
             /* reference of the quadrants covered by this partition must be known before prediction
              * of the next partition looks at it */
-            if (p_type == 0) { for (int q = 0; q < 4; q++) if (resolve_ref(c, q, (int)ref[0])) P2ERR(c); }
+            if (p_type == 0) { if (resolve_ref_all(c, (int)ref[0])) P2ERR(c); }
             else if (p_type == 1) { if (resolve_ref(c, 2 * i, (int)ref[i]) || resolve_ref(c, 2 * i + 1, (int)ref[i])) P2ERR(c); }
             else { if (resolve_ref(c, i, (int)ref[i]) || resolve_ref(c, i + 2, (int)ref[i])) P2ERR(c); }
             predict_mv(c, x, y, w, (int)ref[i], shape, mvp);
@@ -244,7 +265,7 @@ static int infer_skip(MbCtx *c)
 {
     int16_t mv[2] = { 0, 0 };
     c->done = 0;
-    for (int q = 0; q < 4; q++) if (resolve_ref(c, q, 0)) P2ERR(c);
+    if (resolve_ref_all(c, 0)) P2ERR(c);
     Nb a = nb_at(c, -1, 0), b = nb_at(c, 0, -1);
     if (a.avail && b.avail && !(a.ref == 0 && a.mx == 0 && a.my == 0) && !(b.ref == 0 && b.mx == 0 && b.my == 0))
         predict_mv(c, 0, 0, 4, 0, 0, mv);
@@ -567,6 +588,8 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
             const uint16_t quad = (uint16_t)(0x33u << (2 * (q & 1) + 8 * (q >> 1)));
             if ((keep_old & quad) == quad) rec.ref_slot[q] = old_inter ? recs[addr].ref_slot[q] : 0;
         }
+        if (!keep_old && ((rec.pred >> FJ_PRED_PARTS_SHIFT) & 3) == FJ_PARTS_16x16) memcpy(dst, m->mv, 64);   /* 16 equal vectors: the order does not matter */
+        else
         for (int z = 0; z < 16; z++) {
             const int r = 4 * Z_Y[z] + Z_X[z];
             if (keep_old & (1u << r)) { if (!old_inter) dst[r][0] = dst[r][1] = 0; continue; }
