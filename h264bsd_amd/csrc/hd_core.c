@@ -204,9 +204,19 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
             /* cls bit0: uniform (16 equal mvs, one reference, no coefficients); bit1: additionally whole-sample for
              * luma and chroma -> pure copy */
             const int16_t *m0 = mvs[a][0];
-            const int one_ref = r->ref_slot[0] == r->ref_slot[1] && r->ref_slot[0] == r->ref_slot[2] && r->ref_slot[0] == r->ref_slot[3];
+            uint32_t refs;
+            memcpy(&refs, r->ref_slot, 4);
+            const int one_ref = refs == (refs & 255u) * 0x01010101u;
             int same_mv = one_ref;
-            for (int k = 1; same_mv && k < 16; k++) same_mv = mvs[a][k][0] == m0[0] && mvs[a][k][1] == m0[1];
+            if (same_mv) {                                   /* 16 equal vectors: eight 64-bit words equal to the doubled first */
+                uint64_t w[8], acc = 0;
+                uint32_t first;
+                memcpy(w, mvs[a], 64);
+                memcpy(&first, m0, 4);
+                const uint64_t two = (uint64_t)first << 32 | first;
+                for (int k = 0; k < 8; k++) acc |= w[k] ^ two;
+                same_mv = acc == 0;
+            }
             const int uni = same_mv && r->coded == 0;
             cls[a] = (uint8_t)(uni ? (((m0[0] | m0[1]) & 7) == 0 ? 3 : 1) : 0);
             if (recon && !(cls[a] & 2)) {
