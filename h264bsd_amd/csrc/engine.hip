@@ -147,13 +147,64 @@ int current_device()
  * this comes too late; set GPU_MAX_HW_QUEUES=16 in the environment then. */
 __attribute__((constructor)) static void lib_init() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
-/* Lane configuration: H264BSDMI_LANES="<groups>,<heavy lanes>".  Default 4,2 when the runtime was given enough hardware
- * queues for them (GPU_MAX_HW_QUEUES >= 8, see lib_init below), else one lane = the engine's own stream. */
+/* Lane configuration: H264BSDMI_LANES="<groups>,<heavy lanes>".  Default: 4,2 when HIP streams are found to run side
+ * by side (streams_run_concurrently), else one lane = the engine's own stream. */
+/* Do HIP streams really run side by side here?  The answer depends on how many hardware queues the runtime was started
+ * with, which the library cannot see (and can only influence when it is loaded first): it is measured.  One workgroup
+ * that spins for ~150 us on each of eight fresh streams: side by side they take about as long as one, on shared queues
+ * several times as long.  Returns 1 when the eight ran concurrently. */
+__global__ void k_spin(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) { } }
+
+static int streams_run_concurrently(Engine *e)
+{
+    constexpr int N = 8;
+    hipStream_t st[N] = {};
+    hipEvent_t ev[2] = {};
+    int ok = 1;
+    float one = 0, all = 0;
+    for (auto &s : st) if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) ok = 0;
+    for (auto &v : ev) if (hipEventCreate(&v) != hipSuccess) ok = 0;
+    int rate_khz = 100000;                                         /* wall_clock64 ticks at 100 MHz on gfx9 */
+    if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, e->device) != hipSuccess || rate_khz <= 0) rate_khz = 100000;
+    const long long ticks = (long long)rate_khz * 150 / 1000;      /* 150 us */
+    if (ok) {
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[0], ticks);            /* warm-up: code object load */
+        ok = hipStreamSynchronize(st[0]) == hipSuccess;
+    }
+    if (ok) {
+        hipEventRecord(ev[0], st[0]);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[0], ticks);
+        hipEventRecord(ev[1], st[0]);
+        ok = hipEventSynchronize(ev[1]) == hipSuccess && hipEventElapsedTime(&one, ev[0], ev[1]) == hipSuccess;
+    }
+    if (ok) {
+        /* st[0] starts the clock, waits for the other five, stops it */
+        hipEvent_t done[N] = {};
+        hipEventRecord(ev[0], st[0]);
+        for (int i = 1; i < N; i++) hipStreamWaitEvent(st[i], ev[0], 0);
+        for (int i = 0; i < N; i++) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[i], ticks);
+        for (int i = 1; i < N; i++) {
+            if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) { ok = 0; break; }
+            hipEventRecord(done[i], st[i]);
+            hipStreamWaitEvent(st[0], done[i], 0);
+        }
+        hipEventRecord(ev[1], st[0]);
+        ok = ok && hipEventSynchronize(ev[1]) == hipSuccess && hipEventElapsedTime(&all, ev[0], ev[1]) == hipSuccess;
+        for (auto &d : done) if (d) hipEventDestroy(d);
+    }
+    for (auto &s : st) if (s) hipStreamDestroy(s);
+    for (auto &v : ev) if (v) hipEventDestroy(v);
+    return ok && one > 0 && all < 1.6f * one;       /* 4 hardware queues: two rounds, 2 x */
+}
+
 static int lanes_create(Engine *e)
 {
     unsigned g = 1, k = 0;
-    const char *hwq = getenv("GPU_MAX_HW_QUEUES");
-    if (hwq && atoi(hwq) >= 8) { g = 4; k = 2; }
+    if (!getenv("H264BSDMI_LANES")) {
+        if (streams_run_concurrently(e)) { g = 4; k = 2; }
+        else fprintf(stderr, "h264bsd-mi355x: HIP streams do not run side by side in this process (the runtime was probably started with its "
+                             "default of 4 hardware queues before this library was loaded): one lane; set GPU_MAX_HW_QUEUES=16\n");
+    }
     if (const char *cfg = getenv("H264BSDMI_LANES")) {
         unsigned a = 0, b = 0;
         if (sscanf(cfg, "%u,%u", &a, &b) >= 1 && a >= 1 && a <= 8 && b <= 4) { g = a; k = b; }

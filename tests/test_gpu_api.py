@@ -299,3 +299,23 @@ def test_lane_configurations_of_the_product_engine(lanes):
                         "tests/test_damaged_streams.py", "-k", "not lane_configurations and (batch_api or round_robin or redundant_5 or flipped_30)"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_lane_default_follows_the_measured_stream_concurrency():
+    """The default lane configuration is not guessed from the environment: the engine measures whether HIP streams run
+    side by side (engine.hip: streams_run_concurrently).  With the runtime held to 4 hardware queues it must fall back to
+    one lane and say so; with the library's own request for 16 it must not."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-s", "-m", "gpu", "-p", "no:cacheprovider",
+           "tests/test_gpu_api.py::test_many_instances_round_robin_are_batched_and_exact"]
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "H264BSDMI_LANES")}
+    few = subprocess.run(cmd, cwd=root, env=dict(env, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, timeout=600)
+    assert few.returncode == 0, few.stdout[-1500:] + few.stderr[-1500:]
+    assert "do not run side by side" in few.stdout + few.stderr
+    many = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert many.returncode == 0, many.stdout[-1500:] + many.stderr[-1500:]
+    assert "do not run side by side" not in many.stdout + many.stderr
