@@ -316,6 +316,6 @@ def test_lane_default_follows_the_measured_stream_concurrency():
     few = subprocess.run(cmd, cwd=root, env=dict(env, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, timeout=600)
     assert few.returncode == 0, few.stdout[-1500:] + few.stderr[-1500:]
     assert "do not run side by side" in few.stdout + few.stderr
-    many = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    many = subprocess.run(cmd, cwd=root, env=dict(env, GPU_MAX_HW_QUEUES="16"), capture_output=True, text=True, timeout=600)
     assert many.returncode == 0, many.stdout[-1500:] + many.stderr[-1500:]
     assert "do not run side by side" not in many.stdout + many.stderr
