@@ -966,7 +966,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
             make_desc(d, blobs[p], r->d_blobs + (size_t)s * total + offs[p], r->d_frames + (size_t)s * frames_per_stream,
                       r->frame_bytes, r->d_dbk + (size_t)s * dbk_stride, shape, e->d_err);
         };
-        if (!heavy_lanes) {
+        if (!heavy_lanes && groups <= 1) {
             for (u32 i = 0; i < n_pics; i++) {
                 TickShape shape;                          /* a tick is as large as the largest of its pictures */
                 for (u32 s = 0; s < n_streams; s++) desc_of(descs[(size_t)i * n_streams + s], s, (i + r->offsets[s]) % n_pics, &shape);
@@ -978,7 +978,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
             std::vector<int> last_ev(n_streams, -1);     /* event of the heavy launch a stream's previous picture ran in */
             size_t n_desc = 0;
             u32 left = n_streams, heavy_count = 0;
-            auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[p]); return h->n_intra * 4u > h->n_mbs; };
+            auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[p]); return heavy_lanes && h->n_intra * 4u > h->n_mbs; };      /* (no heavy lanes: heavy pictures stay in their group's tick) */
             /* Cost-affine groups: a group's tick lasts as long as its slowest picture, so streams whose next pictures cost
              * about the same belong together.  Every REGROUP rounds the streams are sorted by the estimated per-picture
              * kernel time of their next REGROUP pictures (from the job headers: intra and filtered macroblock counts) and
