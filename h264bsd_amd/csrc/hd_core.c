@@ -895,11 +895,23 @@ int hd_decode(HostDec *d, uint8_t *stream, uint32_t len, uint32_t pic_id, uint32
             d->prev_buf_not_finished = 1;
             d->skip_redundant = 0;
             if (!d->valid_slice_in_au) {
-                /* no slice header of the picture was ever decoded: the reference conceals into a scratch image that
-                 * is neither stored nor output (decoder.c:244-249, 478: MarkDecRefPic only for a valid slice), so no
-                 * pixels are needed — only the state changes: POC from the previous header, PIC_RDY */
+                /* no slice header of the picture was ever decoded: the reference conceals a whole picture — a copy of the
+                 * first usable reference, else grey — that is neither stored nor output (decoder.c:242-249, 478:
+                 * MarkDecRefPic only for a valid slice).  But it conceals INTO the DPB's spare frame buffer
+                 * (h264bsdAllocateDpbImage), and that buffer goes to the next picture or non-existing frame: a later
+                 * picture that leaves a macroblock unwritten (FJ_MB_STALE) in that buffer shows these pixels.  So the
+                 * pixels are made here too, as a reconstruction-only job into the same buffer. */
                 hd_dpb_init_ref_list(&d->dpb);
                 if (d->mb) reset_picture_state(d);
+                if (d->mb && d->sink.submit && hd_dpb_alloc_current(&d->dpb) >= 0) {
+                    if (hd_job_begin(d)) return HD_MEMALLOC_ERROR;
+                    (void)plan_concealment(d, 1);
+                    d->num_decoded_mbs = d->pic_size_mbs;
+                    if (hd_job_finish(d, 0)) ERR_RETURN;
+                    ((FjHeader *)d->job)->ghost = 1;
+                    if (d->sink.submit(d->sink.user, d->job, ((FjHeader *)d->job)->total_bytes)) ERR_RETURN;
+                    reset_picture_state(d);
+                }
                 (void)hd_decode_poc(&d->poc, d->active_sps, &d->slice, d->cur_nal_type, d->cur_nal_ref_idc);
                 d->pic_started = 0;
                 return HD_PIC_RDY;

@@ -641,8 +641,9 @@ int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_
     do {
         if (!sh->redundant_pic_cnt && d->mb_decoded[addr]) FAIL;
         d->mb_slice_id[addr] = d->slice_id;
-        if (d->mb_decoded[addr]) {
-            /* a redundant slice over a decoded macroblock: the slice-level parameters the deblocking filter uses are
+        if (d->mb_decoded[addr] || d->mb_rec_sid[addr]) {
+            /* a redundant slice over a decoded macroblock (or over one that an earlier redundant slice un-decoded and whose
+             * pixels are still in the picture): the slice-level parameters the deblocking filter uses are
              * restamped before the macroblock is parsed (SetMbParams, slice_data.c:53-66,140), so they change even when
              * the parse then fails; edge flags across slice boundaries are settled at the end of the picture */
             FjMbRec *r = (FjMbRec *)(d->job + ((const FjHeader *)d->job)->rec_off) + addr;
