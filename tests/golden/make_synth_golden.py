@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import synth                      # noqa: E402
-from synth_configs import CONFIGS, DAMAGED, DAMAGED_BUNDLED, FLIPPED, OVERFLOW, REDUNDANT  # noqa: E402
+from synth_configs import CONFIGS, DAMAGED, DAMAGED_BUNDLED, FLIPPED, OVERFLOW, REDUNDANT, SWEEP_FINDS  # noqa: E402
 from damage import damage  # noqa: E402
 from h264writer import StreamWriter  # noqa: E402
 
@@ -31,7 +31,7 @@ for name, (cfg, dmg) in DAMAGED.items():
     out[name] = dict(stream_sha1=hashlib.sha1(data).hexdigest(), bytes=len(data), trace=trace, pics=pics)
     print(name, len(data), "bytes", len(pics), "pictures", sum(p[3] for p in pics), "concealed macroblocks")
 undefined = {}
-for name, (cfg, dmg) in list(FLIPPED.items()) + list(OVERFLOW.items()) + list(REDUNDANT.items()):
+for name, (cfg, dmg) in list(FLIPPED.items()) + list(OVERFLOW.items()) + list(REDUNDANT.items()) + list(SWEEP_FINDS.items()):
     data = damage(StreamWriter(**cfg).build(), **dmg)
     if not synth.reference_is_deterministic(data):
         undefined[name] = "reference output changes with the heap fill byte (glibc M_PERTURB 0x55 / 0xAA): it shows memory it never wrote"

@@ -100,5 +100,21 @@ def _redundant(seed, flip):
 _RED_SEEDS = [_s for _s in range(500, 900) if random_config(_s)["redundant"]][:48]
 REDUNDANT = {f"redundant_{_s}": _redundant(_s, 0.3 if _i >= 32 else 0.0) for _i, _s in enumerate(_RED_SEEDS)}
 
+# ---- streams that the large sweeps of round 2 found (tools/sweep.py): kept as regression fixtures.
+# Heavy damage (30 % of the slice NAL units dropped, 30 % truncated, 50 % with a flipped bit, residuals near the range
+# limit, frame_num gaps and redundant slices kept): a picture concealed without any valid slice that still writes the
+# DPB's spare buffer, and slice parameters restamped over a macroblock that a failed redundant slice had un-decoded.
+def _heavy(seed):
+    cfg = random_config(seed)
+    cfg["overflow"] = 0.03
+    cfg["max_qp"] = max(cfg["max_qp"], 40)
+    return cfg, dict(seed=seed, p_drop=0.3, p_flip=0.5, p_trunc=0.3)
+
+
+SWEEP_FINDS = {f"heavy_{_s}": _heavy(_s) for _s in (300513, 300785, 301141, 305207)}
+SWEEP_FINDS["redundant_flipped_106936"] = (random_config(106936), dict(seed=106936, p_drop=0.2, p_flip=0.2, p_trunc=0.2))
+SWEEP_FINDS["redundant_flipped_5483"] = (dict(random_config(5483), gaps=0), dict(seed=5483, p_drop=0.2, p_flip=0.3, p_trunc=0.2))
+SWEEP_FINDS["redundant_flipped_3053"] = (random_config(3053), dict(seed=3053, p_drop=0.2, p_flip=0.3, p_trunc=0.2))
+
 # a bundled x264 stream (one slice per picture, 40x23 macroblocks) with slices cut short: concealment at picture scale
 DAMAGED_BUNDLED = {"damaged_bundled_640x360": ("test_640x360", dict(seed=7, p_drop=0.04, p_flip=0.0, p_trunc=0.3))}

@@ -18,13 +18,13 @@ import pytest
 import synth
 from damage import damage
 from h264writer import StreamWriter
-from synth_configs import DAMAGED, DAMAGED_BUNDLED, FLIPPED, OVERFLOW, REDUNDANT
+from synth_configs import DAMAGED, DAMAGED_BUNDLED, FLIPPED, OVERFLOW, REDUNDANT, SWEEP_FINDS
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth_golden.json")))
 # streams on which the reference's own output is undefined (it shows memory it never wrote; found by
 # tests/golden/make_synth_golden.py with two heap fill bytes): nothing to be bit-exact with
 UNDEFINED = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_undefined.json")))
-ALL = {**DAMAGED, **FLIPPED, **OVERFLOW, **REDUNDANT}
+ALL = {**DAMAGED, **FLIPPED, **OVERFLOW, **REDUNDANT, **SWEEP_FINDS}
 NAMES = [n for n in list(ALL) + list(DAMAGED_BUNDLED) if n not in UNDEFINED]
 _streams = {}
 
