@@ -756,7 +756,10 @@ static void mark_slice_corrupted(HostDec *d, uint32_t first_mb)
     do {
         if (hd_trace) fprintf(stderr, "TRACE   mb %u sid %u decoded %u\n", addr, d->mb_slice_id[addr], d->mb_decoded[addr]);
         if (d->mb_slice_id[addr] != sid || !d->mb_decoded[addr]) break;
-        if (--d->mb_decoded[addr] == 0 && d->mb_rec_sid[addr] == sid) {
+        /* (a macroblock of this slice that was written over an earlier slice's version — set aside in RedoMb — stays: the
+         * picture's macroblock count already includes it, so the picture can complete without concealment and then shows
+         * exactly these pixels, filtered with this metadata) */
+        if (--d->mb_decoded[addr] == 0 && d->mb_rec_sid[addr] == sid && !(d->mb_redone && d->mb_redone[addr])) {
             if (recs[addr].kind != FJ_MB_ABSENT && recs[addr].coef_idx < cut) cut = recs[addr].coef_idx;
             if (d->mb_ghost && makes_pixels(recs[addr].kind)) { d->mb_ghost[addr] = 1; d->ghost_dirty = 1; }
             recs[addr].kind = FJ_MB_ABSENT;

@@ -557,7 +557,8 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
         FAIL;
     }
 
-    if (first_decode && d->mb_rec_sid[addr] && recs[addr].kind != FJ_MB_ABSENT && recs[addr].kind != FJ_MB_STALE) {
+    if (first_decode && d->mb_redone && d->mb_redone[addr]) rec.pred |= FJ_PRED_PHASE2;   /* an earlier version is already set aside: this one is written on top of it */
+    else if (first_decode && d->mb_rec_sid[addr] && recs[addr].kind != FJ_MB_ABSENT && recs[addr].kind != FJ_MB_STALE) {
         /* A macroblock that a failed redundant slice un-decoded (hd_core.c, mark_slice_corrupted) is decoded anew: the
          * reference writes it again, over pixels that other macroblocks may have predicted from.  Those are reconstructed
          * first (RedoMb), this decode on top of them. */

@@ -113,6 +113,7 @@ def _heavy(seed):
 
 SWEEP_FINDS = {f"heavy_{_s}": _heavy(_s) for _s in (300513, 300785, 301141, 305207)}
 SWEEP_FINDS["redundant_flipped_106936"] = (random_config(106936), dict(seed=106936, p_drop=0.2, p_flip=0.2, p_trunc=0.2))
+SWEEP_FINDS["redundant_flipped_505161"] = (random_config(505161), dict(seed=505161, p_drop=0.2, p_flip=0.2, p_trunc=0.2))
 SWEEP_FINDS["redundant_flipped_5483"] = (dict(random_config(5483), gaps=0), dict(seed=5483, p_drop=0.2, p_flip=0.3, p_trunc=0.2))
 SWEEP_FINDS["redundant_flipped_3053"] = (random_config(3053), dict(seed=3053, p_drop=0.2, p_flip=0.3, p_trunc=0.2))
 
