@@ -823,7 +823,11 @@ static uint32_t plan_concealment(HostDec *d, int p_type)
     } while (0)
 
     if (first == n) {
-        /* nothing of the picture survived */
+        /* nothing of the picture survived: no pixel of it is shown or was predicted from by anything that remains, so
+         * first and second versions of macroblocks (RedoMb) are of no interest either */
+        if (d->n_redo && d->mb_redone) memset(d->mb_redone, 0, n);
+        d->n_redo = 0;
+        memset(d->mb_rec_sid, 0, (size_t)n * sizeof(uint32_t));
         if (ref_slot >= 0) {
             for (uint32_t a = 0; a < n; a++) CONCEAL_ONE(a, 1);
         } else {

@@ -111,7 +111,7 @@ def _heavy(seed):
     return cfg, dict(seed=seed, p_drop=0.3, p_flip=0.5, p_trunc=0.3)
 
 
-SWEEP_FINDS = {f"heavy_{_s}": _heavy(_s) for _s in (300513, 300785, 301141, 305207)}
+SWEEP_FINDS = {f"heavy_{_s}": _heavy(_s) for _s in (300513, 300785, 301141, 305207, 800227)}
 SWEEP_FINDS["redundant_flipped_106936"] = (random_config(106936), dict(seed=106936, p_drop=0.2, p_flip=0.2, p_trunc=0.2))
 SWEEP_FINDS["redundant_flipped_505161"] = (random_config(505161), dict(seed=505161, p_drop=0.2, p_flip=0.2, p_trunc=0.2))
 SWEEP_FINDS["redundant_flipped_5483"] = (dict(random_config(5483), gaps=0), dict(seed=5483, p_drop=0.2, p_flip=0.3, p_trunc=0.2))
