@@ -43,6 +43,9 @@ typedef struct MbCtx {
     uint32_t addr, mbx, mby;
     MbInfo *cur, *A, *B, *C, *D;   /* NULL when outside the picture or another slice */
     uint16_t done;                 /* raster bit per 4x4 block of cur whose mv/ref is final */
+    uint8_t  ok_quads;             /* P_8x8: quadrants whose reference was written before the first such error — the reference
+                                      writes refPic / refAddr of a sub-macroblock BEFORE it checks them
+                                      (inter_prediction.c:805-811), so the failing quadrant carries "no picture" */
     uint16_t ok_blocks;            /* ... and was final before the first reconstruction-time error (p2err): the reference
                                       writes motion vectors and references partition by partition and stops at the first
                                       one that fails (inter_prediction.c:520-565 and the partitioned variants) */
@@ -243,7 +246,8 @@ static int parse_inter(MbCtx *c, int p_type)
     if (br_overrun(br)) FAIL;
     k = 0;
     for (int i = 0; i < 4; i++) {
-        if (resolve_ref(c, i, (int)ref[i])) P2ERR(c);
+        if (!c->p2err) c->ok_quads |= (uint8_t)(1u << i);
+        if (resolve_ref(c, i, (int)ref[i])) { if (!c->p2err) c->cur->ref_slot[i] = 0xFF; P2ERR(c); }   /* 0xFF: "no picture", unequal to every slot */
         const int bx = (i & 1) * 2, by = (i >> 1) * 2;
         const int sw = (sub[i] == 0 || sub[i] == 1) ? 2 : 1;   /* 8x8, 8x4 are 2 blocks wide */
         const int shh = (sub[i] == 0 || sub[i] == 2) ? 2 : 1;  /* 8x8, 4x8 are 2 blocks high */
@@ -587,7 +591,7 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
         const int old_inter = recs[addr].kind == FJ_MB_INTER;
         for (int q = 0; q < 4; q++) {
             const uint16_t quad = (uint16_t)(0x33u << (2 * (q & 1) + 8 * (q >> 1)));
-            if ((keep_old & quad) == quad) rec.ref_slot[q] = old_inter ? recs[addr].ref_slot[q] : 0;
+            if ((keep_old & quad) == quad && !(c.ok_quads & (1u << q))) rec.ref_slot[q] = old_inter ? recs[addr].ref_slot[q] : 0;
         }
         if (!keep_old && ((rec.pred >> FJ_PRED_PARTS_SHIFT) & 3) == FJ_PARTS_16x16) memcpy(dst, m->mv, 64);   /* 16 equal vectors: the order does not matter */
         else

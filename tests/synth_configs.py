@@ -119,3 +119,5 @@ SWEEP_FINDS["redundant_flipped_3053"] = (random_config(3053), dict(seed=3053, p_
 
 # a bundled x264 stream (one slice per picture, 40x23 macroblocks) with slices cut short: concealment at picture scale
 DAMAGED_BUNDLED = {"damaged_bundled_640x360": ("test_640x360", dict(seed=7, p_drop=0.04, p_flip=0.0, p_trunc=0.3))}
+for _s in (956431, 953258):                     # P_8x8 re-decode failing on a missing reference: the failing quadrant's refAddr is already NULL
+    SWEEP_FINDS[f"redundant_flipped_{_s}"] = (random_config(_s), dict(seed=_s, p_drop=0.1, p_flip=0.3, p_trunc=0.1))
