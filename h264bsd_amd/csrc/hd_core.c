@@ -51,6 +51,7 @@ void hd_destroy(HostDec *d)
     free(d->mb_ghost);
     free(d->redo);
     free(d->mb_redone);
+    free(d->redo2);
     free(d->nal_buf);
     if (!d->job_from_sink) free(d->job);
     free(d->conv_buf);
@@ -430,13 +431,13 @@ static int activate_param_sets(HostDec *d, uint32_t pps_id, int is_idr)
         free(d->mb_slice_id);
         free(d->mb_rec_sid);
         free(d->mb_ghost); d->mb_ghost = NULL; d->ghost_dirty = 0; d->ghost_len = 0;
-        free(d->mb_redone); d->mb_redone = NULL; d->n_redo = 0;
+        free(d->mb_redone); d->mb_redone = NULL; d->n_redo = 0; d->n_redo2 = 0;
         d->mb_decoded = (uint8_t *)calloc(d->pic_size_mbs, 1);
         d->mb_slice_id = (uint32_t *)calloc(d->pic_size_mbs, sizeof(uint32_t));
         d->mb_rec_sid = (uint32_t *)calloc(d->pic_size_mbs, sizeof(uint32_t));
         d->slice_group_map = (uint32_t *)calloc(d->pic_size_mbs, sizeof(uint32_t));
         if (!d->mb || !d->slice_group_map || !d->mb_decoded || !d->mb_slice_id || !d->mb_rec_sid) return -2;
-        for (uint32_t i = 0; i < d->pic_size_mbs; i++) d->mb[i].kind = FJ_MB_ABSENT;
+        for (uint32_t i = 0; i < d->pic_size_mbs; i++) { d->mb[i].kind = FJ_MB_ABSENT; memset(d->mb[i].ref_slot, 0xFF, 4); }   /* 0xFF: refAddr NULL */
         const Sps *s = d->active_sps;
         int no_reorder = d->no_reordering_app || s->poc_type == 2 ||
                          (s->vui_present && s->bitstream_restriction && s->num_reorder_frames == 0);
@@ -531,7 +532,7 @@ static void reset_picture_state(HostDec *d)
     d->ghost_dirty = d->ghost_needed = 0;
     d->ghost_len = 0;
     if (d->n_redo && d->mb_redone) memset(d->mb_redone, 0, d->pic_size_mbs);
-    d->n_redo = 0;
+    d->n_redo = 0; d->n_redo2 = 0;
     d->slice_ids_rewritten = 0;
 }
 
@@ -666,7 +667,26 @@ static int ghost_submit(HostDec *d)
 int hd_redo_keep_first(HostDec *d, uint32_t addr, const FjMbRec *rec, const int16_t *mv)
 {
     if (!d->mb_redone && !(d->mb_redone = (uint8_t *)calloc(d->pic_size_mbs, 1))) return -1;
-    if (d->mb_redone[addr]) return 0;                      /* decoded a third time: the FIRST decode made the pixels */
+    if (d->mb_redone[addr]) {
+        /* decoded a third time: the FIRST decode made the pixels — unless the record being replaced is itself a version
+         * that was written over them (FJ_PRED_PHASE2); that one still has to be reconstructed, after the first decodes
+         * and before whatever the final records add */
+        if (!(rec->pred & FJ_PRED_PHASE2) || !makes_pixels(rec->kind)) return 0;
+        struct RedoMb *r = NULL;
+        for (uint32_t i = 0; i < d->n_redo2; i++) if (d->redo2[i].addr == addr) r = &d->redo2[i];
+        if (!r) {
+            if (d->n_redo2 == d->redo2_cap) {
+                const uint32_t cap = d->redo2_cap ? 2 * d->redo2_cap : 16;
+                struct RedoMb *nb = (struct RedoMb *)realloc(d->redo2, (size_t)cap * sizeof(*nb));
+                if (!nb) return -1;
+                d->redo2 = nb; d->redo2_cap = cap;
+            }
+            r = &d->redo2[d->n_redo2++];
+        }
+        r->addr = addr; r->rec = *rec;
+        memcpy(r->mv, mv, 64);
+        return 0;
+    }
     if (d->n_redo == d->redo_cap) {
         const uint32_t cap = d->redo_cap ? 2 * d->redo_cap : 64;
         struct RedoMb *nb = (struct RedoMb *)realloc(d->redo, (size_t)cap * sizeof(*nb));
@@ -700,8 +720,9 @@ static void restamp_slice_edges(HostDec *d)
     }
 }
 
-static uint8_t *redo_split(HostDec *d)
+static uint8_t *redo_split(HostDec *d, uint8_t **between)
 {
+    *between = NULL;
     FjHeader *h = (FjHeader *)d->job;
     const uint32_t n = d->pic_size_mbs;
     const size_t used = (size_t)h->coef_off + (size_t)d->coef_blocks * 32u;
@@ -714,6 +735,23 @@ static uint8_t *redo_split(HostDec *d)
         const struct RedoMb *r = &d->redo[i];
         grecs[r->addr] = r->rec;
         memcpy(blob + gh->mv_off + (size_t)r->addr * 64u, r->mv, 64);
+    }
+    if (d->n_redo2) {
+        /* versions written over a first decode and hidden again by later metadata: a job that reconstructs only them */
+        uint8_t *mid = (uint8_t *)malloc(d->job_cap);
+        if (!mid) { free(blob); return NULL; }
+        memcpy(mid, d->job, used);
+        FjHeader *mh = (FjHeader *)mid;
+        FjMbRec *mrecs = (FjMbRec *)(mid + mh->rec_off);
+        for (uint32_t a = 0; a < n; a++) { mrecs[a].pred &= (uint8_t)~FJ_PRED_PHASE2; mrecs[a].dbk = 0; }
+        for (uint32_t i = 0; i < d->n_redo2; i++) {
+            const struct RedoMb *r = &d->redo2[i];
+            mrecs[r->addr] = r->rec;
+            mrecs[r->addr].dbk = 0;
+            memcpy(mid + mh->mv_off + (size_t)r->addr * 64u, r->mv, 64);
+        }
+        mh->ghost = 1; mh->dbk_only = 1;
+        *between = mid;
     }
     /* concealment comes after everything that was decoded (conceal.c works on the finished picture): all of it moves
      * to the second job, where a synthesised macroblock finds its neighbours as the reference does */
@@ -826,7 +864,7 @@ static uint32_t plan_concealment(HostDec *d, int p_type)
         /* nothing of the picture survived: no pixel of it is shown or was predicted from by anything that remains, so
          * first and second versions of macroblocks (RedoMb) are of no interest either */
         if (d->n_redo && d->mb_redone) memset(d->mb_redone, 0, n);
-        d->n_redo = 0;
+        d->n_redo = 0; d->n_redo2 = 0;
         memset(d->mb_rec_sid, 0, (size_t)n * sizeof(uint32_t));
         if (ref_slot >= 0) {
             for (uint32_t a = 0; a < n; a++) CONCEAL_ONE(a, 1);
@@ -1010,20 +1048,22 @@ int hd_decode(HostDec *d, uint8_t *stream, uint32_t len, uint32_t pic_id, uint32
     /* picture complete: queue the frame job, then do the bookkeeping the reference does after
      * deblocking (decoder.c:473-510) */
     const int is_idr = d->cur_nal_type == 5;
-    uint8_t *first_decodes = NULL;
+    uint8_t *earlier[2] = { NULL, NULL };      /* first decodes; versions written over them (redo_split) */
     fill_undecoded(d);
     if (d->slice_ids_rewritten) restamp_slice_edges(d);
-    if (d->n_redo && !(first_decodes = redo_split(d))) ERR_RETURN;
-    if (hd_job_finish(d, is_idr)) { free(first_decodes); ERR_RETURN; }
-    if (d->ghost_needed && ghost_submit(d)) { free(first_decodes); ERR_RETURN; }
-    if (first_decodes) {
-        FjHeader *gh = (FjHeader *)first_decodes;
-        const FjHeader *mh = (const FjHeader *)d->job;
-        int rc = fj_finalize(first_decodes, d->job_cap, mh->n_coef_blocks);
-        gh->cur_slot = mh->cur_slot; gh->n_slots = mh->n_slots; gh->is_idr = mh->is_idr; gh->pic_seq = mh->pic_seq;
-        if (!rc && d->sink.submit && d->sink.submit(d->sink.user, first_decodes, gh->total_bytes)) rc = -1;
-        free(first_decodes);
-        if (rc) ERR_RETURN;
+    if (d->n_redo && !(earlier[0] = redo_split(d, &earlier[1]))) ERR_RETURN;
+    if (hd_job_finish(d, is_idr)) { free(earlier[0]); free(earlier[1]); ERR_RETURN; }
+    if (d->ghost_needed && ghost_submit(d)) { free(earlier[0]); free(earlier[1]); ERR_RETURN; }
+    for (int k = 0, rc = 0; k < 2; k++) {
+        if (earlier[k] && !rc) {
+            FjHeader *gh = (FjHeader *)earlier[k];
+            const FjHeader *mh = (const FjHeader *)d->job;
+            rc = fj_finalize(earlier[k], d->job_cap, mh->n_coef_blocks);
+            gh->cur_slot = mh->cur_slot; gh->n_slots = mh->n_slots; gh->is_idr = mh->is_idr; gh->pic_seq = mh->pic_seq;
+            if (!rc && d->sink.submit && d->sink.submit(d->sink.user, earlier[k], gh->total_bytes)) rc = -1;
+        }
+        free(earlier[k]);
+        if (k == 1 && rc) ERR_RETURN;
     }
     if (d->sink.submit && d->sink.submit(d->sink.user, d->job, ((FjHeader *)d->job)->total_bytes)) {
         fprintf(stderr, "h264bsd-mi355x: frame job submission failed\n");

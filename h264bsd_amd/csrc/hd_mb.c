@@ -50,6 +50,13 @@ typedef struct MbCtx {
                                       writes motion vectors and references partition by partition and stops at the first
                                       one that fails (inter_prediction.c:520-565 and the partitioned variants) */
     uint32_t coef_start;           /* first coefficient block of this macroblock */
+    /* What the macroblock carried before this decode (the reference's mbStorage_t keeps mv / refPic / refAddr across
+     * decodes AND across pictures, only MvPrediction writes them, inter_prediction.c:520-821): the parts a failing
+     * decode did not reach get it back (restore_unwritten). */
+    uint8_t  have_old;
+    int8_t   old_ref_idx[4];
+    uint8_t  old_ref_slot[4];
+    int16_t  old_mv[16][2];
     int p2err;                     /* an error the reference only finds when it RECONSTRUCTS the macroblock
                                       (h264bsdDecodeMacroblock: missing reference picture, motion vector range, intra
                                       mode without its neighbours) — i.e. after the whole macroblock_layer() has been
@@ -200,6 +207,10 @@ static int parse_inter(MbCtx *c, int p_type)
     const uint32_t n_active = c->sh->num_ref_idx_active;
     int16_t mvd[16][2], mvp[2], mv[2];
     c->done = 0;
+    c->have_old = 1;
+    memcpy(c->old_ref_idx, c->cur->ref_idx, 4);
+    memcpy(c->old_ref_slot, c->cur->ref_slot, 4);
+    memcpy(c->old_mv, c->cur->mv, 64);
 
     if (p_type <= 2) {
         const int nparts = p_type == 0 ? 1 : 2;
@@ -269,12 +280,26 @@ static int infer_skip(MbCtx *c)
 {
     int16_t mv[2] = { 0, 0 };
     c->done = 0;
-    if (resolve_ref_all(c, 0)) P2ERR(c);
+    if (resolve_ref_all(c, 0)) { P2ERR(c); return 0; }     /* nothing written (inter_prediction.c:547-551) */
     Nb a = nb_at(c, -1, 0), b = nb_at(c, 0, -1);
     if (a.avail && b.avail && !(a.ref == 0 && a.mx == 0 && a.my == 0) && !(b.ref == 0 && b.mx == 0 && b.my == 0))
         predict_mv(c, 0, 0, 4, 0, 0, mv);
     if (set_partition(c, 0, 0, 4, 4, 0, mv)) P2ERR(c);
     return 0;
+}
+
+/* A decode that failed while the reference reconstructed it (p2err): motion vectors and references the reference had
+ * not written by then are what the macroblock carried before — possibly from an earlier picture. */
+static void restore_unwritten(MbCtx *c)
+{
+    if (!c->have_old) return;
+    MbInfo *m = c->cur;
+    for (int q = 0; q < 4; q++) {
+        const uint16_t quad = (uint16_t)(0x33u << (2 * (q & 1) + 8 * (q >> 1)));
+        if ((c->ok_blocks & quad) != quad && !(c->ok_quads & (1u << q))) { m->ref_idx[q] = c->old_ref_idx[q]; m->ref_slot[q] = c->old_ref_slot[q]; }
+    }
+    for (int z = 0; z < 16; z++)
+        if (!(c->ok_blocks & (1u << (4 * Z_Y[z] + Z_X[z])))) { m->mv[z][0] = c->old_mv[z][0]; m->mv[z][1] = c->old_mv[z][1]; }
 }
 
 /* ---------------------------------------------------------------- Intra4x4PredMode, 8.3.1.1 */
@@ -530,9 +555,10 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
         qi = qi < 0 ? 0 : qi > 51 ? 51 : qi;
         if (hd_residual_out_of_range(coefs + 16u * coef_start, rec.coded, m->qp, qpc_table[qi], rec.kind == FJ_MB_I16x16)) {
             P2ERR(&c);
-            c.ok_blocks = 0;          /* the residual is processed before the prediction: no motion vector was written */
+            c.ok_blocks = 0; c.ok_quads = 0;   /* the residual is processed before the prediction: no motion vector was written */
         }
     }
+    if (c.p2err) restore_unwritten(&c);
     if (c.p2err && first_decode) {
         {
             /* Counted as decoded, never reconstructed.  The reference has by now stored the macroblock type, the
@@ -585,19 +611,12 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
     if (rec.kind == FJ_MB_INTER) {
         memcpy(rec.ref_slot, m->ref_slot, 4);
         int16_t (*dst)[2] = mvs[addr];
-        /* a redundant decode that failed while it reconstructed: the partitions from the failing one on keep what the
-         * macroblock had before (only reachable with !first_decode, see the p2err exit above) */
-        const uint16_t keep_old = c.p2err ? (uint16_t)~c.ok_blocks : 0;
-        const int old_inter = recs[addr].kind == FJ_MB_INTER;
-        for (int q = 0; q < 4; q++) {
-            const uint16_t quad = (uint16_t)(0x33u << (2 * (q & 1) + 8 * (q >> 1)));
-            if ((keep_old & quad) == quad && !(c.ok_quads & (1u << q))) rec.ref_slot[q] = old_inter ? recs[addr].ref_slot[q] : 0;
-        }
-        if (!keep_old && ((rec.pred >> FJ_PRED_PARTS_SHIFT) & 3) == FJ_PARTS_16x16) memcpy(dst, m->mv, 64);   /* 16 equal vectors: the order does not matter */
+        /* (a redundant decode that failed while it reconstructed: m->mv / m->ref_slot are what the reference's
+         * mbStorage_t holds, restore_unwritten) */
+        if (!c.p2err && ((rec.pred >> FJ_PRED_PARTS_SHIFT) & 3) == FJ_PARTS_16x16) memcpy(dst, m->mv, 64);   /* 16 equal vectors: the order does not matter */
         else
         for (int z = 0; z < 16; z++) {
             const int r = 4 * Z_Y[z] + Z_X[z];
-            if (keep_old & (1u << r)) { if (!old_inter) dst[r][0] = dst[r][1] = 0; continue; }
             dst[r][0] = m->mv[z][0];
             dst[r][1] = m->mv[z][1];
         }

@@ -296,6 +296,11 @@ typedef struct HostDec {
      * they go into a reconstruction-only job, and the picture's own job only deblocks (FjHeader.dbk_only). */
     struct RedoMb { uint32_t addr; FjMbRec rec; int16_t mv[32]; } *redo;
     uint32_t n_redo, redo_cap;
+    /* ... and pixel-making versions written ON TOP of a first decode (FJ_PRED_PHASE2: a macroblock that a failed slice
+     * un-decoded, decoded anew) whose metadata a still later decode replaced: they get a reconstruction-only job of their
+     * own between the two */
+    struct RedoMb *redo2;
+    uint32_t n_redo2, redo2_cap;
     uint8_t *mb_redone;     /* per macroblock, allocated on first use */
     uint8_t  slice_ids_rewritten;   /* a redundant slice ran over macroblocks of this picture (it restamps their slice id even when it fails) */
 

@@ -121,3 +121,5 @@ SWEEP_FINDS["redundant_flipped_3053"] = (random_config(3053), dict(seed=3053, p_
 DAMAGED_BUNDLED = {"damaged_bundled_640x360": ("test_640x360", dict(seed=7, p_drop=0.04, p_flip=0.0, p_trunc=0.3))}
 for _s in (956431, 953258):                     # P_8x8 re-decode failing on a missing reference: the failing quadrant's refAddr is already NULL
     SWEEP_FINDS[f"redundant_flipped_{_s}"] = (random_config(_s), dict(seed=_s, p_drop=0.1, p_flip=0.3, p_trunc=0.1))
+for _s in (971573, 972160):                     # stale motion state from an earlier picture under a failed re-decode; three versions of one macroblock
+    SWEEP_FINDS[f"redundant_flipped_{_s}"] = (dict(random_config(_s), gaps=0), dict(seed=_s, p_drop=0.05, p_flip=0.4, p_trunc=0.05))
