@@ -15,6 +15,7 @@
  *  - motion vectors outside [-8192,8191] x [-2048,2047] quarter-pels are a decode error
  *    (inter_prediction.c:538-544).
  */
+#include <stddef.h>
 #include <string.h>
 #include "hostdec.h"
 
@@ -50,18 +51,18 @@ typedef struct MbCtx {
                                       writes motion vectors and references partition by partition and stops at the first
                                       one that fails (inter_prediction.c:520-565 and the partitioned variants) */
     uint32_t coef_start;           /* first coefficient block of this macroblock */
-    /* What the macroblock carried before this decode (the reference's mbStorage_t keeps mv / refPic / refAddr across
-     * decodes AND across pictures, only MvPrediction writes them, inter_prediction.c:520-821): the parts a failing
-     * decode did not reach get it back (restore_unwritten). */
-    uint8_t  have_old;
-    int8_t   old_ref_idx[4];
-    uint8_t  old_ref_slot[4];
-    int16_t  old_mv[16][2];
+    uint8_t  have_old;             /* old_* below are filled in (parse_inter) */
     int p2err;                     /* an error the reference only finds when it RECONSTRUCTS the macroblock
                                       (h264bsdDecodeMacroblock: missing reference picture, motion vector range, intra
                                       mode without its neighbours) — i.e. after the whole macroblock_layer() has been
                                       parsed and after mb.decoded was incremented (macroblock_layer.c:988).  Recorded
                                       here, acted upon once parsing of the macroblock has succeeded. */
+    /* What the macroblock carried before this decode (the reference's mbStorage_t keeps mv / refPic / refAddr across
+     * decodes AND across pictures, only MvPrediction writes them, inter_prediction.c:520-821): the parts a failing
+     * decode did not reach get it back (restore_unwritten). */
+    int8_t   old_ref_idx[4];
+    uint8_t  old_ref_slot[4];
+    int16_t  old_mv[16][2];
 } MbCtx;
 
 static inline MbInfo *usable(HostDec *d, uint32_t idx, uint32_t slice_id) { return d->mb_slice_id[idx] == slice_id ? &d->mb[idx] : NULL; }
@@ -441,7 +442,7 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
     int16_t *coefs = (int16_t *)(d->job + hdr->coef_off);
 
     MbCtx c;
-    memset(&c, 0, sizeof(c));
+    memset(&c, 0, offsetof(MbCtx, old_ref_idx));    /* (old_* are written before they are read: have_old) */
     c.d = d; c.br = br; c.sh = sh; c.pps = pps;
     c.coef_start = d->coef_blocks;
     c.addr = addr; c.mbx = addr % d->width_mbs; c.mby = addr / d->width_mbs;

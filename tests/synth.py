@@ -15,44 +15,34 @@ from oracle import pyoracle
 
 _libc = ctypes.CDLL(None)
 M_PERTURB = -6      # <malloc.h>: every malloc'd block is filled with ~value (glibc)
+ZERO_HEAP = 0xFF    # ... so this makes every block the reference mallocs start out as zeros
 
 
 def reference_is_deterministic(data, no_output_reordering=0):
     """The reference never initialises its frame buffers (src/h264bsd_dpb.c:1026 ALLOCATE, no memset), and on some
     damaged streams it outputs macroblocks it never wrote (e.g. a macroblock whose reconstruction failed but which
-    h264bsdMarkSliceCorrupted does not reach).  Such output is whatever the heap held: undefined behaviour, not a
-    parity target.  Detected by decoding twice with glibc's M_PERTURB fill set to two different bytes."""
-    outs = []
-    for fill in (0x55, 0xAA):
-        _libc.mallopt(M_PERTURB, fill)
-        try:
-            outs.append(decode_reference(data, no_output_reordering))
-        finally:
-            _libc.mallopt(M_PERTURB, 0)
-    return outs[0] == outs[1]
+    h264bsdMarkSliceCorrupted does not reach), or predicts from them.  Such output is whatever the heap held.
+    Detected by decoding twice with glibc's M_PERTURB fill set to two different bytes.  (Informational: the parity
+    target on such streams is the reference with zeroed frame buffers, see decode_reference.)"""
+    return decode_reference(data, no_output_reordering, 0x55) == decode_reference(data, no_output_reordering, 0xAA)
 
 
-def defined_part_matches(data, ref, ours, no_output_reordering=0):
-    """For a stream on which the reference is NOT deterministic: the call trace and every output picture that comes out
-    the same from three reference runs (default heap, M_PERTURB 0x55, 0xAA) are still a parity target.
-    -> (ok, number of pictures that could be compared)"""
-    outs = [ref]
-    for fill in (0x55, 0xAA):
-        _libc.mallopt(M_PERTURB, fill)
-        try:
-            outs.append(decode_reference(data, no_output_reordering))
-        finally:
-            _libc.mallopt(M_PERTURB, 0)
-    if not (outs[0][0] == outs[1][0] == outs[2][0]):
-        return True, 0                        # even the calls depend on the heap: nothing to compare
-    if ours[0] != ref[0] or len(ours[1]) != len(ref[1]):
-        return False, 0
-    defined = [i for i in range(len(ref[1])) if outs[0][1][i] == outs[1][1][i] == outs[2][1][i]]
-    return all(ours[1][i] == ref[1][i] for i in defined), len(defined)
+def decode_reference(data, no_output_reordering=0, heap_fill=ZERO_HEAP):
+    """-> (trace, [(sha1 of frame, picId, isIdr, numErrMbs)])
+
+    The compiled reference is run with glibc's M_PERTURB set so that everything it mallocs starts out as zeros: its
+    frame buffers are the only memory it reads before writing (every other allocation is memset, src/h264bsd_dpb.c:
+    1014-1045, src/h264bsd_storage.c:347-352), a fresh process gets them zeroed from the kernel anyway, and with that
+    the reference is a deterministic function of the stream also on the damaged streams that make it show or predict
+    from pixels it never wrote.  This repository's frame buffers start out zeroed too (engine.hip sink_configure)."""
+    _libc.mallopt(M_PERTURB, heap_fill)
+    try:
+        return _decode_reference(data, no_output_reordering)
+    finally:
+        _libc.mallopt(M_PERTURB, 0)
 
 
-def decode_reference(data, no_output_reordering=0):
-    """-> (trace, [(sha1 of frame, picId, isIdr, numErrMbs)])"""
+def _decode_reference(data, no_output_reordering):
     ref = pyoracle.RefDecoder()
     lib = ref.lib
     buf = ctypes.create_string_buffer(data, len(data))

@@ -62,7 +62,8 @@ DAMAGED = {f"damaged_{_s}": _damaged(_s) for _s in range(0, 48)}
 # shows.  frame_num gaps stay in; redundant slices are still left out ("known deviations").
 # Some damaged streams make the reference OUTPUT memory it never initialised (a macroblock it counts as decoded but
 # never wrote, in a frame buffer used for the first time): tests/golden/make_synth_golden.py finds those by decoding
-# with two different heap fill bytes and lists them in tests/golden/reference_undefined.json; they are skipped.
+# with two different heap fill bytes and lists them in tests/golden/reference_undefined.json; their golden answers (like
+# all others) come from the reference run with its allocations starting out zeroed (tests/synth.py decode_reference).
 def _flipped(seed):
     cfg = random_config(seed)
     cfg["redundant"] = False

@@ -109,20 +109,16 @@ def _live_sweep(first, count, damaged, backend):
     from h264writer import random_config
     if not os.path.exists(pyoracle.REF_SO):
         pytest.skip("oracle/_ref not built")
-    bad, undefined = [], []
+    bad = []
     for seed in range(first, first + count):
         cfg = random_config(seed)
-        if damaged:
-            cfg["redundant"] = False                          # redundant slices + damage: known deviation, DESIGN.md §2
         data = StreamWriter(**cfg).build()
         if damaged:
             data = dmg.damage(data, seed, p_drop=0.15, p_flip=0.25, p_trunc=0.15)
         nor = 0 if damaged else seed & 1
         if synth.decode_reference(data, nor) != synth.decode_ours(data, backend, nor):
-            # not a mismatch when the reference itself shows memory it never wrote (synth.reference_is_deterministic)
-            (bad if synth.reference_is_deterministic(data, nor) else undefined).append(seed)
+            bad.append(seed)
     assert not bad, f"seeds {bad} differ from the reference"
-    assert len(undefined) <= count // 5, f"suspiciously many streams with undefined reference output: {undefined}"
 
 
 def test_random_streams_match_live_reference(built):

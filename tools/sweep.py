@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Parity sweep on the CPU: random valid streams from the bitstream writer (tests/h264writer.py), optionally damaged,
-decoded by the compiled reference (oracle/_ref) and by the host parser + oracle; the h264bsdDecode call traces and the
+decoded by the compiled reference (oracle/_ref, every allocation starting out zeroed: tests/synth.py) and by the host parser + oracle; the h264bsdDecode call traces and the
 output pictures (hash, picId, isIdr, numErrMbs, order) must be identical.  TEST TOOL (uses oracle/): never imported by
 the product.  usage: sweep.py <first seed> <count> [--damage] [--backend gpu]"""
 import argparse, os, sys, time
@@ -18,7 +18,7 @@ ap.add_argument("--keep-redundant", action="store_true"); ap.add_argument("--kee
 ap.add_argument("--backend", default="oracle", choices=("oracle", "gpu"), help="gpu = the product through the C ABI (needs an MI355X)")
 args = ap.parse_args()
 os.dup2(os.open(os.devnull, os.O_WRONLY), 2)      # the reference is built with _ERROR_PRINT
-bad, undef, t0, n_pics, n_defined = [], [], time.time(), 0, 0
+bad, t0, n_pics = [], time.time(), 0
 for seed in range(args.first, args.first + args.count):
     try:
         cfg = h264writer.random_config(seed)
@@ -33,20 +33,11 @@ for seed in range(args.first, args.first + args.count):
         ref = synth.decode_reference(data, nor)
         ours = synth.decode_ours(data, args.backend, nor)
         n_pics += len(ref[1])
-        if ref != ours and not synth.reference_is_deterministic(data, nor):
-            undef.append(seed)                  # the reference's own output depends on uninitialised heap memory ...
-            ok, n_def = synth.defined_part_matches(data, ref, ours, nor)   # ... but the pictures that do not are still compared
-            n_defined += n_def
-            if not ok:
-                bad.append(seed); undef.pop()
-                print(f"MISMATCH seed {seed} in a picture that is the same in three reference runs with different heap fills", flush=True)
-        elif ref != ours:
+        if ref != ours:
             bad.append(seed)
             print(f"MISMATCH seed {seed}: trace equal {ref[0] == ours[0]}, pictures {len(ref[1])} vs {len(ours[1])}", flush=True)
     except Exception as e:                      # a writer/config problem is reported, not hidden
         bad.append(seed)
         print(f"ERROR seed {seed}: {type(e).__name__}: {e}", flush=True)
-print(f"[{args.backend}] seeds {args.first}..{args.first + args.count - 1}{' damaged' if args.damage else ''}: {args.count - len(bad) - len(undef)} identical, "
-      f"{len(bad)} not ({bad[:20]}); {n_pics} pictures compared, {time.time() - t0:.0f} s"
-      + (f"; {len(undef)} streams on which the reference's output depends on uninitialised memory: their {n_defined} "
-         f"pictures that do not were compared as well ({undef[:20]})" if undef else ""))
+print(f"[{args.backend}] seeds {args.first}..{args.first + args.count - 1}{' damaged' if args.damage else ''}: {args.count - len(bad)} identical, "
+      f"{len(bad)} not ({bad[:20]}); {n_pics} pictures compared, {time.time() - t0:.0f} s")
