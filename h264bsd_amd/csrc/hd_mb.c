@@ -150,8 +150,8 @@ static int set_partition(MbCtx *c, int x, int y, int w, int h, int ref, const in
         uint32_t one;
         memcpy(&one, mv, 4);
         const uint64_t two = (uint64_t)one << 32 | one;
-        uint64_t *dst = (uint64_t *)(void *)c->cur->mv;
-        for (int i = 0; i < 8; i++) dst[i] = two;
+        uint8_t *dst = (uint8_t *)c->cur->mv;               /* 4-byte aligned only */
+        for (int i = 0; i < 8; i++) memcpy(dst + 8 * i, &two, 8);
         c->done = 0xFFFF;
         if (!c->p2err) c->ok_blocks = 0xFFFF;
         return 0;

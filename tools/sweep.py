@@ -33,6 +33,7 @@ for seed in range(args.first, args.first + args.count):
         ref = synth.decode_reference(data, nor)
         ours = synth.decode_ours(data, args.backend, nor)
         n_pics += len(ref[1])
+        if (seed - args.first) % 100 == 99: print(f"... {seed - args.first + 1} streams, {len(bad)} not identical", flush=True)
         if ref != ours:
             bad.append(seed)
             print(f"MISMATCH seed {seed}: trace equal {ref[0] == ours[0]}, pictures {len(ref[1])} vs {len(ours[1])}", flush=True)
