@@ -152,6 +152,13 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
         const int recon = RECON(r);
         any_dbk |= r->dbk;
         cls[a] = 0;
+        /* invariant of the job format, checked where the kernels' lists are made: a macroblock that will be reconstructed
+         * has its coefficient blocks inside the section (a parser bug must end in a failed decode, not in a kernel
+         * reading past the job) */
+        if (recon && (r->kind == FJ_MB_INTER || r->kind == FJ_MB_I4x4 || r->kind == FJ_MB_I16x16 || r->kind == FJ_MB_IPCM)) {
+            const uint32_t nb = r->kind == FJ_MB_IPCM ? 12u : (uint32_t)__builtin_popcount(r->coded & 0x03FFFFFFu);
+            if (nb && (r->coef_idx > coef_blocks || nb > coef_blocks - r->coef_idx)) return -1;
+        }
         if (r->kind == FJ_MB_ABSENT || r->kind == FJ_MB_STALE) n_absent++;
         else if (r->kind == FJ_MB_CONCEAL_I) n_conceal += (uint32_t)recon;
         else if (in_intra_schedule(r->kind)) {
@@ -790,7 +797,7 @@ static void mark_slice_corrupted(HostDec *d, uint32_t first_mb)
      * order behind those of the macroblocks that stay (redundant re-decodes append nothing), so the section is cut at
      * the first of them.  Without this a stream that repeats broken slices over the same macroblocks could grow the
      * section past what job_capacity() reserves (27 blocks per macroblock). */
-    uint32_t cut = d->coef_blocks;
+    uint32_t cut = d->coef_blocks, keep_top = 0;
     do {
         if (hd_trace) fprintf(stderr, "TRACE   mb %u sid %u decoded %u\n", addr, d->mb_slice_id[addr], d->mb_decoded[addr]);
         if (d->mb_slice_id[addr] != sid || !d->mb_decoded[addr]) break;
@@ -802,12 +809,17 @@ static void mark_slice_corrupted(HostDec *d, uint32_t first_mb)
             if (d->mb_ghost && makes_pixels(recs[addr].kind)) { d->mb_ghost[addr] = 1; d->ghost_dirty = 1; }
             recs[addr].kind = FJ_MB_ABSENT;
             d->mb_rec_sid[addr] = 0;
+        } else if (d->mb_rec_sid[addr] == sid && recs[addr].kind != FJ_MB_ABSENT) {
+            /* a record of this slice that stays: so do its coefficient blocks, wherever they lie among those given back */
+            const uint32_t top = recs[addr].coef_idx + rec_blocks(&recs[addr]);
+            if (top > keep_top) keep_top = top;
         }
         /* (else, counter at 0 but the record is an earlier slice's: a redundant slice stamped the macroblock and failed
          * before it decoded it — slice_data.c:140 / :322-333.  The macroblock counts as not decoded from here on, but the
          * pixels the earlier slice made stay in the picture unless concealment or a later slice replaces them.) */
         addr = hd_next_mb_in_group(d->slice_group_map, d->pic_size_mbs, addr);
     } while (addr);
+    if (keep_top > cut) cut = keep_top < d->coef_blocks ? keep_top : d->coef_blocks;
     d->coef_blocks = cut;
 }
 

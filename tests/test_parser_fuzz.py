@@ -130,3 +130,17 @@ def test_sanitizer_harness_builds_and_runs(tmp_path):
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "cases 40" in r.stdout and "ERROR: AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout.replace("left shift of negative", "")
+    # the bundled streams have one slice per picture: redundant slices, slice groups and several slices per picture come
+    # from the bitstream writer (this stream + seed once read coefficient blocks past the end of a job: a record that
+    # survived its slice's roll-back had lost them to the reclaim in mark_slice_corrupted)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from synth_configs import SWEEP_FINDS
+    from h264writer import StreamWriter
+    from damage import damage
+    cfg, dmg = SWEEP_FINDS["redundant_flipped_106936"]
+    stream = tmp_path / "redundant.h264"
+    stream.write_bytes(damage(StreamWriter(**cfg).build(), **dmg))
+    r = subprocess.run([os.path.join(str(tmp_path), "h264bsd_fuzz_asan"), str(stream), "150", "3"],
+                       capture_output=True, text=True, timeout=900, env=dict(env, ASAN_OPTIONS="detect_leaks=0"))
+    out = "\n".join(ln for ln in (r.stdout + r.stderr).splitlines() if "left shift of negative" not in ln)   # (mirrors the reference's arithmetic)
+    assert "cases 150" in out and "ERROR: AddressSanitizer" not in out and "runtime error" not in out, out[-1500:]
