@@ -594,19 +594,34 @@ static uint32_t rec_blocks(const FjMbRec *r)
 }
 typedef struct GhostMb { uint32_t addr, n_blocks; FjMbRec rec; int16_t mv[32]; } GhostMb;   /* + n_blocks * 32 bytes */
 
+/* first decode of a macroblock that a redundant slice decoded again (RedoMb), or NULL */
+static const struct RedoMb *redo_first_of(const HostDec *d, uint32_t addr)
+{
+    if (!d->mb_redone || !d->mb_redone[addr]) return NULL;
+    for (uint32_t i = 0; i < d->n_redo; i++) if (d->redo[i].addr == addr) return &d->redo[i];
+    return NULL;
+}
+
 static void ghost_store_slice(HostDec *d, uint32_t sid)
 {
     const FjHeader *h = (const FjHeader *)d->job;
     const FjMbRec *recs = (const FjMbRec *)(d->job + h->rec_off);
     const uint32_t n = d->pic_size_mbs;
     size_t need = sizeof(uint32_t);
-    uint32_t count = 0;
-    for (uint32_t a = 0; a < n; a++)
-        if (d->mb_slice_id[a] == sid && d->mb_decoded[a] == 1 && makes_pixels(recs[a].kind)) {
-            need += sizeof(GhostMb) + (size_t)rec_blocks(&recs[a]) * 32u;
-            count++;
-        }
-    if (!count) return;
+    uint32_t count = 0, wrote = 0;
+    /* The macroblocks this slice WROTE (first decode), and with them those it only decoded again (a redundant slice:
+     * pixels of their first decode stay): the written ones may have predicted from them — same slice id — and the
+     * ghost job runs before the job that reconstructs first decodes, so it brings them along in that first version. */
+    for (uint32_t a = 0; a < n; a++) {
+        if (d->mb_slice_id[a] != sid) continue;
+        const struct RedoMb *f = d->mb_decoded[a] >= 2 ? redo_first_of(d, a) : NULL;
+        const FjMbRec *r = d->mb_decoded[a] == 1 ? &recs[a] : f ? &f->rec : NULL;
+        if (!r || !makes_pixels(r->kind)) continue;
+        need += sizeof(GhostMb) + (size_t)rec_blocks(r) * 32u;
+        count++;
+        wrote += d->mb_decoded[a] == 1;
+    }
+    if (!wrote) return;
     /* bounded: a hostile stream can repeat a failing slice of skipped macroblocks for a few bytes each */
     if (d->ghost_len + need > 4u * (size_t)job_capacity(n)) return;
     if (!d->mb_ghost) d->mb_ghost = (uint8_t *)calloc(n, 1);
@@ -619,15 +634,19 @@ static void ghost_store_slice(HostDec *d, uint32_t sid)
     if (!d->mb_ghost) return;
     uint8_t *p = d->ghost_buf + d->ghost_len;
     memcpy(p, &count, sizeof(count)); p += sizeof(count);
-    for (uint32_t a = 0; a < n; a++)
-        if (d->mb_slice_id[a] == sid && d->mb_decoded[a] == 1 && makes_pixels(recs[a].kind)) {
-            GhostMb g;
-            g.addr = a; g.n_blocks = rec_blocks(&recs[a]); g.rec = recs[a];
-            memcpy(g.mv, d->job + h->mv_off + (size_t)a * 64u, 64);
-            memcpy(p, &g, sizeof(g)); p += sizeof(g);
-            memcpy(p, d->job + h->coef_off + (size_t)recs[a].coef_idx * 32u, (size_t)g.n_blocks * 32u);
-            p += (size_t)g.n_blocks * 32u;
-        }
+    for (uint32_t a = 0; a < n; a++) {
+        if (d->mb_slice_id[a] != sid) continue;
+        const struct RedoMb *f = d->mb_decoded[a] >= 2 ? redo_first_of(d, a) : NULL;
+        const FjMbRec *r = d->mb_decoded[a] == 1 ? &recs[a] : f ? &f->rec : NULL;
+        if (!r || !makes_pixels(r->kind)) continue;
+        GhostMb g;
+        g.addr = a; g.n_blocks = rec_blocks(r); g.rec = *r;
+        g.rec.pred &= (uint8_t)~FJ_PRED_PHASE2;
+        if (f && d->mb_decoded[a] >= 2) memcpy(g.mv, f->mv, 64); else memcpy(g.mv, d->job + h->mv_off + (size_t)a * 64u, 64);
+        memcpy(p, &g, sizeof(g)); p += sizeof(g);
+        memcpy(p, d->job + h->coef_off + (size_t)r->coef_idx * 32u, (size_t)g.n_blocks * 32u);
+        p += (size_t)g.n_blocks * 32u;
+    }
     d->ghost_len = (size_t)(p - d->ghost_buf);
 }
 

@@ -124,3 +124,6 @@ for _s in (956431, 953258):                     # P_8x8 re-decode failing on a m
     SWEEP_FINDS[f"redundant_flipped_{_s}"] = (random_config(_s), dict(seed=_s, p_drop=0.1, p_flip=0.3, p_trunc=0.1))
 for _s in (971573, 972160):                     # stale motion state from an earlier picture under a failed re-decode; three versions of one macroblock
     SWEEP_FINDS[f"redundant_flipped_{_s}"] = (dict(random_config(_s), gaps=0), dict(seed=_s, p_drop=0.05, p_flip=0.4, p_trunc=0.05))
+# a rolled-back slice's pixels under a macroblock that is never written again, predicted from a macroblock the same
+# (redundant) slice had only decoded again: the pre-pass job brings that one along in its first version
+SWEEP_FINDS["redundant_flipped_1122884"] = (random_config(1122884), dict(seed=1122884, p_drop=0.02, p_flip=0.6, p_trunc=0.02))
