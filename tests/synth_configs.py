@@ -119,7 +119,10 @@ SWEEP_FINDS["redundant_flipped_5483"] = (dict(random_config(5483), gaps=0), dict
 SWEEP_FINDS["redundant_flipped_3053"] = (random_config(3053), dict(seed=3053, p_drop=0.2, p_flip=0.3, p_trunc=0.2))
 
 # a bundled x264 stream (one slice per picture, 40x23 macroblocks) with slices cut short: concealment at picture scale
-DAMAGED_BUNDLED = {"damaged_bundled_640x360": ("test_640x360", dict(seed=7, p_drop=0.04, p_flip=0.0, p_trunc=0.3))}
+DAMAGED_BUNDLED = {"damaged_bundled_640x360": ("test_640x360", dict(seed=7, p_drop=0.04, p_flip=0.0, p_trunc=0.3)),
+                   # ... and the full-size one (120x68 macroblocks) with flipped bits and cut slices: roll-back over more than ten
+                   # macroblocks of a row (slice_data.c:318-333 counts max(width, 10)), concealment lists of thousands of entries
+                   "damaged_bundled_1920x1080": ("test_1920x1080", dict(seed=8011, p_drop=0.03, p_flip=0.15, p_trunc=0.05))}
 for _s in (956431, 953258):                     # P_8x8 re-decode failing on a missing reference: the failing quadrant's refAddr is already NULL
     SWEEP_FINDS[f"redundant_flipped_{_s}"] = (random_config(_s), dict(seed=_s, p_drop=0.1, p_flip=0.3, p_trunc=0.1))
 for _s in (971573, 972160):                     # stale motion state from an earlier picture under a failed re-decode; three versions of one macroblock
