@@ -173,8 +173,10 @@ typedef struct MbInfo {
     uint8_t  dbk_idc;       /* disable_deblocking_filter_idc of the slice of the last decode      */
     uint8_t  tc[24];        /* total_coeff per 4x4 block, H.264 block order (luma 0-15, Cb, Cr)   */
     int8_t   i4mode[16];    /* Intra4x4PredMode, H.264 block order                                */
+    /* ref_idx / ref_slot / mv persist like the reference's mbStorage_t.refPic / refAddr / mv: across decodes and across
+     * pictures, written only where MvPrediction writes them (hd_mb.c restore_unwritten) */
     int8_t   ref_idx[4];
-    uint8_t  ref_slot[4];
+    uint8_t  ref_slot[4];   /* frame buffer per quadrant; 0xFF = none (refAddr NULL: never written, or written as missing) */
     int16_t  mv[16][2];     /* H.264 block order                                                  */
 } MbInfo;
 
