@@ -114,6 +114,11 @@ def decode_ours(data, backend="oracle", no_output_reordering=0):
         if r == 1:
             pic_id += 1
             drain()
+        elif r == 2:
+            # HDRS_RDY: the next slice re-allocates the frame buffers (storage.c:340-378 -> h264bsdResetDpb), also when the
+            # new sequence has the same number of macroblocks and buffers as the old one; the product's engine zeroes its
+            # buffers at that point (sink_configure), the oracle's stand-in DPB is rebuilt with the next job
+            state["dpb"] = None
         stall = stall + 1 if rb == 0 else 0
         if stall > 3:
             break

@@ -102,8 +102,10 @@ def test_gpu_sequence_parameter_set_changes(built, names):
     assert synth.decode_ours(data, "gpu") == synth.decode_ours(data, "oracle")
 
 
-def _live_sweep(first, count, damaged, backend):
-    """fresh random streams against the LIVE reference (oracle/_ref travels to the GPU box as a built artefact)"""
+def _live_sweep(first, count, damaged, backend, concat=1):
+    """fresh random streams against the LIVE reference (oracle/_ref travels to the GPU box as a built artefact);
+    concat > 1: several different streams one after the other — parameter sets with the same ids and other picture / DPB
+    sizes, the next sequence sometimes starting in the middle of the previous one"""
     from oracle import pyoracle
     import damage as dmg
     from h264writer import random_config
@@ -111,10 +113,16 @@ def _live_sweep(first, count, damaged, backend):
         pytest.skip("oracle/_ref not built")
     bad = []
     for seed in range(first, first + count):
-        cfg = random_config(seed)
-        data = StreamWriter(**cfg).build()
-        if damaged:
-            data = dmg.damage(data, seed, p_drop=0.15, p_flip=0.25, p_trunc=0.15)
+        parts = []
+        for k in range(concat):
+            sub = seed if concat == 1 else seed * concat + k
+            part = StreamWriter(**random_config(sub)).build()
+            if damaged:
+                part = dmg.damage(part, sub, p_drop=0.15, p_flip=0.25, p_trunc=0.15)
+            if k + 1 < concat and (seed + k) & 1:
+                part = part[: len(part) * 2 // 3]
+            parts.append(part)
+        data = b"".join(parts)
         nor = 0 if damaged else seed & 1
         if synth.decode_reference(data, nor) != synth.decode_ours(data, backend, nor):
             bad.append(seed)
@@ -124,9 +132,11 @@ def _live_sweep(first, count, damaged, backend):
 def test_random_streams_match_live_reference(built):
     _live_sweep(91000, 40, False, "oracle")
     _live_sweep(91500, 60, True, "oracle")
+    _live_sweep(93000, 30, True, "oracle", concat=3)
 
 
 @pytest.mark.gpu
 def test_gpu_random_streams_match_live_reference(built):
     _live_sweep(92000, 120, False, "gpu")
     _live_sweep(92500, 160, True, "gpu")
+    _live_sweep(93500, 60, True, "gpu", concat=3)     # the engine re-allocates (zeroed) frame buffers at every activation

@@ -15,20 +15,29 @@ ap.add_argument("--flip", type=float, default=0.0, help="with --damage: probabil
 ap.add_argument("--drop", type=float, default=0.2); ap.add_argument("--trunc", type=float, default=0.2)
 ap.add_argument("--overflow", type=float, default=0.0, help="probability that a coefficient block carries a level near the residual-range limit")
 ap.add_argument("--keep-redundant", action="store_true"); ap.add_argument("--keep-gaps", action="store_true")
+ap.add_argument("--concat", type=int, default=1, help="N > 1: every case is N different random streams one after the other (new SPS "
+                "/ PPS with the same ids, other picture and DPB sizes: re-activation, possibly in the middle of damage)")
 ap.add_argument("--backend", default="oracle", choices=("oracle", "gpu"), help="gpu = the product through the C ABI (needs an MI355X)")
 args = ap.parse_args()
 os.dup2(os.open(os.devnull, os.O_WRONLY), 2)      # the reference is built with _ERROR_PRINT
 bad, t0, n_pics = [], time.time(), 0
 for seed in range(args.first, args.first + args.count):
     try:
-        cfg = h264writer.random_config(seed)
-        if args.damage:                         # as tests/synth_configs.py: no frame_num gaps, no redundant slices
-            if not args.keep_gaps: cfg["gaps"] = 0
-            if not args.keep_redundant: cfg["redundant"] = False
-        if args.overflow: cfg["overflow"] = args.overflow; cfg["max_qp"] = max(cfg["max_qp"], 40)
-        data = h264writer.StreamWriter(**cfg).build()
-        if args.damage:
-            data = dmg.damage(data, seed, p_drop=args.drop, p_flip=args.flip, p_trunc=args.trunc)
+        parts = []
+        for k in range(args.concat):
+            sub = seed if args.concat == 1 else seed * args.concat + k
+            cfg = h264writer.random_config(sub)
+            if args.damage:                         # as tests/synth_configs.py: no frame_num gaps, no redundant slices
+                if not args.keep_gaps: cfg["gaps"] = 0
+                if not args.keep_redundant: cfg["redundant"] = False
+            if args.overflow: cfg["overflow"] = args.overflow; cfg["max_qp"] = max(cfg["max_qp"], 40)
+            part = h264writer.StreamWriter(**cfg).build()
+            if args.damage:
+                part = dmg.damage(part, sub, p_drop=args.drop, p_flip=args.flip, p_trunc=args.trunc)
+            if args.concat > 1 and k + 1 < args.concat and (seed + k) & 1:
+                part = part[: len(part) * 2 // 3]       # the next sequence starts in the middle of this one
+            parts.append(part)
+        data = b"".join(parts)
         nor = seed & 1 if not args.damage else 0
         ref = synth.decode_reference(data, nor)
         ours = synth.decode_ours(data, args.backend, nor)
