@@ -17,6 +17,7 @@ ap.add_argument("--overflow", type=float, default=0.0, help="probability that a 
 ap.add_argument("--keep-redundant", action="store_true"); ap.add_argument("--keep-gaps", action="store_true")
 ap.add_argument("--concat", type=int, default=1, help="N > 1: every case is N different random streams one after the other (new SPS "
                 "/ PPS with the same ids, other picture and DPB sizes: re-activation, possibly in the middle of damage)")
+ap.add_argument("--no-output-reordering", type=int, default=-1, help="h264bsdInit's flag: 0 / 1; default: seed parity for intact streams, 0 for damaged ones")
 ap.add_argument("--backend", default="oracle", choices=("oracle", "gpu"), help="gpu = the product through the C ABI (needs an MI355X)")
 args = ap.parse_args()
 os.dup2(os.open(os.devnull, os.O_WRONLY), 2)      # the reference is built with _ERROR_PRINT
@@ -38,7 +39,7 @@ for seed in range(args.first, args.first + args.count):
                 part = part[: len(part) * 2 // 3]       # the next sequence starts in the middle of this one
             parts.append(part)
         data = b"".join(parts)
-        nor = seed & 1 if not args.damage else 0
+        nor = args.no_output_reordering if args.no_output_reordering >= 0 else (seed & 1 if not args.damage else 0)
         ref = synth.decode_reference(data, nor)
         ours = synth.decode_ours(data, args.backend, nor)
         n_pics += len(ref[1])
