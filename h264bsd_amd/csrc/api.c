@@ -223,7 +223,7 @@ u32 h264bsdCheckValidParamSets(storage_t *s)
     if (!a) return 0;
     for (int i = 0; i < HD_MAX_PPS; i++) {
         const Pps *p = a->hd->pps[i];
-        if (p && a->hd->sps[p->sps_id]) return 1;
+        if (p && a->hd->sps[p->sps_id] && !hd_check_pps(p, a->hd->sps[p->sps_id])) return 1;     /* h264bsdValidParamSets, storage.c:863-885 */
     }
     return 0;
 }

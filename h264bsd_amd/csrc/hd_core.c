@@ -389,7 +389,8 @@ int hd_job_finish(HostDec *d, int is_idr)
 }
 
 /* ---------------------------------------------------------------- parameter-set activation */
-static int check_pps_against_sps(const Pps *p, const Sps *s)
+/* reference CheckPps, src/h264bsd_storage.c:795-860: slice-group parameters against the picture size of the SPS */
+int hd_check_pps(const Pps *p, const Sps *s)
 {
     const uint32_t n = s->width_mbs * s->height_mbs;
     if (p->num_slice_groups > 1) {
@@ -423,7 +424,7 @@ static int activate_param_sets(HostDec *d, uint32_t pps_id, int is_idr)
 {
     Pps *p = d->pps[pps_id];
     if (!p || !d->sps[p->sps_id]) return -1;
-    if (check_pps_against_sps(p, d->sps[p->sps_id])) return -1;
+    if (hd_check_pps(p, d->sps[p->sps_id])) return -1;
 
     if (d->active_pps_id < 0) {
         /* nothing active yet: phase 1 */

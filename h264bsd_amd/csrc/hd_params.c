@@ -41,7 +41,11 @@ static int skip_hrd(BitReader *br)
     uint32_t cpb_cnt = br_ue(br) + 1;
     if (cpb_cnt > 32) return -1;
     br_get(br, 4); br_get(br, 4);
-    for (uint32_t i = 0; i < cpb_cnt; i++) { br_ue(br); br_ue(br); br_get1(br); }
+    for (uint32_t i = 0; i < cpb_cnt; i++) {
+        /* bit_rate_value_minus1, cpb_size_value_minus1: [0, 2^32 - 2] (vui.c:437-456) */
+        if (br_ue(br) > 4294967294u || br_ue(br) > 4294967294u) return -1;
+        br_get1(br);
+    }
     br_get(br, 5); br_get(br, 5); br_get(br, 5); br_get(br, 5);
     CHECK(br);
     return 0;
@@ -66,8 +70,9 @@ static int parse_vui(BitReader *br, Sps *s)
             s->matrix_coefficients = (uint8_t)br_get(br, 8);
         }
     }
-    if (br_get1(br)) { br_ue(br); br_ue(br); }          /* chroma loc */
-    if (br_get1(br)) { br_get(br, 32); br_get(br, 32); br_get1(br); } /* timing */
+    /* the reference rejects the parameter set on these (vui.c:202-243): the fields themselves are not used */
+    if (br_get1(br)) { if (br_ue(br) > 5 || br_ue(br) > 5) return -1; }                                    /* chroma_sample_loc_type_* */
+    if (br_get1(br)) { if (br_get(br, 32) == 0 || br_get(br, 32) == 0) return -1; br_get1(br); }        /* num_units_in_tick, time_scale */
     CHECK(br);
     uint32_t nal_hrd = br_get1(br);
     if (nal_hrd && skip_hrd(br)) return -1;
@@ -78,7 +83,8 @@ static int parse_vui(BitReader *br, Sps *s)
     s->bitstream_restriction = (uint8_t)br_get1(br);
     if (s->bitstream_restriction) {
         br_get1(br);
-        br_ue(br); br_ue(br); br_ue(br); br_ue(br);
+        /* max_bytes_per_pic_denom, max_bits_per_mb_denom, log2_max_mv_length_horizontal / _vertical: [0, 16] (vui.c:330-356) */
+        for (int i = 0; i < 4; i++) if (br_ue(br) > 16) return -1;
         s->num_reorder_frames = br_ue(br);
         s->max_dec_frame_buffering = br_ue(br);
     }

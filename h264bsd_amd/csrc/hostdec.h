@@ -321,6 +321,7 @@ int hd_parse_sps(BitReader *br, Sps *sps);
 int hd_parse_pps(BitReader *br, Pps *pps);
 void hd_free_pps(Pps *pps);
 int hd_sps_equal(const Sps *a, const Sps *b);
+int hd_check_pps(const Pps *p, const Sps *s);
 /* hd_slice.c */
 int hd_parse_slice_header(BitReader *br, SliceHdr *sh, const Sps *sps, const Pps *pps, int nal_type, int nal_ref_idc);
 int hd_peek_pps_id(const BitReader *br, uint32_t *pps_id);

@@ -53,8 +53,12 @@ def _decode_reference(data, no_output_reordering):
     rb = ctypes.c_uint32(0)
     a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
 
+    dims = [0, 0]
+
     def drain():
-        wmb, hmb = lib.h264bsdPicWidth(dec), lib.h264bsdPicHeight(dec)
+        if lib.h264bsdPicWidth(dec):       # 0 while a replaced active SPS waits for its activation; pictures of the old one still come out
+            dims[:] = [lib.h264bsdPicWidth(dec), lib.h264bsdPicHeight(dec)]
+        wmb, hmb = dims
         while True:
             p = lib.h264bsdNextOutputPicture(dec, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
             if not p:
