@@ -3,7 +3,7 @@ location, timing, HRD, bitstream restriction), boundary and out-of-range values 
 information calls of the compiled reference (oracle/_ref) and of this library: the same accept / reject decisions
 (reference src/h264bsd_seq_param_set.c, src/h264bsd_vui.c:95-372, DecodeHrdParameters :396-500), the same
 h264bsdPicWidth / CroppingParams / VideoRange / MatrixCoefficients / SampleAspectRatio / Profile /
-CheckValidParamSets, the same pictures.  The sweep itself is tools/sweep_sps.py (found: VUI range checks the parser
+CheckValidParamSets, the same pictures.  The sweep itself is tools/sweep_headers.py (found: VUI range checks the parser
 skipped, h264bsdCheckValidParamSets without the reference's CheckPps)."""
 import os
 import subprocess
@@ -18,7 +18,7 @@ def test_random_sequence_parameter_sets_match_the_reference(built):
     from oracle import pyoracle
     if not os.path.exists(pyoracle.REF_SO):
         pytest.skip("oracle/_ref not built")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_sps.py"), "0", "600"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_headers.py"), "0", "600"], capture_output=True, text=True, timeout=900)
     last = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert r.returncode == 0 and "600 identical, 0 not" in last, r.stdout[-2000:]
     accepted = int(last.split("headers accepted in ")[1].split()[0])

@@ -6,7 +6,8 @@ boundary and out-of-range values mixed in (the reference rejects e.g. max_bytes_
 cropping rectangle larger than the picture).  Compared with the compiled reference: the h264bsdDecode call trace, the
 output pictures, and what the information calls return once headers are ready (h264bsdPicWidth / Height,
 CroppingParams, VideoRange, MatrixCoefficients, SampleAspectRatio, Profile, CheckValidParamSets).  TEST TOOL (uses
-oracle/).   usage: sweep_sps.py <first seed> <count>"""
+oracle/).   usage: sweep_headers.py <first seed> <count> [pps|slice]      (slice: 1-4 slice NAL units with random HEADERS are inserted between the stream's own; pps: the PICTURE parameter set is the random one: slice
+group maps of all types with boundary values, QP offsets, reference counts, flags the baseline decoder rejects)"""
 import sys, os, time, random, ctypes, hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
@@ -112,6 +113,126 @@ def random_sps(cfg, rng):
     return nal(3, 7, bw.bytes())
 
 
+def random_pps(cfg, rng):
+    """picture parameter set, every field random around what the stream needs (reference src/h264bsd_pic_param_set.c)"""
+    n = cfg["wmb"] * cfg["hmb"]
+    bw = BitWriter()
+    bw.ue(pick(rng, 0, 1, 255, 256)); bw.ue(pick(rng, 0, 31, 32))
+    bw.u(1, pick(rng, 0, 1))                                           # entropy_coding_mode: CABAC is rejected
+    bw.u(1, pick(rng, cfg.get("pic_order_present", 0), 1))
+    fmo = cfg.get("fmo")
+    if rng.random() < 0.5:
+        fmo = None if rng.random() < 0.4 else dict(type=rng.choice([0, 1, 2, 3, 4, 5, 6, 6, 7]), groups=rng.choice([2, 2, 3, 4, 5, 8, 9]))
+    if not fmo:
+        bw.ue(0)
+    else:
+        g, t = fmo["groups"], fmo["type"]
+        bw.ue(g - 1); bw.ue(t)
+        if t == 0:
+            for r in fmo.get("run_length") or [pick(rng, rng.randrange(1, n + 1), n + 1, 2 ** 20) for _ in range(g)]:
+                bw.ue(r - 1)
+        elif t == 2:
+            for tl, br in fmo.get("rects") or [(rng.randrange(n), pick(rng, rng.randrange(n), n, n + 5)) for _ in range(g - 1)]:
+                bw.ue(tl); bw.ue(br)
+        elif t in (3, 4, 5):
+            bw.u(1, fmo.get("direction", rng.randrange(2))); bw.ue(fmo.get("rate", pick(rng, rng.randrange(1, n + 1), n + 1, n + 2)) - 1)
+        elif t == 6:
+            ids = fmo.get("ids") or [pick(rng, rng.randrange(g), g, 7) & 7 for _ in range(pick(rng, n, n - 1, n + 1, 1))]
+            bw.ue(len(ids) - 1)
+            nb = 3 if g > 4 else 2 if g > 2 else 1
+            for x in ids:
+                bw.u(nb, x & ((1 << nb) - 1))
+    bw.ue(pick(rng, cfg.get("num_ref_idx_active", 1) - 1, 15, 31, 32)); bw.ue(pick(rng, 0, 31, 32))
+    bw.u(1, pick(rng, 0, 1)); bw.u(2, pick(rng, 0, 1, 2, 3))
+    bw.se(pick(rng, cfg.get("pic_init_qp", 26) - 26, -26, 25, -27, 26)); bw.se(pick(rng, 0, -26, 25, 26, -27))
+    bw.se(pick(rng, cfg.get("chroma_qp_offset", 0), -12, 12, -13, 13))
+    bw.u(1, pick(rng, cfg.get("deblocking_control", 1), 0)); bw.u(1, pick(rng, cfg.get("constrained_intra", 0), 1))
+    bw.u(1, pick(rng, cfg.get("redundant_pic_cnt_present", 1 if cfg.get("redundant") else 0), 1, 0))
+    if rng.random() < 0.15:                                            # more_rbsp_data(): the fields of the high profiles
+        bw.u(1, rng.randrange(2)); bw.u(1, 0); bw.se(rng.randrange(-12, 13))
+    if rng.random() < 0.9:
+        bw.trailing()
+    else:
+        bw.align_zero()
+    return nal(3, 8, bw.bytes())
+
+
+def random_slice(cfg, rng):
+    """a slice NAL unit whose HEADER is written field by field with random contents (reference src/h264bsd_slice_header.c:
+    first_mb, type, parameter-set id, frame_num, idr_pic_id, POC fields, redundant_pic_cnt, reference counts, list
+    reordering and reference marking command loops, QP delta, deblocking parameters, slice-group change cycle), followed
+    by a few random bytes of "slice data" """
+    n = cfg["wmb"] * cfg["hmb"]
+    idr = rng.random() < 0.25
+    ref_idc = rng.choice([0, 1, 2, 3]) if not idr else rng.choice([1, 2, 3, 3, 0])
+    bw = BitWriter()
+    bw.ue(pick(rng, rng.randrange(n), n, n + 7, 2 ** 20))
+    st = pick(rng, rng.choice([0, 2, 5, 7]), 1, 3, 4, 6, 8, 9, 10)
+    bw.ue(st)
+    bw.ue(pick(rng, 0, 1, 255, 256))
+    bw.u(cfg.get("log2_max_frame_num", 4), rng.randrange(1 << cfg.get("log2_max_frame_num", 4)))
+    if idr:
+        bw.ue(pick(rng, rng.randrange(16), 65535, 65536))
+    if cfg["poc_type"] == 0:
+        nb = cfg.get("log2_max_poc_lsb", 6)
+        bw.u(nb, rng.randrange(1 << nb))
+    elif cfg["poc_type"] == 1 and not cfg.get("delta_always_zero", 0):
+        bw.se(pick(rng, rng.randrange(-4, 5), 2 ** 20, -2 ** 20))
+    if cfg.get("redundant"):
+        bw.ue(pick(rng, rng.randrange(3), 127, 128))
+    if st % 5 == 0:
+        if rng.random() < 0.5:
+            bw.u(1, 1); bw.ue(pick(rng, rng.randrange(4), 15, 16, 31, 32))
+        else:
+            bw.u(1, 0)
+        if rng.random() < 0.5:
+            bw.u(1, 1)
+            for _ in range(pick(rng, rng.randrange(4), 17, 34, 40)):
+                op = pick(rng, rng.randrange(3), 4, 9)
+                bw.ue(op); bw.ue(pick(rng, rng.randrange(8), 2 ** 16, 2 ** 20))
+            if rng.random() < 0.9:
+                bw.ue(3)
+        else:
+            bw.u(1, 0)
+    if ref_idc:
+        if idr:
+            bw.u(1, rng.randrange(2)); bw.u(1, rng.randrange(2))
+        elif rng.random() < 0.5:
+            bw.u(1, 1)
+            for _ in range(pick(rng, rng.randrange(4), 33, 36, 70)):
+                op = pick(rng, rng.randrange(1, 7), 7, 12)
+                bw.ue(op)
+                if op in (1, 3):
+                    bw.ue(pick(rng, rng.randrange(6), 2 ** 16))
+                if op == 2:
+                    bw.ue(pick(rng, rng.randrange(4), 40))
+                if op in (3, 6):
+                    bw.ue(pick(rng, rng.randrange(4), 16, 40))
+                if op == 4:
+                    bw.ue(pick(rng, rng.randrange(5), 16, 17, 40))
+            if rng.random() < 0.9:
+                bw.ue(0)
+        else:
+            bw.u(1, 0)
+    bw.se(pick(rng, rng.randrange(-6, 7), 25, 26, -26, -27, 52, -52))
+    if cfg.get("deblocking_control", 1):
+        idc = pick(rng, rng.randrange(3), 3, 7)
+        bw.ue(idc)
+        if idc != 1:
+            bw.se(pick(rng, rng.randrange(-6, 7), 7, -7)); bw.se(pick(rng, rng.randrange(-6, 7), 7, -7))
+    if cfg.get("fmo") and cfg["fmo"]["type"] in (3, 4, 5):
+        units = -(-n // cfg["fmo"]["rate"])
+        nb = int(np.ceil(np.log2(units + 1)))
+        bw.u(nb, rng.randrange(1 << nb))
+    for _ in range(rng.randrange(0, 24)):
+        bw.u(8, rng.randrange(256))
+    if rng.random() < 0.7:
+        bw.trailing()
+    else:
+        bw.align_zero()
+    return nal(ref_idc, 5 if idr else 1, bw.bytes())
+
+
 def info_ref(lib, dec):
     dec = ctypes.c_void_p(dec)                      # (no argtypes are declared for the information calls: keep the pointer 64 bits wide)
     v = [ctypes.c_uint32() for _ in range(5)]
@@ -190,7 +311,7 @@ def run_ours(data):
     return trace, pics, infos
 
 
-first, count = int(sys.argv[1]), int(sys.argv[2]); bad = []; t0 = time.time(); n_ok = n_pics = 0
+first, count = int(sys.argv[1]), int(sys.argv[2]); MODE = sys.argv[3] if len(sys.argv) > 3 else "sps"; bad = []; t0 = time.time(); n_ok = n_pics = 0
 for seed in range(first, first + count):
     rng = random.Random(seed)
     cfg = h264writer.random_config(seed)
@@ -199,6 +320,33 @@ for seed in range(first, first + count):
     # the writer's stream starts with its SPS: find the second start code and splice
     second = data.index(b"\x00\x00\x00\x01", 4)
     assert data[4] & 31 == 7
+    third = data.index(b"\x00\x00\x00\x01", second + 4)
+    assert data[second + 4] & 31 == 8
+    if MODE in ("pps", "slice"):
+        if MODE == "pps":
+            data = data[:second] + random_pps(cfg, rng) + data[third:]
+            if rng.random() < 0.2:                     # ... and another one later
+                cut = data.index(b"\x00\x00\x00\x01", len(data) // 2) if b"\x00\x00\x00\x01" in data[len(data) // 2:] else len(data)
+                data = data[:cut] + random_pps(cfg, rng) + data[cut:]
+        else:                                          # 1-4 slices with random headers between the stream's own NAL units
+            starts = [i for i in range(third, len(data) - 4) if data[i:i + 4] == b"\x00\x00\x00\x01" and data[i - 1:i] != b"\x00"] + [len(data)]
+            for _ in range(rng.randrange(1, 5)):
+                at = rng.choice(starts)
+                extra = random_slice(cfg, rng)
+                data = data[:at] + extra + data[at:]
+                starts = [x + len(extra) if x >= at else x for x in starts]
+        r = run_ref(data); o = run_ours(data)
+        n_ok += any(t[0] == 2 for t in r[0]); n_pics += len(r[1])
+        if r != o:
+            bad.append(seed)
+            print("MISMATCH", seed, "trace equal", r[0] == o[0], "pictures equal", r[1] == o[1], "info equal", r[2] == o[2], flush=True)
+            if r[0] != o[0]:
+                for i, (x, y) in enumerate(zip(r[0], o[0])):
+                    if x != y:
+                        print("   first trace difference at call", i, x, y, flush=True); break
+        if (seed - first) % 500 == 499:
+            print("...", seed - first + 1, len(bad), flush=True)
+        continue
     data = random_sps(cfg, rng) + data[second:]
     if rng.random() < 0.2:                         # ... and the original SPS again later: a change of parameter sets mid-stream
         cut = data.index(b"\x00\x00\x00\x01", len(data) // 2) if b"\x00\x00\x00\x01" in data[len(data) // 2:] else len(data)
@@ -215,5 +363,5 @@ for seed in range(first, first + count):
                     print("   first trace difference at call", i, x, y, flush=True); break
     if (seed - first) % 500 == 499:
         print("...", seed - first + 1, len(bad), flush=True)
-print(f"SPS sweep {first}..{first + count - 1}: {count - len(bad)} identical, {len(bad)} not {bad[:20]}; headers accepted in {n_ok} streams, "
+print(f"{MODE.upper()} sweep {first}..{first + count - 1}: {count - len(bad)} identical, {len(bad)} not {bad[:20]}; headers accepted in {n_ok} streams, "
       f"{n_pics} pictures, {time.time() - t0:.0f} s")
