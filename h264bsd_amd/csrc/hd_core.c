@@ -61,7 +61,10 @@ void hd_destroy(HostDec *d)
 /* ---------------------------------------------------------------- frame job */
 static uint32_t job_capacity(uint32_t n_mbs)
 {
-    return 128u + n_mbs * (32u + 64u) + (n_mbs * 27u + 2u) * 32u /* coefficients, worst case */
+    /* coefficients: 27 blocks per macroblock (16 luma, Intra16x16 DC, 2 chroma DC sharing one, 8 chroma AC) + 2, and room
+     * for one more macroblock: a redundant slice that decodes the last macroblock of a full picture again parses its
+     * blocks into the section before it gives them back */
+    return 128u + n_mbs * (32u + 64u) + (n_mbs * 27u + 2u + 27u) * 32u
            + (n_mbs + 2u) * 4u /* level starts */ + fj_align32(n_mbs * 2u) /* intra index */
            + n_mbs * 16u /* copy list + general list */ + fj_align32(n_mbs * 2u) /* deblocking index */ + 512u;
 }
@@ -93,7 +96,7 @@ int hd_job_begin(HostDec *d)
     /* records and motion vectors are NOT pre-initialised: every decoded macroblock writes both, and
      * hd_job_finish() fills in the macroblocks no slice covered (saves two passes over 0.8 MB per 1080p picture) */
     d->coef_blocks = 0;
-    d->coef_cap_blocks = n * 27u + 2u;          /* the share of job_capacity() */
+    d->coef_cap_blocks = n * 27u + 2u + 27u;    /* the share of job_capacity() */
     d->n_inter = d->n_intra = 0;
     d->job_open = 1;
     return 0;
