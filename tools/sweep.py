@@ -15,6 +15,8 @@ ap.add_argument("--flip", type=float, default=0.0, help="with --damage: probabil
 ap.add_argument("--drop", type=float, default=0.2); ap.add_argument("--trunc", type=float, default=0.2)
 ap.add_argument("--overflow", type=float, default=0.0, help="probability that a coefficient block carries a level near the residual-range limit")
 ap.add_argument("--keep-redundant", action="store_true"); ap.add_argument("--keep-gaps", action="store_true")
+ap.add_argument("--sizes", default="", help="WMIN-WMAX,HMIN-HMAX: override the picture size of random_config (2-7 x 2-6 macroblocks) — tiny "
+                "pictures, or rows longer than ten macroblocks (h264bsdMarkSliceCorrupted counts max(width, 10)); slice groups become none / dispersed")
 ap.add_argument("--concat", type=int, default=1, help="N > 1: every case is N different random streams one after the other (new SPS "
                 "/ PPS with the same ids, other picture and DPB sizes: re-activation, possibly in the middle of damage)")
 ap.add_argument("--no-output-reordering", type=int, default=-1, help="h264bsdInit's flag: 0 / 1; default: seed parity for intact streams, 0 for damaged ones")
@@ -28,6 +30,13 @@ for seed in range(args.first, args.first + args.count):
         for k in range(args.concat):
             sub = seed if args.concat == 1 else seed * args.concat + k
             cfg = h264writer.random_config(sub)
+            if args.sizes:
+                import random as _random
+                (w0, w1), (h0, h1) = [tuple(int(v) for v in part.split("-")) for part in args.sizes.split(",")]
+                rr = _random.Random(sub)
+                cfg["wmb"], cfg["hmb"] = rr.randint(w0, w1), rr.randint(h0, h1)
+                cfg["fmo"] = None if rr.random() < 0.6 or cfg["wmb"] * cfg["hmb"] < 2 else dict(type=1, groups=rr.randint(2, min(4, cfg["wmb"] * cfg["hmb"])))
+                cfg["n_pics"] = min(cfg["n_pics"], 10)
             if args.damage:                         # as tests/synth_configs.py: no frame_num gaps, no redundant slices
                 if not args.keep_gaps: cfg["gaps"] = 0
                 if not args.keep_redundant: cfg["redundant"] = False
