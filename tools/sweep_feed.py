@@ -3,7 +3,8 @@
 length (1 byte .. 40 KB, advancing by readBytes) instead of "everything that is left", to the compiled reference and to
 this library's parser; a window that ends inside a NAL unit makes the decoder see a truncated unit, and both must make
 the same calls, return the same codes and readBytes, and output the same pictures.  TEST TOOL (uses oracle/).
-usage: sweep_feed.py <first seed> <count>"""
+usage: sweep_feed.py <first seed> <count> [flush]      (flush: whole-buffer calls, but h264bsdFlushBuffer + draining the
+output queue after 6 % of the calls, as an application does when it seeks)"""
 import sys, os, time, random, ctypes, hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
@@ -13,8 +14,11 @@ from oracle import pyoracle
 from h264bsd_amd import capi
 os.dup2(os.open(os.devnull, os.O_WRONLY), 2)
 libc=ctypes.CDLL(None)
+FLUSH = len(sys.argv) > 3 and sys.argv[3] == 'flush'
 def windows(seed, n):
     rng=random.Random(seed*7+1); 
+    while FLUSH: yield 1 << 30
+
     while True: yield rng.choice([rng.randrange(1,40), rng.randrange(40,400), rng.randrange(400,4000), rng.randrange(400,4000), rng.randrange(4000,40000), rng.randrange(4000,40000), rng.randrange(4000,40000), rng.randrange(4000,40000), rng.randrange(4000,40000), rng.randrange(4000,40000)])
 def run_ref(data, seed):
     libc.mallopt(-6, 0xFF)
@@ -29,11 +33,12 @@ def run_ref(data, seed):
                 p=lib.h264bsdNextOutputPicture(dec, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
                 if not p: break
                 pics.append((hashlib.sha1(ctypes.string_at(p,w*h*384)).hexdigest(), a.value,b.value,c.value))
-        win=windows(seed,len(data))
+        win=windows(seed,len(data)); frng=random.Random(seed*13+5)
         while off<len(data):
             ln=min(len(data)-off, next(win))
             r=lib.h264bsdDecode(dec, base+off, ln, pid, ctypes.byref(rb)); trace.append((int(r),int(rb.value))); off+=rb.value
             if r==1: pid+=1; drain()
+            if FLUSH and frng.random() < 0.06: lib.h264bsdFlushBuffer(dec); drain()      # the application empties the output queue in mid-stream (a seek)
             stall = stall+1 if rb.value==0 else 0
             if stall>12: break
         lib.h264bsdFlushBuffer(dec); drain(); lib.h264bsdShutdown(dec); lib.h264bsdFree(dec)
@@ -54,12 +59,13 @@ def run_ours(data, seed):
             slot,p,idr,nerr=o
             frame=state["dpb"].slots[slot][:state["dpb"].frame_bytes]
             pics.append((hashlib.sha1(np.ascontiguousarray(frame).tobytes()).hexdigest(), p,idr,nerr))
-    win=windows(seed,len(data))
+    win=windows(seed,len(data)); frng=random.Random(seed*13+5)
     while off<len(data):
         ln=min(len(data)-off, next(win))
         r,rb=dec.decode(base+off, ln, pid); trace.append((r,rb)); off+=rb
         if r==1: pid+=1; drain()
         elif r==2: state["dpb"]=None
+        if FLUSH and frng.random() < 0.06: dec.flush_buffer(); drain()
         stall = stall+1 if rb==0 else 0
         if stall>12: break
     dec.flush_buffer(); drain(); dec.close()
