@@ -6,7 +6,7 @@ boundary and out-of-range values mixed in (the reference rejects e.g. max_bytes_
 cropping rectangle larger than the picture).  Compared with the compiled reference: the h264bsdDecode call trace, the
 output pictures, and what the information calls return once headers are ready (h264bsdPicWidth / Height,
 CroppingParams, VideoRange, MatrixCoefficients, SampleAspectRatio, Profile, CheckValidParamSets).  TEST TOOL (uses
-oracle/).   usage: sweep_headers.py <first seed> <count> [pps|slice]      (slice: 1-4 slice NAL units with random HEADERS are inserted between the stream's own; pps: the PICTURE parameter set is the random one: slice
+oracle/).   usage: sweep_headers.py <first seed> <count> [pps|slice|nal]      (nal: NAL units of the skipped types inserted in mid-stream; slice: 1-4 slice NAL units with random HEADERS are inserted between the stream's own; pps: the PICTURE parameter set is the random one: slice
 group maps of all types with boundary values, QP offsets, reference counts, flags the baseline decoder rejects)"""
 import sys, os, time, random, ctypes, hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -322,12 +322,25 @@ for seed in range(first, first + count):
     assert data[4] & 31 == 7
     third = data.index(b"\x00\x00\x00\x01", second + 4)
     assert data[second + 4] & 31 == 8
-    if MODE in ("pps", "slice"):
+    if MODE in ("pps", "slice", "nal"):
         if MODE == "pps":
             data = data[:second] + random_pps(cfg, rng) + data[third:]
             if rng.random() < 0.2:                     # ... and another one later
                 cut = data.index(b"\x00\x00\x00\x01", len(data) // 2) if b"\x00\x00\x00\x01" in data[len(data) // 2:] else len(data)
                 data = data[:cut] + random_pps(cfg, rng) + data[cut:]
+        elif MODE == "nal":
+            # 1-6 NAL units of the types a decoder skips (SEI, access unit delimiter, end of sequence / stream, filler,
+            # reserved, unspecified, data partitions) between the stream's own — some of them end an access unit
+            # (h264bsdCheckAccessUnitBoundary, src/h264bsd_decoder.c / h264bsd_slice_header.c), a few have a forbidden_zero_bit
+            starts = [i for i in range(third, len(data) - 4) if data[i:i + 4] == b"\x00\x00\x00\x01" and data[i - 1:i] != b"\x00"] + [len(data)]
+            for _ in range(rng.randrange(1, 7)):
+                at = rng.choice(starts)
+                t = rng.choice([6, 6, 9, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 2, 3, 4, 23, 24, 31, 0])
+                hdr = (0x80 if rng.random() < 0.05 else 0) | (rng.randrange(4) << 5) | t
+                body = bytes(rng.randrange(1, 256) for _ in range(rng.randrange(0, 30)))     # (no zero bytes: no start codes inside)
+                extra = rng.choice([b"\x00\x00\x00\x01", b"\x00\x00\x01"]) + bytes([hdr]) + body
+                data = data[:at] + extra + data[at:]
+                starts = [x + len(extra) if x >= at else x for x in starts]
         else:                                          # 1-4 slices with random headers between the stream's own NAL units
             starts = [i for i in range(third, len(data) - 4) if data[i:i + 4] == b"\x00\x00\x00\x01" and data[i - 1:i] != b"\x00"] + [len(data)]
             for _ in range(rng.randrange(1, 5)):
