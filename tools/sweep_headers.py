@@ -6,7 +6,7 @@ boundary and out-of-range values mixed in (the reference rejects e.g. max_bytes_
 cropping rectangle larger than the picture).  Compared with the compiled reference: the h264bsdDecode call trace, the
 output pictures, and what the information calls return once headers are ready (h264bsdPicWidth / Height,
 CroppingParams, VideoRange, MatrixCoefficients, SampleAspectRatio, Profile, CheckValidParamSets).  TEST TOOL (uses
-oracle/).   usage: sweep_headers.py <first seed> <count> [pps|slice|nal]      (nal: NAL units of the skipped types inserted in mid-stream; slice: 1-4 slice NAL units with random HEADERS are inserted between the stream's own; pps: the PICTURE parameter set is the random one: slice
+oracle/).   usage: sweep_headers.py <first seed> <count> [pps|slice|nal|bytestream]      (bytestream: the Annex B framing is varied; nal: NAL units of the skipped types inserted in mid-stream; slice: 1-4 slice NAL units with random HEADERS are inserted between the stream's own; pps: the PICTURE parameter set is the random one: slice
 group maps of all types with boundary values, QP offsets, reference counts, flags the baseline decoder rejects)"""
 import sys, os, time, random, ctypes, hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -322,12 +322,30 @@ for seed in range(first, first + count):
     assert data[4] & 31 == 7
     third = data.index(b"\x00\x00\x00\x01", second + 4)
     assert data[second + 4] & 31 == 8
-    if MODE in ("pps", "slice", "nal"):
+    if MODE in ("pps", "slice", "nal", "bytestream"):
         if MODE == "pps":
             data = data[:second] + random_pps(cfg, rng) + data[third:]
             if rng.random() < 0.2:                     # ... and another one later
                 cut = data.index(b"\x00\x00\x00\x01", len(data) // 2) if b"\x00\x00\x00\x01" in data[len(data) // 2:] else len(data)
                 data = data[:cut] + random_pps(cfg, rng) + data[cut:]
+        elif MODE == "bytestream":
+            # the Annex B framing itself (reference h264bsdExtractNalUnit, src/h264bsd_byte_stream.c): 3-byte start codes,
+            # extra zero bytes before and after NAL units, a stream that begins without a start code, emulation-prevention
+            # and forbidden byte patterns (00 00 00, 00 00 02, 00 00 03 xx) at random places inside NAL units
+            starts = [i for i in range(0, len(data) - 4) if data[i:i + 4] == b"\x00\x00\x00\x01" and data[i - 1:i] != b"\x00"] + [len(data)]
+            parts = [data[starts[i]:starts[i + 1]] for i in range(len(starts) - 1)]
+            out = []
+            for k, pnal in enumerate(parts):
+                body = bytearray(pnal[4:])
+                if rng.random() < 0.15 and len(body) > 6:
+                    at = rng.randrange(2, len(body) - 3)
+                    body[at:at] = rng.choice([b"\x00\x00\x00", b"\x00\x00\x02", b"\x00\x00\x03", b"\x00\x00\x03\x04", b"\x00\x00\x03\x00\x00\x03", b"\x00\x00"])
+                sc = rng.choice([b"\x00\x00\x00\x01", b"\x00\x00\x00\x01", b"\x00\x00\x01", b"\x00" * rng.randrange(3, 8) + b"\x01"])
+                if k == 0 and rng.random() < 0.1:
+                    sc = rng.choice([b"", b"\x00", b"\x00\x00", b"\x01"])
+                tail = b"\x00" * rng.randrange(0, 4) if rng.random() < 0.3 else b""
+                out.append(sc + bytes(body) + tail)
+            data = b"".join(out)
         elif MODE == "nal":
             # 1-6 NAL units of the types a decoder skips (SEI, access unit delimiter, end of sequence / stream, filler,
             # reserved, unspecified, data partitions) between the stream's own — some of them end an access unit
