@@ -321,7 +321,8 @@ class StreamWriter:
                       idc=(0,), p_pcm=0.0, constrained_intra=0, fmo=None, idr_period=0, poc_pattern=None, reorder=False,
                       mmco=False, chroma_qp_offset=0, p_intra_in_p=0.2, p_skip=0.3, log2_max_frame_num=4,
                       num_reorder_frames=None, max_qp=28, aso=False, non_ref_every=0, gaps=0,
-                      offset_non_ref=1, redundant=False, level=40, min_qp=6, huge_levels=False, overflow=0.0)
+                      offset_non_ref=1, redundant=False, level=40, min_qp=6, huge_levels=False, overflow=0.0,
+                      p_huge_mv=0.0)   # share of motion vector differences of up to +-2300 samples: far outside the picture, or out of range
         self.c.update(cfg)
         self.rng = np.random.default_rng(self.c["seed"])
         self.sps = dict(level=self.c["level"], poc_type=self.c["poc_type"], num_ref_frames=self.c["num_ref_frames"], wmb=self.c["wmb"], hmb=self.c["hmb"],
@@ -482,6 +483,8 @@ class StreamWriter:
         bw.ue(ptype)
 
         def mvd():
+            if self.c["p_huge_mv"] and r.random() < self.c["p_huge_mv"]:        # (no draw when the option is off: streams of older fixtures stay as they are)
+                return int(r.integers(-9200, 9201))
             return int(r.integers(-6, 7)) if r.random() < 0.7 else int(r.integers(-40, 41))
         if ptype <= 2:
             parts = 1 if ptype == 0 else 2
