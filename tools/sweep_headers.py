@@ -6,7 +6,7 @@ boundary and out-of-range values mixed in (the reference rejects e.g. max_bytes_
 cropping rectangle larger than the picture).  Compared with the compiled reference: the h264bsdDecode call trace, the
 output pictures, and what the information calls return once headers are ready (h264bsdPicWidth / Height,
 CroppingParams, VideoRange, MatrixCoefficients, SampleAspectRatio, Profile, CheckValidParamSets).  TEST TOOL (uses
-oracle/).   usage: sweep_headers.py <first seed> <count> [pps|slice|nal|bytestream]      (bytestream: the Annex B framing is varied; nal: NAL units of the skipped types inserted in mid-stream; slice: 1-4 slice NAL units with random HEADERS are inserted between the stream's own; pps: the PICTURE parameter set is the random one: slice
+oracle/).   usage: sweep_headers.py <first seed> <count> [pps|slice|nal|bytestream|multipps]      (multipps: several PPSs under different ids, slices pointed at them; bytestream: the Annex B framing is varied; nal: NAL units of the skipped types inserted in mid-stream; slice: 1-4 slice NAL units with random HEADERS are inserted between the stream's own; pps: the PICTURE parameter set is the random one: slice
 group maps of all types with boundary values, QP offsets, reference counts, flags the baseline decoder rejects)"""
 import sys, os, time, random, ctypes, hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -233,6 +233,41 @@ def random_slice(cfg, rng):
     return nal(ref_idc, 5 if idr else 1, bw.bytes())
 
 
+def _rbsp(nal_bytes):
+    """payload of a NAL unit (after the one-byte header) without emulation-prevention bytes"""
+    out = bytearray(); zeros = 0
+    for b in nal_bytes:
+        if zeros >= 2 and b == 3:
+            zeros = 0
+            continue
+        out.append(b); zeros = zeros + 1 if b == 0 else 0
+    return bytes(out)
+
+
+def _read_ue(bits, pos):
+    z = 0
+    while bits[pos + z] == 0:
+        z += 1
+    v = 0
+    for i in range(z + 1):
+        v = (v << 1) | bits[pos + z + i]
+    return v - 1, pos + 2 * z + 1
+
+
+def with_pps_id(unit, new_id):
+    """the slice NAL unit `unit` (start code + header + payload) with its pic_parameter_set_id replaced"""
+    sc = 4 if unit[:4] == b"\x00\x00\x00\x01" else 3
+    hdr = unit[sc]
+    bits = np.unpackbits(np.frombuffer(_rbsp(unit[sc + 1:]), dtype=np.uint8)).tolist()
+    _, p = _read_ue(bits, 0); _, p = _read_ue(bits, p)
+    _, q = _read_ue(bits, p)
+    bw = BitWriter(); bw.bits = bits[:p]; bw.ue(new_id)
+    rest = bits[q:]
+    last = len(rest) - 1 - rest[::-1].index(1)           # the stop bit: re-align behind it
+    bw.bits += rest[:last + 1]; bw.align_zero()
+    return nal((hdr >> 5) & 3, hdr & 31, bw.bytes(), start_code=unit[:sc])
+
+
 def info_ref(lib, dec):
     dec = ctypes.c_void_p(dec)                      # (no argtypes are declared for the information calls: keep the pointer 64 bits wide)
     v = [ctypes.c_uint32() for _ in range(5)]
@@ -322,12 +357,41 @@ for seed in range(first, first + count):
     assert data[4] & 31 == 7
     third = data.index(b"\x00\x00\x00\x01", second + 4)
     assert data[second + 4] & 31 == 8
-    if MODE in ("pps", "slice", "nal", "bytestream"):
+    if MODE in ("pps", "slice", "nal", "bytestream", "multipps"):
         if MODE == "pps":
             data = data[:second] + random_pps(cfg, rng) + data[third:]
             if rng.random() < 0.2:                     # ... and another one later
                 cut = data.index(b"\x00\x00\x00\x01", len(data) // 2) if b"\x00\x00\x00\x01" in data[len(data) // 2:] else len(data)
                 data = data[:cut] + random_pps(cfg, rng) + data[cut:]
+        elif MODE == "multipps":
+            # several picture parameter sets under different ids — same syntax-relevant contents, other QP offsets,
+            # constrained-intra and deblocking-control settings left alone — and every slice pointed at one of them:
+            # between pictures (activation of another PPS with the same SPS, storage.c:379-414) and, in every fifth stream,
+            # from slice to slice inside a picture
+            import copy
+            w = h264writer.StreamWriter(**cfg)
+            ids = rng.sample(range(1, 256), rng.randrange(1, 4))
+            extra = b""
+            for i in ids:
+                pp = copy.deepcopy(w.pps); pp["pps_id"] = i
+                pp["chroma_qp_offset"] = rng.randrange(-12, 13)
+                pp["pic_init_qp"] = 26 + rng.randrange(-3, 4)
+                extra += h264writer.write_pps(pp, w.sps)
+            starts = [i for i in range(0, len(data) - 4) if data[i:i + 4] == b"\x00\x00\x00\x01" and data[i - 1:i] != b"\x00"] + [len(data)]
+            units = [data[starts[i]:starts[i + 1]] for i in range(len(starts) - 1)]
+            per_slice = rng.random() < 0.2
+            out, cur = [units[0], units[1], extra], 0
+            for u in units[2:]:
+                t = u[4] & 31
+                if t in (1, 5):
+                    first_mb, _ = _read_ue(np.unpackbits(np.frombuffer(_rbsp(u[5:9]), dtype=np.uint8)).tolist() + [1] * 8, 0)
+                    if per_slice or rng.random() < 0.3:
+                        cur = rng.choice([0] + ids)
+                    if rng.random() < 0.03:
+                        cur = rng.choice([0] + ids + [rng.randrange(256)])      # now and then an id that was never sent
+                    u = with_pps_id(u, cur)
+                out.append(u)
+            data = b"".join(out)
         elif MODE == "bytestream":
             # the Annex B framing itself (reference h264bsdExtractNalUnit, src/h264bsd_byte_stream.c): 3-byte start codes,
             # extra zero bytes before and after NAL units, a stream that begins without a start code, emulation-prevention
