@@ -6,7 +6,7 @@ boundary and out-of-range values mixed in (the reference rejects e.g. max_bytes_
 cropping rectangle larger than the picture).  Compared with the compiled reference: the h264bsdDecode call trace, the
 output pictures, and what the information calls return once headers are ready (h264bsdPicWidth / Height,
 CroppingParams, VideoRange, MatrixCoefficients, SampleAspectRatio, Profile, CheckValidParamSets).  TEST TOOL (uses
-oracle/).   usage: sweep_headers.py <first seed> <count> [pps|slice|nal|bytestream|multipps]      (multipps: several PPSs under different ids, slices pointed at them; bytestream: the Annex B framing is varied; nal: NAL units of the skipped types inserted in mid-stream; slice: 1-4 slice NAL units with random HEADERS are inserted between the stream's own; pps: the PICTURE parameter set is the random one: slice
+oracle/).   usage: sweep_headers.py <first seed> <count> [pps|slice|nal|bytestream|multipps|multisps]      (multisps: three sequences under different SPS / PPS ids; multipps: several PPSs under different ids, slices pointed at them; bytestream: the Annex B framing is varied; nal: NAL units of the skipped types inserted in mid-stream; slice: 1-4 slice NAL units with random HEADERS are inserted between the stream's own; pps: the PICTURE parameter set is the random one: slice
 group maps of all types with boundary values, QP offsets, reference counts, flags the baseline decoder rejects)"""
 import sys, os, time, random, ctypes, hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -357,12 +357,34 @@ for seed in range(first, first + count):
     assert data[4] & 31 == 7
     third = data.index(b"\x00\x00\x00\x01", second + 4)
     assert data[second + 4] & 31 == 8
-    if MODE in ("pps", "slice", "nal", "bytestream", "multipps"):
+    if MODE in ("pps", "slice", "nal", "bytestream", "multipps", "multisps"):
         if MODE == "pps":
             data = data[:second] + random_pps(cfg, rng) + data[third:]
             if rng.random() < 0.2:                     # ... and another one later
                 cut = data.index(b"\x00\x00\x00\x01", len(data) // 2) if b"\x00\x00\x00\x01" in data[len(data) // 2:] else len(data)
                 data = data[:cut] + random_pps(cfg, rng) + data[cut:]
+        elif MODE == "multisps":
+            # three different sequences under DIFFERENT parameter-set ids, all parameter sets up front (or each in front of
+            # its sequence), the slices of sequence k pointed at PPS k: the switch of the active SPS at an IDR picture
+            # (storage.c:379-407), and — when the IDR slices of a sequence are dropped — the refusal to switch elsewhere
+            heads, bodies = [], []
+            for k in range(3):
+                ck = h264writer.random_config(seed * 3 + k); ck["n_pics"] = min(ck.get("n_pics", 6), 5)
+                wk = h264writer.StreamWriter(**ck)
+                dk = wk.build()
+                sid, pid = (k, k) if rng.random() < 0.7 else (rng.randrange(32), rng.randrange(256))
+                st = [i for i in range(0, len(dk) - 4) if dk[i:i + 4] == b"\x00\x00\x00\x01" and dk[i - 1:i] != b"\x00"] + [len(dk)]
+                units = [dk[st[i]:st[i + 1]] for i in range(len(st) - 1)]
+                heads.append(h264writer.write_sps(dict(wk.sps, sps_id=sid)) + h264writer.write_pps(dict(wk.pps, pps_id=pid), dict(wk.sps, sps_id=sid)))
+                sl = [with_pps_id(u, pid) for u in units[2:]]
+                if k and rng.random() < 0.25:
+                    while sl and sl[0][4] & 31 == 5:
+                        sl.pop(0)                       # the sequence starts without its IDR picture
+                bodies.append(b"".join(sl))
+            if rng.random() < 0.5:
+                data = b"".join(heads) + b"".join(bodies)
+            else:
+                data = b"".join(h + b for h, b in zip(heads, bodies))
         elif MODE == "multipps":
             # several picture parameter sets under different ids — same syntax-relevant contents, other QP offsets,
             # constrained-intra and deblocking-control settings left alone — and every slice pointed at one of them:
