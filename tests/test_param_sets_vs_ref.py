@@ -23,3 +23,16 @@ def test_random_sequence_parameter_sets_match_the_reference(built):
     assert r.returncode == 0 and "600 identical, 0 not" in last, r.stdout[-2000:]
     accepted = int(last.split("headers accepted in ")[1].split()[0])
     assert accepted > 60, "the generator no longer produces parameter sets the reference accepts"
+
+
+@pytest.mark.parametrize("mode,count", [("pps", 300), ("slice", 200), ("nal", 200), ("bytestream", 200), ("multipps", 150), ("multisps", 60)])
+def test_header_sweeps_match_the_reference(built, mode, count):
+    """the other modes of tools/sweep_headers.py, a few hundred cases each: random picture parameter sets, random slice
+    headers, skipped NAL unit types in mid-stream, Annex B framing variations, several PPSs / SPSs under different ids"""
+    from oracle import pyoracle
+    if not os.path.exists(pyoracle.REF_SO):
+        pytest.skip("oracle/_ref not built")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_headers.py"), "1000", str(count), mode],
+                       capture_output=True, text=True, timeout=900)
+    last = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert r.returncode == 0 and f"{count} identical, 0 not" in last, r.stdout[-2000:]
