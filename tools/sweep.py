@@ -16,6 +16,7 @@ ap.add_argument("--drop", type=float, default=0.2); ap.add_argument("--trunc", t
 ap.add_argument("--overflow", type=float, default=0.0, help="probability that a coefficient block carries a level near the residual-range limit")
 ap.add_argument("--keep-redundant", action="store_true"); ap.add_argument("--keep-gaps", action="store_true")
 ap.add_argument("--huge-mv", type=float, default=0.0, help="share of motion vector differences of up to +-2300 samples (far outside the picture / out of range)")
+ap.add_argument("--long", action="store_true", help="40-70 pictures per stream, pic_order_cnt_lsb of 4 bits, frame_num of 4: both wrap several times")
 ap.add_argument("--sizes", default="", help="WMIN-WMAX,HMIN-HMAX: override the picture size of random_config (2-7 x 2-6 macroblocks) — tiny "
                 "pictures, or rows longer than ten macroblocks (h264bsdMarkSliceCorrupted counts max(width, 10)); slice groups become none / dispersed")
 ap.add_argument("--concat", type=int, default=1, help="N > 1: every case is N different random streams one after the other (new SPS "
@@ -43,7 +44,12 @@ for seed in range(args.first, args.first + args.count):
                 if not args.keep_redundant: cfg["redundant"] = False
             if args.overflow: cfg["overflow"] = args.overflow; cfg["max_qp"] = max(cfg["max_qp"], 40)
             if args.huge_mv: cfg["p_huge_mv"] = args.huge_mv
-            part = h264writer.StreamWriter(**cfg).build()
+            if args.long:
+                cfg["n_pics"] = 40 + sub % 31
+            w = h264writer.StreamWriter(**cfg)
+            if args.long:
+                w.sps["log2_max_poc_lsb"] = 4
+            part = w.build()
             if args.damage:
                 part = dmg.damage(part, sub, p_drop=args.drop, p_flip=args.flip, p_trunc=args.trunc)
             if args.concat > 1 and k + 1 < args.concat and (seed + k) & 1:
