@@ -160,7 +160,10 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
          * reading past the job) */
         if (recon && (r->kind == FJ_MB_INTER || r->kind == FJ_MB_I4x4 || r->kind == FJ_MB_I16x16 || r->kind == FJ_MB_IPCM)) {
             const uint32_t nb = r->kind == FJ_MB_IPCM ? 12u : (uint32_t)__builtin_popcount(r->coded & 0x03FFFFFFu);
-            if (nb && (r->coef_idx > coef_blocks || nb > coef_blocks - r->coef_idx)) return -1;
+            if (nb && (r->coef_idx > coef_blocks || nb > coef_blocks - r->coef_idx)) {
+                if (hd_trace) fprintf(stderr, "TRACE fj_finalize: mb %u kind %u pred %#x needs blocks %u..%u of %u (ghost %u dbk_only %u)\n", a, r->kind, r->pred, r->coef_idx, r->coef_idx + nb, coef_blocks, h->ghost, h->dbk_only);
+                return -1;
+            }
         }
         if (r->kind == FJ_MB_ABSENT || r->kind == FJ_MB_STALE) n_absent++;
         else if (r->kind == FJ_MB_CONCEAL_I) n_conceal += (uint32_t)recon;
@@ -368,10 +371,15 @@ deblock_index:
 static void fill_undecoded(HostDec *d)
 {
     FjHeader *h = (FjHeader *)d->job;
-    if (d->num_decoded_mbs == d->pic_size_mbs) return;
+    /* The reference's macroblock counter can say "complete" while a macroblock was never decoded (redundant slices and
+     * roll-backs miscount, storage.c:538): such a macroblock — touched by a slice that failed before it wrote a record, or
+     * by none — has no record, and the job buffer is reused from picture to picture.  (A macroblock that a failed
+     * redundant slice un-decoded keeps the record, and the pixels, of the earlier slice: mb_rec_sid.) */
+    const int complete = d->num_decoded_mbs == d->pic_size_mbs;
+    if (complete && !d->pic_irregular) return;
     FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
     for (uint32_t a = 0; a < d->pic_size_mbs; a++)
-        if (!d->mb_decoded[a]) {
+        if (!d->mb_decoded[a] && !(complete && d->mb_rec_sid[a])) {
             memset(&recs[a], 0, sizeof(FjMbRec));
             recs[a].kind = FJ_MB_ABSENT;
             memset(d->job + h->mv_off + (size_t)a * 64u, 0, 64);
@@ -544,6 +552,7 @@ static void reset_picture_state(HostDec *d)
     d->ghost_len = 0;
     if (d->n_redo && d->mb_redone) memset(d->mb_redone, 0, d->pic_size_mbs);
     d->n_redo = 0; d->n_redo2 = 0;
+    d->pic_irregular = 0;
     d->slice_ids_rewritten = 0;
 }
 
@@ -724,6 +733,7 @@ int hd_redo_keep_first(HostDec *d, uint32_t addr, const FjMbRec *rec, const int1
         d->redo = nb; d->redo_cap = cap;
     }
     struct RedoMb *r = &d->redo[d->n_redo++];
+    if (hd_trace) fprintf(stderr, "TRACE redo first version: mb %u kind %u coef_idx %u rec_sid %u decoded %u\n", addr, rec->kind, rec->coef_idx, d->mb_rec_sid[addr], d->mb_decoded[addr]);
     r->addr = addr; r->rec = *rec;
     memcpy(r->mv, mv, 64);
     d->mb_redone[addr] = 1;
@@ -815,6 +825,7 @@ static void mark_slice_corrupted(HostDec *d, uint32_t first_mb)
         addr = i;
     }
     if (hd_trace) fprintf(stderr, "TRACE corrupt: first %u last %u start %u sid %u\n", first_mb, d->last_mb_addr, addr, sid);
+    d->pic_irregular = 1;
     ghost_store_slice(d, sid);
     /* The coefficient blocks of the macroblocks that become undecoded are reclaimed: they were appended in decoding
      * order behind those of the macroblocks that stay (redundant re-decodes append nothing), so the section is cut at

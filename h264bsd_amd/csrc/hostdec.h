@@ -304,6 +304,7 @@ typedef struct HostDec {
     struct RedoMb *redo2;
     uint32_t n_redo2, redo2_cap;
     uint8_t *mb_redone;     /* per macroblock, allocated on first use */
+    uint8_t  pic_irregular;         /* a slice of this picture was rolled back (mark_slice_corrupted) */
     uint8_t  slice_ids_rewritten;   /* a redundant slice ran over macroblocks of this picture (it restamps their slice id even when it fails) */
 
     JobSink sink;

@@ -130,3 +130,6 @@ for _s in (971573, 972160):                     # stale motion state from an ear
 # a rolled-back slice's pixels under a macroblock that is never written again, predicted from a macroblock the same
 # (redundant) slice had only decoded again: the pre-pass job brings that one along in its first version
 SWEEP_FINDS["redundant_flipped_1122884"] = (random_config(1122884), dict(seed=1122884, p_drop=0.02, p_flip=0.6, p_trunc=0.02))
+# the macroblock counter says "complete" while a macroblock was never decoded (a slice failed before it wrote a record):
+# the picture shows what the frame buffer held, and the record must say ABSENT — not what the reused job buffer held
+SWEEP_FINDS["redundant_flipped_2005492"] = (random_config(2005492), dict(seed=2005492, p_drop=0.1, p_flip=0.4, p_trunc=0.1))
