@@ -173,8 +173,9 @@ def main():
         return _cpu_worker(int(sys.argv[2]), float(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=80, help="timed steps of the lock-step variant (default: ~10 s of steady state, SURVEY.md 8d config 4)")
+    ap.add_argument("--side-steps", type=int, default=0, help="timed steps of the other variants (staggered, ARGB, desynchronised); 0 = min(--steps, 20)")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=256, help="concurrent streams per GPU")
     ap.add_argument("--groups", type=int, default=1, help="stream groups on separate HIP streams (overlap)")
     ap.add_argument("--ramp-seconds", type=float, default=4.0, help="untimed load before the warm-up steps (device clock ramp)")
@@ -187,11 +188,23 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end leg through the drop-in C API (host parse + H2D + kernels)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU), exactly as the driver's
+        # `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` would; rank 0 prints the line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but {world} rank(s) were started (WORLD_SIZE): refusing to report a line for another GPU count")
+    side_steps = args.side_steps or min(args.steps, 20)
 
     import torch
     import h264bsd_amd
@@ -228,7 +241,7 @@ def main():
     kernels = h264bsd_amd.Replay.KERNELS
     golden_sums = golden["frame_checksum64"]
 
-    def run_variant(odd_offset):
+    def run_variant(odd_offset, steps):
         """Verify, warm up and time one variant of the workload.  odd_offset = 0: lock-step (every stream on
         the same picture index: two all-IDR ticks per step, the worst case); otherwise odd streams start at the
         second IDR (SURVEY.md §8d config 4 "staggered").  Returns (elapsed s, kernel ms, launches, device ms, job bytes)."""
@@ -271,7 +284,7 @@ def main():
         k_ms = {k: 0.0 for k in kernels}
         k_n = {k: 0 for k in kernels}
         dev_total_ms = 0.0
-        for _ in range(args.steps):
+        for _ in range(steps):
             rep.run()
             t = rep.timings()        # waits for the step; HIP events recorded on the engine's own stream
             for k in kernels:
@@ -288,7 +301,7 @@ def main():
             rep.run(); rep.sync()
             barrier()
             tg = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(side_steps):
                 rep.run()
                 rep.timings()
             barrier()
@@ -297,7 +310,7 @@ def main():
         rep.set_timed_kernels(31)
         if dom is None:
             dom = max(kernels, key=lambda k: k_ms[k])
-            breakdown = {k: (k_ms[k] / args.steps, k_n[k] // args.steps) for k in kernels}
+            breakdown = {k: (k_ms[k] / steps, k_n[k] // steps) for k in kernels}
         verify(n_pics - 1)                                     # the final pictures, after the timed region
         job_bytes = rep.job_bytes
         rep.close()
@@ -308,12 +321,12 @@ def main():
             elapsed = float(tt.item())
         return elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local, extra
 
-    elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local_elapsed, lock_extra = run_variant(0)
+    elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local_elapsed, lock_extra = run_variant(0, args.steps)
     staggered = None
     if not args.no_staggered and args.streams > 1:
         idr = [i for i, h in enumerate(heads) if h["is_idr"] and i > 0]
         if idr:
-            st_elapsed, _, _, st_dev_ms, _, _, st_breakdown, _, _ = run_variant(idr[0])
+            st_elapsed, _, _, st_dev_ms, _, _, st_breakdown, _, _ = run_variant(idr[0], side_steps)
             staggered = dict(odd_stream_offset=idr[0], elapsed=st_elapsed, breakdown=st_breakdown, dev_ms=st_dev_ms)
 
     # ---- BASELINE.json config 3: the same lock-step work with the colour conversion of every produced picture inside
@@ -337,7 +350,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         conv_ms, conv_n, a_dev_ms = 0.0, 0, 0.0
-        for _ in range(args.steps):
+        for _ in range(side_steps):
             rep.run()
             a_dev_ms += rep.timings()["total_ms"]
             ms, n = rep.convert_timings()
@@ -379,7 +392,7 @@ def main():
             verify_lap()
             barrier()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(side_steps):
                 rep.run()
             rep.sync()
             barrier()
@@ -390,8 +403,8 @@ def main():
                 tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = float(tt.item())
-            desync[key] = {"value": n_pics * args.streams * world * n_mbs * args.steps / dt, "unit": "macroblocks/s",
-                           "ms_per_step": dt * 1e3 / args.steps, "lanes": lanes, "rejoin_after_ticks": delay, "stream_groups": groups}
+            desync[key] = {"value": n_pics * args.streams * world * n_mbs * side_steps / dt, "unit": "macroblocks/s",
+                           "ms_per_step": dt * 1e3 / side_steps, "steps": side_steps, "lanes": lanes, "rejoin_after_ticks": delay, "stream_groups": groups}
 
     # on-box ceiling of a plain device-to-device copy (report the fraction of both peaks)
     copy_gbs = None
@@ -460,7 +473,9 @@ def main():
             "config": {"workload": f"{args.streams} concurrent copies of {STREAM}.h264 per GPU "
                                    f"({n_pics} pictures x {n_mbs} MB), kernel-only replay from HBM-resident frame jobs, "
                                    "inter+intra reconstruction + in-loop deblocking, bit-exact vs reference verified on device",
-                       "streams_per_gpu": args.streams, "pictures_per_step": pics_per_step, "parallelism": f"streams/{world}"},
+                       "streams_per_gpu": args.streams, "pictures_per_step": pics_per_step, "parallelism": f"streams/{world}",
+                       "stream_groups": args.groups,
+                       "row_bands": os.environ.get("H264BSDMI_TAIL", "library default (engine.hip TailConfig)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "alg_bytes_per_launch": alg_per_mb * units_per_launch,
@@ -475,32 +490,42 @@ def main():
         }
         if "groups4_elapsed" in lock_extra:
             ge = lock_extra["groups4_elapsed"]
-            out["lock_step_4_stream_groups"] = {"value": n_pics * args.streams * n_mbs * args.steps / ge, "unit": "macroblocks/s",
-                                                "ms_per_step": ge * 1e3 / args.steps,
+            out["lock_step_4_stream_groups"] = {"value": n_pics * args.streams * n_mbs * side_steps / ge, "unit": "macroblocks/s",
+                                                "ms_per_step": ge * 1e3 / side_steps, "steps": side_steps,
                                                 "note": "rank 0's own clock; same work as `value`, streams split into 4 groups on 4 HIP streams"}
         if staggered is not None:
             # same work per step, odd streams start at the second IDR: I pictures never fill a whole tick
-            out["staggered"] = {"value": mbs / staggered["elapsed"], "unit": "macroblocks/s",
-                                "fps": pics_per_step * args.steps / staggered["elapsed"],
-                                "ms_per_step": staggered["elapsed"] * 1e3 / args.steps,
+            side_mbs = pics_per_step * n_mbs * side_steps
+            st_gbs = alg_bytes_stream * args.streams * world * side_steps / staggered["elapsed"] / 1e9
+            out["staggered"] = {"value": side_mbs / staggered["elapsed"], "unit": "macroblocks/s",
+                                "fps": pics_per_step * side_steps / staggered["elapsed"],
+                                "ms_per_step": staggered["elapsed"] * 1e3 / side_steps, "steps": side_steps,
                                 "odd_stream_offset_pictures": staggered["odd_stream_offset"],
+                                "vs_lock_step": side_mbs / staggered["elapsed"] / (mbs / elapsed),
+                                "whole_path_GBs": st_gbs, "whole_path_frac": st_gbs / HBM_PEAK_GBS / world,
                                 "device_ms_per_step": dict({k: staggered["breakdown"][k][0] for k in kernels},
-                                                           total=staggered["dev_ms"] / args.steps)}
+                                                           total=staggered["dev_ms"] / side_steps)}
         if argb is not None:
             # config 3: algorithmic bytes per macroblock + 1024 (32-bit pixels written); k_convert's own roofline:
             # 384 B read + 1024 B written per macroblock, every launch covers one picture of every stream
             a_launches = max(argb["conv_n"], 1)
             conv_us = argb["conv_ms"] * 1e3 / a_launches
             conv_bytes = (384 + 1024) * n_mbs * args.streams
-            out["argb"] = {"value": mbs / argb["elapsed"], "unit": "macroblocks/s", "fps": pics_per_step * args.steps / argb["elapsed"],
-                           "ms_per_step": argb["elapsed"] * 1e3 / args.steps, "format": "BGRA (the reference's ARGB word, h264bsdConvertToBGRA)",
+            out["argb"] = {"value": pics_per_step * n_mbs * side_steps / argb["elapsed"], "unit": "macroblocks/s", "fps": pics_per_step * side_steps / argb["elapsed"],
+                           "ms_per_step": argb["elapsed"] * 1e3 / side_steps, "steps": side_steps, "format": "BGRA (the reference's ARGB word, h264bsdConvertToBGRA)",
                            "alg_bytes_per_mb": alg_per_mb + 1024,
-                           "whole_path_GBs": (alg_bytes_stream + 1024 * n_mbs * n_pics) * args.streams * args.steps / (argb["dev_ms"] * 1e-3) / 1e9,
+                           "whole_path_GBs": (alg_bytes_stream + 1024 * n_mbs * n_pics) * args.streams * side_steps / (argb["dev_ms"] * 1e-3) / 1e9,
                            "k_convert": {"avg_launch_us": conv_us, "launches": argb["conv_n"], "alg_bytes_per_launch": conv_bytes,
                                          "achieved_GBs": conv_bytes / (conv_us * 1e-6) / 1e9, "frac": conv_bytes / (conv_us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
         if per_gpu is not None:
             out["per_gpu"] = {"value": per_gpu, "unit": "macroblocks/s", "note": "lock-step variant, each rank's own clock over the timed steps"}
         if desync is not None:
+            # the same algorithmic bytes per lap as a lock-step step: fraction of the HBM peak and of the lock-step value
+            for key, d in desync.items():
+                if isinstance(d, dict):
+                    d["whole_path_GBs"] = alg_bytes_stream * args.streams * world / (d["ms_per_step"] * 1e-3) / 1e9
+                    d["whole_path_frac"] = d["whole_path_GBs"] / HBM_PEAK_GBS / world
+                    d["vs_lock_step"] = d["value"] / (mbs / elapsed)
             out["desynchronised"] = desync
         if world == 1 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end(data, min(args.streams, 256), 0)      # 0: the library's default (usable CPUs, at most 64)

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads",
     "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayCreateSched", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
-    "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
+    "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiDebugSetTail", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
 ]
 
 class DevicePicture(ctypes.Structure):
@@ -140,6 +140,7 @@ def lib():
     L.h264bsdmiReplaySetStages.argtypes = [vp, ctypes.c_uint]
     L.h264bsdmiReplaySetTimedKernels.argtypes = [vp, ctypes.c_uint]
     L.h264bsdmiReplaySetGroups.argtypes = [vp, u32]
+    L.h264bsdmiDebugSetTail.argtypes = [u32] * 6
     L.h264bsdmiReplayJobBytes.argtypes = [vp]
     L.h264bsdmiReplayJobBytes.restype = ctypes.c_ulonglong
     L.h264bsdmiReplayFrameBytes.argtypes = [vp]
@@ -150,6 +151,15 @@ def lib():
 
 def device_count():
     return int(lib().h264bsdmiDeviceCount())
+
+
+KEEP = 0xFFFFFFFF
+
+
+def set_tail(dbk_rows_light=KEEP, dbk_rows_heavy=KEEP, dbk_waves=KEEP, intra_rows_light=KEEP, intra_rows_heavy=KEEP, intra_waves=KEEP):
+    """How the per-picture kernels split the pictures of replay sets / decoders created from now on into row bands
+    (h264bsdmiDebugSetTail): rows per band for light / heavy pictures (0 = one band) and wavefronts per workgroup."""
+    lib().h264bsdmiDebugSetTail(dbk_rows_light, dbk_rows_heavy, dbk_waves, intra_rows_light, intra_rows_heavy, intra_waves)
 
 
 def device_errors():

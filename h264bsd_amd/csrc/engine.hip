@@ -43,6 +43,7 @@
 
 namespace {
 
+constexpr int MAX_DEVICES = 16;
 struct PendingJob { uint8_t *host; uint32_t bytes, cap; };
 constexpr size_t MAX_QUEUED_PICTURES = 8;    /* per decoder instance, before sink_submit starts the device on its own */
 
@@ -126,7 +127,6 @@ struct Engine {
  * current for the thread that initialises it: h264bsdmiSetDevice() sets it for the calling thread (and, the first time,
  * the process default); one process can therefore drive several GPUs, and the usual one-process-per-GPU launch just
  * calls it once. */
-constexpr int MAX_DEVICES = 16;
 Engine *g_engines[MAX_DEVICES] = {};
 std::mutex g_engine_mu;
 int g_default_device = -1;
@@ -251,12 +251,63 @@ Engine *engine_get(int device = -1)
     return e;
 }
 
+/* ---- how the two per-picture kernels split a picture (row bands, kernels.hip.h) ----
+ * rows per band for light / heavy pictures (heavy = more than a quarter of the macroblocks intra coded), wavefronts per
+ * workgroup, and a cap on the bands of one launch.  H264BSDMI_TAIL="dbk_rows_light,dbk_rows_heavy,dbk_waves,intra_rows_light,
+ * intra_rows_heavy,intra_waves" overrides the defaults (0 rows = one band); h264bsdmiDebugSetTail() does the same for tests. */
+struct TailConfig {
+    uint32_t dbk_rows_light = 17, dbk_rows_heavy = 9, dbk_waves = 4;
+    uint32_t intra_rows_light = 0, intra_rows_heavy = 9, intra_waves = 4;
+    bool from_env = false;
+};
+TailConfig g_tail;
+std::mutex g_tail_mu;
+TailConfig tail_config()
+{
+    std::lock_guard<std::mutex> lk(g_tail_mu);
+    if (!g_tail.from_env) {
+        g_tail.from_env = true;
+        if (const char *cfg = getenv("H264BSDMI_TAIL")) {
+            unsigned v[6];
+            if (sscanf(cfg, "%u,%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
+                g_tail.dbk_rows_light = v[0]; g_tail.dbk_rows_heavy = v[1]; g_tail.dbk_waves = v[2];
+                g_tail.intra_rows_light = v[3]; g_tail.intra_rows_heavy = v[4]; g_tail.intra_waves = v[5];
+            } else fprintf(stderr, "h264bsd-mi355x: H264BSDMI_TAIL=%s ignored (expected six numbers)\n", cfg);
+        }
+    }
+    return g_tail;
+}
+static uint16_t bands_for(uint32_t hmb, uint32_t rows)
+{
+    if (!rows || rows >= hmb) return 1;
+    return (uint16_t)std::min<uint32_t>((hmb + rows - 1) / rows, 64u);
+}
+
+/* ticket counters of the per-picture kernels (take_ticket, kernels.hip.h): one set per HIP stream that launches ticks —
+ * launches on one stream run one after the other, launches on different streams may overlap.  [0,1] k_frame_dbk,
+ * [2,3] k_frame_intra. */
+std::mutex g_ticket_mu;
+std::vector<std::pair<hipStream_t, uint32_t *>> g_tickets[MAX_DEVICES];
+static uint32_t *tickets_for(hipStream_t st)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    for (auto &p : g_tickets[dev]) if (p.first == st) return p.second;
+    uint32_t *d = nullptr;
+    if (hipMalloc((void **)&d, 64) != hipSuccess || hipMemset(d, 0, 64) != hipSuccess) return nullptr;
+    g_tickets[dev].emplace_back(st, d);
+    return d;
+}
+
 /* ---- launch of one tick ---- */
 struct TickShape {
     uint32_t n_frames = 0, max_mbs = 0;
     uint32_t max_copy = 0, max_gen = 0, max_gen_uni = 0, max_gen_rest = 0, max_dbk = 0, max_levels = 0, max_w = 0, max_h = 0;
     bool any_tail = false, any_deblock = false;
-    uint32_t dbk_waves = 0;          /* wavefronts per workgroup of k_frame_dbk; 0 = the compiled maximum (launch_tick) */
+    uint32_t dbk_waves = 0;          /* wavefronts per workgroup of k_frame_dbk; 0 = the configured default (launch_tick) */
+    uint32_t dbk_bands = 1, intra_bands = 1;   /* most bands any picture of the tick wants ... */
+    uint32_t dbk_rows = 0, intra_rows = 0;     /* ... and the most rows a band of any of its pictures has */
 };
 
 /* descriptor of one picture: device addresses of the sections of its (device-resident) frame job */
@@ -283,6 +334,14 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     d.wmb = h->width_mbs;
     d.hmb = h->height_mbs;
     d.any_deblock = h->any_deblock;
+    {
+        const TailConfig tc = tail_config();
+        const bool heavy = h->n_intra * 4u > h->n_mbs;
+        d.dbk_bands = bands_for(h->height_mbs, heavy ? tc.dbk_rows_heavy : tc.dbk_rows_light);
+        /* a concealed macroblock may wait for the macroblocks below it (FJ_NEED_D*): such a picture stays in one band,
+         * a band never waits for a band that started after it */
+        d.intra_bands = h->intra_down_deps ? 1 : bands_for(h->height_mbs, heavy ? tc.intra_rows_heavy : tc.intra_rows_light);
+    }
     d.err = dev_err;
     for (uint32_t k = 0; k < FJ_MAX_SLOTS; k++) d.slot[k] = k < h->n_slots ? dev_frames + (size_t)k * frame_bytes : nullptr;
     if (shape) {
@@ -298,6 +357,14 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
         shape->max_w = std::max<uint32_t>(shape->max_w, h->width_mbs);
         shape->max_h = std::max<uint32_t>(shape->max_h, h->height_mbs);
         shape->any_tail |= h->n_intra_levels != 0 || h->any_deblock != 0;
+        if (h->any_deblock) {
+            shape->dbk_bands = std::max<uint32_t>(shape->dbk_bands, d.dbk_bands);
+            shape->dbk_rows = std::max<uint32_t>(shape->dbk_rows, (h->height_mbs + d.dbk_bands - 1u) / d.dbk_bands);
+        }
+        if (h->n_intra_levels) {
+            shape->intra_bands = std::max<uint32_t>(shape->intra_bands, d.intra_bands);
+            shape->intra_rows = std::max<uint32_t>(shape->intra_rows, (h->height_mbs + d.intra_bands - 1u) / d.intra_bands);
+        }
     }
 }
 
@@ -344,34 +411,61 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
      * pictures that leave less than 16 wavefronts' worth of tile space in the 160 KB of a CU, fewer wavefronts run. */
     constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
     if (s.max_levels && (stages & 2u)) {
-        const uint32_t n = s.max_mbs;
-        const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 64 + h264k::I4TAB_BYTES;
-        if (arrays + h264k::INTRA_WAVE_LDS > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_intra\n", n); return -1; }
-        const uint32_t waves = (uint32_t)std::min<size_t>(h264k::TAIL_WAVES, (LDS_BUDGET - arrays) / h264k::INTRA_WAVE_LDS);
-        const size_t lds = (size_t)waves * h264k::INTRA_WAVE_LDS + arrays;
-        static size_t lds_enabled = 0;
-        if (lds > lds_enabled) {
-            HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_intra, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_enabled = lds;
+        const TailConfig tc = tail_config();
+        uint32_t rows = std::max<uint32_t>(1u, std::min<uint32_t>(s.intra_rows ? s.intra_rows : s.max_h, s.max_h));
+        uint32_t waves = std::max<uint32_t>(1u, std::min<uint32_t>(tc.intra_waves, h264k::TAIL_WAVES));
+        /* a picture with concealed macroblocks must stay in one band (FjHeader.intra_down_deps): fewer wavefronts before
+         * shorter bands */
+        while (h264k::intra_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && waves > 1) waves--;
+        if (h264k::intra_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u x %u macroblocks is too large for k_frame_intra\n", s.max_w, s.max_h); return -1; }
+        const size_t lds = h264k::intra_lds_bytes(waves, s.max_w, rows);
+        const uint32_t bands = std::max<uint32_t>(s.intra_bands, (s.max_h + rows - 1) / rows);
+        uint32_t *tickets = tickets_for(st);
+        if (!tickets) return -1;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        static size_t lds_enabled[MAX_DEVICES] = {};
+        static std::mutex lds_mu;
+        {
+            std::lock_guard<std::mutex> lk(lds_mu);
+            if (lds > lds_enabled[dev]) {
+                HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_intra, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_enabled[dev] = lds;
+            }
         }
-        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof);
+        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets + 2, bands, rows);
         if (launches) launches[3]++;
     }
     if (EV_NEEDED(4)) HIP_TRY(hipEventRecord(tt->ev[4], st));
     if (aside) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
     if (s.any_deblock && (stages & 4u)) {
-        const uint32_t n = s.max_mbs;
-        const size_t arrays = 2 * (size_t)((n + 15) & ~15u) + 2 * (size_t)((n + 7) & ~7u) + 16 + 384 + 64;
-        const size_t per_wave = 4 * (size_t)h264k::WORKER_LDS;
-        if (arrays + per_wave > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u macroblocks is too large for k_frame_dbk\n", n); return -1; }
-        const uint32_t waves = (uint32_t)std::min<size_t>(s.dbk_waves ? std::min<uint32_t>(s.dbk_waves, h264k::DBK_WAVES) : h264k::DBK_WAVES, (LDS_BUDGET - arrays) / per_wave);
-        const size_t lds = (size_t)waves * per_wave + arrays;
-        static size_t lds_enabled = 0;
-        if (lds > lds_enabled) {
-            HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_dbk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_enabled = lds;
+        /* row bands: max_bands workgroups per picture (k_frame_dbk); the scheduling state of a band's rows lives in LDS
+         * next to its wavefronts' tiles */
+        const TailConfig tc = tail_config();
+        uint32_t rows = std::max<uint32_t>(1u, std::min<uint32_t>(s.dbk_rows ? s.dbk_rows : s.max_h, s.max_h));   /* no band has more rows than this */
+        uint32_t waves = std::min<uint32_t>(s.dbk_waves ? s.dbk_waves : tc.dbk_waves, h264k::DBK_WAVES);
+        waves = std::max<uint32_t>(waves, 1u);
+        /* pictures whose rows do not fit: shorter bands first (rows is a cap the kernel applies to every picture), fewer
+         * wavefronts then */
+        while (h264k::dbk_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && rows > 1) rows = (rows + 1) / 2;
+        while (h264k::dbk_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && waves > 1) waves--;
+        const size_t lds = h264k::dbk_lds_bytes(waves, s.max_w, rows);
+        if (lds > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture %u macroblocks wide is too large for k_frame_dbk\n", s.max_w); return -1; }
+        const uint32_t bands = std::max<uint32_t>(s.dbk_bands, (s.max_h + rows - 1) / rows);
+        uint32_t *tickets = tickets_for(st);
+        if (!tickets) return -1;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        static size_t lds_enabled[MAX_DEVICES] = {};
+        static std::mutex lds_mu;
+        {
+            std::lock_guard<std::mutex> lk(lds_mu);
+            if (lds > lds_enabled[dev]) {
+                HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_dbk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_enabled[dev] = lds;
+            }
         }
-        hipLaunchKernelGGL(h264k::k_frame_dbk, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof);
+        hipLaunchKernelGGL(h264k::k_frame_dbk, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets, bands, rows);
         if (launches) launches[4]++;
     }
     if (EV_NEEDED(5)) HIP_TRY(hipEventRecord(tt->ev[5], st));
@@ -549,8 +643,8 @@ int sink_configure(void *user, uint32_t wmb, uint32_t hmb, uint32_t n_slots)
     const size_t total = (size_t)n_slots * u->s->frame_bytes + 256;
     HIP_TRY(hipMalloc((void **)&u->s->d_frames, total));
     HIP_TRY(hipMemsetAsync(u->s->d_frames, 0, total, u->e->stream));
-    HIP_TRY(hipMalloc((void **)&u->s->d_dbk, (size_t)wmb * hmb * (DBK_REC_BYTES + 1) + 64));
-    HIP_TRY(hipMemsetAsync(u->s->d_dbk, 0, (size_t)wmb * hmb * (DBK_REC_BYTES + 1) + 64, u->e->stream));
+    HIP_TRY(hipMalloc((void **)&u->s->d_dbk, DBK_SCRATCH_BYTES(wmb * hmb)));
+    HIP_TRY(hipMemsetAsync(u->s->d_dbk, 0, DBK_SCRATCH_BYTES(wmb * hmb), u->e->stream));
     HIP_TRY(hipStreamSynchronize(u->e->stream));           /* the lanes do not order themselves behind this stream */
     u->s->last_lane = -1;
     return 0;
@@ -937,7 +1031,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
     r->blob_stride = total;
     r->d_blobs = nullptr; r->d_frames = nullptr; r->d_desc = nullptr; r->d_conv = nullptr; r->d_sums = nullptr; r->d_dbk = nullptr;
     const size_t frames_per_stream = (size_t)r->n_slots * r->frame_bytes;
-    const size_t dbk_stride = (((size_t)h0->n_mbs * (DBK_REC_BYTES + 1) + 64) + 255) & ~(size_t)255;
+    const size_t dbk_stride = (DBK_SCRATCH_BYTES(h0->n_mbs) + 255) & ~(size_t)255;
     bool ok = hipMalloc((void **)&r->d_blobs, total * n_streams) == hipSuccess &&
               hipMalloc((void **)&r->d_frames, frames_per_stream * n_streams + 256) == hipSuccess &&
               hipMalloc((void **)&r->d_desc, sizeof(FrameDesc) * (size_t)n_pics * n_streams) == hipSuccess &&
@@ -1358,6 +1452,22 @@ int h264bsdmiDebugTailProfile(int enable, unsigned long long *out)
         HIP_TRY(hipFree(e->tail_prof));
         e->tail_prof = nullptr;
     }
+    return 0;
+}
+
+/* Test / tuning hook: how the per-picture kernels split pictures from now on (TailConfig; descriptors built earlier keep their
+ * bands): rows per band for light and heavy pictures (0 = one band) and wavefronts per workgroup, for k_frame_dbk and
+ * k_frame_intra.  A value of 0xFFFFFFFF leaves that setting alone. */
+int h264bsdmiDebugSetTail(u32 dbk_rows_light, u32 dbk_rows_heavy, u32 dbk_waves, u32 intra_rows_light, u32 intra_rows_heavy, u32 intra_waves)
+{
+    (void)tail_config();                                     /* the environment first, once */
+    std::lock_guard<std::mutex> lk(g_tail_mu);
+    if (dbk_rows_light != 0xFFFFFFFFu) g_tail.dbk_rows_light = dbk_rows_light;
+    if (dbk_rows_heavy != 0xFFFFFFFFu) g_tail.dbk_rows_heavy = dbk_rows_heavy;
+    if (dbk_waves != 0xFFFFFFFFu && dbk_waves >= 1) g_tail.dbk_waves = dbk_waves;
+    if (intra_rows_light != 0xFFFFFFFFu) g_tail.intra_rows_light = intra_rows_light;
+    if (intra_rows_heavy != 0xFFFFFFFFu) g_tail.intra_rows_heavy = intra_rows_heavy;
+    if (intra_waves != 0xFFFFFFFFu && intra_waves >= 1) g_tail.intra_waves = intra_waves;
     return 0;
 }
 

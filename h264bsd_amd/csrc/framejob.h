@@ -127,7 +127,10 @@ typedef struct FjHeader {
     uint32_t dbk_only;        /* 1: the pixels of this picture were reconstructed by the job before it (a ghost job with the records
                                  they were made from); this job only deblocks, with the records the reference ends up with
                                  (macroblocks re-decoded by a redundant slice: it keeps the first pixels, the last metadata) */
-    uint32_t reserved[8];
+    uint32_t intra_down_deps; /* 1: the intra schedule holds concealed macroblocks, which may wait for the macroblock BELOW them
+                                 (FJ_NEED_D) and read all four neighbours: the picture's intra reconstruction must not be split
+                                 into row bands (k_frame_intra) */
+    uint32_t reserved[7];
 } FjHeader;                   /* 128 bytes */
 
 /* An inter macroblock with no coefficients whose 16 motion vectors are equal and whole-sample for

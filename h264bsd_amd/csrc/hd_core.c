@@ -362,6 +362,7 @@ deblock_index:
     }
     h->n_intra = n_intra;
     h->n_intra_levels = n_levels;
+    h->intra_down_deps = n_conceal ? 1 : 0;      /* concealed macroblocks may wait for the macroblock below them (FJ_NEED_D) */
     h->n_inter = n - n_intra - n_absent;
     h->any_deblock = any_dbk ? 1 : 0;
     return 0;

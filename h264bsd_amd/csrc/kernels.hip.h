@@ -55,6 +55,7 @@ struct FrameDesc {
     uint32_t        n_gen_uni;    /* the first n_gen_uni entries of gen have one motion vector for the whole macroblock */
     uint16_t        wmb, hmb;
     uint32_t        any_deblock;
+    uint16_t        dbk_bands, intra_bands;   /* row bands (= workgroups) the per-picture kernels may split this picture into (>= 1; the launch caps it) */
     uint32_t       *err;          /* device error word of the engine (DEVERR_* bits, atomicOr): must stay 0 */
     uint8_t        *slot[FJ_MAX_SLOTS];
 };
@@ -76,6 +77,10 @@ struct FrameDesc {
 #define DBKF_ANY  1u   /* at least one non-zero strength: the macroblock is filtered                         */
 #define DBKF_LEFT 2u   /* its left macroblock edge has a non-zero strength: it reads and rewrites the last columns of (x-1,y) */
 #define DBKF_TOP  4u   /* its upper macroblock edge has one: it reads and rewrites the last rows of (x,y-1)                   */
+/* Per-stream deblocking scratch (FrameDesc.dbk): n_mbs records | n4 flag bytes (DBKF_*) | n4 "done" bytes of k_frame_dbk's row
+ * bands | n4 "done" bytes of k_frame_intra's row bands | exit counters of the two kernels (u32 each) — n4 = n_mbs rounded up
+ * to a multiple of 4.  Flags, done bytes and counters are zero between pictures (the last band to leave cleans up). */
+#define DBK_SCRATCH_BYTES(n_mbs) ((size_t)(n_mbs) * (DBK_REC_BYTES + 3) + 64)
 
 namespace h264k {
 
@@ -108,6 +113,54 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
     uint32_t v;
     __builtin_memcpy(&v, p, 4);
     return v;
+}
+
+/* ---- hand-over between workgroups (row bands of one picture, k_frame_dbk / k_frame_intra) ----
+ * Workgroups of one launch may sit on different XCDs, whose L2s are not coherent with each other, and a CU's vector L1 is
+ * never refreshed by another CU's stores (MI355X_MICROARCH.md, "inter-workgroup visibility").  The samples a band hands to
+ * the band below therefore travel write-through: relaxed agent-scope stores (global_store ... sc1: the line leaves the
+ * producer's L2) and relaxed agent-scope loads (global_load ... sc1: past the L1) on the consumer's side, the "done" byte
+ * stored after s_waitcnt vmcnt(0) the same way.  No fences: a release fence writes back the whole L2 of the XCD. */
+#define H264K_GLOBAL __attribute__((address_space(1)))      /* HBM pointers: global_load / global_store instead of flat */
+#define H264K_LDS    __attribute__((address_space(3)))
+__device__ __forceinline__ uint32_t ld_agent_u32(const void *p)
+{
+    return __hip_atomic_load((const H264K_GLOBAL uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_agent_u8(const void *p)
+{
+    return __hip_atomic_load((const H264K_GLOBAL uint8_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_u32(void *p, uint32_t v)
+{
+    __hip_atomic_store((H264K_GLOBAL uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_u8(void *p, uint32_t v)
+{
+    __hip_atomic_store((H264K_GLOBAL uint8_t *)p, (uint8_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/* 4 / 8 / 16 bytes to a picture: plain, or write-through for samples another band will read */
+__device__ __forceinline__ void put4(void *p, uint32_t v, bool wt) { if (wt) st_agent_u32(p, v); else *reinterpret_cast<uint32_t *>(p) = v; }
+__device__ __forceinline__ void put8(void *p, uint2 v, bool wt)
+{
+    if (wt) { st_agent_u32(p, v.x); st_agent_u32(reinterpret_cast<uint8_t *>(p) + 4, v.y); }
+    else *reinterpret_cast<uint2 *>(p) = v;
+}
+__device__ __forceinline__ void put16(void *p, uint4 v, bool wt)
+{
+    if (wt) {
+        uint8_t *q = reinterpret_cast<uint8_t *>(p);
+        st_agent_u32(q, v.x); st_agent_u32(q + 4, v.y); st_agent_u32(q + 8, v.z); st_agent_u32(q + 12, v.w);
+    } else *reinterpret_cast<uint4 *>(p) = v;
+}
+__device__ __forceinline__ uint8_t *scratch_flags(const FrameDesc &fd) { return fd.dbk + (size_t)fd.n_mbs * DBK_REC_BYTES; }
+__device__ __forceinline__ uint8_t *scratch_done(const FrameDesc &fd, int which)      /* 0: k_frame_dbk, 1: k_frame_intra */
+{
+    return scratch_flags(fd) + (size_t)(1 + which) * ((fd.n_mbs + 3u) & ~3u);
+}
+__device__ __forceinline__ uint32_t *scratch_exits(const FrameDesc &fd, int which)
+{
+    return reinterpret_cast<uint32_t *>(scratch_flags(fd) + (size_t)3 * ((fd.n_mbs + 3u) & ~3u)) + which;
 }
 
 /* 4x4 transpose across the 4 lanes of a quad: lane q holds row q in v[0..3] -> holds column q */
@@ -1050,7 +1103,9 @@ __device__ __forceinline__ FjMbRec rec_from_lds(const uint32_t *rec_lds)
 /* The global loads of one intra macroblock — neighbour samples of the un-deblocked current picture and the coefficient
  * rows — issued one macroblock AHEAD of their use (k_frame_intra: while the previous macroblock of the group is being
  * reconstructed), so that the round trip hides behind that work. */
-__device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, const uint32_t *rec_lds, int lane, IntraLoads &L)
+/* cross: the macroblock lies in the first row of a row band (k_frame_intra): the tiles above were written by another
+ * workgroup and are read past the L1 (ld_agent_u8). */
+__device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, const uint32_t *rec_lds, int lane, IntraLoads &L, bool cross = false)
 {
     const FjMbRec rec = rec_from_lds(rec_lds);
     L.nb_y = L.nb_c = 128;
@@ -1062,7 +1117,10 @@ __device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, co
     if (lane < 21) {
         const int c = lane;                               /* corner, 16 above, 4 above-right: last row of the tiles above */
         const bool ok = c == 0 ? av_d : c <= 16 ? av_b : av_c;
-        if (ok) L.nb_y = c == 0 ? Y[up - TILE + 255] : c <= 16 ? Y[up + 240 + (c - 1)] : Y[up + TILE + 240 + (c - 17)];
+        if (ok) {
+            const uint8_t *q = c == 0 ? Y + up - TILE + 255 : c <= 16 ? Y + up + 240 + (c - 1) : Y + up + TILE + 240 + (c - 17);
+            L.nb_y = cross ? (int)ld_agent_u8(q) : (int)*q;
+        }
     } else if (lane >= 32 && lane < 48) {
         if (av_a) L.nb_y = Y[-TILE + (lane - 32) * 16 + 15];   /* last column of the tile to the left */
     }
@@ -1070,7 +1128,10 @@ __device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, co
         const int plane = lane / 9, c = lane % 9;
         const uint8_t *P = Y + T_CB + plane * 64;
         const bool ok = c == 0 ? av_d : av_b;
-        if (ok) L.nb_c = c == 0 ? P[up - TILE + 63] : P[up + 56 + (c - 1)];
+        if (ok) {
+            const uint8_t *q = c == 0 ? P + up - TILE + 63 : P + up + 56 + (c - 1);
+            L.nb_c = cross ? (int)ld_agent_u8(q) : (int)*q;
+        }
     } else if (lane >= 32 && lane < 48) {
         const int plane = (lane - 32) >> 3, r = (lane - 32) & 7;
         if (av_a) L.nb_c = (Y + T_CB + plane * 64)[-TILE + r * 8 + 7];
@@ -1079,7 +1140,7 @@ __device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, co
 }
 
 __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0,
-                                         const uint4 *i4tab, const uint32_t *rec_lds, const IntraLoads &L, int16_t *res_defer = nullptr)
+                                         const uint4 *i4tab, const uint32_t *rec_lds, const IntraLoads &L, bool wt, int16_t *res_defer = nullptr)
 {
     const FjMbRec rec = rec_from_lds(rec_lds);
     const int16_t *coef = fd.coefs + 16 * (size_t)rec.coef_idx;
@@ -1090,8 +1151,8 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
     if (rec.kind == FJ_MB_IPCM) {
         /* the 384 raw samples arrive in tile order (Y raster, Cb, Cr: macroblock_layer.c:992-1022) */
         const uint8_t *s = reinterpret_cast<const uint8_t *>(coef);
-        *reinterpret_cast<uint32_t *>(Y + 4 * lane) = *reinterpret_cast<const uint32_t *>(s + 4 * lane);
-        if (lane < 32) *reinterpret_cast<uint32_t *>(Y + 256 + 4 * lane) = *reinterpret_cast<const uint32_t *>(s + 256 + 4 * lane);
+        put4(Y + 4 * lane, *reinterpret_cast<const uint32_t *>(s + 4 * lane), wt);
+        if (lane < 32) put4(Y + 256 + 4 * lane, *reinterpret_cast<const uint32_t *>(s + 256 + 4 * lane), wt);
         return;
     }
 
@@ -1135,8 +1196,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
 #pragma unroll
             for (int i = 0; i < 4; i++) pr[i] = clip255((a + b * (x0 + i - 7) + c * (y - 7) + 16) >> 5);
         }
-        *reinterpret_cast<uint32_t *>(Y + y * 16 + x0) =
-            pack4(clip255(pr[0] + ry[0]), clip255(pr[1] + ry[1]), clip255(pr[2] + ry[2]), clip255(pr[3] + ry[3]));
+        put4(Y + y * 16 + x0, pack4(clip255(pr[0] + ry[0]), clip255(pr[1] + ry[1]), clip255(pr[2] + ry[2]), clip255(pr[3] + ry[3])), wt);
     } else {
         /* Intra4x4.  Block (bx,by) needs the blocks left, above, above-left and above-right of it, so the
          * blocks with bx + 2*by == d are independent: 10 steps instead of 16, two blocks (8 lanes) at a time.
@@ -1170,8 +1230,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
             }
             wave_sync();
         }
-        *reinterpret_cast<uint32_t *>(Y + (by * 4 + row) * 16 + bx * 4) =
-            *reinterpret_cast<const uint32_t *>(&tile[(by * 4 + 1 + row) * TS + 4 + bx * 4]);
+        put4(Y + (by * 4 + row) * 16 + bx * 4, *reinterpret_cast<const uint32_t *>(&tile[(by * 4 + 1 + row) * TS + 4 + bx * 4]), wt);
         }
     }
 
@@ -1212,8 +1271,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
 #pragma unroll
             for (int i = 0; i < 4; i++) pr[i] = clip255((a + b * (x0 + i - 3) + c * (y - 3) + 16) >> 5);
         }
-        *reinterpret_cast<uint32_t *>(Y + T_CB + plane * 64 + y * 8 + x0) =
-            pack4(clip255(pr[0] + rc[0]), clip255(pr[1] + rc[1]), clip255(pr[2] + rc[2]), clip255(pr[3] + rc[3]));
+        put4(Y + T_CB + plane * 64 + y * 8 + x0, pack4(clip255(pr[0] + rc[0]), clip255(pr[1] + rc[1]), clip255(pr[2] + rc[2]), clip255(pr[3] + rc[3])), wt);
     }
     wave_sync();          /* the tiles are reused by this wave's next macroblock */
 }
@@ -1228,7 +1286,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
  * my_mb < 0: the group has no macroblock.  Afterwards lane s of a group stores row s of the finished macroblock. */
 constexpr int INTRA_SLOT = 1024;                     /* LDS per prepared macroblock: luma tile 17 x TS + chroma tiles 2 x 144 */
 constexpr int INTRA_WAVE_LDS = 4 * INTRA_SLOT + 4 * 512 + 128;   /* four slots + four residual blocks of 16 x 16 int16 + four records */
-__device__ __forceinline__ void intra4_joint(const FrameDesc &fd, int my_mb, int lane, uint8_t *wave_lds, const uint4 *i4tab)
+__device__ __forceinline__ void intra4_joint(const FrameDesc &fd, int my_mb, int lane, uint8_t *wave_lds, const uint4 *i4tab, bool wt)
 {
     const int g = lane >> 4, sub = lane & 15, a = sub >> 2, y = sub & 3;
     uint8_t *tile = wave_lds + g * INTRA_SLOT;
@@ -1260,7 +1318,7 @@ __device__ __forceinline__ void intra4_joint(const FrameDesc &fd, int my_mb, int
     }
     if (on) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&tile[(sub + 1) * TS + 4]);
-        *reinterpret_cast<uint4 *>(fd.cur + (size_t)my_mb * TILE + sub * 16) = make_uint4(src[0], src[1], src[2], src[3]);
+        put16(fd.cur + (size_t)my_mb * TILE + sub * 16, make_uint4(src[0], src[1], src[2], src[3]), wt);
     }
     wave_sync();
 }
@@ -1329,7 +1387,10 @@ __device__ __forceinline__ void filter_edge8_pk(s2 v[8], int bs, int alpha, int 
  * A worker is a QUARTER of a wavefront (16 lanes, ql = lane & 15). */
 struct DbkPrefetch { uint4 y; uint2 c; uint32_t bsb; uint4 thr; uint32_t s_ly, s_ty, s_lc, s_tc; };
 
-__device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int ql, DbkPrefetch &p)
+/* cross: the macroblock lies in the first row of a row band (k_frame_dbk): the tile above belongs to another workgroup, its
+ * last rows are read past the L1 (ld_agent_u32) — and only when this macroblock's upper edge is filtered at all (want_top),
+ * because an unconditional load could run ahead of the other band's stores. */
+__device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int ql, DbkPrefetch &p, bool cross = false, bool want_top = true)
 {
     if (mb < 0) return;
     const int wmb = fd.wmb;
@@ -1353,15 +1414,21 @@ __device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int ql
     }
     if (mby > 0) {
         const uint8_t *U = T - (size_t)wmb * TILE;
-        p.s_ty = *reinterpret_cast<const uint32_t *>(U + (12 + (ql >> 2)) * 16 + 4 * (ql & 3));
-        if (ql < 8) p.s_tc = *reinterpret_cast<const uint32_t *>(U + T_CB + (ql >> 2) * 64 + (6 + ((ql >> 1) & 1)) * 8 + 4 * (ql & 1));
+        const uint8_t *uy = U + (12 + (ql >> 2)) * 16 + 4 * (ql & 3), *uc = U + T_CB + (ql >> 2) * 64 + (6 + ((ql >> 1) & 1)) * 8 + 4 * (ql & 1);
+        if (!cross) {
+            p.s_ty = *reinterpret_cast<const uint32_t *>(uy);
+            if (ql < 8) p.s_tc = *reinterpret_cast<const uint32_t *>(uc);
+        } else if (want_top) {
+            p.s_ty = ld_agent_u32(uy);
+            if (ql < 8) p.s_tc = ld_agent_u32(uc);
+        }
     }
 }
 
 /* In-loop filter of one macroblock by one worker = 16 lanes: vertical edges, then horizontal edges (8.7).
  * mb < 0: this quarter of the wavefront idles.  w = worker-private LDS.  q16 = 16 * (quarter index). */
 __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, int q16, const DbkPrefetch &p, uint8_t *w,
-                                           int nxt, DbkPrefetch &nxt_pf, const uint8_t *tabs, unsigned long long *tp = nullptr)
+                                           int nxt, DbkPrefetch &nxt_pf, const uint8_t *tabs, bool wt, unsigned long long *tp = nullptr)
 {
 #define DTICK() (tp ? __builtin_readcyclecounter() : 0ull)
     const unsigned long long d0 = DTICK();
@@ -1487,30 +1554,30 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, 
     wave_sync();
     const unsigned long long d3 = DTICK();
 
-    /* ---- store: own macroblock, the 3 (1) columns of the left and rows of the upper neighbour ---- */
+    /* ---- store: own macroblock, the 3 (1) columns of the left and rows of the upper neighbour.  wt: the macroblock lies in
+     * the last row of a row band, the band below reads its last rows: everything it writes goes write-through ---- */
     if (act) {
         {
             const uint32_t *ysrc = reinterpret_cast<const uint32_t *>(&lt[(4 + ql) * LS + 4]);
-            *reinterpret_cast<uint4 *>(Y + ql * 16) = make_uint4(ysrc[0], ysrc[1], ysrc[2], ysrc[3]);
+            put16(Y + ql * 16, make_uint4(ysrc[0], ysrc[1], ysrc[2], ysrc[3]), wt);
         }
         uint8_t *PCq = Y + T_CB + (ql >> 3) * 64;                 /* this lane's chroma plane inside the tile */
         {
             const uint32_t *csrc = reinterpret_cast<const uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS + 4]);
-            *reinterpret_cast<uint2 *>(PCq + (ql & 7) * 8) = make_uint2(csrc[0], csrc[1]);
+            put8(PCq + (ql & 7) * 8, make_uint2(csrc[0], csrc[1]), wt);
         }
         if (f_left) {
-            *reinterpret_cast<uint32_t *>(Y - TILE + ql * 16 + 12) = *reinterpret_cast<const uint32_t *>(&lt[(4 + ql) * LS]);
-            *reinterpret_cast<uint32_t *>(PCq - TILE + (ql & 7) * 8 + 4) =
-                *reinterpret_cast<const uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS]);
+            put4(Y - TILE + ql * 16 + 12, *reinterpret_cast<const uint32_t *>(&lt[(4 + ql) * LS]), wt);
+            put4(PCq - TILE + (ql & 7) * 8 + 4, *reinterpret_cast<const uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS]), wt);
         }
         if (f_top) {
             uint8_t *U = Y - (size_t)wmb * TILE;                  /* the tile above */
             if (ql < 12) {
                 const int r = 1 + ql / 4, cw2 = ql % 4;                /* tile rows 1..3 = rows 13..15 of the macroblock above */
-                *reinterpret_cast<uint32_t *>(U + (12 + r) * 16 + 4 * cw2) = *reinterpret_cast<const uint32_t *>(&lt[r * LS + 4 + 4 * cw2]);
+                put4(U + (12 + r) * 16 + 4 * cw2, *reinterpret_cast<const uint32_t *>(&lt[r * LS + 4 + 4 * cw2]), wt);
             } else {
                 const int i = ql - 12, plane = i >> 1, cw2 = i & 1;    /* chroma tile row 1 of both planes = row 7 above */
-                *reinterpret_cast<uint32_t *>(U + T_CB + plane * 64 + 7 * 8 + 4 * cw2) = *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + 1 * CS + 4 + 4 * cw2]);
+                put4(U + T_CB + plane * 64 + 7 * 8 + 4 * cw2, *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + 1 * CS + 4 + 4 * cw2]), wt);
             }
         }
     }
@@ -1536,38 +1603,92 @@ constexpr int DBK_WAVES = DBK_WAVES_N;              /* wavefronts of k_frame_dbk
                                                         (a 1024-thread workgroup caps the kernel at 128 VGPRs: spills) */
 constexpr int TAIL_WORKERS = 4 * DBK_WAVES;       /* deblocking workers = quarter wavefronts */
 
-/* Intra (and concealed) macroblocks of one picture, dataflow-scheduled inside one workgroup.  A macroblock of the
+/* Which picture and which row band a workgroup of the two per-picture kernels works on.  Workgroups take a ticket when they
+ * start (one device-scope atomic): ticket t = band t % max_bands of picture t / max_bands.  A band only ever waits for the
+ * band above it, which holds a smaller ticket and has therefore STARTED — whatever order the dispatcher chose — so a waiting
+ * workgroup can never keep the one it waits for off the machine.  tickets[0] = tickets taken, tickets[1] = workgroups that
+ * left: the last one to leave zeroes both for the next launch on this HIP stream (one pair per stream, engine.hip).
+ * tickets == nullptr: blockIdx.x is the ticket (single-band launches). */
+__device__ __forceinline__ uint32_t take_ticket(uint32_t *tickets, uint32_t *slot)
+{
+    if (threadIdx.x == 0) *slot = tickets ? atomicAdd(&tickets[0], 1u) : blockIdx.x;
+    __syncthreads();
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)*slot);
+}
+__device__ __forceinline__ void return_ticket(uint32_t *tickets)
+{
+    if (tickets && threadIdx.x == 0 && atomicAdd(&tickets[1], 1u) == gridDim.x - 1u) { atomicExch(&tickets[0], 0u); atomicExch(&tickets[1], 0u); }
+}
+/* rows per band and number of bands for a picture of hmb macroblock rows that wants `want` bands, in a launch with
+ * max_bands workgroups per picture whose LDS holds the state of at most rows_cap rows */
+__device__ __forceinline__ void band_split(int hmb, uint32_t want, uint32_t max_bands, uint32_t rows_cap, int &rows, int &bands)
+{
+    int w = (int)(want < max_bands ? want : max_bands);
+    if (w < 1) w = 1;
+    rows = (hmb + w - 1) / w;
+    if (rows > (int)rows_cap) rows = (int)rows_cap;
+    bands = (hmb + rows - 1) / rows;
+}
+
+/* Intra (and concealed) macroblocks of one picture, dataflow-scheduled.  A macroblock of the
  * intra schedule waits for those of the neighbours named by its FJ_NEED_* mask that are themselves in the schedule
  * (inter macroblocks were reconstructed by the earlier kernels).  LDS: dep[mb] = outstanding predecessors (0xFF = not
- * scheduled), need[mb] = the mask, a ready queue with claim / publish cursors.  A free wavefront takes ONE ready
- * macroblock, reconstructs it (intra_mb / conceal_mb), waits for its stores and then releases the neighbours that
- * wait for it.  No level barriers: the picture's time is its dependency critical path, not levels x slowest wave.
- * Dynamic LDS: per wavefront INTRA_WAVE_LDS (4 macroblock slots + deferred residuals + records) | need[n_mbs] | dep[n_mbs] |
- * queue[n_mbs] u16 | counters | Intra4x4 table. */
-__global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames, unsigned long long *prof)
+ * scheduled), need[mb] = the mask, a ready queue with claim / publish cursors.  A free wavefront takes up to four ready
+ * macroblocks, reconstructs them (intra_mb / conceal_mb), waits for its stores and then releases the neighbours that
+ * wait for them.  No level barriers: the picture's time is its dependency critical path, not levels x slowest wave.
+ *
+ * ROW BANDS as in k_frame_dbk (which see): up to max_bands workgroups per picture, band-local state for rows r0-1 .. r1-1.
+ * Intra prediction only looks up and to the left, so the only dependencies that cross a band boundary are those of a band's
+ * first row on the last row of the band above (FJ_NEED_UL / U / UR): the producers write their tiles write-through and set
+ * a "done" byte (scratch_done(fd, 1)), an idle wavefront of the band below polls, the consumers read the row above past
+ * the L1 (intra_issue, cross).  Pictures with concealed macroblocks (which may wait for the macroblock BELOW them) are never
+ * split (FjHeader.intra_down_deps -> FrameDesc.intra_bands = 1).
+ * Dynamic LDS: per wavefront INTRA_WAVE_LDS (4 macroblock slots + deferred residuals + records) | need | dep |
+ * queue u16 | counters | seen bits | Intra4x4 table (intra_lds_bytes). */
+__host__ __device__ inline size_t intra_lds_bytes(uint32_t waves, uint32_t wmb, uint32_t band_rows)
+{
+    const size_t n_loc16 = (((size_t)band_rows + 1) * wmb + 15) & ~(size_t)15, nq8 = ((size_t)band_rows * wmb + 7) & ~(size_t)7;
+    return (size_t)waves * INTRA_WAVE_LDS + 2 * n_loc16 + 2 * nq8 + 32 + 4 * ((((size_t)wmb + 31) / 32 + 3) & ~(size_t)3) + I4TAB_BYTES;
+}
+__global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames, unsigned long long *prof,
+                                                                 uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const FrameDesc &fd = frames[blockIdx.x];
-    if (!fd.n_levels) return;
-    const uint32_t total = fd.lvl[fd.n_levels];
+    __shared__ uint32_t s_misc[4];
+    const uint32_t ticket = take_ticket(tickets, &s_misc[0]);
+    const uint32_t pic = ticket / max_bands, band = ticket - pic * max_bands;
+    const FrameDesc &fd = frames[pic];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
+    const int wmb = fd.wmb, hmb = fd.hmb;
+    int R, nb;
+    band_split(hmb, fd.intra_bands, max_bands, rows_cap, R, nb);
+    if (!fd.n_levels || (int)band >= nb) { return_ticket(tickets); return; }
+    const uint32_t total_all = fd.lvl[fd.n_levels];
+    const int r0 = (int)band * R, r1 = min(hmb, r0 + R);
+    const int base = (r0 - 1) * wmb;                        /* band-local index of macroblock mb: mb - base (row r0-1 first) */
+    const int lo = r0 * wmb, hi = r1 * wmb;                 /* the band's own macroblocks */
+    const int n_loc = (R + 1) * wmb, n_loc16 = (n_loc + 15) & ~15, nq8 = (R * wmb + 7) & ~7;
+    const bool has_up = band > 0, has_down = r1 < hmb;
     uint8_t *my = lds + wave * INTRA_WAVE_LDS;
-    uint8_t *need = lds + (blockDim.x >> 6) * INTRA_WAVE_LDS;      /* the host launches fewer wavefronts when n_mbs leaves less LDS */
-    uint8_t *dep = need + ((n_mbs + 15) & ~15);
-    uint16_t *queue = reinterpret_cast<uint16_t *>(dep + ((n_mbs + 15) & ~15));
-    uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + ((n_mbs + 7) & ~7));   /* [0] head, [1] tail */
-    uint4 *i4tab = reinterpret_cast<uint4 *>(ctr + 4);
+    uint8_t *need = lds + (blockDim.x >> 6) * INTRA_WAVE_LDS;
+    uint8_t *dep = need + n_loc16;
+    uint16_t *queue = reinterpret_cast<uint16_t *>(dep + n_loc16);
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + nq8);   /* [0] head, [1] tail, [2] total, [3] producers awaited, [4] producers seen, [5] poll lock */
+    uint32_t *seen = ctr + 8;
+    uint4 *i4tab = reinterpret_cast<uint4 *>(seen + ((((wmb + 31) >> 5) + 3) & ~3));
+    uint8_t *done_g = scratch_done(fd, 1);
 
-    for (int i = tid; i < (n_mbs + 3) / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dep)[i] = 0xFFFFFFFFu;
-    for (int i = tid; i < (n_mbs + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
-    if (tid < 4) ctr[tid] = 0;
-    for (int i = tid; i < 144; i += blockDim.x) i4tab[i] = c_i4tab[i >> 2][i & 3];      /* (huge pictures run with as few as 2 wavefronts) */
+    for (int i = tid; i < n_loc16 / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dep)[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < nq8 / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
+    if (tid < 8) ctr[tid] = 0;
+    for (int i = tid; i < (wmb + 31) >> 5; i += blockDim.x) seen[i] = 0;
+    for (int i = tid; i < 144; i += blockDim.x) i4tab[i] = c_i4tab[i >> 2][i & 3];      /* (huge pictures run with as few as 1 wavefront) */
     __syncthreads();
-    for (uint32_t i = tid; i < total; i += blockDim.x) {
-        const uint32_t mb = fd.idx[i];
-        need[mb] = fd.recs[mb].ref_slot[0];
-        dep[mb] = 0xFE;                                   /* scheduled, count pending */
+    for (uint32_t i = tid; i < total_all; i += blockDim.x) {
+        const int mb = fd.idx[i];
+        if (mb < base || mb >= hi) continue;               /* (base < 0 for band 0: every mb >= 0 passes) */
+        need[mb - base] = fd.recs[mb].ref_slot[0];
+        dep[mb - base] = 0xFE;                              /* scheduled, count pending */
     }
     __syncthreads();
     /* neighbour b of (x,y): b = 0 L, 1 UL, 2 U, 3 UR, 4 R, 5 DR, 6 D, 7 DL  (b ^ 4 = opposite direction) */
@@ -1578,34 +1699,48 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
         const int nx = x + dx, ny = y + dy;
         return (nx < 0 || ny < 0 || nx >= wmb || ny >= hmb) ? -1 : ny * wmb + nx;
     };
-    for (uint32_t i = tid; i < total; i += blockDim.x) {
+    for (uint32_t i = tid; i < total_all; i += blockDim.x) {
         const int mb = fd.idx[i];
-        const uint32_t nd = need[mb];
+        if (mb < lo || mb >= hi) continue;
+        const uint32_t nd = need[mb - base];
         int cnt = 0;
 #pragma unroll
         for (int b = 0; b < 8; b++)
             if ((nd >> b) & 1u) {
                 const int s = neighbour(mb, b);
-                if (s >= 0 && dep[s] != 0xFF) cnt++;
+                /* (a neighbour below the band can only be named by a concealed macroblock, and those pictures have one band) */
+                if (s >= 0 && s >= base && s < hi && dep[s - base] != 0xFF) cnt++;
             }
-        dep[mb] = (uint8_t)cnt;                            /* byte store: other threads only test != 0xFF */
+        dep[mb - base] = (uint8_t)cnt;                     /* byte store: other threads only test != 0xFF */
+        atomicAdd(&ctr[2], 1u);
         if (cnt == 0) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)mb;
     }
+    if (has_up)
+        for (int x = tid; x < wmb; x += blockDim.x)
+            if (dep[x] != 0xFF) atomicAdd(&ctr[3], 1u);
     __syncthreads();
+    const uint32_t total = ctr[2], n_await = ctr[3];
 
-    volatile uint16_t *vq = queue;
-    volatile uint32_t *vctr = ctr;
+    auto release = [&](int li) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(dep + (li & ~3));
+        const uint32_t sh = 8u * (li & 3);
+        const uint32_t old = atomicSub(w, 1u << sh);
+        if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)(li + base);
+    };
+
+    volatile H264K_LDS uint16_t *vq = (volatile H264K_LDS uint16_t *)queue;      /* (a generic volatile pointer would read LDS through flat_load) */
+    volatile H264K_LDS uint32_t *vctr = (volatile H264K_LDS uint32_t *)ctr;
     uint32_t spins = 0;                  /* safety net: a scheduling bug must end in a reported error (DEVERR_*), never in a hung GPU */
-    /* debug accounting (h264bsdmiDebugTailProfile, second half of the buffer): workgroup 0, per wavefront:
+    /* debug accounting (h264bsdmiDebugTailProfile, second half of the buffer): band 0 of picture 0, per wavefront:
      * [0] cycles with nothing ready, [1] cycles reconstructing, [2] cycles waiting for stores + release, [3] MBs */
-    unsigned long long *tp = (prof && blockIdx.x == 0) ? prof + 256 + wave * 8 : nullptr;
+    unsigned long long *tp = (prof && ticket == 0) ? prof + 256 + wave * 8 : nullptr;
     unsigned long long t_idle = 0, t_work = 0, t_rel = 0, n_done = 0, t_mark = tp ? __builtin_readcyclecounter() : 0ull;
     /* Pull model: a free wavefront takes up to FOUR ready macroblocks at once.  Each is prepared by the whole wavefront
      * in turn (neighbours, residual, chroma; Intra16x16 / I_PCM / concealed macroblocks completely); the luma of the
      * Intra4x4 ones among them — 10 dependent steps with at most two blocks each — is then predicted jointly, one quarter
      * of the wavefront per macroblock (intra4_joint).  A lone ready macroblock takes the single-macroblock path. */
     for (;;) {
-        uint32_t base = 0, k = 0;
+        uint32_t cbase = 0, k = 0;
         if (lane == 0) {
             const uint32_t h = vctr[0], t = vctr[1];
             if (t > h) {
@@ -1614,16 +1749,47 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
                 const uint32_t share = (t - h) / (blockDim.x >> 6);
                 k = share < 1u ? 1u : share > 4u ? 4u : share;
                 if (atomicCAS(&ctr[0], h, h + k) != h) k = 0;       /* lost the race: look again */
-                base = h;
+                cbase = h;
             } else if (h >= total) k = 0xFFFFFFFFu;                /* everything has been claimed */
         }
-        base = __shfl(base, 0); k = __shfl(k, 0);
+        cbase = __shfl(cbase, 0); k = __shfl(k, 0);
         if (k == 0xFFFFFFFFu) break;
         if (++spins > (1u << 24)) { if (lane == 0) atomicOr(fd.err, DEVERR_INTRA_SCHED); break; }
-        if (k == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+        if (k == 0) {
+            /* nothing ready: have macroblocks of the band above, which the first row waits for, finished? (k_frame_dbk) */
+            bool polled = false;
+            if (has_up && vctr[4] < n_await) {
+                uint32_t got = 0;
+                if (lane == 0) got = atomicCAS(&ctr[5], 0u, 1u) == 0u;
+                got = __shfl(got, 0);
+                if (got) {
+                    polled = true;
+                    for (int x = lane; x < wmb; x += 64) {
+                        const uint32_t bit = 1u << (x & 31);
+                        if (dep[x] == 0xFF || (seen[x >> 5] & bit)) continue;
+                        if (!ld_agent_u8(done_g + base + x)) continue;
+                        if (atomicOr(&seen[x >> 5], bit) & bit) continue;
+                        atomicAdd(&ctr[4], 1u);
+                        /* (x, r0-1) is the UR / U / UL neighbour of (x-1, r0) / (x, r0) / (x+1, r0) */
+#pragma unroll
+                        for (int d = -1; d <= 1; d++) {
+                            const int cx = x + d;
+                            if (cx < 0 || cx >= wmb) continue;
+                            const int li = wmb + cx;
+                            const uint32_t wants = d < 0 ? FJ_NEED_UR : d == 0 ? FJ_NEED_U : FJ_NEED_UL;
+                            if (li < n_loc && r0 < r1 && dep[li] != 0xFF && (need[li] & wants)) release(li);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) atomicExch(&ctr[5], 0u);
+                }
+            }
+            if (polled) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
         /* lane j < k fetches queue slot base + j (the publisher bumps the cursor, then writes the slot) */
         int v = 0;
-        if ((uint32_t)lane < k) do { v = vq[base + lane]; } while (v == 0xFFFF);
+        if ((uint32_t)lane < k) do { v = vq[cbase + lane]; } while (v == 0xFFFF);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
         int joint_mb = -1;                                          /* per 16-lane group: its Intra4x4 macroblock, if any */
@@ -1635,91 +1801,141 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
             rec_lds[lane] = reinterpret_cast<const uint32_t *>(&fd.recs[mbj])[lane & 7];
         }
         wave_sync();
+        /* first row of the band: the row above comes from another workgroup; last row: the band below reads this one */
+        const int cross_lo = has_up ? lo : -1, cross_hi = has_up ? lo + wmb : -1, wt_lo = has_down ? hi - wmb : 0x7FFFFFFF;
         /* software pipeline over the group: the loads of macroblock j + 1 are in flight while macroblock j is reconstructed */
         IntraLoads cur_loads, next_loads;
-        intra_issue(fd, (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(v, 0)), rec_lds, lane, cur_loads);
+        {
+            const int mb0 = __builtin_amdgcn_readfirstlane(__shfl(v, 0));
+            intra_issue(fd, (uint32_t)mb0, rec_lds, lane, cur_loads, mb0 >= cross_lo && mb0 < cross_hi);
+        }
         for (uint32_t j = 0; j < k; j++) {
             const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(v, (int)j));
             const uint32_t head = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_lds[8 * j]);     /* kind, qp_y, qp_c, avail */
             const uint32_t kind = head & 255u;
+            const bool wt = (int)mb >= wt_lo;
             uint8_t *slot = my + j * INTRA_SLOT;
-            if (j + 1 < k) intra_issue(fd, (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(v, (int)j + 1)), rec_lds + 8 * (j + 1), lane, next_loads);
+            if (j + 1 < k) {
+                const int mbn = __builtin_amdgcn_readfirstlane(__shfl(v, (int)j + 1));
+                intra_issue(fd, (uint32_t)mbn, rec_lds + 8 * (j + 1), lane, next_loads, mbn >= cross_lo && mbn < cross_hi);
+            }
             /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
             if (kind == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
             else if (kind == FJ_MB_I4x4 && k > 1) {
-                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512));
+                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, wt, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512));
                 if ((uint32_t)(lane >> 4) == j) joint_mb = (int)mb;
-            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads);
+            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, wt);
             if (j + 1 < k) cur_loads = next_loads;
         }
-        if (__ballot(joint_mb >= 0) != 0ull) intra4_joint(fd, joint_mb, lane, my, i4tab);
+        if (__ballot(joint_mb >= 0) != 0ull) intra4_joint(fd, joint_mb, lane, my, i4tab, joint_mb >= wt_lo);
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += k; }
         /* release: stores done -> the neighbours that wait for these macroblocks (lanes 16j + b: neighbour b of macroblock j) */
         __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             /* (the compiler may drop the builtin in front of an agent-scope store) */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         {
             const int j = lane >> 4, b = lane & 15;
             const int mbj = __shfl(v, j);
+            if ((uint32_t)j < k && b == 8 && mbj >= wt_lo) st_agent_u8(done_g + mbj, 1u);      /* hand-over to the band below */
             if ((uint32_t)j < k && b < 8) {
                 const int s = neighbour(mbj, b);
-                if (s >= 0 && dep[s] != 0xFF && ((need[s] >> (b ^ 4)) & 1u)) {
-                    uint32_t *w = reinterpret_cast<uint32_t *>(dep + (s & ~3));
-                    const uint32_t sh = 8u * (s & 3);
-                    const uint32_t old = atomicSub(w, 1u << sh);
-                    if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)s;
-                }
+                if (s >= lo && s < hi && dep[s - base] != 0xFF && ((need[s - base] >> (b ^ 4)) & 1u)) release(s - base);
             }
         }
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_rel += t - t_mark; t_mark = t; }
     }
     if (tp && lane == 0) { tp[0] += t_idle; tp[1] += t_work; tp[2] += t_rel; tp[3] += n_done; }
+    /* the last band of the picture to leave zeroes the done bytes for the next picture of this stream */
+    if (nb > 1) {
+        __syncthreads();
+        if (tid == 0) s_misc[1] = atomicAdd(scratch_exits(fd, 1), 1u);
+        __syncthreads();
+        if (s_misc[1] == (uint32_t)nb - 1u) {
+            uint32_t *z = reinterpret_cast<uint32_t *>(done_g);
+            for (int i = tid; i < (int)((fd.n_mbs + 3u) >> 2); i += blockDim.x) z[i] = 0;
+            if (tid == 0) atomicExch(scratch_exits(fd, 1), 0u);
+        }
+    }
+    return_ticket(tickets);
 }
 
 /* In-loop deblocking of one picture.  The filter of macroblock (x,y) touches its own samples, the last
  * 4 columns of (x-1,y) and the last 4 rows of (x,y-1); in the standard's raster order that makes it
  * depend on exactly three earlier steps: (x-1,y), (x,y-1) and (x+1,y-1) — and only if those macroblocks
  * are filtered at all (most P-picture macroblocks have all-zero strengths and are never touched).
- * Dataflow scheduling inside the workgroup, all state in LDS:
+ *
+ * ROW BANDS.  A picture is split into up to max_bands bands of consecutive macroblock rows, one workgroup each
+ * (grid = max_bands x pictures; a picture that wants fewer bands leaves the surplus workgroups idle).  Inside a band
+ * the dependencies are tracked in LDS as before; the only dependencies that cross a band boundary are those of a
+ * band's FIRST row on the LAST row of the band above — (x,y-1) and (x+1,y-1) — and they are handed over through HBM:
+ *   producer: a macroblock of a band's last row writes everything write-through (put4/8/16 with wt), waits for its stores
+ *             (s_waitcnt vmcnt(0)) and then sets its "done" byte (scratch_done, agent scope);
+ *   consumer: a wavefront of the band below that finds nothing ready polls the done bytes of the producers its first row
+ *             still waits for (one poller per band at a time, relaxed agent-scope loads, s_sleep between passes), marks
+ *             each seen producer once (LDS bit) and releases its dependants into the band's ready queue; the first-row
+ *             macroblock then reads the last rows of the tile above past the L1 (dbk_prefetch, cross).
+ * Every pair of macroblocks that touches a common sample is ordered as in the reference's raster scan
+ * (src/h264bsd_deblocking.c:604-638) whether both lie in one band or not.  The same spin limit that guards the LDS scheduler
+ * ends a wait that never finishes in DEVERR_DBK_SCHED.  Small workgroups (4 wavefronts by default) leave most of a
+ * compute unit's registers to other workgroups — bands of other pictures, the list-driven kernels of other stream groups.
+ *
+ * Dataflow scheduling inside a band, all state in LDS (indices are band-local: row r0-1 .. r1-1):
+ *   anyf[]    DBKF_* flags of the band's rows and of the row above
  *   dep[mb]   number of filtered macroblocks among those three that are not finished yet
  *   queue[]   ready list: every filtered macroblock is pushed exactly once, when its dep reaches 0
  *   head/tail claim / publish cursors (LDS atomics)
- * A worker is a QUARTER wavefront (16 lanes, two sample lines per lane, packed 16-bit arithmetic): 64 workers.  A
+ * A worker is a QUARTER wavefront (16 lanes, two sample lines per lane, packed 16-bit arithmetic).  A
  * free wavefront pulls up to four READY macroblocks at once (compare-and-swap on head), one per quarter, fetches their
  * samples, records and neighbour strips in one memory round trip, filters, waits for its stores, then releases the
  * three dependants (x+1,y), (x,y+1), (x-1,y+1).  No level barriers; ready macroblocks are packed into as few
  * wavefronts as possible because the loop is instruction-issue bound (a step costs the same with one busy quarter as
  * with four).  Same-CU visibility of the stores needs only s_waitcnt vmcnt(0) before the LDS release.
- * Dynamic LDS: 64 x WORKER_LDS tiles | any[n_mbs] u8 | dep[n_mbs] u8 | queue[n_mbs] u16 | counters | threshold tables. */
-__global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof)
+ * Dynamic LDS: workers x WORKER_LDS tiles | anyf | dep | queue u16 | counters | seen bits | threshold tables (dbk_lds_bytes). */
+__host__ __device__ inline size_t dbk_lds_bytes(uint32_t waves, uint32_t wmb, uint32_t band_rows)
+{
+    const size_t n_loc16 = (((size_t)band_rows + 1) * wmb + 15) & ~(size_t)15, nq8 = ((size_t)band_rows * wmb + 7) & ~(size_t)7;
+    return (size_t)waves * 4 * WORKER_LDS + 2 * n_loc16 + 2 * nq8 + 32 + 4 * ((((size_t)wmb + 31) / 32 + 3) & ~(size_t)3) + 384;
+}
+__global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof,
+                                                              uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const FrameDesc &fd = frames[blockIdx.x];
-    if (!fd.any_deblock) return;
+    __shared__ uint32_t s_misc[4];
+    const uint32_t ticket = take_ticket(tickets, &s_misc[0]);
+    const uint32_t pic = ticket / max_bands, band = ticket - pic * max_bands;
+    const FrameDesc &fd = frames[pic];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, quarter = lane >> 4, ql = lane & 15, q16 = 16 * quarter;
     const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
-    uint8_t *anyf = lds + (blockDim.x >> 4) * WORKER_LDS;   /* 4 workers per launched wavefront (fewer wavefronts for huge pictures) */
-    uint8_t *dep = anyf + ((n_mbs + 15) & ~15);
-    uint16_t *queue = reinterpret_cast<uint16_t *>(dep + ((n_mbs + 15) & ~15));
-    uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + ((n_mbs + 7) & ~7));   /* [0] head, [1] tail, [2] total */
-    uint8_t *tabs = reinterpret_cast<uint8_t *>(ctr + 4);                       /* alpha[64] | beta[64] | tc0[64][4] */
+    int R, nb;
+    band_split(hmb, fd.dbk_bands, max_bands, rows_cap, R, nb);
+    if (!fd.any_deblock || (int)band >= nb) { return_ticket(tickets); return; }
+    const int r0 = (int)band * R, r1 = min(hmb, r0 + R);
+    const int base = (r0 - 1) * wmb;                        /* band-local index of macroblock mb: mb - base (row r0-1 first) */
+    const int n_loc = (R + 1) * wmb, n_loc16 = (n_loc + 15) & ~15, nq8 = (R * wmb + 7) & ~7;
+    const bool has_up = band > 0, has_down = r1 < hmb;
+    uint8_t *anyf = lds + (blockDim.x >> 4) * WORKER_LDS;   /* 4 workers per launched wavefront */
+    uint8_t *dep = anyf + n_loc16;
+    uint16_t *queue = reinterpret_cast<uint16_t *>(dep + n_loc16);
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + nq8);   /* [0] head, [1] tail, [2] total, [3] producers awaited, [4] producers seen, [5] poll lock */
+    uint32_t *seen = ctr + 8;                                    /* one bit per column: the done byte of (x, r0-1) has been seen */
+    uint8_t *tabs = reinterpret_cast<uint8_t *>(seen + ((((wmb + 31) >> 5) + 3) & ~3));   /* alpha[64] | beta[64] | tc0[64][4] */
     uint8_t *wlds = lds + (wave * 4 + quarter) * WORKER_LDS;
-    (void)hmb;
-    /* debug accounting (h264bsdmiDebugTailProfile): workgroup 0 only, per wavefront: [0] cycles with nothing ready,
+    uint8_t *flags_g = scratch_flags(fd), *done_g = scratch_done(fd, 0);
+    /* debug accounting (h264bsdmiDebugTailProfile): band 0 of picture 0 only, per wavefront: [0] cycles with nothing ready,
      * [1] cycles filtering, [2] cycles waiting for own stores, [3] macroblocks filtered (both halves), [4] total */
-    unsigned long long *tp = (prof && blockIdx.x == 0) ? prof + wave * 16 : nullptr;
+    unsigned long long *tp = (prof && ticket == 0) ? prof + wave * 16 : nullptr;
     unsigned long long t_idle = 0, t_work = 0, t_store = 0, n_done = 0, n_steps = 0;
     const unsigned long long t_begin = tp ? __builtin_readcyclecounter() : 0ull;
     unsigned long long t_mark = t_begin;
 
     {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(fd.dbk + (size_t)n_mbs * DBK_REC_BYTES);
-        uint32_t *srcw = reinterpret_cast<uint32_t *>(fd.dbk + (size_t)n_mbs * DBK_REC_BYTES);
-        for (int i = tid; i < (n_mbs + 3) / 4; i += blockDim.x) {
-            reinterpret_cast<uint32_t *>(anyf)[i] = src[i];
-            srcw[i] = 0;                 /* k_dbk only visits non-trivial MBs: leave the flags clean for the next picture */
+        for (int i = tid; i < n_loc; i += blockDim.x) {
+            const int mb = base + i;
+            anyf[i] = (mb >= 0 && mb < r1 * wmb) ? flags_g[mb] : 0;
         }
-        for (int i = tid; i < (n_mbs + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
-        if (tid < 4) ctr[tid] = 0;
+        for (int i = tid; i < nq8 / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
+        if (tid < 8) ctr[tid] = 0;
+        for (int i = tid; i < (wmb + 31) >> 5; i += blockDim.x) seen[i] = 0;
         if (tid < 64) {
             tabs[tid] = tid < 52 ? c_alpha[tid] : 0;
             tabs[64 + tid] = tid < 52 ? c_beta[tid] : 0;
@@ -1734,83 +1950,144 @@ __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *_
      *   (x+1,y-1)  only if its upper edge is active AND that macroblock's left edge is: only then does (x+1,y-1)
      *              rewrite the columns of (x,y-1) whose last rows this macroblock reads and rewrites.
      * Every pair of macroblocks that touches a common sample is still ordered as in the reference's raster scan
-     * (deblocking.c:604-638); the longest chain of the bundled 1080p stream shrinks by 21 % (9562 -> 7512 steps). */
-    for (int mb = tid; mb < n_mbs; mb += blockDim.x) {
-        const uint32_t f = anyf[mb];
+     * (deblocking.c:604-638); the longest chain of the bundled 1080p stream shrinks by 21 % (9562 -> 7512 steps).
+     * For the band's first row the macroblocks above belong to the band above: they count like any other and are
+     * released by the poller (below) instead of by the wavefront that filtered them. */
+    for (int mb = r0 * wmb + tid; mb < r1 * wmb; mb += blockDim.x) {
+        const int li = mb - base;
+        const uint32_t f = anyf[li];
         if (!(f & DBKF_ANY)) continue;
         const int x = mb % wmb, y = mb / wmb;
-        const int d = (x > 0 && (f & DBKF_LEFT) && (anyf[mb - 1] & DBKF_ANY) ? 1 : 0) +
-                      (y > 0 && (f & DBKF_TOP) && (anyf[mb - wmb] & DBKF_ANY) ? 1 : 0) +
-                      (y > 0 && x + 1 < wmb && (f & DBKF_TOP) && (anyf[mb - wmb + 1] & DBKF_LEFT) ? 1 : 0);
-        dep[mb] = (uint8_t)d;
+        const int d = (x > 0 && (f & DBKF_LEFT) && (anyf[li - 1] & DBKF_ANY) ? 1 : 0) +
+                      (y > 0 && (f & DBKF_TOP) && (anyf[li - wmb] & DBKF_ANY) ? 1 : 0) +
+                      (y > 0 && x + 1 < wmb && (f & DBKF_TOP) && (anyf[li - wmb + 1] & DBKF_LEFT) ? 1 : 0);
+        dep[li] = (uint8_t)d;
         atomicAdd(&ctr[2], 1u);
         if (d == 0) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)mb;
     }
+    if (has_up)
+        for (int x = tid; x < wmb; x += blockDim.x)
+            if (anyf[x] & DBKF_ANY) atomicAdd(&ctr[3], 1u);
     __syncthreads();
-    const uint32_t total = ctr[2];
-    volatile uint16_t *vq = queue;
+    const uint32_t total = ctr[2], n_await = ctr[3];
+    volatile H264K_LDS uint16_t *vq = (volatile H264K_LDS uint16_t *)queue;      /* (a generic volatile pointer would read LDS through flat_load) */
+
+    /* one dependency of band-local macroblock li is gone: publish it when it was the last */
+    auto release = [&](int li) {
+        /* byte-wide counters: decrement through a 32-bit LDS atomic on the containing word */
+        uint32_t *w = reinterpret_cast<uint32_t *>(dep + (li & ~3));
+        const uint32_t sh = 8u * (li & 3);
+        const uint32_t old = atomicSub(w, 1u << sh);
+        if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)(li + base);
+    };
 
     /* Pull model: a free wavefront takes up to four READY macroblocks at once (one per quarter).  Ready macroblocks
      * are therefore packed into as few wavefronts as possible — the loop is instruction-issue bound, so a step that
      * runs with one busy quarter costs as much as a full one — and a wavefront with nothing to do issues nothing. */
     uint32_t spins = 0;                  /* safety net: a scheduling bug must end in a reported error (DEVERR_*), never in a hung GPU */
-    volatile uint32_t *vctr = ctr;
+    volatile H264K_LDS uint32_t *vctr = (volatile H264K_LDS uint32_t *)ctr;
     for (;;) {
-        uint32_t base = 0, k = 0;
+        uint32_t cbase = 0, k = 0;
         if (lane == 0) {
             const uint32_t h = vctr[0], t = vctr[1];
             if (t > h) {
                 k = t - h < 4u ? t - h : 4u;
                 if (atomicCAS(&ctr[0], h, h + k) != h) k = 0;       /* lost the race: look again */
-                base = h;
+                cbase = h;
             } else if (h >= total) {
                 k = 0xFFFFFFFFu;                                    /* everything has been claimed */
             }
         }
-        base = __shfl(base, 0); k = __shfl(k, 0);
+        cbase = __shfl(cbase, 0); k = __shfl(k, 0);
         if (k == 0xFFFFFFFFu) break;
         if (++spins > (1u << 24)) { if (lane == 0) atomicOr(fd.err, DEVERR_DBK_SCHED); break; }
-        if (k == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+        if (k == 0) {
+            /* nothing ready.  If the first row still waits for macroblocks of the band above, look whether they are done:
+             * one wavefront of the band at a time, lane -> column */
+            bool polled = false;
+            if (has_up && vctr[4] < n_await) {
+                uint32_t got = 0;
+                if (lane == 0) got = atomicCAS(&ctr[5], 0u, 1u) == 0u;
+                got = __shfl(got, 0);
+                if (got) {
+                    polled = true;
+                    for (int x = lane; x < wmb; x += 64) {
+                        const uint32_t fu = anyf[x];
+                        const uint32_t bit = 1u << (x & 31);
+                        if (!(fu & DBKF_ANY) || (seen[x >> 5] & bit)) continue;
+                        if (!ld_agent_u8(done_g + base + x)) continue;
+                        if (atomicOr(&seen[x >> 5], bit) & bit) continue;
+                        atomicAdd(&ctr[4], 1u);
+                        /* the mirror image of the dependency rule: (x, r0) waits for it through its upper edge, (x-1, r0)
+                         * if this producer's left edge was filtered */
+                        const uint32_t fc = anyf[wmb + x];
+                        if ((fc & DBKF_ANY) && (fc & DBKF_TOP)) release(wmb + x);
+                        if (x > 0 && (fu & DBKF_LEFT)) {
+                            const uint32_t fl = anyf[wmb + x - 1];
+                            if ((fl & DBKF_ANY) && (fl & DBKF_TOP)) release(wmb + x - 1);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) atomicExch(&ctr[5], 0u);
+                }
+            }
+            if (polled) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
         int run = -1;
         if ((uint32_t)quarter < k) {
             int v;
-            do { v = vq[base + quarter]; } while (v == 0xFFFF);     /* the publisher bumps the cursor, then writes the slot */
+            do { v = vq[cbase + quarter]; } while (v == 0xFFFF);     /* the publisher bumps the cursor, then writes the slot */
             run = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int ry = run >= 0 ? run / wmb : -1;
+        const bool cross = has_up && ry == r0;                      /* the tile above belongs to the band above */
+        const bool wt = has_down && ry == r1 - 1;                   /* the band below reads what this macroblock writes */
+        bool want_top = true;
+        if (__ballot(cross) != 0ull) want_top = !cross || (anyf[run - base] & DBKF_TOP);
         DbkPrefetch cp = {}, np = {};
-        dbk_prefetch(fd, run, ql, cp);
-        deblock_mb(fd, run, ql, q16, cp, wlds, -1, np, tabs, (tp && lane == 0) ? tp : nullptr);
+        dbk_prefetch(fd, run, ql, cp, cross, want_top);
+        deblock_mb(fd, run, ql, q16, cp, wlds, -1, np, tabs, wt, (tp && lane == 0) ? tp : nullptr);
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && ql == 0)); n_steps++; }
         /* release: stores done -> dependants */
         __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             /* (the compiler may drop the builtin in front of an agent-scope store) */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (wt && ql == 3) st_agent_u8(done_g + run, 1u);            /* hand-over to the band below */
         if (run >= 0 && ql < 3) {
-            const int x = run % wmb, y = run / wmb;
+            const int x = run % wmb, y = ry;
             int dmb = -1;
             if (ql == 0) { if (x + 1 < wmb) dmb = run + 1; }
-            else if (ql == 1) { if (y + 1 < hmb) dmb = run + wmb; }
-            else { if (y + 1 < hmb && x > 0) dmb = run + wmb - 1; }
+            else if (ql == 1) { if (y + 1 < r1) dmb = run + wmb; }
+            else { if (y + 1 < r1 && x > 0) dmb = run + wmb - 1; }
             /* the mirror image of the dependency rule above */
             bool waits = false;
             if (dmb >= 0) {
-                const uint32_t fd_ = anyf[dmb], fm = anyf[run];
-                waits = ql == 0 ? (fd_ & DBKF_LEFT) != 0u : ql == 1 ? (fd_ & DBKF_TOP) != 0u : ((fd_ & DBKF_TOP) != 0u && (fm & DBKF_LEFT) != 0u);
+                const uint32_t fd_ = anyf[dmb - base], fm = anyf[run - base];
+                waits = (fd_ & DBKF_ANY) && (ql == 0 ? (fd_ & DBKF_LEFT) != 0u : ql == 1 ? (fd_ & DBKF_TOP) != 0u : ((fd_ & DBKF_TOP) != 0u && (fm & DBKF_LEFT) != 0u));
             }
-            if (waits) {
-                /* byte-wide counters: decrement through a 32-bit LDS atomic on the containing word */
-                uint32_t *w = reinterpret_cast<uint32_t *>(dep + (dmb & ~3));
-                const uint32_t sh = 8u * (dmb & 3);
-                const uint32_t old = atomicSub(w, 1u << sh);
-                if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)dmb;
-            }
+            if (waits) release(dmb - base);
         }
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_store += t - t_mark; t_mark = t; }
     }
     if (tp && lane == 0) {
         tp[0] += t_idle; tp[1] += t_work; tp[2] += t_store; tp[3] += n_done; tp[4] += __builtin_readcyclecounter() - t_begin; tp[5] += n_steps;
     }
+    /* the last band of the picture to leave zeroes the flags (k_dbk only visits non-trivial macroblocks) and the done bytes
+     * for the next picture of this stream */
+    __syncthreads();
+    if (tid == 0) s_misc[1] = atomicAdd(scratch_exits(fd, 0), 1u);
+    __syncthreads();
+    if (s_misc[1] == (uint32_t)nb - 1u) {
+        uint32_t *z = reinterpret_cast<uint32_t *>(flags_g);
+        const int words = 2 * (int)((fd.n_mbs + 3u) >> 2);        /* flags and this kernel's done bytes are adjacent */
+        for (int i = tid; i < words; i += blockDim.x) z[i] = 0;
+        if (tid == 0) atomicExch(scratch_exits(fd, 0), 0u);
+    }
+    (void)n_mbs;
+    return_ticket(tickets);
 }
 
 /* ------------------------------------------------------------------ pictures leaving the device */

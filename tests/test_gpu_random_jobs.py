@@ -58,3 +58,41 @@ def test_no_deblocking_at_all(built):
     lib = built.lib()
     jobs = [build_job(lib, rng, 7, 5, 0, 2, [], any_deblock=False), build_job(lib, rng, 7, 5, 1, 2, [0], any_deblock=False)]
     _run(built, jobs)
+
+
+# ---- row bands of the two per-picture kernels (k_frame_dbk / k_frame_intra, kernels.hip.h): a picture split over several
+# workgroups with the hand-over through HBM must give the same samples as one workgroup ----
+DEFAULT_TAIL = (17, 9, 4, 0, 9, 4)
+
+
+@pytest.fixture
+def tail(built):
+    def set_(*cfg):
+        built.set_tail(*cfg)
+    yield set_
+    built.set_tail(*DEFAULT_TAIL)
+
+
+@pytest.mark.parametrize("rows,waves", [(1, 1), (1, 4), (2, 2), (3, 12)])
+@pytest.mark.parametrize("seed,wmb,hmb", [(31, 6, 5), (32, 11, 7), (33, 1, 1), (34, 1, 9), (35, 9, 1), (36, 20, 12)])
+def test_random_pictures_in_row_bands(built, tail, seed, wmb, hmb, rows, waves):
+    """bands of 1-3 macroblock rows (>= 4 bands wherever the picture has the rows), 1-12 wavefronts per workgroup, on
+    pictures 1 macroblock high / wide and ordinary ones; light (P) and heavy (intra) pictures both split"""
+    tail(rows, rows, waves, rows, rows, waves)
+    rng = np.random.default_rng(seed)
+    lib = built.lib()
+    jobs = [build_job(lib, rng, wmb, hmb, 0, 4, [])]
+    jobs.append(build_job(lib, rng, wmb, hmb, 1, 4, [0]))
+    jobs.append(build_job(lib, rng, wmb, hmb, 2, 4, [0, 1], p_inter=0.9))
+    jobs.append(build_job(lib, rng, wmb, hmb, 3, 4, [0, 1, 2], p_inter=0.97, mv_range=64))
+    _run(built, jobs, n_streams=3)
+
+
+def test_huge_picture_in_row_bands(built, tail):
+    """4096x2304 (256 x 144 macroblocks, the largest level-5.1 frame): 8 bands of 18 rows (intra picture) and 4 bands of
+    36 rows (P picture); the scheduling state of a band must fit the LDS next to its wavefronts"""
+    tail(36, 18, 4, 36, 18, 4)
+    rng = np.random.default_rng(41)
+    lib = built.lib()
+    jobs = [build_job(lib, rng, 256, 144, 0, 2, []), build_job(lib, rng, 256, 144, 1, 2, [0], p_inter=0.9, mv_range=300)]
+    _run(built, jobs, n_streams=1)
