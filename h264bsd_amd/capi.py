@@ -140,7 +140,7 @@ def lib():
     L.h264bsdmiReplaySetStages.argtypes = [vp, ctypes.c_uint]
     L.h264bsdmiReplaySetTimedKernels.argtypes = [vp, ctypes.c_uint]
     L.h264bsdmiReplaySetGroups.argtypes = [vp, u32]
-    L.h264bsdmiDebugSetTail.argtypes = [u32] * 6
+    L.h264bsdmiDebugSetTail.argtypes = [u32] * 7
     L.h264bsdmiReplayJobBytes.argtypes = [vp]
     L.h264bsdmiReplayJobBytes.restype = ctypes.c_ulonglong
     L.h264bsdmiReplayFrameBytes.argtypes = [vp]
@@ -156,10 +156,11 @@ def device_count():
 KEEP = 0xFFFFFFFF
 
 
-def set_tail(dbk_rows_light=KEEP, dbk_rows_heavy=KEEP, dbk_waves=KEEP, intra_rows_light=KEEP, intra_rows_heavy=KEEP, intra_waves=KEEP):
+def set_tail(dbk_rows_light=KEEP, dbk_rows_heavy=KEEP, dbk_waves=KEEP, intra_rows_light=KEEP, intra_rows_heavy=KEEP, intra_waves=KEEP,
+             band_budget=KEEP):
     """How the per-picture kernels split the pictures of replay sets / decoders created from now on into row bands
     (h264bsdmiDebugSetTail): rows per band for light / heavy pictures (0 = one band) and wavefronts per workgroup."""
-    lib().h264bsdmiDebugSetTail(dbk_rows_light, dbk_rows_heavy, dbk_waves, intra_rows_light, intra_rows_heavy, intra_waves)
+    lib().h264bsdmiDebugSetTail(dbk_rows_light, dbk_rows_heavy, dbk_waves, intra_rows_light, intra_rows_heavy, intra_waves, band_budget)
 
 
 def device_errors():

@@ -256,8 +256,14 @@ Engine *engine_get(int device = -1)
  * workgroup, and a cap on the bands of one launch.  H264BSDMI_TAIL="dbk_rows_light,dbk_rows_heavy,dbk_waves,intra_rows_light,
  * intra_rows_heavy,intra_waves" overrides the defaults (0 rows = one band); h264bsdmiDebugSetTail() does the same for tests. */
 struct TailConfig {
-    uint32_t dbk_rows_light = 17, dbk_rows_heavy = 9, dbk_waves = 4;
-    uint32_t intra_rows_light = 0, intra_rows_heavy = 9, intra_waves = 4;
+    uint32_t dbk_rows_light = 17, dbk_rows_heavy = 9, dbk_waves = 12;
+    uint32_t intra_rows_light = 0, intra_rows_heavy = 9, intra_waves = 12;
+    /* A picture is only split where that puts idle compute units to work: a launch gets at most band_budget workgroups
+     * (bands per picture <= band_budget / pictures of the tick, at least 1).  256 pictures in lock-step: one workgroup per
+     * picture and compute unit (measured: 4 bands x 4 wavefronts 92 instead of 57 ms per step in k_frame_dbk — a picture's
+     * filtering needs about one compute unit's worth of instruction issue whichever way it is cut); the small ticks of
+     * stream groups and heavy lanes: several workgroups per picture.  H264BSDMI_BAND_BUDGET overrides. */
+    uint32_t band_budget = 320;
     bool from_env = false;
 };
 TailConfig g_tail;
@@ -274,6 +280,7 @@ TailConfig tail_config()
                 g_tail.intra_rows_light = v[3]; g_tail.intra_rows_heavy = v[4]; g_tail.intra_waves = v[5];
             } else fprintf(stderr, "h264bsd-mi355x: H264BSDMI_TAIL=%s ignored (expected six numbers)\n", cfg);
         }
+        if (const char *cfg = getenv("H264BSDMI_BAND_BUDGET")) g_tail.band_budget = (uint32_t)strtoul(cfg, nullptr, 10);
     }
     return g_tail;
 }
@@ -412,28 +419,32 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
     if (s.max_levels && (stages & 2u)) {
         const TailConfig tc = tail_config();
+        const uint32_t cap = std::max<uint32_t>(1u, tc.band_budget / std::max<uint32_t>(1u, s.n_frames));     /* bands per picture this launch can afford */
         uint32_t rows = std::max<uint32_t>(1u, std::min<uint32_t>(s.intra_rows ? s.intra_rows : s.max_h, s.max_h));
+        rows = std::min<uint32_t>(s.max_h, std::max<uint32_t>(rows, (s.max_h + cap - 1) / cap));
         uint32_t waves = std::max<uint32_t>(1u, std::min<uint32_t>(tc.intra_waves, h264k::TAIL_WAVES));
         /* a picture with concealed macroblocks must stay in one band (FjHeader.intra_down_deps): fewer wavefronts before
          * shorter bands */
         while (h264k::intra_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && waves > 1) waves--;
         if (h264k::intra_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u x %u macroblocks is too large for k_frame_intra\n", s.max_w, s.max_h); return -1; }
         const size_t lds = h264k::intra_lds_bytes(waves, s.max_w, rows);
-        const uint32_t bands = std::max<uint32_t>(s.intra_bands, (s.max_h + rows - 1) / rows);
-        uint32_t *tickets = tickets_for(st);
-        if (!tickets) return -1;
+        const uint32_t bands = std::max<uint32_t>(std::min<uint32_t>(s.intra_bands, cap), (s.max_h + rows - 1) / rows);
+        uint32_t *tickets = bands > 1 ? tickets_for(st) : nullptr;
+        if (bands > 1 && !tickets) return -1;
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
-        static size_t lds_enabled[MAX_DEVICES] = {};
+        static size_t lds_enabled[2][MAX_DEVICES] = {};
         static std::mutex lds_mu;
         {
             std::lock_guard<std::mutex> lk(lds_mu);
-            if (lds > lds_enabled[dev]) {
-                HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_intra, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                lds_enabled[dev] = lds;
+            if (lds > lds_enabled[bands > 1][dev]) {
+                HIP_TRY(hipFuncSetAttribute(bands > 1 ? (const void *)h264k::k_frame_intra<true> : (const void *)h264k::k_frame_intra<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_enabled[bands > 1][dev] = lds;
             }
         }
-        hipLaunchKernelGGL(h264k::k_frame_intra, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets + 2, bands, rows);
+        if (bands > 1) hipLaunchKernelGGL(h264k::k_frame_intra<true>, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets + 2, bands, rows);
+        else hipLaunchKernelGGL(h264k::k_frame_intra<false>, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof, nullptr, 1u, rows);
         if (launches) launches[3]++;
     }
     if (EV_NEEDED(4)) HIP_TRY(hipEventRecord(tt->ev[4], st));
@@ -442,7 +453,9 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         /* row bands: max_bands workgroups per picture (k_frame_dbk); the scheduling state of a band's rows lives in LDS
          * next to its wavefronts' tiles */
         const TailConfig tc = tail_config();
+        const uint32_t cap = std::max<uint32_t>(1u, tc.band_budget / std::max<uint32_t>(1u, s.n_frames));     /* bands per picture this launch can afford */
         uint32_t rows = std::max<uint32_t>(1u, std::min<uint32_t>(s.dbk_rows ? s.dbk_rows : s.max_h, s.max_h));   /* no band has more rows than this */
+        rows = std::min<uint32_t>(s.max_h, std::max<uint32_t>(rows, (s.max_h + cap - 1) / cap));
         uint32_t waves = std::min<uint32_t>(s.dbk_waves ? s.dbk_waves : tc.dbk_waves, h264k::DBK_WAVES);
         waves = std::max<uint32_t>(waves, 1u);
         /* pictures whose rows do not fit: shorter bands first (rows is a cap the kernel applies to every picture), fewer
@@ -451,21 +464,23 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         while (h264k::dbk_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && waves > 1) waves--;
         const size_t lds = h264k::dbk_lds_bytes(waves, s.max_w, rows);
         if (lds > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture %u macroblocks wide is too large for k_frame_dbk\n", s.max_w); return -1; }
-        const uint32_t bands = std::max<uint32_t>(s.dbk_bands, (s.max_h + rows - 1) / rows);
-        uint32_t *tickets = tickets_for(st);
-        if (!tickets) return -1;
+        const uint32_t bands = std::max<uint32_t>(std::min<uint32_t>(s.dbk_bands, cap), (s.max_h + rows - 1) / rows);
+        uint32_t *tickets = bands > 1 ? tickets_for(st) : nullptr;
+        if (bands > 1 && !tickets) return -1;
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
-        static size_t lds_enabled[MAX_DEVICES] = {};
+        static size_t lds_enabled[2][MAX_DEVICES] = {};
         static std::mutex lds_mu;
         {
             std::lock_guard<std::mutex> lk(lds_mu);
-            if (lds > lds_enabled[dev]) {
-                HIP_TRY(hipFuncSetAttribute((const void *)h264k::k_frame_dbk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                lds_enabled[dev] = lds;
+            if (lds > lds_enabled[bands > 1][dev]) {
+                HIP_TRY(hipFuncSetAttribute(bands > 1 ? (const void *)h264k::k_frame_dbk<true> : (const void *)h264k::k_frame_dbk<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_enabled[bands > 1][dev] = lds;
             }
         }
-        hipLaunchKernelGGL(h264k::k_frame_dbk, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets, bands, rows);
+        if (bands > 1) hipLaunchKernelGGL(h264k::k_frame_dbk<true>, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets, bands, rows);
+        else hipLaunchKernelGGL(h264k::k_frame_dbk<false>, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof, nullptr, 1u, rows);
         if (launches) launches[4]++;
     }
     if (EV_NEEDED(5)) HIP_TRY(hipEventRecord(tt->ev[5], st));
@@ -1458,7 +1473,7 @@ int h264bsdmiDebugTailProfile(int enable, unsigned long long *out)
 /* Test / tuning hook: how the per-picture kernels split pictures from now on (TailConfig; descriptors built earlier keep their
  * bands): rows per band for light and heavy pictures (0 = one band) and wavefronts per workgroup, for k_frame_dbk and
  * k_frame_intra.  A value of 0xFFFFFFFF leaves that setting alone. */
-int h264bsdmiDebugSetTail(u32 dbk_rows_light, u32 dbk_rows_heavy, u32 dbk_waves, u32 intra_rows_light, u32 intra_rows_heavy, u32 intra_waves)
+int h264bsdmiDebugSetTail(u32 dbk_rows_light, u32 dbk_rows_heavy, u32 dbk_waves, u32 intra_rows_light, u32 intra_rows_heavy, u32 intra_waves, u32 band_budget)
 {
     (void)tail_config();                                     /* the environment first, once */
     std::lock_guard<std::mutex> lk(g_tail_mu);
@@ -1468,6 +1483,7 @@ int h264bsdmiDebugSetTail(u32 dbk_rows_light, u32 dbk_rows_heavy, u32 dbk_waves,
     if (intra_rows_light != 0xFFFFFFFFu) g_tail.intra_rows_light = intra_rows_light;
     if (intra_rows_heavy != 0xFFFFFFFFu) g_tail.intra_rows_heavy = intra_rows_heavy;
     if (intra_waves != 0xFFFFFFFFu && intra_waves >= 1) g_tail.intra_waves = intra_waves;
+    if (band_budget != 0xFFFFFFFFu) g_tail.band_budget = band_budget;
     return 0;
 }
 

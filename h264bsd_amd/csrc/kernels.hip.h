@@ -84,8 +84,14 @@ struct FrameDesc {
 
 namespace h264k {
 
-__constant__ int c_level_scale[6][3] = {
-    { 10, 13, 16 }, { 11, 14, 18 }, { 13, 16, 20 }, { 14, 18, 23 }, { 16, 20, 25 }, { 18, 23, 29 } };
+/* LevelScale(qp % 6, class) of 8.5.9 — classes: both indices even (10,11,13,14,16,18), mixed (13,14,16,18,20,23), both odd
+ * (16,18,20,23,25,29) — five bits per entry in an immediate: a lookup is a shift and a mask, not a (lane-indexed = global
+ * memory) table read in the middle of every macroblock's residual */
+__device__ __forceinline__ int level_scale(int m, int cls)
+{
+    const uint32_t c = cls == 0 ? 0x2507356Au : cls == 1 ? 0x2F4941CDu : 0x3B9BD250u;
+    return (int)((c >> (5 * m)) & 31u);
+}
 __constant__ uint8_t c_alpha[52] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13,
     15, 17, 20, 22, 25, 28, 32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255 };
 __constant__ uint8_t c_beta[52] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6,
@@ -123,6 +129,8 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
  * stored after s_waitcnt vmcnt(0) the same way.  No fences: a release fence writes back the whole L2 of the XCD. */
 #define H264K_GLOBAL __attribute__((address_space(1)))      /* HBM pointers: global_load / global_store instead of flat */
 #define H264K_LDS    __attribute__((address_space(3)))
+#define H264K_CONST  __attribute__((address_space(4)))      /* frame-job sections: nothing writes them while kernels run, so a load
+                                                               from a wave-uniform address may be a scalar load (s_load) */
 __device__ __forceinline__ uint32_t ld_agent_u32(const void *p)
 {
     return __hip_atomic_load((const H264K_GLOBAL uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -153,6 +161,19 @@ __device__ __forceinline__ void put16(void *p, uint4 v, bool wt)
         st_agent_u32(q, v.x); st_agent_u32(q + 4, v.y); st_agent_u32(q + 8, v.z); st_agent_u32(q + 12, v.w);
     } else *reinterpret_cast<uint4 *>(p) = v;
 }
+/* The launch descriptors are read-only while kernels run: reached through the constant address space, a descriptor field is a
+ * scalar load from the scalar cache wherever it is used — not a vector load from global memory that a wavefront waits for
+ * in the middle of a macroblock (the reference is handed through the inlined helpers as an ordinary one; the address space is
+ * inferred from this cast). */
+#define FD_REF(frames, i) (*(const FrameDesc *)((const H264K_CONST FrameDesc *)(frames) + (i)))
+/* plain loads / stores with the address space spelled out (global_load / global_store / s_load instead of flat); the HIP vector
+ * classes cannot be copied out of a qualified address space, the native vector types can */
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 ld16g(const H264K_GLOBAL uint8_t *p) { const u32x4 v = *(const H264K_GLOBAL u32x4 *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 ld8g(const H264K_GLOBAL uint8_t *p) { const u32x2 v = *(const H264K_GLOBAL u32x2 *)p; return make_uint2(v.x, v.y); }
+__device__ __forceinline__ void st16g(H264K_GLOBAL uint8_t *p, uint4 v) { *(H264K_GLOBAL u32x4 *)p = (u32x4){ v.x, v.y, v.z, v.w }; }
+__device__ __forceinline__ uint4 ld16c(const H264K_CONST void *p) { const u32x4 v = *(const H264K_CONST u32x4 *)p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint8_t *scratch_flags(const FrameDesc &fd) { return fd.dbk + (size_t)fd.n_mbs * DBK_REC_BYTES; }
 __device__ __forceinline__ uint8_t *scratch_done(const FrameDesc &fd, int which)      /* 0: k_frame_dbk, 1: k_frame_intra */
 {
@@ -186,7 +207,7 @@ __device__ __forceinline__ void idct_quad(int c[4], int q, int qp, bool use_dc, 
 {
     const int m = qp % 6, sh = qp / 6;
     /* the QP is wave-uniform: three scalar table reads and a select, not a lane-indexed (= global-memory) lookup */
-    const int ls0 = c_level_scale[m][0], ls1 = c_level_scale[m][1], ls2 = c_level_scale[m][2];
+    const int ls0 = level_scale(m, 0), ls1 = level_scale(m, 1), ls2 = level_scale(m, 2);
     const int lsa = (q & 1) ? ls1 : ls0, lsb = (q & 1) ? ls2 : ls1;
     int d0 = (c[0] * lsa) << sh, d1 = (c[1] * lsb) << sh, d2 = (c[2] * lsa) << sh, d3 = (c[3] * lsb) << sh;
     if (use_dc && q == 0) d0 = dc;
@@ -211,13 +232,15 @@ __device__ __forceinline__ void load_row4(const int16_t *p, bool valid, int c[4]
  * Must be called by all 64 lanes (quad shuffles).  coef = first coefficient block of the MB. */
 /* The coefficient rows a lane needs, fetched ahead of their use (k_recon_inter requests them together with the
  * reference windows): luma row, chroma AC row, chroma DC quartet. */
-struct ResidRows { int2 y, c, cdc; };
+struct ResidRows { int2 y, c, cdc; int ldc; };     /* ldc: level (lane & 15) of the Intra16x16 luma DC block */
 __device__ __forceinline__ ResidRows mb_residual_fetch(uint32_t coded, const int16_t *coef, int lane)
 {
     ResidRows r;
     r.y = r.c = r.cdc = make_int2(0, 0);
+    r.ldc = 0;
     const int q = lane & 3;
     const int has_ldc = (coded >> 24) & 1, has_cdc = (coded >> 25) & 1;
+    if (has_ldc) r.ldc = coef[lane & 15];                        /* wave-uniform; the first block of the macroblock */
     if (coded & 0x0100FFFFu) {                                   /* wave-uniform */
         const int blk = lane >> 2, bx = blk & 3, by = blk >> 2, z = z_of(bx, by);
         const int off = has_ldc + __popc(coded & ((1u << z) - 1u));
@@ -238,7 +261,9 @@ __device__ __forceinline__ void unpack_row4(int2 w, int c[4])
     c[0] = (int16_t)(w.x & 0xFFFF); c[1] = w.x >> 16; c[2] = (int16_t)(w.y & 0xFFFF); c[3] = w.y >> 16;
 }
 
-/* returns true in the lanes that hold a residual sample outside [-512,511] (DEVERR_RESIDUAL_RANGE) */
+/* returns true in the lanes that hold a residual sample outside [-512,511] (DEVERR_RESIDUAL_RANGE).  LDC = false: the caller
+ * never sees an Intra16x16 luma DC block (inter macroblocks) and the code for it is left out. */
+template <bool LDC = true>
 __device__ __forceinline__ bool mb_residual_compute(uint32_t coded, int qp_y, int qp_c, bool is_i16, const int16_t *coef, int lane,
                                                     const ResidRows &rows, int ry[4], int rc[4])
 {
@@ -249,8 +274,10 @@ __device__ __forceinline__ bool mb_residual_compute(uint32_t coded, int qp_y, in
     if (coded & 0x0100FFFFu) {                                   /* wave-uniform */
         const int blk = lane >> 2, bx = blk & 3, by = blk >> 2;
         int dc = 0;
-        if (has_ldc) {
-            /* 4x4 Hadamard element (by,bx) of the DC block, then the 8.5.10 scaling */
+        if (LDC && has_ldc) {
+            /* 4x4 Hadamard element (by,bx) of the DC block, then the 8.5.10 scaling.  The 16 levels arrived with the other
+             * coefficient rows (one per lane, mb_residual_fetch): they are read out of lanes 0..15 into scalar registers —
+             * no memory access in the middle of the macroblock */
             const uint32_t neg = 0xA6C0u;                        /* sign rows: 0000 1100 0110 1010 (bit k of row i) */
             const uint32_t nr = (neg >> (4 * by)) & 15, ncl = (neg >> (4 * bx)) & 15;
             int acc = 0;
@@ -258,12 +285,12 @@ __device__ __forceinline__ bool mb_residual_compute(uint32_t coded, int qp_y, in
             for (int k = 0; k < 4; k++)
 #pragma unroll
                 for (int l = 0; l < 4; l++) {
-                    const int v = coef[4 * k + l];
+                    const int v = __builtin_amdgcn_readlane(rows.ldc, 4 * k + l);
                     acc += (((nr >> k) ^ (ncl >> l)) & 1) ? -v : v;
                 }
-            const int ls = c_level_scale[qp_y % 6][0], q6 = qp_y / 6;
+            const int ls = level_scale(qp_y % 6, 0), q6 = qp_y / 6;
             dc = q6 >= 2 ? (acc * ls) << (q6 - 2) : (acc * ls + (1 << (1 - q6))) >> (2 - q6);
-            if (coded & FJ_CODED_LUMA_DC_RAW) dc = coef[4 * by + bx];   /* wave-uniform; damaged streams only (framejob.h) */
+            if (coded & FJ_CODED_LUMA_DC_RAW) dc = __shfl(rows.ldc, 4 * by + bx);   /* wave-uniform; damaged streams only (framejob.h) */
         }
         unpack_row4(rows.y, ry);
         idct_quad(ry, q, qp_y, is_i16, dc);
@@ -276,7 +303,7 @@ __device__ __forceinline__ bool mb_residual_compute(uint32_t coded, int qp_y, in
             int cc[4];
             unpack_row4(rows.cdc, cc);
             const int f = cc[0] + ((i & 1) ? -cc[1] : cc[1]) + ((i & 2) ? -cc[2] : cc[2]) + ((i == 1 || i == 2) ? -cc[3] : cc[3]);
-            const int ls = c_level_scale[qp_c % 6][0], q6 = qp_c / 6;
+            const int ls = level_scale(qp_c % 6, 0), q6 = qp_c / 6;
             dc = q6 >= 1 ? (f * ls) << (q6 - 1) : (f * ls) >> 1;
         }
         unpack_row4(rows.c, rc);
@@ -493,7 +520,7 @@ __device__ __forceinline__ void wave_sync()
 #endif
 __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frames)
 {
-    const FrameDesc &fd = frames[blockIdx.y];
+    const FrameDesc &fd = FD_REF(frames, blockIdx.y);
     const int n = threadIdx.x & 31;
     const int wmb = fd.wmb;
     const uint32_t n_dbk = fd.n_dbk;
@@ -597,7 +624,7 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
 #endif
 __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ frames)
 {
-    const FrameDesc &fd = frames[blockIdx.y];
+    const FrameDesc &fd = FD_REF(frames, blockIdx.y);
     const int lane = threadIdx.x & 63;
     const int wmb = fd.wmb;
     const uint32_t n_copy = fd.n_copy;
@@ -686,21 +713,33 @@ template <int PATH>
 __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * INTER_WAVE_LDS];
-    const FrameDesc &fd = frames[blockIdx.y];
+    const FrameDesc &fd = FD_REF(frames, blockIdx.y);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform: the list entry, the record and
                                                                                  everything derived live in scalar registers */
     const uint32_t gi = (PATH == 0 ? 0u : fd.n_gen_uni) + blockIdx.x * 4 + wave;
     if (gi >= (PATH == 0 ? fd.n_gen_uni : fd.n_gen)) return;
-    const FjGen ge = fd.gen[gi];
+    /* list entry and record as whole dwords from a wave-uniform address in read-only memory: scalar loads (there is no scalar
+     * byte load: a struct copy would fetch the byte-sized members with vector loads and wait for them) */
+    FjGen ge;
+    {
+        const uint4 w = ld16c((const H264K_CONST FjGen *)fd.gen + gi);
+        __builtin_memcpy(&ge, &w, 16);
+    }
     const uint32_t mb = ge.mb;
-    const FjMbRec rec = fd.recs[mb];                  /* only the QPs are needed from it (in flight meanwhile) */
+    FjMbRec rec;                                     /* only the QPs (and, partitioned, the references) are needed from it */
+    {
+        const uint4 w = ld16c((const H264K_CONST FjMbRec *)fd.recs + mb), w2 = ld16c((const H264K_CONST uint8_t *)((const H264K_CONST FjMbRec *)fd.recs + mb) + 16);
+        __builtin_memcpy(&rec, &w, 16);
+        __builtin_memcpy(reinterpret_cast<uint8_t *>(&rec) + 16, &w2, 16);
+    }
     const int lane = threadIdx.x & 63;
     uint8_t *lw = lds + wave * INTER_WAVE_LDS, *lc = lw + 21 * IW_STRIDE;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mbx = mb % wmb, mby = mb / wmb;
-    const int16_t *mvs = fd.mvs + 32 * (size_t)mb;
-    const int16_t *coef = fd.coefs + 16 * (size_t)ge.coef_idx;
-    uint8_t *cur = fd.cur;
+    /* (address spaces spelled out once: the loads below become global_load / s_load instead of flat_load) */
+    const int16_t *mvs = (const int16_t *)((const H264K_CONST int16_t *)fd.mvs + 32 * (size_t)mb);
+    const int16_t *coef = (const int16_t *)((const H264K_CONST int16_t *)fd.coefs + 16 * (size_t)ge.coef_idx);
+    H264K_GLOBAL uint8_t *cur = (H264K_GLOBAL uint8_t *)fd.cur;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
     const bool uniform = PATH == 0, quadwise = PATH == 1 && ge.uniform == 2;
     uint32_t refs = ge.slot * 0x01010101u, mv_mine = 0;
@@ -710,11 +749,14 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
         mv_mine = *reinterpret_cast<const uint32_t *>(mvs + 2 * blk);
     }
 
-    const ResidRows rrows = mb_residual_fetch(ge.coded, coef, lane);   /* in flight together with the reference windows */
+    /* the coefficient rows are requested right behind the reference windows (whose loads come first: they are needed
+     * first) and consumed after the prediction */
+    ResidRows rrows;
+    if (!uniform) rrows = mb_residual_fetch(ge.coded, coef, lane);
     int pl[4], pc[4] = { 0, 0, 0, 0 };
     if (uniform) {
         const int mvx = (int16_t)(mv0 & 0xFFFFu), mvy = (int32_t)mv0 >> 16;
-        const uint8_t *ref = slot_ptr(fd, refs & 255u);
+        const H264K_GLOBAL uint8_t *ref = (const H264K_GLOBAL uint8_t *)slot_ptr(fd, refs & 255u);
         const int xi = mbx * 16 + (mvx >> 2) - 2, yi = mby * 16 + (mvy >> 2) - 2;
         const int xs = (xi >> 4) << 4;                           /* first column of the window's first tile */
         const int cxi = mbx * 8 + (mvx >> 3), cyi = mby * 8 + (mvy >> 3);
@@ -724,21 +766,24 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
          * (lane = 3 * row + tile: 63 lanes), one 8-byte load for chroma (lane = 18 * plane + 2 * row + tile: 36 lanes). */
         const bool lfast = xi >= 0 && xi + 21 <= W && yi >= 0 && yi + 21 <= H;
         const bool cfast = cxi >= 0 && cxi + 9 <= CW && cyi >= 0 && cyi + 9 <= CH;
-        if (lfast) {
-            const int lr = lane / 3, lk = lane - 3 * lr, lx = xs + 16 * lk;
-            if (lane < 63 && lx < W) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(ref + luma_at(wmb, lx, yi + lr));
-                uint32_t *d32 = reinterpret_cast<uint32_t *>(lw + lr * IW_STRIDE + 16 * lk);
-                d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
-            }
+        /* All global loads of the macroblock are issued back to back — the window pieces here, the coefficient rows above —
+         * and only then consumed: one memory round trip per macroblock.  (A load and the LDS store of its result inside one
+         * `if` make the wavefront wait for that load before it issues the next one.)  Lanes without a piece load the first
+         * bytes of the reference frame and drop them. */
+        const int lr = (lane * 43) >> 7, lk = lane - 3 * lr, lx = xs + 16 * lk;          /* lane / 3, lane % 3 */
+        const bool l_on = lfast && lane < 63 && lx < W;
+        const uint4 vl = ld16g(ref + (l_on ? luma_at(wmb, lx, yi + lr) : (size_t)0));
+        const int cp = lane >= 18, rem = cp ? lane - 18 : lane, cr = rem >> 1, ck = rem & 1, cx = cxs + 8 * ck;
+        const bool c_on = cfast && lane < 36 && cx < CW;
+        const uint2 vc = ld8g(ref + (c_on ? chroma_at(wmb, cp, cx, cyi + cr) : (size_t)0));
+        rrows = mb_residual_fetch(ge.coded, coef, lane);
+        if (l_on) {
+            uint32_t *d32 = reinterpret_cast<uint32_t *>(lw + lr * IW_STRIDE + 16 * lk);
+            d32[0] = vl.x; d32[1] = vl.y; d32[2] = vl.z; d32[3] = vl.w;
         }
-        if (cfast) {
-            const int cp = lane >= 18, rem = cp ? lane - 18 : lane, cr = rem >> 1, ck = rem & 1, cx = cxs + 8 * ck;
-            if (lane < 36 && cx < CW) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(ref + chroma_at(wmb, cp, cx, cyi + cr));
-                uint32_t *d32 = reinterpret_cast<uint32_t *>(lc + cp * 9 * IC_STRIDE + cr * IC_STRIDE + 8 * ck);
-                d32[0] = v.x; d32[1] = v.y;
-            }
+        if (c_on) {
+            uint32_t *d32 = reinterpret_cast<uint32_t *>(lc + cp * 9 * IC_STRIDE + cr * IC_STRIDE + 8 * ck);
+            d32[0] = vc.x; d32[1] = vc.y;
         }
         if (!lfast) {
             for (int d = lane; d < 21 * 48; d += 64) {
@@ -785,7 +830,43 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
         uint8_t *lq = lw, *cq = lw + 4 * 13 * QW_STRIDE;
         {
             /* staging: per quadrant 13 luma rows x 2 tiles (104 aligned 16-byte loads: two per lane) and 2 planes x 5 chroma
-             * rows x 2 tiles (80 aligned 8-byte loads); a window that leaves the picture is gathered sample by sample */
+             * rows x 2 tiles (80 aligned 8-byte loads), all four requested before the first is consumed (one memory round
+             * trip); a window that leaves the picture is gathered sample by sample afterwards */
+            uint4 lv[2]; uint2 cv[2];
+            uint32_t *ldst[2], *cdst[2];
+            bool lon[2], con[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int idx = min(lane + 64 * j, 103);
+                const int q = idx / 26, rem = idx - 26 * q, r = rem >> 1, k = rem & 1;
+                const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
+                const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
+                const H264K_GLOBAL uint8_t *ref = (const H264K_GLOBAL uint8_t *)slot_ptr(fd, (refs >> (8 * q)) & 255u);
+                const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
+                const int xs = ((xi >> 4) << 4) + 16 * k;
+                ldst[j] = reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + r * QW_STRIDE + 16 * k);
+                lon[j] = lane + 64 * j < 104 && xi >= 0 && xi + 13 <= W && yi >= 0 && yi + 13 <= H && xs < W;
+                lv[j] = ld16g(ref + (lon[j] ? luma_at(wmb, xs, yi + r) : (size_t)0));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int idx = min(lane + 64 * j, 79);
+                const int q = idx / 20, rem = idx - 20 * q, pp = rem >= 10, e2 = pp ? rem - 10 : rem, r = e2 >> 1, k = e2 & 1;
+                const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
+                const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
+                const H264K_GLOBAL uint8_t *ref = (const H264K_GLOBAL uint8_t *)slot_ptr(fd, (refs >> (8 * q)) & 255u);
+                const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
+                const int cxs = ((cxi >> 3) << 3) + 8 * k;
+                cdst[j] = reinterpret_cast<uint32_t *>(cq + (q * 2 + pp) * 5 * QC_STRIDE + r * QC_STRIDE + 8 * k);
+                con[j] = lane + 64 * j < 80 && cxi >= 0 && cxi + 5 <= CW && cyi >= 0 && cyi + 5 <= CH && cxs < CW;
+                cv[j] = ld8g(ref + (con[j] ? chroma_at(wmb, pp, cxs, cyi + r) : (size_t)0));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                if (lon[j]) { ldst[j][0] = lv[j].x; ldst[j][1] = lv[j].y; ldst[j][2] = lv[j].z; ldst[j][3] = lv[j].w; }
+                if (con[j]) { cdst[j][0] = cv[j].x; cdst[j][1] = cv[j].y; }
+            }
+            /* windows that leave the picture (h264bsdFillBlock, reconstruct.c:2244) */
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int idx = lane + 64 * j;
@@ -797,12 +878,7 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
                     const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
                     const int xs = ((xi >> 4) << 4) + 16 * k;
                     uint32_t *d32 = reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + r * QW_STRIDE + 16 * k);
-                    if (xi >= 0 && xi + 13 <= W && yi >= 0 && yi + 13 <= H) {
-                        if (xs < W) {
-                            const uint4 v = *reinterpret_cast<const uint4 *>(ref + luma_at(wmb, xs, yi + r));
-                            d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
-                        }
-                    } else {
+                    if (!(xi >= 0 && xi + 13 <= W && yi >= 0 && yi + 13 <= H)) {
                         const int yy = clip3(0, H - 1, yi + r);
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
@@ -825,12 +901,7 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
                     const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
                     const int cxs = ((cxi >> 3) << 3) + 8 * k;
                     uint32_t *d32 = reinterpret_cast<uint32_t *>(cq + (q * 2 + pp) * 5 * QC_STRIDE + r * QC_STRIDE + 8 * k);
-                    if (cxi >= 0 && cxi + 5 <= CW && cyi >= 0 && cyi + 5 <= CH) {
-                        if (cxs < CW) {
-                            const uint2 v = *reinterpret_cast<const uint2 *>(ref + chroma_at(wmb, pp, cxs, cyi + r));
-                            d32[0] = v.x; d32[1] = v.y;
-                        }
-                    } else {
+                    if (!(cxi >= 0 && cxi + 5 <= CW && cyi >= 0 && cyi + 5 <= CH)) {
                         const int yy = clip3(0, CH - 1, cyi + r);
 #pragma unroll
                         for (int c = 0; c < 2; c++) {
@@ -903,8 +974,11 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
         }
     }
 
+    /* (an unconditional use of the coefficient rows here — they arrived long ago — keeps the compiler from sinking their loads
+     * into the residual code, where every coded macroblock would wait for a second memory round trip) */
+    asm volatile("" :: "v"(rrows.y.x), "v"(rrows.y.y), "v"(rrows.c.x), "v"(rrows.c.y), "v"(rrows.cdc.x), "v"(rrows.cdc.y));
     int ry[4], rc[4];
-    report_residual_range(fd, mb_residual_compute(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc), lane);
+    report_residual_range(fd, mb_residual_compute<false>(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc), lane);
     /* ---- residual add, clip; the macroblock is gathered in LDS (the windows are dead by now) so that it leaves as
      * its tile: 24 x 16 contiguous bytes ---- */
     wave_sync();
@@ -918,7 +992,7 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
     wave_sync();
     /* the LDS image IS the tile (Y 16x16 | Cb 8x8 | Cr 8x8): 24 x 16 bytes, three cache lines */
     if (lane < TILE / 16)
-        *reinterpret_cast<uint4 *>(cur + (size_t)mb * TILE + lane * 16) = *reinterpret_cast<const uint4 *>(lw + lane * 16);
+        st16g(cur + (size_t)mb * TILE + lane * 16, *reinterpret_cast<const uint4 *>(lw + lane * 16));
 }
 
 /* ------------------------------------------------------------------ intra macroblocks */
@@ -1110,6 +1184,7 @@ __device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, co
     const FjMbRec rec = rec_from_lds(rec_lds);
     L.nb_y = L.nb_c = 128;
     L.rows.y = L.rows.c = L.rows.cdc = make_int2(0, 0);
+    L.rows.ldc = 0;
     if (rec.kind == FJ_MB_IPCM || rec.kind == FJ_MB_CONCEAL_I) return;
     const uint8_t *Y = fd.cur + (size_t)mb * TILE;       /* neighbours: one tile to the left, wmb tiles up */
     const ptrdiff_t up = -(ptrdiff_t)fd.wmb * TILE;
@@ -1650,25 +1725,28 @@ __host__ __device__ inline size_t intra_lds_bytes(uint32_t waves, uint32_t wmb, 
     const size_t n_loc16 = (((size_t)band_rows + 1) * wmb + 15) & ~(size_t)15, nq8 = ((size_t)band_rows * wmb + 7) & ~(size_t)7;
     return (size_t)waves * INTRA_WAVE_LDS + 2 * n_loc16 + 2 * nq8 + 32 + 4 * ((((size_t)wmb + 31) / 32 + 3) & ~(size_t)3) + I4TAB_BYTES;
 }
+/* BANDED = false: the launch gives every picture one workgroup (max_bands == 1, blockIdx.x = picture): no tickets, no
+ * hand-over code in the loop. */
+template <bool BANDED>
 __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames, unsigned long long *prof,
                                                                  uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint32_t s_misc[4];
-    const uint32_t ticket = take_ticket(tickets, &s_misc[0]);
-    const uint32_t pic = ticket / max_bands, band = ticket - pic * max_bands;
-    const FrameDesc &fd = frames[pic];
+    const uint32_t ticket = BANDED ? take_ticket(tickets, &s_misc[0]) : blockIdx.x;
+    const uint32_t pic = BANDED ? ticket / max_bands : ticket, band = BANDED ? ticket - pic * max_bands : 0u;
+    const FrameDesc &fd = FD_REF(frames, pic);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wmb = fd.wmb, hmb = fd.hmb;
-    int R, nb;
-    band_split(hmb, fd.intra_bands, max_bands, rows_cap, R, nb);
-    if (!fd.n_levels || (int)band >= nb) { return_ticket(tickets); return; }
+    int R = hmb, nb = 1;
+    if (BANDED) band_split(hmb, fd.intra_bands, max_bands, rows_cap, R, nb);
+    if (!fd.n_levels || (int)band >= nb) { if (BANDED) return_ticket(tickets); return; }
     const uint32_t total_all = fd.lvl[fd.n_levels];
     const int r0 = (int)band * R, r1 = min(hmb, r0 + R);
     const int base = (r0 - 1) * wmb;                        /* band-local index of macroblock mb: mb - base (row r0-1 first) */
     const int lo = r0 * wmb, hi = r1 * wmb;                 /* the band's own macroblocks */
     const int n_loc = (R + 1) * wmb, n_loc16 = (n_loc + 15) & ~15, nq8 = (R * wmb + 7) & ~7;
-    const bool has_up = band > 0, has_down = r1 < hmb;
+    const bool has_up = BANDED && band > 0, has_down = BANDED && r1 < hmb;
     uint8_t *my = lds + wave * INTRA_WAVE_LDS;
     uint8_t *need = lds + (blockDim.x >> 6) * INTRA_WAVE_LDS;
     uint8_t *dep = need + n_loc16;
@@ -1807,17 +1885,17 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
         IntraLoads cur_loads, next_loads;
         {
             const int mb0 = __builtin_amdgcn_readfirstlane(__shfl(v, 0));
-            intra_issue(fd, (uint32_t)mb0, rec_lds, lane, cur_loads, mb0 >= cross_lo && mb0 < cross_hi);
+            intra_issue(fd, (uint32_t)mb0, rec_lds, lane, cur_loads, BANDED && mb0 >= cross_lo && mb0 < cross_hi);
         }
         for (uint32_t j = 0; j < k; j++) {
             const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(v, (int)j));
             const uint32_t head = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_lds[8 * j]);     /* kind, qp_y, qp_c, avail */
             const uint32_t kind = head & 255u;
-            const bool wt = (int)mb >= wt_lo;
+            const bool wt = BANDED && (int)mb >= wt_lo;
             uint8_t *slot = my + j * INTRA_SLOT;
             if (j + 1 < k) {
                 const int mbn = __builtin_amdgcn_readfirstlane(__shfl(v, (int)j + 1));
-                intra_issue(fd, (uint32_t)mbn, rec_lds + 8 * (j + 1), lane, next_loads, mbn >= cross_lo && mbn < cross_hi);
+                intra_issue(fd, (uint32_t)mbn, rec_lds + 8 * (j + 1), lane, next_loads, BANDED && mbn >= cross_lo && mbn < cross_hi);
             }
             /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
             if (kind == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
@@ -1827,7 +1905,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
             } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, wt);
             if (j + 1 < k) cur_loads = next_loads;
         }
-        if (__ballot(joint_mb >= 0) != 0ull) intra4_joint(fd, joint_mb, lane, my, i4tab, joint_mb >= wt_lo);
+        if (__ballot(joint_mb >= 0) != 0ull) intra4_joint(fd, joint_mb, lane, my, i4tab, BANDED && joint_mb >= wt_lo);
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += k; }
         /* release: stores done -> the neighbours that wait for these macroblocks (lanes 16j + b: neighbour b of macroblock j) */
         __builtin_amdgcn_s_waitcnt(0);
@@ -1836,7 +1914,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
         {
             const int j = lane >> 4, b = lane & 15;
             const int mbj = __shfl(v, j);
-            if ((uint32_t)j < k && b == 8 && mbj >= wt_lo) st_agent_u8(done_g + mbj, 1u);      /* hand-over to the band below */
+            if (BANDED && (uint32_t)j < k && b == 8 && mbj >= wt_lo) st_agent_u8(done_g + mbj, 1u);      /* hand-over to the band below */
             if ((uint32_t)j < k && b < 8) {
                 const int s = neighbour(mbj, b);
                 if (s >= lo && s < hi && dep[s - base] != 0xFF && ((need[s - base] >> (b ^ 4)) & 1u)) release(s - base);
@@ -1846,7 +1924,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
     }
     if (tp && lane == 0) { tp[0] += t_idle; tp[1] += t_work; tp[2] += t_rel; tp[3] += n_done; }
     /* the last band of the picture to leave zeroes the done bytes for the next picture of this stream */
-    if (nb > 1) {
+    if (BANDED && nb > 1) {
         __syncthreads();
         if (tid == 0) s_misc[1] = atomicAdd(scratch_exits(fd, 1), 1u);
         __syncthreads();
@@ -1856,7 +1934,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
             if (tid == 0) atomicExch(scratch_exits(fd, 1), 0u);
         }
     }
-    return_ticket(tickets);
+    if (BANDED) return_ticket(tickets);
 }
 
 /* In-loop deblocking of one picture.  The filter of macroblock (x,y) touches its own samples, the last
@@ -1896,23 +1974,24 @@ __host__ __device__ inline size_t dbk_lds_bytes(uint32_t waves, uint32_t wmb, ui
     const size_t n_loc16 = (((size_t)band_rows + 1) * wmb + 15) & ~(size_t)15, nq8 = ((size_t)band_rows * wmb + 7) & ~(size_t)7;
     return (size_t)waves * 4 * WORKER_LDS + 2 * n_loc16 + 2 * nq8 + 32 + 4 * ((((size_t)wmb + 31) / 32 + 3) & ~(size_t)3) + 384;
 }
+template <bool BANDED>
 __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof,
                                                               uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint32_t s_misc[4];
-    const uint32_t ticket = take_ticket(tickets, &s_misc[0]);
-    const uint32_t pic = ticket / max_bands, band = ticket - pic * max_bands;
-    const FrameDesc &fd = frames[pic];
+    const uint32_t ticket = BANDED ? take_ticket(tickets, &s_misc[0]) : blockIdx.x;
+    const uint32_t pic = BANDED ? ticket / max_bands : ticket, band = BANDED ? ticket - pic * max_bands : 0u;
+    const FrameDesc &fd = FD_REF(frames, pic);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, quarter = lane >> 4, ql = lane & 15, q16 = 16 * quarter;
     const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
-    int R, nb;
-    band_split(hmb, fd.dbk_bands, max_bands, rows_cap, R, nb);
-    if (!fd.any_deblock || (int)band >= nb) { return_ticket(tickets); return; }
+    int R = hmb, nb = 1;
+    if (BANDED) band_split(hmb, fd.dbk_bands, max_bands, rows_cap, R, nb);
+    if (!fd.any_deblock || (int)band >= nb) { if (BANDED) return_ticket(tickets); return; }
     const int r0 = (int)band * R, r1 = min(hmb, r0 + R);
     const int base = (r0 - 1) * wmb;                        /* band-local index of macroblock mb: mb - base (row r0-1 first) */
     const int n_loc = (R + 1) * wmb, n_loc16 = (n_loc + 15) & ~15, nq8 = (R * wmb + 7) & ~7;
-    const bool has_up = band > 0, has_down = r1 < hmb;
+    const bool has_up = BANDED && band > 0, has_down = BANDED && r1 < hmb;
     uint8_t *anyf = lds + (blockDim.x >> 4) * WORKER_LDS;   /* 4 workers per launched wavefront */
     uint8_t *dep = anyf + n_loc16;
     uint16_t *queue = reinterpret_cast<uint16_t *>(dep + n_loc16);
@@ -1929,9 +2008,15 @@ __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *_
     unsigned long long t_mark = t_begin;
 
     {
-        for (int i = tid; i < n_loc; i += blockDim.x) {
-            const int mb = base + i;
-            anyf[i] = (mb >= 0 && mb < r1 * wmb) ? flags_g[mb] : 0;
+        /* flags of rows r0-1 .. r1-1 (row -1 of band 0: zeros) */
+        const int src0 = base < 0 ? 0 : base, n_src = r1 * wmb - src0;
+        for (int i = tid; i < src0 - base; i += blockDim.x) anyf[i] = 0;
+        if (((src0 | (src0 - base)) & 3) == 0) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(flags_g + src0);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(anyf + (src0 - base));
+            for (int i = tid; i < (n_src + 3) / 4; i += blockDim.x) dst[i] = src[i];       /* (the scratch area is padded) */
+        } else {
+            for (int i = tid; i < n_src; i += blockDim.x) anyf[src0 - base + i] = flags_g[src0 + i];
         }
         for (int i = tid; i < nq8 / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
         if (tid < 8) ctr[tid] = 0;
@@ -2077,17 +2162,21 @@ __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *_
     }
     /* the last band of the picture to leave zeroes the flags (k_dbk only visits non-trivial macroblocks) and the done bytes
      * for the next picture of this stream */
-    __syncthreads();
-    if (tid == 0) s_misc[1] = atomicAdd(scratch_exits(fd, 0), 1u);
-    __syncthreads();
-    if (s_misc[1] == (uint32_t)nb - 1u) {
+    bool last = true;
+    if (BANDED && nb > 1) {
+        __syncthreads();
+        if (tid == 0) s_misc[1] = atomicAdd(scratch_exits(fd, 0), 1u);
+        __syncthreads();
+        last = s_misc[1] == (uint32_t)nb - 1u;
+    }
+    if (last) {
         uint32_t *z = reinterpret_cast<uint32_t *>(flags_g);
-        const int words = 2 * (int)((fd.n_mbs + 3u) >> 2);        /* flags and this kernel's done bytes are adjacent */
+        const int words = (BANDED && nb > 1 ? 2 : 1) * (int)((fd.n_mbs + 3u) >> 2);   /* flags and this kernel's done bytes are adjacent */
         for (int i = tid; i < words; i += blockDim.x) z[i] = 0;
-        if (tid == 0) atomicExch(scratch_exits(fd, 0), 0u);
+        if (BANDED && nb > 1 && tid == 0) atomicExch(scratch_exits(fd, 0), 0u);
     }
     (void)n_mbs;
-    return_ticket(tickets);
+    if (BANDED) return_ticket(tickets);
 }
 
 /* ------------------------------------------------------------------ pictures leaving the device */

@@ -85,9 +85,11 @@ int  h264bsdmiReplayConvertTimings(h264bsdmi_replay *r, float *ms, u32 *launches
 int  h264bsdmiDebugTailProfile(int enable, unsigned long long *out);
 /* Test / tuning hook: how the two per-picture kernels split the pictures of replay sets and decoder instances created
  * from now on into row bands (one workgroup per band): rows per band for light and for heavy pictures (more than a quarter of
- * the macroblocks intra coded; 0 = one band per picture) and wavefronts per workgroup, for k_frame_dbk and for k_frame_intra.
- * 0xFFFFFFFF leaves a setting alone.  Also settable through H264BSDMI_TAIL="a,b,c,d,e,f" in the environment. */
-int  h264bsdmiDebugSetTail(u32 dbk_rows_light, u32 dbk_rows_heavy, u32 dbk_waves, u32 intra_rows_light, u32 intra_rows_heavy, u32 intra_waves);
+ * the macroblocks intra coded; 0 = one band per picture) and wavefronts per workgroup, for k_frame_dbk and for k_frame_intra;
+ * band_budget: most workgroups of one launch (bands per picture <= band_budget / pictures of the tick, at least 1).
+ * 0xFFFFFFFF leaves a setting alone.  Also settable through H264BSDMI_TAIL="a,b,c,d,e,f" / H264BSDMI_BAND_BUDGET. */
+int  h264bsdmiDebugSetTail(u32 dbk_rows_light, u32 dbk_rows_heavy, u32 dbk_waves, u32 intra_rows_light, u32 intra_rows_heavy, u32 intra_waves,
+                           u32 band_budget);
 /* Bytes of packed syntax (frame jobs) per stream and of one frame, for the byte accounting. */
 unsigned long long h264bsdmiReplayJobBytes(h264bsdmi_replay *r);
 u32  h264bsdmiReplayFrameBytes(h264bsdmi_replay *r);

@@ -62,7 +62,7 @@ def test_no_deblocking_at_all(built):
 
 # ---- row bands of the two per-picture kernels (k_frame_dbk / k_frame_intra, kernels.hip.h): a picture split over several
 # workgroups with the hand-over through HBM must give the same samples as one workgroup ----
-DEFAULT_TAIL = (17, 9, 4, 0, 9, 4)
+DEFAULT_TAIL = (17, 9, 12, 0, 9, 12, 320)      # engine.hip TailConfig
 
 
 @pytest.fixture
@@ -78,7 +78,7 @@ def tail(built):
 def test_random_pictures_in_row_bands(built, tail, seed, wmb, hmb, rows, waves):
     """bands of 1-3 macroblock rows (>= 4 bands wherever the picture has the rows), 1-12 wavefronts per workgroup, on
     pictures 1 macroblock high / wide and ordinary ones; light (P) and heavy (intra) pictures both split"""
-    tail(rows, rows, waves, rows, rows, waves)
+    tail(rows, rows, waves, rows, rows, waves, 1 << 20)
     rng = np.random.default_rng(seed)
     lib = built.lib()
     jobs = [build_job(lib, rng, wmb, hmb, 0, 4, [])]
@@ -91,7 +91,7 @@ def test_random_pictures_in_row_bands(built, tail, seed, wmb, hmb, rows, waves):
 def test_huge_picture_in_row_bands(built, tail):
     """4096x2304 (256 x 144 macroblocks, the largest level-5.1 frame): 8 bands of 18 rows (intra picture) and 4 bands of
     36 rows (P picture); the scheduling state of a band must fit the LDS next to its wavefronts"""
-    tail(36, 18, 4, 36, 18, 4)
+    tail(36, 18, 4, 36, 18, 4, 1 << 20)
     rng = np.random.default_rng(41)
     lib = built.lib()
     jobs = [build_job(lib, rng, 256, 144, 0, 2, []), build_job(lib, rng, 256, 144, 1, 2, [0], p_inter=0.9, mv_range=300)]
