@@ -107,6 +107,13 @@ __constant__ uint8_t c_tc0[52][4] = {
 __constant__ uint8_t c_qpc[52] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23,
     24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39 };
 
+/* QPc of a chroma qp index (Table 8-15, the c_qpc table) without a lane-indexed (= global memory) lookup */
+__device__ __forceinline__ int qpc_of(int qpi)
+{
+    const int i = qpi - 30;
+    const uint32_t c = i < 8 ? 0x55433210u : i < 16 ? 0x98887766u : 0x00AAAA99u;     /* (QPc - 29) for qp index 30..51, a nibble each */
+    return qpi < 30 ? qpi : 29 + (int)((c >> (4 * (i & 7))) & 15u);
+}
 __device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
 __device__ __forceinline__ int z_of(int x, int y) { return ((y >> 1) << 3) | ((x >> 1) << 2) | ((y & 1) << 1) | (x & 1); }
@@ -536,14 +543,25 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
     uint32_t nmb = mb;
     if (ndi < n_dbk) nmb = fd.dbki[ndi];
     const uint32_t mbl = mb % (uint32_t)wmb ? mb - 1 : mb, mbt = mb >= (uint32_t)wmb ? mb - wmb : mb;    /* in-picture stand-ins */
-    const FjMbRec q = fd.recs[mb];
-    const FjMbRec pl = fd.recs[mbl], pt = fd.recs[mbt];
+    /* the three records as whole 16-byte pieces, the motion vectors of both sides — all requested before anything is looked
+     * at (a struct copy lets the compiler fetch member by member where each is used: five dependent round trips) */
+    FjMbRec q, pl, pt;
     const int dir = n >> 4, e = (n >> 2) & 3, k = n & 3;
     const int qx = dir ? k : e, qy = dir ? e : k;
     const int px = dir ? k : (e ? e - 1 : 3), py = dir ? (e ? e - 1 : 3) : k;
     const uint32_t pmb = e ? mb : (dir ? mbt : mbl);
-    const uint32_t mva = *reinterpret_cast<const uint32_t *>(fd.mvs + 32 * (size_t)mb + 2 * (4 * qy + qx));
-    const uint32_t mvb = *reinterpret_cast<const uint32_t *>(fd.mvs + 32 * (size_t)pmb + 2 * (4 * py + px));
+    uint32_t mva, mvb;
+    {
+        const H264K_GLOBAL uint8_t *rq = (const H264K_GLOBAL uint8_t *)(fd.recs + mb), *rl = (const H264K_GLOBAL uint8_t *)(fd.recs + mbl),
+                                   *rt = (const H264K_GLOBAL uint8_t *)(fd.recs + mbt);
+        uint4 w[6] = { ld16g(rq), ld16g(rq + 16), ld16g(rl), ld16g(rl + 16), ld16g(rt), ld16g(rt + 16) };
+        mva = *(const H264K_GLOBAL uint32_t *)(fd.mvs + 32 * (size_t)mb + 2 * (4 * qy + qx));
+        mvb = *(const H264K_GLOBAL uint32_t *)(fd.mvs + 32 * (size_t)pmb + 2 * (4 * py + px));
+#pragma unroll
+        for (int i = 0; i < 6; i++) asm volatile("" : "+v"(w[i].x), "+v"(w[i].y), "+v"(w[i].z), "+v"(w[i].w));
+        asm volatile("" : "+v"(mva), "+v"(mvb));
+        __builtin_memcpy(&q, &w[0], 32); __builtin_memcpy(&pl, &w[2], 32); __builtin_memcpy(&pt, &w[4], 32);
+    }
     uint8_t *out = fd.dbk + (size_t)mb * DBK_REC_BYTES;
     uint8_t *any_out = fd.dbk + (size_t)fd.n_mbs * DBK_REC_BYTES + mb;
     if (!q.dbk || q.kind == FJ_MB_ABSENT) {
@@ -586,10 +604,10 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
     const uint32_t sched = (any ? DBKF_ANY : 0u) | ((bal32 & 0x000Fu) ? DBKF_LEFT : 0u) | ((bal32 & 0x000F0000u) ? DBKF_TOP : 0u);
     if ((n & 7) == 0) *reinterpret_cast<uint32_t *>(out + (n >> 3) * 4) = v;
     if (n == 1) {
-        const int qcq = c_qpc[clip3(0, 51, (int)q.qp_y + q.cqp_off)];
+        const int qcq = qpc_of(clip3(0, 51, (int)q.qp_y + q.cqp_off));
         const int ql = (q.qp_y + pl.qp_y + 1) >> 1, qt = (q.qp_y + pt.qp_y + 1) >> 1;
-        const int cl = (qcq + c_qpc[clip3(0, 51, (int)pl.qp_y + q.cqp_off)] + 1) >> 1;   /* current MB's offset: deblocking.c:1501,1523 */
-        const int ct = (qcq + c_qpc[clip3(0, 51, (int)pt.qp_y + q.cqp_off)] + 1) >> 1;
+        const int cl = (qcq + qpc_of(clip3(0, 51, (int)pl.qp_y + q.cqp_off)) + 1) >> 1;   /* current MB's offset: deblocking.c:1501,1523 */
+        const int ct = (qcq + qpc_of(clip3(0, 51, (int)pt.qp_y + q.cqp_off)) + 1) >> 1;
         const int qp6[6] = { ql, qt, (int)q.qp_y, cl, ct, qcq };
         uint32_t w[3] = { 0, 0, 0 };
 #pragma unroll
@@ -630,26 +648,33 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
     const uint32_t n_copy = fd.n_copy;
     /* a fixed number of workgroups per picture, every wavefront walks the run list with a stride: no workgroup is
      * launched for nothing (the grid used to be sized by the longest list of the tick), and the next list entry is
-     * requested while the current run moves */
-    uint32_t ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+     * requested while the current run moves.  The list position is wave-uniform and the list read-only: entries come
+     * through the scalar cache (one s_load_dwordx2), not through the vector memory pipeline the samples use. */
+    uint32_t ci = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (ci >= n_copy) return;
-    FjCopy e = fd.copy[ci];
+    const H264K_CONST u32x2 *list = (const H264K_CONST u32x2 *)fd.copy;
+    u32x2 ew = list[ci];
   for (;;) {
     const uint32_t nci = ci + 4u * gridDim.x;
-    FjCopy ne = e;
-    if (nci < n_copy) ne = fd.copy[nci];
+    u32x2 nw = ew;
+    if (nci < n_copy) nw = list[nci];
+    FjCopy e;
+    __builtin_memcpy(&e, &ew, 8);
     const int cnt = e.count;
     const uint8_t *ref = slot_ptr(fd, e.slot);
     if ((e.dx | e.dy) == 0) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(ref + (size_t)e.mb * TILE);
-        uint4 *dst = reinterpret_cast<uint4 *>(fd.cur + (size_t)e.mb * TILE);
+        /* every load of the run before its first store, and none of them inside a branch (a load whose result leaves an
+         * `if` is waited for at the end of that `if`: the three pieces used to take three memory round trips): lanes behind
+         * the end of the run load its last piece again and drop it */
+        const H264K_GLOBAL uint8_t *src = (const H264K_GLOBAL uint8_t *)ref + (size_t)e.mb * TILE;
+        H264K_GLOBAL uint8_t *dst = (H264K_GLOBAL uint8_t *)fd.cur + (size_t)e.mb * TILE;
         const int n16 = cnt * (TILE / 16);
         constexpr int PIECES = (FJ_COPY_RUN * (TILE / 16) + 63) / 64;
         uint4 v[PIECES];
 #pragma unroll
-        for (int j = 0; j < PIECES; j++) if (lane + 64 * j < n16) v[j] = src[lane + 64 * j];
+        for (int j = 0; j < PIECES; j++) v[j] = ld16g(src + 16 * min(lane + 64 * j, n16 - 1));
 #pragma unroll
-        for (int j = 0; j < PIECES; j++) if (lane + 64 * j < n16) dst[lane + 64 * j] = v[j];
+        for (int j = 0; j < PIECES; j++) if (lane + 64 * j < n16) st16g(dst + 16 * (lane + 64 * j), v[j]);
     } else {
     /* displaced: clamp-to-edge sample gather (h264bsdFillBlock, reconstruct.c:2244), lane = (row, 4-sample piece) */
     const int W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
@@ -677,7 +702,7 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
     }
     }
     if (nci >= n_copy) return;
-    ci = nci; e = ne;
+    ci = nci; ew = nw;
   }
 }
 
