@@ -1004,20 +1004,17 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
     asm volatile("" :: "v"(rrows.y.x), "v"(rrows.y.y), "v"(rrows.c.x), "v"(rrows.c.y), "v"(rrows.cdc.x), "v"(rrows.cdc.y));
     int ry[4], rc[4];
     report_residual_range(fd, mb_residual_compute<false>(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc), lane);
-    /* ---- residual add, clip; the macroblock is gathered in LDS (the windows are dead by now) so that it leaves as
-     * its tile: 24 x 16 contiguous bytes ---- */
-    wave_sync();
-    *reinterpret_cast<uint32_t *>(lw + (by * 4 + row) * 16 + bx * 4) =
+    /* ---- residual add, clip, store.  Lane (block, row) holds 4 samples of row 4*by+row at column 4*bx: the 64 dwords of the
+     * wavefront ARE the 256 luma bytes of the tile (each group of 16 lanes one 64-byte piece), the 32 chroma dwords its third
+     * line — two coalesced stores, no detour through LDS ---- */
+    H264K_GLOBAL uint8_t *T = cur + (size_t)mb * TILE;
+    *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + (by * 4 + row) * 16 + bx * 4) =
         pack4(clip255(pl[0] + ry[0]), clip255(pl[1] + ry[1]), clip255(pl[2] + ry[2]), clip255(pl[3] + ry[3]));
     if (lane < 32) {
         const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
-        *reinterpret_cast<uint32_t *>(lw + 256 + plane * 64 + (cby * 4 + row) * 8 + cbx * 4) =
+        *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + T_CB + plane * 64 + (cby * 4 + row) * 8 + cbx * 4) =
             pack4(clip255(pc[0] + rc[0]), clip255(pc[1] + rc[1]), clip255(pc[2] + rc[2]), clip255(pc[3] + rc[3]));
     }
-    wave_sync();
-    /* the LDS image IS the tile (Y 16x16 | Cb 8x8 | Cr 8x8): 24 x 16 bytes, three cache lines */
-    if (lane < TILE / 16)
-        st16g(cur + (size_t)mb * TILE + lane * 16, *reinterpret_cast<const uint4 *>(lw + lane * 16));
 }
 
 /* ------------------------------------------------------------------ intra macroblocks */

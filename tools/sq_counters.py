@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""gpurun_out/sq/pass*.txt (tools/sq_profile.sh) -> profiles/<tag>_sq_counters.txt: per kernel and dispatch (= one tick of 256
+pictures) the SQ counters that say what bounds it.  usage: sq_counters.py <tag>"""
+import collections, glob, json, os, re, sys
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "sq")
+vals = collections.defaultdict(dict)
+cmds = []
+for f in sorted(glob.glob(os.path.join(src, "pass*.txt"))):
+    for l in open(f):
+        if l.startswith("#"):
+            cmds.append(l.rstrip()); continue
+        m = re.match(r"(?:void )?h264k::(\w+)(<\w+>)?\(.*?\s+(\w+)\s+total=(\S+) per_dispatch=(\S+) n=(\d+)", l)
+        if m:
+            k = m.group(1)
+            d = vals[k].setdefault(m.group(3), [0.0, 0])
+            d[0] += float(m.group(4)); d[1] = max(d[1], int(m.group(6)))     # the two instantiations of a template add up
+bl = json.loads(open(os.path.join(src, "bench_line.json")).read())
+ms = bl["roofline"]["device_ms_per_step"]
+ticks = 73
+GHZ = 2.3
+order = ["k_copy", "k_recon_inter", "k_dbk", "k_frame_intra", "k_frame_dbk"]
+out = ["# SQ / TCC counters of the lock-step bench (256 x 1080p streams), " + tag + "; one rocprofv3 --pmc pass per group, no runtime traces:"]
+out += ["#   " + c[2:] for c in cmds]
+out += ["# per dispatch (= one tick of 256 pictures; values of the two instantiations of a templated kernel added).  SQ_WAVE_CYCLES / SQ_WAIT_* /",
+        "# SQ_ACTIVE_* count quad-cycles summed over wavefronts (MI355X_MICROARCH.md); WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES.",
+        f"# 'valu pipe' = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time per tick from the un-profiled bench line of the same build x {GHZ} GHz).",
+        f"# bench line of this build: {bl['value'] / 1e6:.1f} M MB/s, device ms per step " + json.dumps({k: round(v, 1) for k, v in ms.items() if isinstance(v, (int, float))}),
+        "kernel           dispatches  VALU instr  SALU instr   LDS instr  VMEM rd/wr   parked  issue-stall  issuing  LDS-stall  bank-confl  L2 hit  valu pipe"]
+for k in order:
+    v = {n: (t / c if c else 0.0) for n, (t, c) in vals.get(k, {}).items()}
+    if not v:
+        continue
+    wc = v.get("SQ_WAVE_CYCLES", 0) or 1
+    t_us = ms[k] * 1e3 / ticks
+    pipe = v.get("SQ_INSTS_VALU", 0) * 4 / (1024 * t_us * 1e-6 * GHZ * 1e9)
+    hit = v.get("TCC_HIT_sum", 0) / max(1.0, v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0))
+    n = max(c for _, c in vals[k].values())
+    out.append(f"{k:16s} {n:10d}  {v.get('SQ_INSTS_VALU', 0):10.3e}  {v.get('SQ_INSTS_SALU', 0):10.3e}  {v.get('SQ_INSTS_LDS', 0):10.3e}  "
+               f"{v.get('SQ_INSTS_VMEM_RD', 0):.2e}/{v.get('SQ_INSTS_VMEM_WR', 0):.2e}  {v.get('SQ_WAIT_ANY', 0) / wc:5.0%}  {v.get('SQ_WAIT_INST_ANY', 0) / wc:10.0%}  "
+               f"{v.get('SQ_ACTIVE_INST_ANY', 0) / wc:6.0%}  {v.get('SQ_WAIT_INST_LDS', 0) / wc:8.1%}  {v.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, v.get('SQ_LDS_IDX_ACTIVE', 0)):9.1%}  {hit:5.0%}  {pipe:8.0%}")
+out.append("")
+out.append("# raw per-dispatch values")
+for k in order:
+    for n in sorted(vals.get(k, {})):
+        t, c = vals[k][n]
+        out.append(f"{k:16s} {n:24s} {t / c:.4g}")
+open(os.path.join(root, "profiles", f"{tag}_sq_counters.txt"), "w").write("\n".join(out) + "\n")
+print("\n".join(out[:24]))
