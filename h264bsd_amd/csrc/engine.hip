@@ -377,8 +377,30 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
 
 struct TickTimers { hipEvent_t ev[6]; hipEvent_t sev[3] = { nullptr, nullptr, nullptr }; bool on = false; unsigned mask = 31u; };   /* mask bit k: kernel k of KERNELS is timed */   /* boundaries of the 5 kernels of a tick; sev = k_copy, k_dbk on the side stream */
 
+/* k_dbk of one tick on the side stream (which must already wait for whatever frees the tick's deblocking scratch);
+ * records the join event of the scratch buffer `parity` behind it */
+static int launch_kdbk_aside(const SideLane *side, int parity, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5], unsigned stages)
+{
+    const bool do_dbk = (stages & 4u) && s.any_deblock && s.max_dbk;
+    const bool timed = tt && tt->on && (tt->mask & 4u);
+    if (timed && tt->sev[1]) HIP_TRY(hipEventRecord(tt->sev[1], side->stream));
+    if (do_dbk) {
+        hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 15) / 16, DBK_WGS), s.n_frames), dim3(256), 0, side->stream, d_desc);
+        if (launches) launches[2]++;
+    }
+    if (timed && tt->sev[2]) HIP_TRY(hipEventRecord(tt->sev[2], side->stream));
+    HIP_TRY(hipEventRecord(parity ? side->join_copy : side->join, side->stream));
+    return 0;
+}
+
+/* "k_dbk ahead" (replay sets): the boundary strengths of tick i+1 need nothing but its frame job, so they are computed
+ * while tick i is in its two per-picture kernels — whose wavefronts wait for their dependency chains half of the time —
+ * instead of next to the copy and inter kernels of their own tick, which are bound by instruction issue and lose a
+ * quarter of it to k_dbk.  The deblocking scratch is double-buffered for this (parity = tick & 1). */
+struct AheadDbk { const FrameDesc *next_desc; const TickShape *next_shape; TickTimers *next_tt; int parity; };
+
 int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5],
-                unsigned stages = 7u, const SideLane *side = nullptr, unsigned long long *prof = nullptr)
+                unsigned stages = 7u, const SideLane *side = nullptr, unsigned long long *prof = nullptr, const AheadDbk *ahead = nullptr)
 {
     const bool timed = tt && tt->on;
     const unsigned tmask = timed ? tt->mask : 0u;
@@ -386,17 +408,12 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     if (EV_NEEDED(0)) HIP_TRY(hipEventRecord(tt->ev[0], st));
     const bool do_dbk = (stages & 4u) && s.any_deblock && s.max_dbk;
     const bool do_copy = (stages & 1u) && s.max_copy;
-    const bool aside = side && side->stream && do_dbk;
+    const bool use_ahead = ahead && side && side->stream;        /* this tick's k_dbk was launched by the tick before it (or the caller) */
+    const bool aside = !use_ahead && side && side->stream && do_dbk;
     if (aside) {
         HIP_TRY(hipEventRecord(side->fork, st));                 /* after the previous tick's k_frame_dbk: the records are free */
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-        if ((tmask & 4u) && tt->sev[1]) HIP_TRY(hipEventRecord(tt->sev[1], side->stream));
-        if (do_dbk) {
-            hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 7) / 8, DBK_WGS), s.n_frames), dim3(256), 0, side->stream, d_desc);
-            if (launches) launches[2]++;
-        }
-        if ((tmask & 4u) && tt->sev[2]) HIP_TRY(hipEventRecord(tt->sev[2], side->stream));
-        HIP_TRY(hipEventRecord(side->join, side->stream));
+        if (launch_kdbk_aside(side, 0, d_desc, s, tt, launches, stages)) return -1;
     }
     if (do_copy) {
         hipLaunchKernelGGL(h264k::k_copy, dim3(std::min<uint32_t>((s.max_copy + 3) / 4, COPY_WGS), s.n_frames), dim3(256), 0, st, d_desc);   /* COPY_WGS workgroups per picture walk its run list */
@@ -409,8 +426,14 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         if (launches) launches[1]++;
     }
     if (EV_NEEDED(2)) HIP_TRY(hipEventRecord(tt->ev[2], st));
-    if (do_dbk && !aside) {
-        hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 7) / 8, DBK_WGS), s.n_frames), dim3(256), 0, st, d_desc);
+    if (use_ahead && ahead->next_desc) {
+        /* the next tick's strengths go into the other scratch buffer, which the PREVIOUS tick's k_frame_dbk has left by now */
+        HIP_TRY(hipEventRecord(side->fork, st));
+        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        if (launch_kdbk_aside(side, ahead->parity ^ 1, ahead->next_desc, *ahead->next_shape, ahead->next_tt, launches, stages)) return -1;
+    }
+    if (do_dbk && !aside && !use_ahead) {
+        hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 15) / 16, DBK_WGS), s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[2]++;
     }
     if (EV_NEEDED(3)) HIP_TRY(hipEventRecord(tt->ev[3], st));
@@ -449,6 +472,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     }
     if (EV_NEEDED(4)) HIP_TRY(hipEventRecord(tt->ev[4], st));
     if (aside) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
+    if (use_ahead) HIP_TRY(hipStreamWaitEvent(st, ahead->parity ? side->join_copy : side->join, 0));
     if (s.any_deblock && (stages & 4u)) {
         /* row bands: max_bands workgroups per picture (k_frame_dbk); the scheduling state of a band's rows lives in LDS
          * next to its wavefronts' tiles */
@@ -968,6 +992,7 @@ struct h264bsdmi_replay {
     hipStream_t gstream[8];
     hipEvent_t gdone[8];
     bool overlap_dbk = true;
+    bool dbk_ahead = false;           /* lock-step / staggered sets: k_dbk of tick i+1 next to the per-picture kernels of tick i (AheadDbk) */
     unsigned timed_mask = 31u;
     /* desynchronised sets with heavy lanes (h264bsdmiReplayCreateDesync, lanes > 0): a static launch schedule */
     struct Launch { size_t first; TickShape shape; int lane; std::vector<int> waits; int record_ev; bool light; };
@@ -1046,7 +1071,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
     r->blob_stride = total;
     r->d_blobs = nullptr; r->d_frames = nullptr; r->d_desc = nullptr; r->d_conv = nullptr; r->d_sums = nullptr; r->d_dbk = nullptr;
     const size_t frames_per_stream = (size_t)r->n_slots * r->frame_bytes;
-    const size_t dbk_stride = (DBK_SCRATCH_BYTES(h0->n_mbs) + 255) & ~(size_t)255;
+    const size_t dbk_half = (DBK_SCRATCH_BYTES(h0->n_mbs) + 255) & ~(size_t)255, dbk_stride = 2 * dbk_half;   /* two buffers per stream: "k_dbk ahead" */
     bool ok = hipMalloc((void **)&r->d_blobs, total * n_streams) == hipSuccess &&
               hipMalloc((void **)&r->d_frames, frames_per_stream * n_streams + 256) == hipSuccess &&
               hipMalloc((void **)&r->d_desc, sizeof(FrameDesc) * (size_t)n_pics * n_streams) == hipSuccess &&
@@ -1071,14 +1096,14 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
         ok = hipMemcpyAsync(r->d_blobs + (size_t)s * total, r->d_blobs, total, hipMemcpyDeviceToDevice, e->stream) == hipSuccess;
     if (ok) {
         std::vector<FrameDesc> descs((size_t)n_pics * n_streams);
-        auto desc_of = [&](FrameDesc &d, u32 s, u32 p, TickShape *shape) {
+        auto desc_of = [&](FrameDesc &d, u32 s, u32 p, TickShape *shape, u32 tick = 0) {
             make_desc(d, blobs[p], r->d_blobs + (size_t)s * total + offs[p], r->d_frames + (size_t)s * frames_per_stream,
-                      r->frame_bytes, r->d_dbk + (size_t)s * dbk_stride, shape, e->d_err);
+                      r->frame_bytes, r->d_dbk + (size_t)s * dbk_stride + (tick & 1u) * dbk_half, shape, e->d_err);
         };
         if (!heavy_lanes && groups <= 1) {
             for (u32 i = 0; i < n_pics; i++) {
                 TickShape shape;                          /* a tick is as large as the largest of its pictures */
-                for (u32 s = 0; s < n_streams; s++) desc_of(descs[(size_t)i * n_streams + s], s, (i + r->offsets[s]) % n_pics, &shape);
+                for (u32 s = 0; s < n_streams; s++) desc_of(descs[(size_t)i * n_streams + s], s, (i + r->offsets[s]) % n_pics, &shape, i);
                 r->shapes[i] = shape;
             }
         } else {
@@ -1200,6 +1225,8 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
                  hipEventCreateWithFlags(&r->gdone_any, hipEventDisableTiming) == hipSuccess;
     r->timed_first = r->timed_count = 0;
     r->stages = 7u;
+    r->dbk_ahead = getenv("H264BSDMI_AHEAD") != nullptr;       /* measured: 128.2 vs 126.4 ms per step — it moves k_dbk's instructions from one
+                                                                    instruction-bound phase into another (kept as an experiment) */
     r->n_groups = 1;
     for (int g = 0; g < 8; g++) { r->gstream[g] = nullptr; r->gdone[g] = nullptr; }
     if (!ok) {
@@ -1265,9 +1292,17 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
             HIP_TRY(hipStreamWaitEvent(r->e->stream, r->gdone_any, 0));
         }
     } else if (r->n_groups <= 1) {
+        const bool ahead_on = r->overlap_dbk && !(r->stages & 8u) && r->dbk_ahead && count > 0;
+        for (u32 i = first; i < first + count; i++) { r->timers[i].on = true; r->timers[i].mask = r->timed_mask; }
+        if (ahead_on) {                                       /* the first tick's strengths: nothing to hide behind yet */
+            HIP_TRY(hipEventRecord(r->e->side.fork, r->e->stream));
+            HIP_TRY(hipStreamWaitEvent(r->e->side.stream, r->e->side.fork, 0));
+            if (launch_kdbk_aside(&r->e->side, (int)(first & 1u), r->d_desc + (size_t)first * r->n_streams, r->shapes[first], &r->timers[first], r->launches, r->stages)) return -1;
+        }
         for (u32 i = first; i < first + count; i++) {
-            r->timers[i].on = true; r->timers[i].mask = r->timed_mask;
-            if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr, r->e->tail_prof)) return -1;
+            AheadDbk ah = { nullptr, nullptr, nullptr, (int)(i & 1u) };
+            if (i + 1 < first + count) { ah.next_desc = r->d_desc + (size_t)(i + 1) * r->n_streams; ah.next_shape = &r->shapes[i + 1]; ah.next_tt = &r->timers[i + 1]; }
+            if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr, r->e->tail_prof, ahead_on ? &ah : nullptr)) return -1;
             if (r->convert_fmt >= 0) {
                 /* the picture every stream has just produced, converted where it lies (tiles -> packed 32-bit pixels) */
                 const uint32_t w = r->wmb * 16, h = r->hmb * 16;

@@ -528,48 +528,59 @@ __device__ __forceinline__ void wave_sync()
 __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frames)
 {
     const FrameDesc &fd = FD_REF(frames, blockIdx.y);
-    const int n = threadIdx.x & 31;
+    /* One macroblock per 16 lanes, four per wavefront: lane m of a group owns byte m of the 16-byte strength array, i.e. the
+     * two segments k = 2*kh, 2*kh+1 of edge (dir, e) — m = 8*dir + 2*e + kh.  (Two macroblocks per wavefront with one segment
+     * per lane cost the wavefront 1.7 times the instructions per macroblock: the index walk, the record decode, the threshold
+     * indices and the stores are per wavefront, not per segment.) */
+    const int m = threadIdx.x & 15;
     const int wmb = fd.wmb;
     const uint32_t n_dbk = fd.n_dbk;
     /* A fixed number of workgroups per picture walks the index list with a stride; the next index is requested while
      * the current macroblock is worked on, and everything a macroblock needs — its record, the records of its left and
-     * upper neighbours, the motion vectors on both sides of the lane's edge — is requested TOGETHER, whether the flags in
-     * the record (still in flight) will want it or not: two dependent memory round trips per macroblock instead of four. */
-    uint32_t di = blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (di >= n_dbk) return;
-    uint32_t mb = fd.dbki[di];
+     * upper neighbours, the motion vectors on both sides of the lane's segments — is requested TOGETHER, whether the flags in
+     * the record (still in flight) will want it or not: two dependent memory round trips per macroblock. */
+    uint32_t di = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live0 = di < n_dbk;
+    if (__ballot(live0) == 0ull) return;
+    uint32_t mb = live0 ? fd.dbki[di] : 0u;
+    bool live = live0;
   for (;;) {
-    const uint32_t ndi = di + 8u * gridDim.x;
+    const uint32_t ndi = di + 16u * gridDim.x;
     uint32_t nmb = mb;
-    if (ndi < n_dbk) nmb = fd.dbki[ndi];
+    const bool nlive = live && ndi < n_dbk;
+    if (nlive) nmb = fd.dbki[ndi];
     const uint32_t mbl = mb % (uint32_t)wmb ? mb - 1 : mb, mbt = mb >= (uint32_t)wmb ? mb - wmb : mb;    /* in-picture stand-ins */
-    /* the three records as whole 16-byte pieces, the motion vectors of both sides — all requested before anything is looked
-     * at (a struct copy lets the compiler fetch member by member where each is used: five dependent round trips) */
     FjMbRec q, pl, pt;
-    const int dir = n >> 4, e = (n >> 2) & 3, k = n & 3;
-    const int qx = dir ? k : e, qy = dir ? e : k;
-    const int px = dir ? k : (e ? e - 1 : 3), py = dir ? (e ? e - 1 : 3) : k;
+    const int dir = m >> 3, e = (m >> 1) & 3, kh = m & 1;
     const uint32_t pmb = e ? mb : (dir ? mbt : mbl);
-    uint32_t mva, mvb;
+    int qx[2], qy[2], px[2], py[2];
+    uint32_t mva[2], mvb[2];
     {
+        /* the three records as whole 16-byte pieces, the motion vectors of both sides — all requested before anything is
+         * looked at (a struct copy lets the compiler fetch member by member where each is used: five dependent round trips) */
         const H264K_GLOBAL uint8_t *rq = (const H264K_GLOBAL uint8_t *)(fd.recs + mb), *rl = (const H264K_GLOBAL uint8_t *)(fd.recs + mbl),
                                    *rt = (const H264K_GLOBAL uint8_t *)(fd.recs + mbt);
         uint4 w[6] = { ld16g(rq), ld16g(rq + 16), ld16g(rl), ld16g(rl + 16), ld16g(rt), ld16g(rt + 16) };
-        mva = *(const H264K_GLOBAL uint32_t *)(fd.mvs + 32 * (size_t)mb + 2 * (4 * qy + qx));
-        mvb = *(const H264K_GLOBAL uint32_t *)(fd.mvs + 32 * (size_t)pmb + 2 * (4 * py + px));
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const int k = 2 * kh + kk;
+            qx[kk] = dir ? k : e; qy[kk] = dir ? e : k;
+            px[kk] = dir ? k : (e ? e - 1 : 3); py[kk] = dir ? (e ? e - 1 : 3) : k;
+            mva[kk] = *(const H264K_GLOBAL uint32_t *)(fd.mvs + 32 * (size_t)mb + 2 * (4 * qy[kk] + qx[kk]));
+            mvb[kk] = *(const H264K_GLOBAL uint32_t *)(fd.mvs + 32 * (size_t)pmb + 2 * (4 * py[kk] + px[kk]));
+        }
 #pragma unroll
         for (int i = 0; i < 6; i++) asm volatile("" : "+v"(w[i].x), "+v"(w[i].y), "+v"(w[i].z), "+v"(w[i].w));
-        asm volatile("" : "+v"(mva), "+v"(mvb));
+        asm volatile("" : "+v"(mva[0]), "+v"(mvb[0]), "+v"(mva[1]), "+v"(mvb[1]));
         __builtin_memcpy(&q, &w[0], 32); __builtin_memcpy(&pl, &w[2], 32); __builtin_memcpy(&pt, &w[4], 32);
     }
     uint8_t *out = fd.dbk + (size_t)mb * DBK_REC_BYTES;
     uint8_t *any_out = fd.dbk + (size_t)fd.n_mbs * DBK_REC_BYTES + mb;
-    if (!q.dbk || q.kind == FJ_MB_ABSENT) {
-        if (n == 0) { *reinterpret_cast<uint32_t *>(out + 28) = 0; *any_out = 0; }
-    } else {
-    const bool f_left = q.dbk & FJ_DBK_LEFT, f_top = q.dbk & FJ_DBK_TOP;
-    int my_bs = 0;
-    {
+    const bool filtered = live && q.dbk && q.kind != FJ_MB_ABSENT;
+    if (live && !filtered && m == 0) { *reinterpret_cast<uint32_t *>(out + 28) = 0; *any_out = 0; }
+    uint32_t bs2 = 0;                                              /* the lane's two strengths: low and high nibble of byte m */
+    if (filtered) {
+        const bool f_left = q.dbk & FJ_DBK_LEFT, f_top = q.dbk & FJ_DBK_TOP;
         const bool edge_on = e ? true : (dir ? f_top : f_left);
         if (edge_on) {
             const int p_kind = e ? q.kind : (dir ? pt.kind : pl.kind);
@@ -580,51 +591,57 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
             __builtin_memcpy(&t0, pl.ref_slot, 4);
             __builtin_memcpy(&t1, pt.ref_slot, 4);
             prefs = e ? qrefs : (dir ? t1 : t0);
-            if (is_intra_kind(q.kind) || is_intra_kind(p_kind)) my_bs = e ? 3 : 4;
-            else if (((q.coded >> z_of(qx, qy)) & 1) || ((p_coded >> z_of(px, py)) & 1)) my_bs = 2;
+            const bool intra_edge = is_intra_kind(q.kind) || is_intra_kind(p_kind);
             /* inside a macroblock motion is compared only across the partition boundaries its type has (FJ_PARTS_*,
              * reference deblocking.c:1266-1345) */
-            else if (e && (parts == FJ_PARTS_16x16 || (parts == FJ_PARTS_16x8 && !(dir == 1 && e == 2)) || (parts == FJ_PARTS_8x16 && !(dir == 0 && e == 2)))) my_bs = 0;
-            else if (((qrefs >> (8 * ((qy >> 1) * 2 + (qx >> 1)))) & 255u) != ((prefs >> (8 * ((py >> 1) * 2 + (px >> 1)))) & 255u)) my_bs = 1;
-            else {
-                const int ax = (int16_t)(mva & 0xFFFFu), ay = (int32_t)mva >> 16, bx2 = (int16_t)(mvb & 0xFFFFu), by2 = (int32_t)mvb >> 16;
-                my_bs = (abs(ax - bx2) >= 4 || abs(ay - by2) >= 4) ? 1 : 0;
+            const bool no_motion_edge = e && (parts == FJ_PARTS_16x16 || (parts == FJ_PARTS_16x8 && !(dir == 1 && e == 2)) || (parts == FJ_PARTS_8x16 && !(dir == 0 && e == 2)));
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                int my_bs;
+                if (intra_edge) my_bs = e ? 3 : 4;
+                else if (((q.coded >> z_of(qx[kk], qy[kk])) & 1) || ((p_coded >> z_of(px[kk], py[kk])) & 1)) my_bs = 2;
+                else if (no_motion_edge) my_bs = 0;
+                else if (((qrefs >> (8 * ((qy[kk] >> 1) * 2 + (qx[kk] >> 1)))) & 255u) != ((prefs >> (8 * ((py[kk] >> 1) * 2 + (px[kk] >> 1)))) & 255u)) my_bs = 1;
+                else {
+                    const int ax = (int16_t)(mva[kk] & 0xFFFFu), ay = (int32_t)mva[kk] >> 16, bx2 = (int16_t)(mvb[kk] & 0xFFFFu), by2 = (int32_t)mvb[kk] >> 16;
+                    my_bs = (abs(ax - bx2) >= 4 || abs(ay - by2) >= 4) ? 1 : 0;
+                }
+                bs2 |= (uint32_t)my_bs << (4 * kk);
             }
         }
     }
-    /* pack 32 nibbles: lanes n = 0,8,16,24 of the half-wave end up with one dword each */
-    uint32_t v = (uint32_t)my_bs;
-    v |= (uint32_t)__shfl_down((int)v, 1) << 4;
-    v |= (uint32_t)__shfl_down((int)v, 2) << 8;
-    v |= (uint32_t)__shfl_down((int)v, 4) << 16;
-    const unsigned long long bal = __ballot(my_bs != 0);
-    const uint32_t bal32 = (threadIdx.x & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;     /* bit n = 16*dir + 4*e + k */
-    const bool any = bal32 != 0u;
-    /* scheduling flags of k_frame_dbk: does this macroblock touch its left / upper neighbour at all? */
-    const uint32_t sched = (any ? DBKF_ANY : 0u) | ((bal32 & 0x000Fu) ? DBKF_LEFT : 0u) | ((bal32 & 0x000F0000u) ? DBKF_TOP : 0u);
-    if ((n & 7) == 0) *reinterpret_cast<uint32_t *>(out + (n >> 3) * 4) = v;
-    if (n == 1) {
-        const int qcq = qpc_of(clip3(0, 51, (int)q.qp_y + q.cqp_off));
-        const int ql = (q.qp_y + pl.qp_y + 1) >> 1, qt = (q.qp_y + pt.qp_y + 1) >> 1;
-        const int cl = (qcq + qpc_of(clip3(0, 51, (int)pl.qp_y + q.cqp_off)) + 1) >> 1;   /* current MB's offset: deblocking.c:1501,1523 */
-        const int ct = (qcq + qpc_of(clip3(0, 51, (int)pt.qp_y + q.cqp_off)) + 1) >> 1;
-        const int qp6[6] = { ql, qt, (int)q.qp_y, cl, ct, qcq };
-        uint32_t w[3] = { 0, 0, 0 };
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const uint32_t ia = (uint32_t)clip3(0, 51, qp6[i] + q.alpha_off), ib = (uint32_t)clip3(0, 51, qp6[i] + q.beta_off);
-            w[i >> 2] |= ia << (8 * (i & 3));                    /* bytes 16..21 */
-            w[(6 + i) >> 2] |= ib << (8 * ((6 + i) & 3));        /* bytes 22..27 */
+    /* bytes -> dwords: lanes m = 0,4,8,12 of a group end up with one dword each (DPP row_shl:1/2: lane i reads lane i+1/2) */
+    uint32_t v = bs2;
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true) << 8;
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xF, 0xF, true) << 16;
+    const unsigned long long bal = __ballot(bs2 != 0u);
+    const uint32_t bal16 = (uint32_t)(bal >> (threadIdx.x & 48)) & 0xFFFFu;      /* bit m: byte m of this macroblock is non-zero */
+    const bool any = bal16 != 0u;
+    /* scheduling flags of k_frame_dbk: does this macroblock touch its left / upper neighbour at all? (bytes 0,1 = left edge, 8,9 = upper) */
+    const uint32_t sched = (any ? DBKF_ANY : 0u) | ((bal16 & 0x0003u) ? DBKF_LEFT : 0u) | ((bal16 & 0x0300u) ? DBKF_TOP : 0u);
+    if (filtered) {
+        if ((m & 3) == 0) *reinterpret_cast<uint32_t *>(out + m) = v;
+        /* threshold indices: lane m < 12 computes ONE of them — indexA (m < 6) or indexB of class m % 6 (luma left / top / inner,
+         * chroma left / top / inner) — and stores its byte (one lane doing all twelve costs the wavefront six times the instructions) */
+        if (m < 12) {
+            const int c = m < 6 ? m : m - 6;                           /* class */
+            const int side = c % 3;                                    /* 0: across the left edge, 1: across the upper edge, 2: inside */
+            const int pqp = side == 0 ? (int)pl.qp_y : side == 1 ? (int)pt.qp_y : (int)q.qp_y;
+            int a = (int)q.qp_y, b = pqp;
+            if (c >= 3) {                                              /* chroma: QPc of both sides with the CURRENT macroblock's offset (deblocking.c:1501,1523) */
+                a = qpc_of(clip3(0, 51, a + q.cqp_off));
+                b = qpc_of(clip3(0, 51, b + q.cqp_off));
+            }
+            const int qpav = (a + b + 1) >> 1;
+            out[16 + m] = (uint8_t)clip3(0, 51, qpav + (m < 6 ? q.alpha_off : q.beta_off));
         }
-        *reinterpret_cast<uint32_t *>(out + 16) = w[0];
-        *reinterpret_cast<uint32_t *>(out + 20) = w[1];
-        *reinterpret_cast<uint32_t *>(out + 24) = w[2];
-        *reinterpret_cast<uint32_t *>(out + 28) = (uint32_t)q.dbk | (any ? 0x100u : 0u);
-        *any_out = (uint8_t)sched;
+        if (m == 12) {
+            *reinterpret_cast<uint32_t *>(out + 28) = (uint32_t)q.dbk | (any ? 0x100u : 0u);
+            *any_out = (uint8_t)sched;
+        }
     }
-    }
-    if (ndi >= n_dbk) return;
-    di = ndi; mb = nmb;
+    if (__ballot(nlive) == 0ull) return;
+    di = ndi; mb = nmb; live = nlive;
   }
 }
 
@@ -1755,6 +1772,9 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint32_t s_misc[4];
+    /* these wavefronts walk dependency chains: whatever shares their SIMDs (k_dbk of the next tick, other lanes' list
+     * kernels) takes the issue slots they leave, not the ones they need */
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t ticket = BANDED ? take_ticket(tickets, &s_misc[0]) : blockIdx.x;
     const uint32_t pic = BANDED ? ticket / max_bands : ticket, band = BANDED ? ticket - pic * max_bands : 0u;
     const FrameDesc &fd = FD_REF(frames, pic);
@@ -2002,6 +2022,9 @@ __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *_
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint32_t s_misc[4];
+    /* these wavefronts walk dependency chains: whatever shares their SIMDs (k_dbk of the next tick, other lanes' list
+     * kernels) takes the issue slots they leave, not the ones they need */
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t ticket = BANDED ? take_ticket(tickets, &s_misc[0]) : blockIdx.x;
     const uint32_t pic = BANDED ? ticket / max_bands : ticket, band = BANDED ? ticket - pic * max_bands : 0u;
     const FrameDesc &fd = FD_REF(frames, pic);
