@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdProfile", "h264bsdAlloc", "h264bsdFree", "h264bsdConvertToRGBA", "h264bsdConvertToBGRA",
     "h264bsdConvertToYCbCrA",
     "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync", "h264bsdmiDeviceErrors",
-    "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads",
+    "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads", "h264bsdmiSetInputReadOnly",
     "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayCreateSched", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiDebugSetTail", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
@@ -115,6 +115,7 @@ def lib():
     L.h264bsdmiDecodePicture.restype = u32
     L.h264bsdmiDecodePictureBatch.argtypes = [u32, ctypes.POINTER(vp), ctypes.POINTER(vp), P32, P32, P32, P32, P32]
     L.h264bsdmiSetParserThreads.argtypes = [ctypes.c_int]
+    L.h264bsdmiSetInputReadOnly.argtypes = [vp, u32]
     L.h264bsdmiJobFinalize.argtypes = [ctypes.c_void_p, u32, u32]
     L.h264bsdmiSetDevice.argtypes = [ctypes.c_int]
     L.h264bsdmiReplayCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32]

@@ -108,6 +108,14 @@ u8 *h264bsdNextOutputPicture(storage_t *s, u32 *picId, u32 *isIdrPic, u32 *numEr
     return a->hd->sink.fetch(a->hd->sink.user, o->slot);
 }
 
+int h264bsdmiSetInputReadOnly(storage_t *s, u32 on)
+{
+    ApiDec *a = dec_of(s);
+    if (!a) return -1;
+    a->hd->input_readonly = on ? 1 : 0;
+    return 0;
+}
+
 int h264bsdmiNextOutputInfo(storage_t *s, u32 *picId, u32 *isIdrPic, u32 *numErrMbs)
 {
     ApiDec *a = dec_of(s);
@@ -329,10 +337,15 @@ static void pin_worker(u32 me, int device, int *pinned_to)
         int cpus[1024];
         const int n = eng_device_cpus(device, cpus, 1024);
         if (n > 0) {
-            cpu_set_t set;
+            /* only CPUs this process may run on (a cpuset-restricted container may not own the GPU's node at all: then the
+             * worker stays where the scheduler puts it) */
+            cpu_set_t set, allowed;
             CPU_ZERO(&set);
-            for (int i = 0; i < n; i++) if (cpus[i] < CPU_SETSIZE) CPU_SET(cpus[i], &set);
-            pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+            int usable = 0;
+            if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+                for (int i = 0; i < n; i++) if (cpus[i] < CPU_SETSIZE && CPU_ISSET(cpus[i], &allowed)) { CPU_SET(cpus[i], &set); usable++; }
+            }
+            if (usable > 0) pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
         }
         *pinned_to = device;
     }

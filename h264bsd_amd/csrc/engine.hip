@@ -96,6 +96,7 @@ struct Lane {
     const SideLane *side = nullptr;
 };
 constexpr unsigned HEAVY_DELAY = 4;
+constexpr unsigned MAX_LANES_TOTAL = 10;     /* light + heavy lanes of an engine (the engine's own stream and the side stream come on top) */
 #ifndef CONVERT_WGS_N
 #define CONVERT_WGS_N 512       /* 64: 808, 128: 744, 256: 703, 512: 680 us per tick of 256 pictures */
 #endif
@@ -115,6 +116,7 @@ struct Engine {
     uint8_t *conv_in = nullptr; uint32_t *conv_out = nullptr; size_t conv_cap = 0; /* eng_convert_host scratch */
     std::vector<std::pair<StreamCtx *, PendingJob>> inflight;   /* staging buffers of enqueued, unfinished ticks */
     hipEvent_t inflight_done = nullptr;
+    bool inflight_recorded = false;          /* inflight_done has been recorded behind everything in `inflight` */
     SideLane side;
     /* device error word (DEVERR_* bits, kernels.hip.h): the kernels OR into d_err, poll_errors() folds it into `errors`
      * whenever the host has waited for the device anyway */
@@ -209,8 +211,13 @@ static int lanes_create(Engine *e)
     }
     if (const char *cfg = getenv("H264BSDMI_LANES")) {
         unsigned a = 0, b = 0;
-        if (sscanf(cfg, "%u,%u", &a, &b) >= 1 && a >= 1 && a <= 8 && b <= 4) { g = a; k = b; }
-        else fprintf(stderr, "h264bsd-mi355x: H264BSDMI_LANES=%s ignored (expected <groups 1-8>,<heavy lanes 0-4>)\n", cfg);
+        if (sscanf(cfg, "%u,%u", &a, &b) >= 1 && a >= 1) {
+            /* whatever is asked for, stay below the cliff: more than ~12 busy HIP streams (lanes + the engine's own two) make
+             * this runtime crawl (19-53 s instead of 0.2 s per lap, tools/probes/queue_probe.hip) */
+            g = std::min(a, 8u); k = std::min(b, 4u);
+            while (g + k > MAX_LANES_TOTAL && g > 1) g--;
+            if (g != a || k != b) fprintf(stderr, "h264bsd-mi355x: H264BSDMI_LANES=%s clamped to %u,%u (at most %u lanes)\n", cfg, g, k, MAX_LANES_TOTAL);
+        } else fprintf(stderr, "h264bsd-mi355x: H264BSDMI_LANES=%s ignored (expected <groups>,<heavy lanes>)\n", cfg);
     }
     std::vector<Lane> lanes(g + k);                        /* (handed to the engine only when complete) */
     for (unsigned i = 0; i < g + k; i++) {
@@ -533,8 +540,11 @@ int poll_errors(Engine *e)
 int reap_locked(Engine *e, bool wait)
 {
     if (e->inflight.empty()) return 0;
-    if (wait) { if (poll_errors(e)) return -1; }
-    else if (hipEventQuery(e->inflight_done) != hipSuccess) return 0;
+    if (wait) {
+        /* (after a failed flush the event may be missing: wait for the lanes themselves before the staging buffers go back) */
+        if (!e->inflight_recorded) for (auto &l : e->lanes) if (l.st) (void)hipStreamSynchronize(l.st);
+        if (poll_errors(e)) return -1;
+    } else if (!e->inflight_recorded || hipEventQuery(e->inflight_done) != hipSuccess) return 0;
     for (auto &f : e->inflight) {
         std::lock_guard<std::mutex> ql(f.first->qmu);
         f.first->free_bufs.push_back(f.second);
@@ -589,6 +599,7 @@ static int lane_launch(Engine *e, unsigned lane_idx, const std::vector<StreamCtx
         make_desc(descs[i], j.host, l.d_arena + off, s->d_frames, s->frame_bytes, s->d_dbk, &shape, e->d_err);
         off += (j.bytes + 255u) & ~255u;
         e->inflight.emplace_back(s, j);
+        e->inflight_recorded = false;
         s->last_lane = (int)lane_idx; s->last_launch = l.launches;
     }
     HIP_TRY(hipMemcpyAsync(l.d_desc, descs, part.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, l.st));
@@ -645,7 +656,7 @@ int flush_locked(Engine *e, bool wait = true)
             HIP_TRY(hipEventRecord(l.tail, l.st));
             HIP_TRY(hipStreamWaitEvent(e->stream, l.tail, 0));
         }
-    if (!e->inflight.empty()) HIP_TRY(hipEventRecord(e->inflight_done, e->stream));
+    if (!e->inflight.empty()) { HIP_TRY(hipEventRecord(e->inflight_done, e->stream)); e->inflight_recorded = true; }
     return wait ? reap_locked(e, true) : 0;
 }
 

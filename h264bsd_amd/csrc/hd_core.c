@@ -628,8 +628,9 @@ static void ghost_store_slice(HostDec *d, uint32_t sid)
      * ghost job runs before the job that reconstructs first decodes, so it brings them along in that first version. */
     for (uint32_t a = 0; a < n; a++) {
         if (d->mb_slice_id[a] != sid) continue;
-        const struct RedoMb *f = d->mb_decoded[a] >= 2 ? redo_first_of(d, a) : NULL;
-        const FjMbRec *r = d->mb_decoded[a] == 1 ? &recs[a] : f ? &f->rec : NULL;
+        const int own_rec = d->mb_decoded[a] == 1 && d->mb_rec_sid[a] == sid;      /* (see the second loop) */
+        const struct RedoMb *f = !own_rec && d->mb_decoded[a] >= 1 ? redo_first_of(d, a) : NULL;
+        const FjMbRec *r = own_rec ? &recs[a] : f ? &f->rec : NULL;
         if (!r || !makes_pixels(r->kind)) continue;
         need += sizeof(GhostMb) + (size_t)rec_blocks(r) * 32u;
         count++;
@@ -650,13 +651,16 @@ static void ghost_store_slice(HostDec *d, uint32_t sid)
     memcpy(p, &count, sizeof(count)); p += sizeof(count);
     for (uint32_t a = 0; a < n; a++) {
         if (d->mb_slice_id[a] != sid) continue;
-        const struct RedoMb *f = d->mb_decoded[a] >= 2 ? redo_first_of(d, a) : NULL;
-        const FjMbRec *r = d->mb_decoded[a] == 1 ? &recs[a] : f ? &f->rec : NULL;
+        /* recs[a] belongs to this slice only while no later (redundant) decode replaced it: after such a decode was rolled
+         * back (counter 2 -> 1) the record — and the coefficient blocks it points to — are the discarded decode's */
+        const int own_rec = d->mb_decoded[a] == 1 && d->mb_rec_sid[a] == sid;
+        const struct RedoMb *f = !own_rec && d->mb_decoded[a] >= 1 ? redo_first_of(d, a) : NULL;
+        const FjMbRec *r = own_rec ? &recs[a] : f ? &f->rec : NULL;
         if (!r || !makes_pixels(r->kind)) continue;
         GhostMb g;
         g.addr = a; g.n_blocks = rec_blocks(r); g.rec = *r;
         g.rec.pred &= (uint8_t)~FJ_PRED_PHASE2;
-        if (f && d->mb_decoded[a] >= 2) memcpy(g.mv, f->mv, 64); else memcpy(g.mv, d->job + h->mv_off + (size_t)a * 64u, 64);
+        if (f) memcpy(g.mv, f->mv, 64); else memcpy(g.mv, d->job + h->mv_off + (size_t)a * 64u, 64);
         memcpy(p, &g, sizeof(g)); p += sizeof(g);
         memcpy(p, d->job + h->coef_off + (size_t)r->coef_idx * 32u, (size_t)g.n_blocks * 32u);
         p += (size_t)g.n_blocks * 32u;

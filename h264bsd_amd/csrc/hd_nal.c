@@ -88,7 +88,11 @@ int hd_extract_nal(HostDec *d, uint8_t *s, uint32_t len, uint32_t *read_bytes)
             zeros = b ? 0 : zeros + 1;
             w[out++] = b;
         }
-        if (out < n) memcpy(r, w, out);                  /* the caller's buffer, compacted as far as the reference gets */
+        /* the caller's buffer, compacted as far as the reference gets (src/h264bsd_byte_stream.c unescapes in place and a
+         * caller that feeds the same bytes again — after H264BSD_HDRS_RDY the reference consumes nothing — parses the
+         * compacted unit): the default, for an identical call trace.  An application that shares one (possibly read-only)
+         * stream buffer between decoder instances switches it off (h264bsdmiSetInputReadOnly). */
+        if (out < n && !d->input_readonly) memcpy(r, w, out);
         if (rc) return rc;
     }
     memset(w + out, 0, 16);

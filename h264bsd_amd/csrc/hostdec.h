@@ -246,6 +246,7 @@ typedef struct HostDec {
     Sps *active_sps; Pps *active_pps;
     uint8_t pending_activation;
     uint8_t no_reordering_app;
+    uint8_t input_readonly;         /* h264bsdmiSetInputReadOnly: never write to the caller's buffer (hd_extract_nal) */
 
     uint32_t pic_size_mbs, width_mbs, height_mbs;
     MbInfo  *mb;

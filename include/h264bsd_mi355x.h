@@ -67,6 +67,14 @@ int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *pStorage, u8 *const *bu
                                 u32 *status, u32 *consumed, u32 *nErrors);
 /* Number of parser threads (default: online CPUs, at most 64; env H264BSDMI_THREADS).  Returns the value in use. */
 int h264bsdmiSetParserThreads(int n);
+/* INPUT BUFFERS ARE MODIFIED by h264bsdDecode() and by the two calls above, exactly as by the reference: the emulation-
+ * prevention bytes of the NAL unit just parsed are removed IN the caller's buffer (src/h264bsd_byte_stream.c), so that a
+ * caller who feeds the same bytes again sees what the reference's caller sees.  Consequences: every decoder instance needs
+ * its own private, writable copy of the stream (never hand one buffer to several instances of a batch, never a read-only
+ * mapping).  on != 0 switches the write-back off for this instance: the buffer may then be shared and read-only; pictures are
+ * the same, the h264bsdDecode() call trace can differ from the reference's only where a NAL unit that contains emulation-
+ * prevention bytes is fed a second time.  Returns 0. */
+int h264bsdmiSetInputReadOnly(storage_t *pStorage, u32 on);
 
 /* ---- device engine ---- */
 /* Number of usable GPUs (0 when the HIP runtime finds none); selects the device for this process. */

@@ -319,3 +319,29 @@ def test_lane_default_follows_the_measured_stream_concurrency():
     many = subprocess.run(cmd, cwd=root, env=dict(env, GPU_MAX_HW_QUEUES="16"), capture_output=True, text=True, timeout=600)
     assert many.returncode == 0, many.stdout[-1500:] + many.stderr[-1500:]
     assert "do not run side by side" not in many.stdout + many.stderr
+
+
+@pytest.mark.gpu
+def test_too_many_lanes_are_clamped_below_the_stream_cliff():
+    """More than ~12 busy HIP streams make this runtime crawl: whatever H264BSDMI_LANES asks for, the
+    engine stays at 10 lanes.  A request for 16 groups + 4 heavy lanes must be clamped (and say so) and must not take more
+    than twice the default configuration for the same work."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-s", "-m", "gpu", "-p", "no:cacheprovider",
+           "tests/test_gpu_api.py::test_72_different_streams_through_the_batch_api"]
+    env = {k: v for k, v in os.environ.items() if k != "H264BSDMI_LANES"}
+    env["GPU_MAX_HW_QUEUES"] = "16"
+    t0 = time.perf_counter()
+    base = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    t_base = time.perf_counter() - t0
+    assert base.returncode == 0, base.stdout[-1500:] + base.stderr[-1500:]
+    t0 = time.perf_counter()
+    many = subprocess.run(cmd, cwd=root, env=dict(env, H264BSDMI_LANES="16,4"), capture_output=True, text=True, timeout=900)
+    t_many = time.perf_counter() - t0
+    assert many.returncode == 0, many.stdout[-1500:] + many.stderr[-1500:]
+    assert "clamped to" in many.stdout + many.stderr
+    assert t_many < 2.0 * t_base + 5.0, (t_base, t_many)

@@ -63,3 +63,42 @@ def test_decode_picture_loop_counts_errors_and_conceals(built):
     dec.close()
     assert n_err == sum(1 for t in gold["trace"] if t[0] >= 3)
     assert n_pic == sum(1 for t in gold["trace"] if t[0] == 1)
+
+
+def test_shared_read_only_input_buffer(built):
+    """h264bsdDecode() removes emulation-prevention bytes IN the caller's buffer like the reference does, so by
+    default every instance needs a private writable copy.  With h264bsdmiSetInputReadOnly() two instances parse ONE
+    read-only mapping of the stream (a write would fault) and produce the frame jobs of an ordinary decode."""
+    import ctypes
+    import mmap
+    import os
+    from conftest import ROOT
+    data = open(os.path.join(ROOT, "tests", "golden", "test_640x360.h264"), "rb").read()
+    assert b"\x00\x00\x03" in data                                   # the stream does contain emulation-prevention bytes
+    want, want_trace, _ = built.capture_stream(data)
+    m = mmap.mmap(-1, len(data))
+    m.write(data)
+    addr = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    libc = ctypes.CDLL(None, use_errno=True)
+    page = mmap.PAGESIZE
+    assert addr % page == 0
+    assert libc.mprotect(ctypes.c_void_p(addr), ctypes.c_size_t((len(data) + page - 1) // page * page), mmap.PROT_READ) == 0
+    try:
+        got = [[], []]
+        decs = [built.Decoder(capture=got[i].append) for i in range(2)]
+        offs, traces = [0, 0], [[], []]
+        for d in decs:
+            assert built.lib().h264bsdmiSetInputReadOnly(d._st, 1) == 0
+        while any(o < len(data) for o in offs):                      # interleaved: both instances walk the same bytes
+            for i, d in enumerate(decs):
+                if offs[i] < len(data):
+                    r, rb = d.decode(addr + offs[i], len(data) - offs[i])
+                    traces[i].append((r, rb))
+                    offs[i] += rb
+                    assert r < built.H264BSD_ERROR
+        for d in decs:
+            d.close()
+        assert got[0] == want and got[1] == want
+        assert traces[0] == want_trace and traces[1] == want_trace
+    finally:
+        libc.mprotect(ctypes.c_void_p(addr), ctypes.c_size_t((len(data) + page - 1) // page * page), mmap.PROT_READ | mmap.PROT_WRITE)
