@@ -379,11 +379,43 @@ static void fill_undecoded(HostDec *d)
     const int complete = d->num_decoded_mbs == d->pic_size_mbs;
     if (complete && !d->pic_irregular) return;
     FjMbRec *recs = (FjMbRec *)(d->job + h->rec_off);
+    const uint32_t w = d->width_mbs;
     for (uint32_t a = 0; a < d->pic_size_mbs; a++)
         if (!d->mb_decoded[a] && !(complete && d->mb_rec_sid[a])) {
             memset(&recs[a], 0, sizeof(FjMbRec));
             recs[a].kind = FJ_MB_ABSENT;
             memset(d->job + h->mv_off + (size_t)a * 64u, 0, 64);
+            if (!complete) continue;                   /* (an incomplete picture is concealed: every macroblock gets a record) */
+            /* Counter-complete picture, macroblock never decoded: nothing writes its pixels, but h264bsdFilterPicture filters
+             * every macroblock with what its mbStorage_t holds (src/h264bsd_deblocking.c:236-275 and :575-640) — type, QP,
+             * coefficient counts and motion of the LAST decode of this macroblock in any earlier picture, slice-level
+             * parameters of the last slice that started on it (MbInfo persists like mbStorage_t).  The picture becomes the
+             * two-job form of redo_split: no record in the reconstruction job, this record in the deblock-only job. */
+            const MbInfo *m = &d->mb[a];
+            FjMbRec absent = recs[a], keep;
+            int16_t zero_mv[32] = { 0 };
+            if (hd_redo_keep_first(d, a, &absent, zero_mv)) continue;         /* out of memory: stays absent */
+            memset(&keep, 0, sizeof(keep));
+            const int intra = m->mb_type >= 6;
+            keep.kind = intra ? FJ_MB_STALE : FJ_MB_INTER;                  /* (FJ_MB_STALE: filtered as intra, pixels untouched in any job) */
+            keep.qp_y = m->qp;
+            keep.alpha_off = m->alpha_off; keep.beta_off = m->beta_off; keep.cqp_off = m->cqp_off;
+            if (m->dbk_idc != 1) {
+                const int same_l = m->dbk_idc != 2 || (a % w && d->mb_slice_id[a - 1] == d->mb_slice_id[a]);
+                const int same_t = m->dbk_idc != 2 || (a >= w && d->mb_slice_id[a - w] == d->mb_slice_id[a]);
+                keep.dbk = (uint8_t)(FJ_DBK_INNER | ((a % w) && same_l ? FJ_DBK_LEFT : 0) | (a >= w && same_t ? FJ_DBK_TOP : 0));
+            }
+            if (!intra) {
+                for (int z = 0; z < 16; z++) if (m->tc[z]) keep.coded |= 1u << z;
+                const int parts = m->mb_type <= 1 ? FJ_PARTS_16x16 : m->mb_type == 2 ? FJ_PARTS_16x8 : m->mb_type == 3 ? FJ_PARTS_8x16 : FJ_PARTS_8x8;
+                keep.pred = (uint8_t)(parts << FJ_PRED_PARTS_SHIFT);
+                memcpy(keep.ref_slot, m->ref_slot, 4);
+                int16_t (*dst)[2] = (int16_t (*)[2])(d->job + h->mv_off + (size_t)a * 64u);
+                static const uint8_t zx[16] = { 0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3 }, zy[16] = { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 };
+                for (int z = 0; z < 16; z++) { dst[4 * zy[z] + zx[z]][0] = m->mv[z][0]; dst[4 * zy[z] + zx[z]][1] = m->mv[z][1]; }
+            }
+            recs[a] = keep;
+            d->mb_rec_sid[a] = d->mb_slice_id[a] ? d->mb_slice_id[a] : 0xFFFFFFFFu;      /* the record is settled (hd_job_finish calls this again) */
         }
 }
 

@@ -666,6 +666,12 @@ int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_
     do {
         if (!sh->redundant_pic_cnt && d->mb_decoded[addr]) FAIL;
         d->mb_slice_id[addr] = d->slice_id;
+        {
+            MbInfo *m = &d->mb[addr];               /* SetMbParams: stamped whether the parse below succeeds or not */
+            m->dbk_idc = (uint8_t)sh->disable_deblocking_filter_idc;
+            m->alpha_off = (int8_t)sh->alpha_off; m->beta_off = (int8_t)sh->beta_off;
+            m->cqp_off = (int8_t)pps->chroma_qp_index_offset;
+        }
         if (d->mb_decoded[addr] || d->mb_rec_sid[addr]) {
             /* a redundant slice over a decoded macroblock (or over one that an earlier redundant slice un-decoded and whose
              * pixels are still in the picture): the slice-level parameters the deblocking filter uses are

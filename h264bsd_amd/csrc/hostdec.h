@@ -170,7 +170,10 @@ typedef struct MbInfo {
     uint8_t  kind;          /* FJ_MB_* of the last decode of this MB                             */
     uint8_t  mb_type;       /* reference numbering: 0 P_Skip, 1..5 P, 6 I4x4, 7..30 I16x16, 31 PCM */
     uint8_t  qp;
-    uint8_t  dbk_idc;       /* disable_deblocking_filter_idc of the slice of the last decode      */
+    uint8_t  dbk_idc;       /* disable_deblocking_filter_idc ... */
+    int8_t   alpha_off, beta_off, cqp_off;   /* ... FilterOffsetA / B and chroma_qp_index_offset of the last slice that STARTED on this
+                               macroblock, in this picture or an earlier one: the reference stamps them on its mbStorage_t before it
+                               parses the macroblock (SetMbParams, src/h264bsd_slice_data.c:53-66,140) and filters with whatever is there */
     uint8_t  tc[24];        /* total_coeff per 4x4 block, H.264 block order (luma 0-15, Cb, Cr)   */
     int8_t   i4mode[16];    /* Intra4x4PredMode, H.264 block order                                */
     /* ref_idx / ref_slot / mv persist like the reference's mbStorage_t.refPic / refAddr / mv: across decodes and across

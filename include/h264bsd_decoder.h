@@ -7,14 +7,15 @@
  *   - storage_t is opaque (same size, 4648 bytes on LP64, so it can still live on the caller's
  *     stack as in posix/test_h264bsd.c:129);
  *   - like the reference, h264bsdDecode() removes the emulation-prevention bytes of the NAL unit it extracts IN the
- *     caller's buffer (byte_stream.c:193-235): a caller that decodes a buffer twice keeps a private copy;
+ *     caller's buffer (byte_stream.c:193-235): a caller that decodes a buffer twice keeps a private copy, and every
+ *     decoder instance needs its own writable copy (h264bsdmiSetInputReadOnly() in h264bsd_mi355x.h switches this off);
  *   - pixels are produced on the GPU: h264bsdDecode() only parses and queues a frame job, the
  *     picture is materialised (and copied to host memory) by h264bsdNextOutputPicture*();
  *   - damaged streams are handled like the reference: H264BSD_ERROR for the broken NAL unit — including the one
  *     error the reference finds after dequantisation, a residual sample outside [-512,511]
  *     (src/h264bsd_transform.c:184-188), which the host parser decides while it parses — the same macroblocks
  *     rolled back (src/h264bsd_slice_data.c:298-354) and concealed (src/h264bsd_conceal.c), numErrMbs reported.
- *     Known deviation: a redundant slice that differs from the primary slice it repeats.
+ *     No deviation from the reference (run with zeroed allocations) is known.
  */
 #ifndef H264BSD_MI355X_DECODER_H
 #define H264BSD_MI355X_DECODER_H

@@ -133,3 +133,7 @@ SWEEP_FINDS["redundant_flipped_1122884"] = (random_config(1122884), dict(seed=11
 # the macroblock counter says "complete" while a macroblock was never decoded (a slice failed before it wrote a record):
 # the picture shows what the frame buffer held, and the record must say ABSENT — not what the reused job buffer held
 SWEEP_FINDS["redundant_flipped_2005492"] = (random_config(2005492), dict(seed=2005492, p_drop=0.1, p_flip=0.4, p_trunc=0.1))
+# ... and the deblocking filter treats that macroblock with the type, QP, coefficient counts and motion its mbStorage_t kept
+# from an EARLIER picture and the slice parameters of the last slice that started on it (the one deviation left open at the
+# end of round 2): a deblock-only record from the parser's persistent MbInfo
+SWEEP_FINDS["redundant_flipped_2010846"] = (random_config(2010846), dict(seed=2010846, p_drop=0.1, p_flip=0.4, p_trunc=0.1))

@@ -76,3 +76,21 @@ def test_gpu_bench_two_ranks_on_one_box(built):
     assert len(res["per_gpu"]["value"]) == 2 and all(v > 0 for v in res["per_gpu"]["value"])
     assert abs(res["value"] - 2 * 32 * 73 * 8160 * 1000 / res["ms_per_step"]) < 1e-3 * res["value"]
     assert res["device_errors"] == 0 and "cpu_baseline" not in res
+
+
+@pytest.mark.gpu
+def test_gpu_bench_starts_its_own_ranks(built):
+    """`python bench.py --gpus 2` without a launcher (how the driver calls it): bench.py starts the two ranks itself and the
+    line says n_gpus 2; a rank count that does not match --gpus is refused instead of silently measuring one GPU"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "32", "--steps", "1", "--warmup", "0",
+                          "--ramp-seconds", "0", "--no-staggered", "--no-desync", "--no-argb"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and len(res["per_gpu"]["value"]) == 2
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert bad.returncode != 0 and "refusing" in bad.stderr + bad.stdout
