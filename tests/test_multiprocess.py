@@ -88,7 +88,7 @@ def test_gpu_bench_starts_its_own_ranks(built):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "32", "--steps", "1", "--warmup", "0",
                           "--ramp-seconds", "0", "--no-staggered", "--no-desync", "--no-argb"],
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 0, "\n".join(l for l in out.stderr.splitlines() if "socket.cpp" not in l and "amdgpu.ids" not in l)[-6000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["n_gpus"] == 2 and len(res["per_gpu"]["value"]) == 2
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "1"],
