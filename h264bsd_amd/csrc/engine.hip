@@ -104,7 +104,9 @@ constexpr unsigned CONVERT_WGS = CONVERT_WGS_N;      /* workgroups per picture o
 /* Under lane scheduling a k_frame_dbk workgroup shares its compute unit with the other lanes' kernels: 8 wavefronts
  * hold less of the register file than the 12 that are best when a tick has the GPU to itself (desynchronised replay
  * with 9 groups: 763 vs 734 M MB/s; lock-step, single lane: 12 wavefronts 54.9 ms per step, 8: 56.8). */
-constexpr uint32_t LANE_DBK_WAVES = 8;
+constexpr uint32_t LANE_DBK_WAVES_DEFAULT = 8;
+static uint32_t lane_dbk_waves() { const char *e = getenv("H264BSDMI_LANE_DBK_WAVES"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v ? v : LANE_DBK_WAVES_DEFAULT; }
+#define LANE_DBK_WAVES lane_dbk_waves()
 
 struct Engine {
     std::mutex mu;
@@ -271,6 +273,9 @@ struct TailConfig {
      * filtering needs about one compute unit's worth of instruction issue whichever way it is cut); the small ticks of
      * stream groups and heavy lanes: several workgroups per picture.  H264BSDMI_BAND_BUDGET overrides. */
     uint32_t band_budget = 320;
+    /* ... and the heavy pictures of a tick that has the device to itself share heavy_budget further workgroups: the compute
+     * units the tick's light pictures leave idle long before its heavy ones are done (H264BSDMI_HEAVY_BUDGET) */
+    uint32_t heavy_budget = 64;
     bool from_env = false;
 };
 TailConfig g_tail;
@@ -288,6 +293,7 @@ TailConfig tail_config()
             } else fprintf(stderr, "h264bsd-mi355x: H264BSDMI_TAIL=%s ignored (expected six numbers)\n", cfg);
         }
         if (const char *cfg = getenv("H264BSDMI_BAND_BUDGET")) g_tail.band_budget = (uint32_t)strtoul(cfg, nullptr, 10);
+        if (const char *cfg = getenv("H264BSDMI_HEAVY_BUDGET")) g_tail.heavy_budget = (uint32_t)strtoul(cfg, nullptr, 10);
     }
     return g_tail;
 }
@@ -320,8 +326,11 @@ struct TickShape {
     uint32_t max_copy = 0, max_gen = 0, max_gen_uni = 0, max_gen_rest = 0, max_dbk = 0, max_levels = 0, max_w = 0, max_h = 0;
     bool any_tail = false, any_deblock = false;
     uint32_t dbk_waves = 0;          /* wavefronts per workgroup of k_frame_dbk; 0 = the configured default (launch_tick) */
-    uint32_t dbk_bands = 1, intra_bands = 1;   /* most bands any picture of the tick wants ... */
-    uint32_t dbk_rows = 0, intra_rows = 0;     /* ... and the most rows a band of any of its pictures has */
+    /* row bands of the two per-picture kernels: most bands a light / a heavy picture of the tick wants, for k_frame_dbk [0]
+     * and k_frame_intra [1]; number of heavy pictures (more than a quarter of the macroblocks intra coded) */
+    uint32_t want_light[2] = { 1, 1 }, want_heavy[2] = { 1, 1 }, n_heavy = 0;
+    uint32_t load = 0;               /* pictures the device works on at the same time as this tick (other lanes' ticks included): the
+                                        band budget is shared between them; 0 = this tick only */
 };
 
 /* descriptor of one picture: device addresses of the sections of its (device-resident) frame job */
@@ -351,6 +360,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     {
         const TailConfig tc = tail_config();
         const bool heavy = h->n_intra * 4u > h->n_mbs;
+        d.heavy = heavy ? 1 : 0;
         d.dbk_bands = bands_for(h->height_mbs, heavy ? tc.dbk_rows_heavy : tc.dbk_rows_light);
         /* a concealed macroblock may wait for the macroblocks below it (FJ_NEED_D*): such a picture stays in one band,
          * a band never waits for a band that started after it */
@@ -371,14 +381,9 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
         shape->max_w = std::max<uint32_t>(shape->max_w, h->width_mbs);
         shape->max_h = std::max<uint32_t>(shape->max_h, h->height_mbs);
         shape->any_tail |= h->n_intra_levels != 0 || h->any_deblock != 0;
-        if (h->any_deblock) {
-            shape->dbk_bands = std::max<uint32_t>(shape->dbk_bands, d.dbk_bands);
-            shape->dbk_rows = std::max<uint32_t>(shape->dbk_rows, (h->height_mbs + d.dbk_bands - 1u) / d.dbk_bands);
-        }
-        if (h->n_intra_levels) {
-            shape->intra_bands = std::max<uint32_t>(shape->intra_bands, d.intra_bands);
-            shape->intra_rows = std::max<uint32_t>(shape->intra_rows, (h->height_mbs + d.intra_bands - 1u) / d.intra_bands);
-        }
+        shape->n_heavy += d.heavy;
+        if (h->any_deblock) (d.heavy ? shape->want_heavy : shape->want_light)[0] = std::max<uint32_t>((d.heavy ? shape->want_heavy : shape->want_light)[0], d.dbk_bands);
+        if (h->n_intra_levels) (d.heavy ? shape->want_heavy : shape->want_light)[1] = std::max<uint32_t>((d.heavy ? shape->want_heavy : shape->want_light)[1], d.intra_bands);
     }
 }
 
@@ -447,18 +452,42 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     /* The two per-picture kernels keep per-macroblock scheduling state in LDS next to their wavefronts' tiles: for
      * pictures that leave less than 16 wavefronts' worth of tile space in the 160 KB of a CU, fewer wavefronts run. */
     constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
+    /* Row bands of the per-picture kernels (kernels.hip.h).  A picture is split only where that puts IDLE compute units to
+     * work — measured: with 256 pictures on 256 compute units every split loses (a picture's work is about one compute unit's
+     * worth of instruction issue however it is cut: 4 bands x 4 wavefronts 92 instead of 57 ms per step in k_frame_dbk, bands on
+     * the heavy lanes of a saturated desynchronised schedule 775 instead of 827 M MB/s); with few pictures on the device it wins
+     * (4-32 streams: +18-20 %), and so it does for the few heavy pictures of a tick that is otherwise done long before them.
+     *   light_cap: bands a light picture may use = band_budget / pictures on the device (this tick, or all lanes' ticks: load)
+     *   heavy_cap: when the tick is (nearly) alone on the device, its heavy pictures share what the budget leaves */
+    const TailConfig tc = tail_config();
+    const uint32_t on_device = std::max<uint32_t>(1u, std::max(s.n_frames, s.load));
+    const uint32_t light_cap = std::max<uint32_t>(1u, tc.band_budget / on_device);
+    uint32_t heavy_cap = light_cap;
+    if (s.n_heavy && 2u * s.n_frames >= s.load) heavy_cap = std::max(light_cap, 1u + tc.heavy_budget / s.n_heavy);
+    struct BandPlan { uint32_t bands, rows, waves; size_t lds; };
+    auto plan = [&](int which, uint32_t waves, size_t (*lds_bytes)(uint32_t, uint32_t, uint32_t), bool may_shorten, BandPlan &bp) -> int {
+        const uint32_t eff_l = std::min(s.want_light[which], light_cap), eff_h = std::min(s.want_heavy[which], heavy_cap);
+        /* rows a band can have: the picture with the fewest bands decides (all pictures of a tick have the tick's size in
+         * practice; max_h / fewest bands is the bound) */
+        const uint32_t fewest = s.n_heavy >= s.n_frames ? eff_h : s.n_heavy ? std::min(eff_l, eff_h) : eff_l;
+        uint32_t rows = (s.max_h + fewest - 1) / std::max<uint32_t>(1u, fewest);
+        rows = std::max<uint32_t>(1u, std::min<uint32_t>(rows, s.max_h));
+        while (may_shorten && lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && rows > 1) rows = (rows + 1) / 2;      /* (rows is a cap the kernel applies to every picture) */
+        while (lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && waves > 1) waves--;
+        if (lds_bytes(waves, s.max_w, rows) > LDS_BUDGET) return -1;
+        bp.rows = rows; bp.waves = waves; bp.lds = lds_bytes(waves, s.max_w, rows);
+        bp.bands = std::max<uint32_t>(std::max(s.n_heavy < s.n_frames ? eff_l : 1u, s.n_heavy ? eff_h : 1u), (s.max_h + rows - 1) / rows);
+        return 0;
+    };
     if (s.max_levels && (stages & 2u)) {
-        const TailConfig tc = tail_config();
-        const uint32_t cap = std::max<uint32_t>(1u, tc.band_budget / std::max<uint32_t>(1u, s.n_frames));     /* bands per picture this launch can afford */
-        uint32_t rows = std::max<uint32_t>(1u, std::min<uint32_t>(s.intra_rows ? s.intra_rows : s.max_h, s.max_h));
-        rows = std::min<uint32_t>(s.max_h, std::max<uint32_t>(rows, (s.max_h + cap - 1) / cap));
-        uint32_t waves = std::max<uint32_t>(1u, std::min<uint32_t>(tc.intra_waves, h264k::TAIL_WAVES));
-        /* a picture with concealed macroblocks must stay in one band (FjHeader.intra_down_deps): fewer wavefronts before
+        BandPlan bp;
+        /* a picture with concealed macroblocks must stay in one band (FjHeader.intra_down_deps): fewer wavefronts, never
          * shorter bands */
-        while (h264k::intra_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && waves > 1) waves--;
-        if (h264k::intra_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture of %u x %u macroblocks is too large for k_frame_intra\n", s.max_w, s.max_h); return -1; }
-        const size_t lds = h264k::intra_lds_bytes(waves, s.max_w, rows);
-        const uint32_t bands = std::max<uint32_t>(std::min<uint32_t>(s.intra_bands, cap), (s.max_h + rows - 1) / rows);
+        if (plan(1, std::max<uint32_t>(1u, std::min<uint32_t>(tc.intra_waves, h264k::TAIL_WAVES)), h264k::intra_lds_bytes, false, bp)) {
+            fprintf(stderr, "h264bsd-mi355x: picture of %u x %u macroblocks is too large for k_frame_intra\n", s.max_w, s.max_h); return -1;
+        }
+        const uint32_t bands = bp.bands, rows = bp.rows, waves = bp.waves;
+        const size_t lds = bp.lds;
         uint32_t *tickets = bands > 1 ? tickets_for(st) : nullptr;
         if (bands > 1 && !tickets) return -1;
         int dev = 0;
@@ -473,29 +502,20 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
                 lds_enabled[bands > 1][dev] = lds;
             }
         }
-        if (bands > 1) hipLaunchKernelGGL(h264k::k_frame_intra<true>, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets + 2, bands, rows);
-        else hipLaunchKernelGGL(h264k::k_frame_intra<false>, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof, nullptr, 1u, rows);
+        if (bands > 1) hipLaunchKernelGGL(h264k::k_frame_intra<true>, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets + 2, bands, rows, light_cap);
+        else hipLaunchKernelGGL(h264k::k_frame_intra<false>, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof, nullptr, 1u, rows, 1u);
         if (launches) launches[3]++;
     }
     if (EV_NEEDED(4)) HIP_TRY(hipEventRecord(tt->ev[4], st));
     if (aside) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
     if (use_ahead) HIP_TRY(hipStreamWaitEvent(st, ahead->parity ? side->join_copy : side->join, 0));
     if (s.any_deblock && (stages & 4u)) {
-        /* row bands: max_bands workgroups per picture (k_frame_dbk); the scheduling state of a band's rows lives in LDS
-         * next to its wavefronts' tiles */
-        const TailConfig tc = tail_config();
-        const uint32_t cap = std::max<uint32_t>(1u, tc.band_budget / std::max<uint32_t>(1u, s.n_frames));     /* bands per picture this launch can afford */
-        uint32_t rows = std::max<uint32_t>(1u, std::min<uint32_t>(s.dbk_rows ? s.dbk_rows : s.max_h, s.max_h));   /* no band has more rows than this */
-        rows = std::min<uint32_t>(s.max_h, std::max<uint32_t>(rows, (s.max_h + cap - 1) / cap));
-        uint32_t waves = std::min<uint32_t>(s.dbk_waves ? s.dbk_waves : tc.dbk_waves, h264k::DBK_WAVES);
-        waves = std::max<uint32_t>(waves, 1u);
-        /* pictures whose rows do not fit: shorter bands first (rows is a cap the kernel applies to every picture), fewer
-         * wavefronts then */
-        while (h264k::dbk_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && rows > 1) rows = (rows + 1) / 2;
-        while (h264k::dbk_lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && waves > 1) waves--;
-        const size_t lds = h264k::dbk_lds_bytes(waves, s.max_w, rows);
-        if (lds > LDS_BUDGET) { fprintf(stderr, "h264bsd-mi355x: picture %u macroblocks wide is too large for k_frame_dbk\n", s.max_w); return -1; }
-        const uint32_t bands = std::max<uint32_t>(std::min<uint32_t>(s.dbk_bands, cap), (s.max_h + rows - 1) / rows);
+        BandPlan bp;
+        if (plan(0, std::max<uint32_t>(1u, std::min<uint32_t>(s.dbk_waves ? s.dbk_waves : tc.dbk_waves, h264k::DBK_WAVES)), h264k::dbk_lds_bytes, true, bp)) {
+            fprintf(stderr, "h264bsd-mi355x: picture %u macroblocks wide is too large for k_frame_dbk\n", s.max_w); return -1;
+        }
+        const uint32_t bands = bp.bands, rows = bp.rows, waves = bp.waves;
+        const size_t lds = bp.lds;
         uint32_t *tickets = bands > 1 ? tickets_for(st) : nullptr;
         if (bands > 1 && !tickets) return -1;
         int dev = 0;
@@ -510,8 +530,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
                 lds_enabled[bands > 1][dev] = lds;
             }
         }
-        if (bands > 1) hipLaunchKernelGGL(h264k::k_frame_dbk<true>, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets, bands, rows);
-        else hipLaunchKernelGGL(h264k::k_frame_dbk<false>, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof, nullptr, 1u, rows);
+        if (bands > 1) hipLaunchKernelGGL(h264k::k_frame_dbk<true>, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets, bands, rows, light_cap);
+        else hipLaunchKernelGGL(h264k::k_frame_dbk<false>, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof, nullptr, 1u, rows, 1u);
         if (launches) launches[4]++;
     }
     if (EV_NEEDED(5)) HIP_TRY(hipEventRecord(tt->ev[5], st));
@@ -607,6 +627,7 @@ static int lane_launch(Engine *e, unsigned lane_idx, const std::vector<StreamCtx
     l.flip ^= 1;
     l.ticks++;
     if (e->lanes.size() > 1) shape.dbk_waves = LANE_DBK_WAVES;
+    shape.load = (uint32_t)e->streams.size();
     if (launch_tick(l.st, l.d_desc, shape, nullptr, nullptr, 7u, l.side)) return -1;
     HIP_TRY(hipEventRecord(l.ring[l.launches % Lane::RING], l.st));
     l.launches++;
@@ -1294,7 +1315,7 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
                     HIP_TRY(hipStreamWaitEvent(st, r->gdone_any, 0));
                 }
             }
-            if (l.shape.n_frames && launch_tick(st, r->d_desc + l.first, l.shape, nullptr, r->launches, r->stages,
+            if (l.shape.n_frames && launch_tick(st, r->d_desc + l.first, [&] { TickShape sh = l.shape; sh.load = r->n_streams; return sh; }(), nullptr, r->launches, r->stages,
                                                 (l.light && r->overlap_dbk && !(r->stages & 8u) && r->lane_side[l.lane].stream) ? &r->lane_side[l.lane] : nullptr)) return -1;
             if (l.record_ev >= 0) HIP_TRY(hipEventRecord(r->sched_ev[l.record_ev], st));
         }
@@ -1336,6 +1357,7 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
                 if (s0 >= s1) continue;
                 TickShape sh = r->shapes[i];
                 sh.n_frames = s1 - s0;
+                sh.load = r->n_streams;
                 TickTimers &tt = r->timers[(size_t)g * r->n_pics + i];
                 tt.on = true; tt.mask = r->timed_mask;
                 /* de-phase the groups once: group g starts when group g-1 has entered its first tail */

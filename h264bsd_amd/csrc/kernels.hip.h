@@ -56,6 +56,7 @@ struct FrameDesc {
     uint16_t        wmb, hmb;
     uint32_t        any_deblock;
     uint16_t        dbk_bands, intra_bands;   /* row bands (= workgroups) the per-picture kernels may split this picture into (>= 1; the launch caps it) */
+    uint16_t        heavy;                    /* 1: mostly intra coded — several times the work of the other pictures of its tick */
     uint32_t       *err;          /* device error word of the engine (DEVERR_* bits, atomicOr): must stay 0 */
     uint8_t        *slot[FJ_MAX_SLOTS];
 };
@@ -1735,8 +1736,9 @@ __device__ __forceinline__ void return_ticket(uint32_t *tickets)
 }
 /* rows per band and number of bands for a picture of hmb macroblock rows that wants `want` bands, in a launch with
  * max_bands workgroups per picture whose LDS holds the state of at most rows_cap rows */
-__device__ __forceinline__ void band_split(int hmb, uint32_t want, uint32_t max_bands, uint32_t rows_cap, int &rows, int &bands)
+__device__ __forceinline__ void band_split(int hmb, uint32_t want, uint32_t heavy, uint32_t max_bands, uint32_t light_cap, uint32_t rows_cap, int &rows, int &bands)
 {
+    if (!heavy && want > light_cap) want = light_cap;         /* (the launch may grant bands to the heavy pictures of a tick only) */
     int w = (int)(want < max_bands ? want : max_bands);
     if (w < 1) w = 1;
     rows = (hmb + w - 1) / w;
@@ -1768,7 +1770,7 @@ __host__ __device__ inline size_t intra_lds_bytes(uint32_t waves, uint32_t wmb, 
  * hand-over code in the loop. */
 template <bool BANDED>
 __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames, unsigned long long *prof,
-                                                                 uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap)
+                                                                 uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap, uint32_t light_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint32_t s_misc[4];
@@ -1781,7 +1783,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wmb = fd.wmb, hmb = fd.hmb;
     int R = hmb, nb = 1;
-    if (BANDED) band_split(hmb, fd.intra_bands, max_bands, rows_cap, R, nb);
+    if (BANDED) band_split(hmb, fd.intra_bands, fd.heavy, max_bands, light_cap, rows_cap, R, nb);
     if (!fd.n_levels || (int)band >= nb) { if (BANDED) return_ticket(tickets); return; }
     const uint32_t total_all = fd.lvl[fd.n_levels];
     const int r0 = (int)band * R, r1 = min(hmb, r0 + R);
@@ -2018,7 +2020,7 @@ __host__ __device__ inline size_t dbk_lds_bytes(uint32_t waves, uint32_t wmb, ui
 }
 template <bool BANDED>
 __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof,
-                                                              uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap)
+                                                              uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap, uint32_t light_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint32_t s_misc[4];
@@ -2031,7 +2033,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *_
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, quarter = lane >> 4, ql = lane & 15, q16 = 16 * quarter;
     const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
     int R = hmb, nb = 1;
-    if (BANDED) band_split(hmb, fd.dbk_bands, max_bands, rows_cap, R, nb);
+    if (BANDED) band_split(hmb, fd.dbk_bands, fd.heavy, max_bands, light_cap, rows_cap, R, nb);
     if (!fd.any_deblock || (int)band >= nb) { if (BANDED) return_ticket(tickets); return; }
     const int r0 = (int)band * R, r1 = min(hmb, r0 + R);
     const int base = (r0 - 1) * wmb;                        /* band-local index of macroblock mb: mb - base (row r0-1 first) */
