@@ -454,20 +454,24 @@ def main():
         # HBM bytes per launch of the dominant kernel: PMC counters need rocprofv3 (separate --pmc passes,
         # tools/refresh_profiles.sh), so they cannot be collected inside this run; the committed table is only used
         # while it belongs to the kernels that just ran (sha256 of the kernel sources), otherwise traffic is null
-        traffic, traffic_note = None, "no traffic table in profiles/"
+        traffic, traffic_note, traffic_all, traffic_whole = None, "no traffic table in profiles/", None, None
         try:
-            import hashlib
-            tfile = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            import glob
+            tpath = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+            tname = os.path.relpath(tpath, ROOT)
+            tfile = json.load(open(tpath))
             from h264bsd_amd.srchash import kernel_source_sha256
             src_sha = kernel_source_sha256(ROOT)
             if tfile.get("kernel_source_sha256") != src_sha:
-                traffic_note = "profiles/r02_traffic.json was measured with other kernel sources: stale, not reported (rerun tools/refresh_profiles.sh)"
+                traffic_note = f"{tname} was measured with other kernel sources: stale, not reported (rerun tools/refresh_profiles.sh)"
             else:
-                tj = tfile["kernels"][dom]
-                traffic = (tj.get("fetch_bytes_per_launch_calibrated", tj["fetch_bytes_per_launch"]) +
-                           tj.get("write_bytes_per_launch_calibrated", tj["write_bytes_per_launch"]))
-                traffic_note = "profiles/r02_traffic.json: FETCH_SIZE + WRITE_SIZE of this kernel, separate rocprofv3 --pmc passes of this command, calibrated on k_copy's known byte count"
-        except (OSError, KeyError, ValueError):
+                per_kernel = {k: v.get("fetch_bytes_per_launch_calibrated", v["fetch_bytes_per_launch"]) +
+                              v.get("write_bytes_per_launch_calibrated", v["write_bytes_per_launch"]) for k, v in tfile["kernels"].items() if k in kernels}
+                traffic = per_kernel[dom]
+                traffic_all = per_kernel
+                traffic_whole = sum(per_kernel.values())          # every kernel is launched once per tick: HBM bytes of one tick of the whole path
+                traffic_note = f"{tname}: FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes of this command, calibrated on k_copy's known byte count"
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         out = {
             "metric": "1080p macroblocks/s", "value": mbs / elapsed, "unit": "macroblocks/s",
@@ -483,6 +487,8 @@ def main():
                        "row_bands": os.environ.get("H264BSDMI_TAIL", "library default (engine.hip TailConfig)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "traffic_per_kernel": traffic_all, "traffic_whole_path": traffic_whole,
+                         "traffic_ratio": (traffic_whole / (alg_per_mb * units_per_launch)) if traffic_whole else None,
                          "alg_bytes_per_launch": alg_per_mb * units_per_launch,
                          "alg_bytes_per_mb": alg_per_mb, "mbs_per_launch": units_per_launch,
                          "avg_launch_us": avg_launch_us, "launches": launches,

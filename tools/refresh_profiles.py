@@ -18,9 +18,10 @@ body = open(os.path.join(src, "pmc_FETCH_SIZE.txt")).read() + open(os.path.join(
 open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w").write(head + body)
 kern = {}
 for l in body.splitlines():
-    m = re.match(r"(?:void )?h264k::(\w+)(<\d>)?\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+total=\S+ per_dispatch=(\S+)", l)
+    m = re.match(r"(?:void )?h264k::(\w+)(<\w+>)?\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+total=\S+ per_dispatch=(\S+)", l)
     if m:
-        # k_recon_inter<0> and <1> are the two halves of one tick's inter reconstruction: their bytes add up
+        # k_recon_inter<0> and <1> are the two halves of one tick's inter reconstruction: their bytes add up (the banded and the
+        # single-band instantiations of the per-picture kernels never run in the same tick of this command)
         k = kern.setdefault(m.group(1), {})
         key = "fetch_bytes_per_launch" if m.group(3) == "FETCH_SIZE" else "write_bytes_per_launch"
         k[key] = k.get(key, 0.0) + float(m.group(4)) * 1024
@@ -49,5 +50,10 @@ if bl["roofline"].get("traffic") is None and dom in kern:
     bl["roofline"]["traffic"] = kern[dom]["fetch_bytes_per_launch_calibrated"] + kern[dom]["write_bytes_per_launch_calibrated"]
     bl["roofline"]["traffic_source"] = (f"profiles/{tag}_traffic.json: FETCH_SIZE + WRITE_SIZE of this kernel, separate rocprofv3 --pmc passes run "
                                         "right after this line on the same box (filled in by tools/refresh_profiles.py), calibrated on k_copy's known byte count")
+    names = ("k_copy", "k_recon_inter", "k_dbk", "k_frame_intra", "k_frame_dbk")
+    per = {k: kern[k]["fetch_bytes_per_launch_calibrated"] + kern[k]["write_bytes_per_launch_calibrated"] for k in names if k in kern}
+    bl["roofline"]["traffic_per_kernel"] = per
+    bl["roofline"]["traffic_whole_path"] = sum(per.values())
+    bl["roofline"]["traffic_ratio"] = sum(per.values()) / bl["roofline"]["alg_bytes_per_launch"]
     open(os.path.join(dst, f"{tag}_bench_line.json"), "w").write(json.dumps(bl) + "\n")
 print(line[:300]); print(json.dumps(kern)[:600])
