@@ -63,6 +63,9 @@
 #define FJ_PRED_PHASE2 0x80u  /* in a deblock-only job (FjHeader.dbk_only): this macroblock is nevertheless reconstructed, on top of
                                  the pixels of the job before — it replaced pixels that other macroblocks had already predicted
                                  from (concealment of, or a later slice over, a macroblock that a failed redundant slice un-decoded) */
+#define FJ_PRED_UNIFORM_MV 0x40u /* inter macroblocks: a hint of the parser to fj_finalize() — the 16 motion vectors were written as 16 copies of
+                                  one vector and the four references are equal (P_Skip, P_L0_16x16): no need to compare them.  A job
+                                  built elsewhere may leave it clear. */
 #define FJ_PRED_PARTS_SHIFT 4  /* inter macroblocks, pred bits 4-5: where the macroblock TYPE allows motion to differ inside it — the
                                  deblocking filter compares motion vectors / references only there (reference
                                  deblocking.c:1266-1345) */

@@ -143,42 +143,86 @@ static const uint8_t zigzag4x4[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7,
 
 int hd_cavlc_block(BitReader *br, int nc, int max_coeff, int16_t *coef, int *spill)
 {
+    uint32_t unused = 0;
+    return hd_cavlc_block_sum(br, nc, max_coeff, coef, spill, &unused);
+}
+
+/* ... and adds the magnitudes of the levels it stored in the block to *abs_sum (hd_mb.c: the residual-range bound of the
+ * macroblock falls out of the parse instead of a second pass over the coefficients) */
+/* A window of the bit stream kept in registers for the duration of one block: bits [pos, pos + avail) of the stream are the
+ * top `avail` bits of win.  One 8-byte load per ~32 consumed bits instead of one per syntax element (BitReader's br_peek32
+ * assembles its word from memory every time); the position goes back to the BitReader when the block is done.  Reading past
+ * the end of the data yields zeros — the caller fails the block for the overrun in any case — and never touches memory behind
+ * the 8 pad bytes. */
+typedef struct { const uint8_t *buf; uint64_t win; uint32_t pos, size_bits; int avail; } BitWin;
+static inline void bw_refill(BitWin *w)
+{
+    if (w->pos > w->size_bits) { w->win = 0; w->avail = 64; return; }
+    const uint8_t *p = w->buf + (w->pos >> 3);
+    const uint64_t v = ((uint64_t)p[0] << 56) | ((uint64_t)p[1] << 48) | ((uint64_t)p[2] << 40) | ((uint64_t)p[3] << 32) |
+                       ((uint64_t)p[4] << 24) | ((uint64_t)p[5] << 16) | ((uint64_t)p[6] << 8) | (uint64_t)p[7];
+    w->win = v << (w->pos & 7);
+    w->avail = 64 - (int)(w->pos & 7);
+}
+static inline uint32_t bw_peek32(BitWin *w) { if (w->avail < 32) bw_refill(w); return (uint32_t)(w->win >> 32); }
+static inline void bw_skip(BitWin *w, uint32_t n) { w->win <<= n; w->avail -= (int)n; w->pos += n; }      /* n <= 32, after a peek */
+static inline uint32_t bw_get(BitWin *w, uint32_t n) { if (!n) return 0; const uint32_t v = bw_peek32(w) >> (32 - n); bw_skip(w, n); return v; }
+static inline int bw_vlc(const Vlc *v, BitWin *w)
+{
+    const uint32_t x = bw_peek32(w);
+    int e = v->l1[x >> 24];
+    if (e < 0) e = v->l2[-e - 1][(x >> 16) & 0xFF];
+    if (e == VLC_BAD) return -1;
+    bw_skip(w, (uint32_t)e >> 8);
+    return e & 0xFF;
+}
+/* hand the position back; 1 = the block ran past the end of the data */
+static inline int bw_done(const BitWin *w, BitReader *br)
+{
+    if (br->pos <= br->size_bits) br->pos = w->pos;
+    if (br->pos > br->size_bits) { br->pos = br->size_bits + 1; return 1; }
+    return 0;
+}
+
+int hd_cavlc_block_sum(BitReader *br, int nc, int max_coeff, int16_t *coef, int *spill, uint32_t *abs_sum)
+{
+    BitWin bw = { br->buf, 0, br->pos, br->size_bits, 0 };
     int sym;
     if (spill) *spill = 0;
-    if (nc < 0) sym = vlc_get(&vlc_cdc, br);
-    else if (nc < 2) sym = vlc_get(&vlc_ct[0], br);
-    else if (nc < 4) sym = vlc_get(&vlc_ct[1], br);
-    else if (nc < 8) sym = vlc_get(&vlc_ct[2], br);
+    if (nc < 0) sym = bw_vlc(&vlc_cdc, &bw);
+    else if (nc < 2) sym = bw_vlc(&vlc_ct[0], &bw);
+    else if (nc < 4) sym = bw_vlc(&vlc_ct[1], &bw);
+    else if (nc < 8) sym = bw_vlc(&vlc_ct[2], &bw);
     else {
         /* 6-bit fixed length: 000011 = (0,0), otherwise xxxxyy = (total_coeff-1, trailing_ones) */
-        uint32_t c = br_get(br, 6);
+        uint32_t c = bw_get(&bw, 6);
         if (c == 3) sym = 0;
         else if ((c & 3) > (c >> 2) + 1) sym = -1;        /* trailing_ones > total_coeff */
         else sym = (int)(((c >> 2) + 1) * 4 + (c & 3));
     }
-    if (sym < 0) return -1;
+    if (sym < 0) { bw_done(&bw, br); return -1; }
     const int total = sym >> 2, t1 = sym & 3;
-    if (total == 0) return 0;
-    if (total > max_coeff) return -1;
+    if (total == 0) { bw_done(&bw, br); return 0; }               /* (an overrun here is the caller's to notice, as before) */
+    if (total > max_coeff) { bw_done(&bw, br); return -1; }
 
     int level[16];
     /* trailing ones */
     if (t1) {
-        uint32_t signs = br_get(br, (uint32_t)t1);
+        uint32_t signs = bw_get(&bw, (uint32_t)t1);
         for (int i = 0; i < t1; i++) level[i] = (signs >> (t1 - 1 - i)) & 1 ? -1 : 1;
     }
     /* remaining levels, 9.2.2.1 */
     int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
     for (int i = t1; i < total; i++) {
-        uint32_t w = br_peek32(br);
-        if (w < (1u << 16)) return -1;                    /* level_prefix > 15 */
+        uint32_t w = bw_peek32(&bw);
+        if (w < (1u << 16)) { bw_done(&bw, br); return -1; }      /* level_prefix > 15 */
         int prefix = __builtin_clz(w);
-        br_skip(br, (uint32_t)prefix + 1);
+        bw_skip(&bw, (uint32_t)prefix + 1);
         int code = prefix << suffix_len;
         int suffix_size = suffix_len;
         if (prefix == 14 && suffix_len == 0) suffix_size = 4;
         else if (prefix == 15) { suffix_size = 12; code = 15 << suffix_len; }
-        if (suffix_size) code += (int)br_get(br, (uint32_t)suffix_size);
+        if (suffix_size) code += (int)bw_get(&bw, (uint32_t)suffix_size);
         if (prefix == 15 && suffix_len == 0) code += 15;
         if (i == t1 && t1 < 3) code += 2;
         level[i] = (code & 1) ? -((code + 1) >> 1) : ((code + 2) >> 1);
@@ -189,32 +233,32 @@ int hd_cavlc_block(BitReader *br, int nc, int max_coeff, int16_t *coef, int *spi
     /* total_zeros */
     int zeros_left = 0;
     if (total < max_coeff) {
-        zeros_left = nc < 0 ? vlc_get(&vlc_ctz[total - 1], br) : vlc_get(&vlc_tz[total - 1], br);
+        zeros_left = nc < 0 ? bw_vlc(&vlc_ctz[total - 1], &bw) : bw_vlc(&vlc_tz[total - 1], &bw);
         /* A 15-coefficient block is parsed with the total_zeros tables of the 16-coefficient case (9.2.3 gives it
          * tzVlcIndex = total_coeff all the same), which allow total_coeff + total_zeros == 16.  The reference accepts
          * that (src/h264bsd_cavlc.c:862-873): the coefficient lands one element past the block, i.e. in element 0 of
          * the NEXT block of residual_t.level[][] (macroblock_layer.c:745-753 pass level[b]+1).  Mirrored: accepted,
          * the stray level is handed to the caller through *spill. */
-        if (zeros_left < 0 || total + zeros_left > (max_coeff == 15 ? 16 : max_coeff)) return -1;
+        if (zeros_left < 0 || total + zeros_left > (max_coeff == 15 ? 16 : max_coeff)) { bw_done(&bw, br); return -1; }
     }
     /* run_before + placement: level[0] is the highest-frequency coefficient */
     int pos = total + zeros_left - 1;                     /* scan index of level[0] */
     const int first = max_coeff == 15 ? 1 : 0;            /* AC blocks start at scan position 1 */
     for (int i = 0; i < total; i++) {
-        if (pos < 0) return -1;
+        if (pos < 0) { bw_done(&bw, br); return -1; }
         int16_t v = (int16_t)level[i];
-        if (nc < 0) coef[pos] = v;
-        else if (pos + first < 16) coef[zigzag4x4[pos + first]] = v;
+        if (nc < 0) { coef[pos] = v; *abs_sum += (uint32_t)(v < 0 ? -v : v); }
+        else if (pos + first < 16) { coef[zigzag4x4[pos + first]] = v; *abs_sum += (uint32_t)(v < 0 ? -v : v); }
         else if (spill) *spill = level[i];
         if (i + 1 == total) break;
         int run = 0;
         if (zeros_left > 0) {
-            run = vlc_get(&vlc_rb[(zeros_left > 7 ? 7 : zeros_left) - 1], br);
-            if (run < 0 || run > zeros_left) return -1;
+            run = bw_vlc(&vlc_rb[(zeros_left > 7 ? 7 : zeros_left) - 1], &bw);
+            if (run < 0 || run > zeros_left) { bw_done(&bw, br); return -1; }
             zeros_left -= run;
         }
         pos -= run + 1;
     }
-    if (br_overrun(br)) return -1;
+    if (bw_done(&bw, br)) return -1;
     return total;
 }

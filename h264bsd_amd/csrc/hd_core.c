@@ -222,7 +222,7 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
             memcpy(&refs, r->ref_slot, 4);
             const int one_ref = refs == (refs & 255u) * 0x01010101u;
             int same_mv = one_ref;
-            if (same_mv) {                                   /* 16 equal vectors: eight 64-bit words equal to the doubled first */
+            if (same_mv && !(r->pred & FJ_PRED_UNIFORM_MV)) {   /* 16 equal vectors: eight 64-bit words equal to the doubled first */
                 uint64_t w[8], acc = 0;
                 uint32_t first;
                 memcpy(w, mvs[a], 64);

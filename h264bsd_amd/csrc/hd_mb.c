@@ -340,13 +340,14 @@ static inline int16_t *next_block(HostDec *d, int16_t *coefs)
     return p;
 }
 
-static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, uint32_t *coded_out)
+static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, uint32_t *coded_out, uint32_t sums[3])
 {
     HostDec *d = c->d;
     BitReader *br = c->br;
     MbInfo *m = c->cur;
     uint32_t coded = 0;
     int n;
+    sums[0] = sums[1] = sums[2] = 0;                 /* level magnitudes: luma blocks, chroma DC, chroma AC (hd_residual_bound_ok) */
 
     if (is_i16) {
         int16_t *blk = next_block(d, coefs);
@@ -359,7 +360,7 @@ static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, ui
         if (!(cbp & (1u << (z >> 2)))) { m->tc[z] = 0; continue; }
         int16_t *blk = next_block(d, coefs);
         if (!blk) FAIL;
-        n = hd_cavlc_block(br, nc_luma(c, z), is_i16 ? 15 : 16, blk, NULL);
+        n = hd_cavlc_block_sum(br, nc_luma(c, z), is_i16 ? 15 : 16, blk, NULL, &sums[0]);
         if (n < 0) FAIL;
         m->tc[z] = (uint8_t)n;
         if (n) { coded |= 1u << z; d->coef_blocks++; }
@@ -368,9 +369,9 @@ static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, ui
     if (cbp & 0x30) {
         int16_t *blk = next_block(d, coefs);
         if (!blk) FAIL;
-        int n0 = hd_cavlc_block(br, -1, 4, blk, NULL);
+        int n0 = hd_cavlc_block_sum(br, -1, 4, blk, NULL, &sums[1]);
         if (n0 < 0) FAIL;
-        int n1 = hd_cavlc_block(br, -1, 4, blk + 4, NULL);
+        int n1 = hd_cavlc_block_sum(br, -1, 4, blk + 4, NULL, &sums[1]);
         if (n1 < 0) FAIL;
         if (n0 || n1) { coded |= FJ_CODED_CHROMA_DC; d->coef_blocks++; }
     }
@@ -379,7 +380,7 @@ static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, ui
             int16_t *blk = next_block(d, coefs);
             int spill;
             if (!blk) FAIL;
-            n = hd_cavlc_block(br, nc_chroma(c, k >> 2, k & 3), 15, blk, &spill);
+            n = hd_cavlc_block_sum(br, nc_chroma(c, k >> 2, k & 3), 15, blk, &spill, &sums[2]);
             if (n < 0) FAIL;
             m->tc[16 + k] = (uint8_t)n;
             if (n) { coded |= 1u << (16 + k); d->coef_blocks++; }
@@ -455,6 +456,7 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
 
     const int first_decode = d->mb_decoded[addr] == 0;
     const uint32_t coef_start = d->coef_blocks;
+    uint32_t level_sums[3] = { 0, 0, 0 };
     FjMbRec rec;
     memset(&rec, 0, sizeof(rec));
     rec.coef_idx = coef_start;
@@ -541,7 +543,7 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
             if (cbp || is_i16) {
                 int32_t dq = br_se(br);
                 if (br_overrun(br) || dq < -26 || dq > 25) FAIL;
-                if (parse_residual(&c, is_i16, cbp, coefs, &rec.coded)) FAIL;
+                if (parse_residual(&c, is_i16, cbp, coefs, &rec.coded, level_sums)) FAIL;
                 *qp += dq;
                 if (*qp < 0) *qp += 52; else if (*qp >= 52) *qp -= 52;
             }
@@ -554,7 +556,9 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
     if (!c.p2err && rec.coded && rec.kind != FJ_MB_IPCM) {
         int qi = (int)m->qp + pps->chroma_qp_index_offset;
         qi = qi < 0 ? 0 : qi > 51 ? 51 : qi;
-        if (hd_residual_out_of_range(coefs + 16u * coef_start, rec.coded, m->qp, qpc_table[qi], rec.kind == FJ_MB_I16x16)) {
+        /* (almost every macroblock is cleared by the bound on the level magnitudes the parse has summed up) */
+        if (!((rec.coded & FJ_CODED_LUMA_DC) == 0 && hd_residual_bound_ok(level_sums[0], level_sums[1], level_sums[2], m->qp, qpc_table[qi])) &&
+            hd_residual_out_of_range(coefs + 16u * coef_start, rec.coded, m->qp, qpc_table[qi], rec.kind == FJ_MB_I16x16)) {
             P2ERR(&c);
             c.ok_blocks = 0; c.ok_quads = 0;   /* the residual is processed before the prediction: no motion vector was written */
         }
@@ -614,7 +618,7 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
         int16_t (*dst)[2] = mvs[addr];
         /* (a redundant decode that failed while it reconstructed: m->mv / m->ref_slot are what the reference's
          * mbStorage_t holds, restore_unwritten) */
-        if (!c.p2err && ((rec.pred >> FJ_PRED_PARTS_SHIFT) & 3) == FJ_PARTS_16x16) memcpy(dst, m->mv, 64);   /* 16 equal vectors: the order does not matter */
+        if (!c.p2err && ((rec.pred >> FJ_PRED_PARTS_SHIFT) & 3) == FJ_PARTS_16x16) { memcpy(dst, m->mv, 64); rec.pred |= FJ_PRED_UNIFORM_MV; }   /* 16 equal vectors: the order does not matter */
         else
         for (int z = 0; z < 16; z++) {
             const int r = 4 * Z_Y[z] + Z_X[z];

@@ -56,6 +56,16 @@ static inline int block_check(const int16_t *c, int qp, int use_dc, int32_t dc)
     return block_out_of_range(c, qp, use_dc, dc);
 }
 
+int hd_residual_bound_ok(uint32_t sum_l, uint32_t sum_d, uint32_t sum_c, int qp_y, int qp_c)
+{
+    /* the same bound as the first pass of hd_residual_out_of_range(), from sums the parser collected on the way */
+    const uint64_t bound_l = (uint64_t)sum_l * ((uint32_t)level_scale[qp_y % 6][2] << (qp_y / 6));
+    const int q6c = qp_c / 6;
+    const uint64_t dc_max = ((uint64_t)sum_d * level_scale[qp_c % 6][0]) << (q6c >= 1 ? q6c - 1 : 0);
+    const uint64_t bound_c = (uint64_t)sum_c * ((uint32_t)level_scale[qp_c % 6][2] << q6c) + dc_max;
+    return bound_l <= 32735u && bound_c <= 32735u;
+}
+
 static const int16_t zero_block[16];
 
 /* blk: the macroblock's coefficient blocks in frame-job order (framejob.h); coded: FjMbRec.coded.
