@@ -48,6 +48,12 @@ int hd_extract_nal(HostDec *d, uint8_t *s, uint32_t len, uint32_t *read_bytes)
         /* payload extends to the next start code prefix or the end of the buffer */
         zeros = 0;
         for (;;) {
+            if (zeros == 0) {
+                /* nothing below looks at a non-zero byte while no zero precedes it: on to the next zero byte at memchr's speed */
+                const uint8_t *z = (const uint8_t *)memchr(s + i, 0, len - i);
+                if (!z) { end = len; consumed = len; break; }
+                i = (uint32_t)(z - s);
+            }
             uint8_t b = s[i++];
             if (b == 0) zeros++;
             if (b == 3 && zeros == 2) has_emulation = 1;
