@@ -156,7 +156,7 @@ def end_to_end(data, streams, threads, laps=2):
         timed += pic >= 73
     assert L.h264bsdmiFlush() == 0
     dt = time.perf_counter() - t0
-    jobs, _, _ = h.capture_stream(data)
+    jobs, _, _ = h.capture_stream(data, copy_elision=os.environ.get("H264BSDMI_COPY_ELISION", "1")[:1] != "0")
     h2d = sum(len(j) for j in jobs) * streams * laps
     for d in decs:
         d.close()
@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--groups", type=int, default=1, help="stream groups on separate HIP streams (overlap)")
     ap.add_argument("--ramp-seconds", type=float, default=4.0, help="untimed load before the warm-up steps (device clock ramp)")
     ap.add_argument("--time-all-kernels", action="store_true", help="bracket all five kernels with events in the timed steps too (A/B of the event overhead)")
+    ap.add_argument("--no-copy-elision", action="store_true", help="capture the replayed frame jobs without copy elision (the product's default with a device is ON: copies that would rewrite what the destination frame holds are left out, include/h264bsd_mi355x.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-groups-variant", action="store_true", help="skip the lock-step measurement with 4 stream groups")
     ap.add_argument("--no-desync", action="store_true", help="skip the fully desynchronised variants (reported next to the lock-step value)")
@@ -240,8 +241,11 @@ def main():
     gdir = os.path.join(ROOT, "tests", "golden")
     golden = json.load(open(os.path.join(gdir, "golden.json")))[STREAM]
     data = open(os.path.join(gdir, STREAM + ".h264"), "rb").read()
-    jobs, _, info = h264bsd_amd.capture_stream(data)                 # host parse, once
+    elide = not args.no_copy_elision
+    jobs, _, info = h264bsd_amd.capture_stream(data, copy_elision=elide)          # host parse, once
     heads = [h264bsd_amd.job_header(j) for j in jobs]
+    copy_mbs = sum(h["n_copy_mbs"] for h in heads)
+    copy_mbs_full = sum(h264bsd_amd.job_header(j)["n_copy_mbs"] for j in h264bsd_amd.capture_stream(data)[0]) if elide else copy_mbs
     n_pics, n_mbs = len(jobs), heads[0]["n_mbs"]
     kernels = h264bsd_amd.Replay.KERNELS
     golden_sums = golden["frame_checksum64"]
@@ -484,13 +488,19 @@ def main():
                                    "inter+intra reconstruction + in-loop deblocking, bit-exact vs reference verified on device",
                        "streams_per_gpu": args.streams, "pictures_per_step": pics_per_step, "parallelism": f"streams/{world}",
                        "stream_groups": args.groups,
-                       "row_bands": os.environ.get("H264BSDMI_TAIL", "library default (engine.hip TailConfig)")},
+                       "row_bands": os.environ.get("H264BSDMI_TAIL", "library default (engine.hip TailConfig)"),
+                       "copy_elision": {"on": elide, "copy_mbs_per_stream_pass": copy_mbs_full, "elided": copy_mbs_full - copy_mbs,
+                                        "note": "the parser leaves out whole-tile copies whose destination frame buffer already holds the "
+                                                "source's bytes (unchanged since the buffer's previous picture, untouched by deblocking): "
+                                                "same pictures, verified on device; alg_bytes_per_mb below still counts them (SURVEY 8d formula), "
+                                                "alg_bytes_per_mb_moved does not"}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "traffic_per_kernel": traffic_all, "traffic_whole_path": traffic_whole,
                          "traffic_ratio": (traffic_whole / (alg_per_mb * units_per_launch)) if traffic_whole else None,
                          "alg_bytes_per_launch": alg_per_mb * units_per_launch,
-                         "alg_bytes_per_mb": alg_per_mb, "mbs_per_launch": units_per_launch,
+                         "alg_bytes_per_mb": alg_per_mb, "alg_bytes_per_mb_moved": alg_per_mb - 768.0 * (copy_mbs_full - copy_mbs) / (n_mbs * n_pics),
+                         "mbs_per_launch": units_per_launch,
                          "avg_launch_us": avg_launch_us, "launches": launches,
                          "whole_path_GBs": path_gbs, "whole_path_frac": path_gbs / HBM_PEAK_GBS,
                          "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,

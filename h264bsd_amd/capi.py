@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdProfile", "h264bsdAlloc", "h264bsdFree", "h264bsdConvertToRGBA", "h264bsdConvertToBGRA",
     "h264bsdConvertToYCbCrA",
     "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync", "h264bsdmiDeviceErrors",
-    "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads", "h264bsdmiSetInputReadOnly",
+    "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads", "h264bsdmiSetInputReadOnly", "h264bsdmiSetCopyElision",
     "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayCreateSched", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiDebugSetTail", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
@@ -116,6 +116,8 @@ def lib():
     L.h264bsdmiDecodePictureBatch.argtypes = [u32, ctypes.POINTER(vp), ctypes.POINTER(vp), P32, P32, P32, P32, P32]
     L.h264bsdmiSetParserThreads.argtypes = [ctypes.c_int]
     L.h264bsdmiSetInputReadOnly.argtypes = [vp, u32]
+    L.h264bsdmiSetCopyElision.argtypes = [vp, u32]
+    L.h264bsdmiSetCopyElision.restype = ctypes.c_int
     L.h264bsdmiJobFinalize.argtypes = [ctypes.c_void_p, u32, u32]
     L.h264bsdmiSetDevice.argtypes = [ctypes.c_int]
     L.h264bsdmiReplayCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32]
@@ -174,9 +176,10 @@ def device_errors():
 class Decoder:
     """One decoder instance.  Method names follow the reference API (h264bsd_decoder.h)."""
 
-    def __init__(self, no_output_reordering=0, capture=None):
+    def __init__(self, no_output_reordering=0, capture=None, copy_elision=None):
         """capture: None -> pixels on the GPU (h264bsdInit; raises when there is no device);
-        a callable(bytes) -> parser only, every picture's frame job is handed to it."""
+        a callable(bytes) -> parser only, every picture's frame job is handed to it.
+        copy_elision: None -> the library's default (on with a device, off in capture mode), else h264bsdmiSetCopyElision."""
         L = lib()
         self._L = L
         self._st = L.h264bsdAlloc()
@@ -192,6 +195,8 @@ class Decoder:
             L.h264bsdFree(self._st)
             self._st = None
             raise RuntimeError("h264bsdInit failed: the HIP engine is not available (no CPU pixel path exists)")
+        if copy_elision is not None:
+            L.h264bsdmiSetCopyElision(self._st, 1 if copy_elision else 0)
 
     def close(self):
         if self._st:
@@ -364,11 +369,13 @@ def job_header(blob):
                 n_gen_uniform=n_gen_uniform, ghost=ghost, dbk_only=dbk_only)
 
 
-def capture_stream(data):
+def capture_stream(data, copy_elision=False):
     """Parse a byte stream on the host only.  Returns (jobs, trace, info): the packed frame job of every
-    picture in decode order, the h264bsdDecode call trace, and stream geometry."""
+    picture in decode order, the h264bsdDecode call trace, and stream geometry.  copy_elision: leave out the copies that
+    would rewrite what the destination frame buffer holds, like a decoder bound to a device does — such jobs are only
+    good for an in-order replay from an IDR picture onto persistent frames (Replay), not for rendering a picture alone."""
     jobs = []
-    dec = Decoder(capture=jobs.append)
+    dec = Decoder(capture=jobs.append, copy_elision=copy_elision)
     trace = dec.decode_stream(data, drain=False)
     info = dict(width_mbs=dec.pic_width(), height_mbs=dec.pic_height(), cropping=dec.cropping_params(),
                 video_range=dec.video_range(), matrix_coefficients=dec.matrix_coefficients(),

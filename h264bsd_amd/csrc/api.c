@@ -59,6 +59,11 @@ static u32 init_common(storage_t *s, u32 no_reorder, h264bsdmi_job_cb cb, void *
         hd_destroy(a->hd);
         free(a);
         return HANTRO_NOK;
+    } else {
+        /* bound to a device: the frames live from job to job, copies that would rewrite what a tile holds are left out
+         * (hostdec.h, copy elision).  H264BSDMI_COPY_ELISION=0 switches it off for the process. */
+        const char *e = getenv("H264BSDMI_COPY_ELISION");
+        a->hd->copy_elision = !(e && *e == '0');
     }
     s->opaque = a;
     return HANTRO_OK;
@@ -113,6 +118,14 @@ int h264bsdmiSetInputReadOnly(storage_t *s, u32 on)
     ApiDec *a = dec_of(s);
     if (!a) return -1;
     a->hd->input_readonly = on ? 1 : 0;
+    return 0;
+}
+
+int h264bsdmiSetCopyElision(storage_t *s, u32 on)
+{
+    ApiDec *a = dec_of(s);
+    if (!a) return -1;
+    a->hd->copy_elision = on ? 1 : 0;
     return 0;
 }
 

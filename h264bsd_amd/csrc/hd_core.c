@@ -55,6 +55,7 @@ void hd_destroy(HostDec *d)
     free(d->nal_buf);
     if (!d->job_from_sink) free(d->job);
     free(d->conv_buf);
+    free(d->tile_ver); free(d->tile_pending);
     free(d);
 }
 
@@ -120,7 +121,9 @@ static int in_intra_schedule(int kind)
 static __thread uint8_t *tl_scratch;
 static __thread size_t tl_scratch_cap;
 
-int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
+int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks) { return fj_finalize_ex(job, cap, coef_blocks, NULL); }
+
+int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *elide)
 {
     FjHeader *h = (FjHeader *)job;
     const uint32_t n = h->n_mbs, w = h->width_mbs;
@@ -249,20 +252,6 @@ int fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks)
                 gi->mvx = m0[0]; gi->mvy = m0[1]; gi->coef_idx = r->coef_idx; gi->coded = r->coded;
             }
         }
-        if (recon && (cls[a] & 2)) {
-            /* copy list: runs of up to FJ_COPY_RUN copy MBs with consecutive addresses, equal reference and mv; a run whose
-             * displacement is zero may continue into the next row (tiles are contiguous in address order) */
-            const int16_t *m0 = mvs[a][0];
-            FjCopy *last = n_copy ? &copy_tmp[n_copy - 1] : NULL;
-            if (last && last->count < FJ_COPY_RUN && (uint32_t)last->mb + last->count == a && (a % w != 0 || (m0[0] | m0[1]) == 0) &&
-                last->slot == r->ref_slot[0] && last->dx == (m0[0] >> 2) && last->dy == (m0[1] >> 2)) {
-                last->count++;
-            } else {
-                copy_tmp[n_copy].mb = (uint16_t)a; copy_tmp[n_copy].slot = r->ref_slot[0]; copy_tmp[n_copy].count = 1;
-                copy_tmp[n_copy].dx = (int16_t)(m0[0] >> 2); copy_tmp[n_copy].dy = (int16_t)(m0[1] >> 2);
-                n_copy++;
-            }
-        }
 deblock_index:
         {
             /* deblocking: a uniform MB whose filtered left/top neighbours are uniform too, with the same reference and
@@ -281,6 +270,34 @@ deblock_index:
             }
             r->dbk_trivial = (uint8_t)trivial;
             if (!trivial) dbk_tmp[n_dbk++] = (uint16_t)a;
+        }
+    }
+    /* ---- copy list: runs of up to FJ_COPY_RUN copy MBs with consecutive addresses, equal reference and mv; a run whose
+     * displacement is zero may continue into the next row (tiles are contiguous in address order).  Built after the raster
+     * pass because copy elision looks at the deblocking verdict of the macroblocks to the right and below: a zero-motion
+     * copy is CLEAN when neither its own filter nor that of the two macroblocks that could reach into its tile runs; a
+     * clean copy makes the destination tile equal to the source tile, so its tile inherits the source's number, and when
+     * the destination carried that number already the copy would write what is there — it is left out. ---- */
+    if (elide && !recon_all) elide = NULL;                 /* (callers do not ask for it either) */
+    for (uint32_t a = 0; a < n; a++) {
+        const FjMbRec *r = &recs[a];
+        if (elide) elide->out[a] = elide->serial;
+        if (!(RECON(r) && (cls[a] & 2))) continue;
+        const int16_t *m0 = mvs[a][0];
+        if (elide && (m0[0] | m0[1]) == 0 && r->ref_slot[0] < elide->n_slots && r->ref_slot[0] != elide->cur_slot && r->dbk_trivial &&
+            ((a + 1) % w == 0 || recs[a + 1].dbk_trivial) && (a + w >= n || recs[a + w].dbk_trivial)) {
+            const uint32_t v = elide->ver[(size_t)r->ref_slot[0] * n + a];
+            elide->out[a] = v;
+            if (elide->ver[(size_t)elide->cur_slot * n + a] == v) { elide->n_elided++; continue; }
+        }
+        FjCopy *last = n_copy ? &copy_tmp[n_copy - 1] : NULL;
+        if (last && last->count < FJ_COPY_RUN && (uint32_t)last->mb + last->count == a && (a % w != 0 || (m0[0] | m0[1]) == 0) &&
+            last->slot == r->ref_slot[0] && last->dx == (m0[0] >> 2) && last->dy == (m0[1] >> 2)) {
+            last->count++;
+        } else {
+            copy_tmp[n_copy].mb = (uint16_t)a; copy_tmp[n_copy].slot = r->ref_slot[0]; copy_tmp[n_copy].count = 1;
+            copy_tmp[n_copy].dx = (int16_t)(m0[0] >> 2); copy_tmp[n_copy].dy = (int16_t)(m0[1] >> 2);
+            n_copy++;
         }
     }
     if (n_conceal) {
@@ -419,12 +436,64 @@ static void fill_undecoded(HostDec *d)
         }
 }
 
-int hd_job_finish(HostDec *d, int is_idr)
+/* ---- copy elision: the numbers of the tiles (hostdec.h) ---- */
+static void tiles_fresh_slot(HostDec *d, uint32_t slot)
+{
+    const uint32_t v = ++d->tile_serial;
+    uint32_t *t = d->tile_ver + (size_t)slot * d->tile_mbs;
+    for (uint32_t a = 0; a < d->tile_mbs; a++) t[a] = v;
+}
+
+static void tiles_forget(HostDec *d)
+{
+    for (uint32_t s = 0; d->tile_ver && s < d->tile_slots; s++) tiles_fresh_slot(d, s);
+    d->tile_uncommitted = 0;
+}
+
+/* a new sequence: the sink (re)allocates the frames */
+static int tiles_reset(HostDec *d, uint32_t n_slots, uint32_t n_mbs)
+{
+    free(d->tile_ver); free(d->tile_pending);
+    d->tile_ver = (uint32_t *)malloc((size_t)n_slots * n_mbs * sizeof(uint32_t));
+    d->tile_pending = (uint32_t *)malloc((size_t)n_mbs * sizeof(uint32_t));
+    d->tile_slots = n_slots; d->tile_mbs = n_mbs;
+    if (!d->tile_ver || !d->tile_pending) { free(d->tile_ver); free(d->tile_pending); d->tile_ver = d->tile_pending = NULL; d->tile_slots = 0; return -1; }
+    tiles_forget(d);
+    return 0;
+}
+
+/* the sink has taken the picture's last job: its tiles are what the job said */
+static void tiles_commit(HostDec *d)
+{
+    if (!d->tile_uncommitted) return;
+    memcpy(d->tile_ver + (size_t)d->tile_pending_slot * d->tile_mbs, d->tile_pending, (size_t)d->tile_mbs * sizeof(uint32_t));
+    d->tile_uncommitted = 0;
+}
+
+/* single_job: the picture is this one job (no reconstruction-only jobs before it, not a deblock-only job): the only case in
+ * which copies are left out; any other picture just gives all its tiles a new number */
+int hd_job_finish(HostDec *d, int is_idr, int single_job)
 {
     FjHeader *h = (FjHeader *)d->job;
     fill_undecoded(d);
-    if (fj_finalize(d->job, d->job_cap, d->coef_blocks)) return -1;
-    h->cur_slot = (uint8_t)hd_dpb_cur_slot(&d->dpb);
+    const uint32_t cur = (uint32_t)hd_dpb_cur_slot(&d->dpb);
+    FjElide el, *elide = NULL;
+    d->n_elided = 0;
+    if (d->tile_ver && d->tile_mbs == h->n_mbs && cur < d->tile_slots) {
+        if (d->tile_uncommitted) tiles_forget(d);             /* the previous picture never reached the sink */
+        /* An IDR picture starts a sequence that must be decodable on its own — replay sets start there — so nothing that
+         * the other slots held before it is relied on afterwards */
+        if (is_idr) for (uint32_t s = 0; s < d->tile_slots; s++) if (s != cur) tiles_fresh_slot(d, s);
+        el.ver = d->tile_ver; el.n_slots = d->tile_slots; el.cur_slot = cur; el.serial = ++d->tile_serial;
+        el.out = d->tile_pending; el.n_elided = 0;
+        if (d->copy_elision && single_job && !h->dbk_only && !h->ghost) elide = &el;
+        else for (uint32_t a = 0; a < d->tile_mbs; a++) d->tile_pending[a] = el.serial;
+        d->tile_pending_slot = cur;
+        d->tile_uncommitted = 1;
+    }
+    if (fj_finalize_ex(d->job, d->job_cap, d->coef_blocks, elide)) return -1;
+    if (elide) d->n_elided = el.n_elided;
+    h->cur_slot = (uint8_t)cur;
     h->n_slots = (uint8_t)d->dpb.n_slots;
     h->is_idr = (uint8_t)is_idr;
     h->pic_seq = d->pic_seq++;
@@ -496,6 +565,7 @@ static int activate_param_sets(HostDec *d, uint32_t pps_id, int is_idr)
         if (hd_dpb_reset(&d->dpb, s->max_dpb_size, s->num_ref_frames, s->max_frame_num, no_reorder)) return -1;
         if (d->sink.configure &&
             d->sink.configure(d->sink.user, d->width_mbs, d->height_mbs, d->dpb.n_slots)) return -2;
+        if (tiles_reset(d, d->dpb.n_slots, d->pic_size_mbs)) return -2;
         d->sink_configured = 1;
     } else if ((int)pps_id != d->active_pps_id) {
         if (p->sps_id != d->active_sps_id) {
@@ -1035,9 +1105,10 @@ int hd_decode(HostDec *d, uint8_t *stream, uint32_t len, uint32_t pic_id, uint32
                     if (hd_job_begin(d)) return HD_MEMALLOC_ERROR;
                     (void)plan_concealment(d, 1);
                     d->num_decoded_mbs = d->pic_size_mbs;
-                    if (hd_job_finish(d, 0)) ERR_RETURN;
+                    if (hd_job_finish(d, 0, 1)) ERR_RETURN;
                     ((FjHeader *)d->job)->ghost = 1;
                     if (d->sink.submit(d->sink.user, d->job, ((FjHeader *)d->job)->total_bytes)) ERR_RETURN;
+                    tiles_commit(d);
                     reset_picture_state(d);
                 }
                 (void)hd_decode_poc(&d->poc, d->active_sps, &d->slice, d->cur_nal_type, d->cur_nal_ref_idc);
@@ -1135,7 +1206,7 @@ int hd_decode(HostDec *d, uint8_t *stream, uint32_t len, uint32_t pic_id, uint32
     fill_undecoded(d);
     if (d->slice_ids_rewritten) restamp_slice_edges(d);
     if (d->n_redo && !(earlier[0] = redo_split(d, &earlier[1]))) ERR_RETURN;
-    if (hd_job_finish(d, is_idr)) { free(earlier[0]); free(earlier[1]); ERR_RETURN; }
+    if (hd_job_finish(d, is_idr, !d->ghost_needed && !earlier[0] && !earlier[1])) { free(earlier[0]); free(earlier[1]); ERR_RETURN; }
     if (d->ghost_needed && ghost_submit(d)) { free(earlier[0]); free(earlier[1]); ERR_RETURN; }
     for (int k = 0, rc = 0; k < 2; k++) {
         if (earlier[k] && !rc) {
@@ -1152,6 +1223,7 @@ int hd_decode(HostDec *d, uint8_t *stream, uint32_t len, uint32_t pic_id, uint32
         fprintf(stderr, "h264bsd-mi355x: frame job submission failed\n");
         ERR_RETURN;
     }
+    tiles_commit(d);
     reset_picture_state(d);
     int32_t poc = hd_decode_poc(&d->poc, d->active_sps, &d->slice, d->cur_nal_type, d->cur_nal_ref_idc);
     hd_dpb_mark_current(&d->dpb, &d->slice, d->cur_nal_ref_idc != 0, is_idr, poc, d->current_pic_id, err_mbs);

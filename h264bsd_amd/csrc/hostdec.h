@@ -314,7 +314,27 @@ typedef struct HostDec {
     JobSink sink;
     uint8_t  sink_configured;
     uint32_t *conv_buf; size_t conv_cap;
+
+    /* Copy elision (hd_core.c, hd_tiles_*): what every tile of every DPB slot holds, as the serial number of the job that
+     * last produced NEW content for it; a whole-tile copy that nothing filters afterwards inherits the number of its source.
+     * A copy whose destination already carries the source's number would write the bytes that are there: it is left out
+     * of the job's copy list.  tile_ver = [n_slots][pic_size_mbs]; tile_pending = the numbers of the job being submitted,
+     * committed when the sink has taken it. */
+    uint8_t  copy_elision;          /* on for decoders bound to a device, off in capture mode unless asked for (h264bsdmiSetCopyElision) */
+    uint8_t  tile_uncommitted;      /* a job was finalised but its submission was never confirmed: nothing is known any more */
+    uint32_t *tile_ver, *tile_pending;
+    uint32_t tile_slots, tile_mbs, tile_serial, tile_pending_slot;
+    uint32_t n_elided;              /* macroblocks left out of the last job's copy list */
 } HostDec;
+
+/* what fj_finalize_ex needs to leave copies out (NULL: a frame job is a pure function of records, vectors and coefficients) */
+typedef struct FjElide {
+    const uint32_t *ver;            /* [n_slots][n_mbs] */
+    uint32_t n_slots, cur_slot;
+    uint32_t serial;                /* number for the tiles this job gives new content */
+    uint32_t *out;                  /* [n_mbs]: the numbers of cur_slot after this job */
+    uint32_t n_elided;
+} FjElide;
 
 /* return codes shared with the public API (reference src/h264bsd_decoder.h:45-52) */
 enum { HD_RDY = 0, HD_PIC_RDY = 1, HD_HDRS_RDY = 2, HD_ERROR = 3, HD_PARAM_SET_ERROR = 4, HD_MEMALLOC_ERROR = 5 };
@@ -364,8 +384,9 @@ int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_
 int hd_redo_keep_first(HostDec *d, uint32_t addr, const FjMbRec *rec, const int16_t *mv);
 /* hd_api.c helpers used across files */
 int  hd_job_begin(HostDec *d);
-int  hd_job_finish(HostDec *d, int is_idr);
+int  hd_job_finish(HostDec *d, int is_idr, int single_job);
 int  fj_finalize(uint8_t *job, uint32_t cap, uint32_t coef_blocks);
+int  fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *elide);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,15 @@ int h264bsdmiSetParserThreads(int n);
  * the same, the h264bsdDecode() call trace can differ from the reference's only where a NAL unit that contains emulation-
  * prevention bytes is fed a second time.  Returns 0. */
 int h264bsdmiSetInputReadOnly(storage_t *pStorage, u32 on);
+/* Copy elision.  The parser knows what every macroblock tile of every frame buffer holds: a P macroblock that copies the
+ * co-located macroblock of its reference (zero motion, no residual) and that no deblocking edge touches leaves its tile
+ * equal to the reference's, and frame buffers are reused in rotation — so the buffer a picture is decoded into often holds
+ * exactly those bytes already (a region that has not changed since the buffer's previous picture).  Such copies are left out
+ * of the frame job: nothing is read, nothing is written, the picture is bit-identical.  ON by default for decoders bound
+ * to a device (env H264BSDMI_COPY_ELISION=0 switches it off for the process), OFF by default in capture mode, where a
+ * frame job is then a pure function of its picture; a capture that is replayed IN ORDER from an IDR picture onto frames
+ * that persist (the bench harness's replay sets) may switch it on.  Call before the first h264bsdDecode().  Returns 0. */
+int h264bsdmiSetCopyElision(storage_t *pStorage, u32 on);
 
 /* ---- device engine ---- */
 /* Number of usable GPUs (0 when the HIP runtime finds none); selects the device for this process. */

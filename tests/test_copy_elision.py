@@ -1,0 +1,149 @@
+"""Copy elision (include/h264bsd_mi355x.h, h264bsdmiSetCopyElision; hd_core.c, hd_job_finish / fj_finalize_ex).
+
+The parser leaves a whole-tile copy out of a frame job when the destination frame buffer already holds the source's
+bytes.  What must hold for that to be invisible: after every job, a frame buffer that only receives the tiles the
+ELIDED job still writes — and keeps its old bytes everywhere else — equals the buffer of the full decode.  The CPU
+tests replay exactly that with the oracle's pictures as the truth (the oracle renders from the records and knows
+nothing about copy lists): tile by tile, job by job, on the bundled, the synthetic and the damaged streams.  The GPU
+tests run elided captures through the replay harness and compare with the reference's checksums; every GPU test that
+goes through h264bsdInit() exercises elision anyway (it is on by default with a device)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import STREAMS, stream_bytes
+from oracle import pyoracle
+from h264writer import StreamWriter
+from synth_configs import CONFIGS
+import test_damaged_streams as dmg
+
+
+def _copy_mbs(job, h):
+    mbs = np.zeros(h["n_mbs"], dtype=bool)
+    for i in range(h["n_copy"]):
+        mb, slot, count, dx, dy = struct.unpack_from("<HBBhh", job, h["copy_off"] + 8 * i)
+        mbs[mb:mb + count] = True
+    return mbs
+
+
+
+def _tiles(frame, wmb, hmb):
+    """planar I420 picture (the oracle's frame buffers) -> [n_mbs][384]: the samples of every macroblock"""
+    w, h = 16 * wmb, 16 * hmb
+    y = frame[: w * h].reshape(hmb, 16, wmb, 16).transpose(0, 2, 1, 3).reshape(wmb * hmb, 256)
+    c = frame[w * h: w * h * 3 // 2].reshape(2, hmb, 8, wmb, 8).transpose(1, 3, 0, 2, 4).reshape(wmb * hmb, 128)
+    return np.concatenate([y, c], axis=1)
+
+
+def replay_with_elision(built, data):
+    """-> (copy macroblocks of the full decode, macroblocks left out).  Raises AssertionError where a tile that an elided
+    job does not write differs from the full decode."""
+    full, _, _ = built.capture_stream(data)
+    lean, _, _ = built.capture_stream(data, copy_elision=True)
+    assert len(full) == len(lean)
+    dpb, sim, n_copy, n_elided = None, None, 0, 0
+    for k, (jf, jl) in enumerate(zip(full, lean)):
+        hf, hl = built.job_header(jf), built.job_header(jl)
+        if dpb is None or hf["n_slots"] != len(dpb.slots) or dpb.frame_bytes != hf["n_mbs"] * 384:
+            dpb = pyoracle.OracleDpb(jf)
+            sim = [np.zeros((hf["n_mbs"], 384), dtype=np.uint8) for _ in dpb.slots]
+        # elision changes the copy list and nothing else
+        for key in ("n_mbs", "cur_slot", "is_idr", "n_intra", "n_gen", "n_dbk", "n_gen_uniform", "ghost", "dbk_only", "n_coef_blocks", "copy_off"):
+            assert hf[key] == hl[key], (k, key)
+        assert jf[128:hf["copy_off"]] == jl[128:hl["copy_off"]], f"job {k}: records / vectors / coefficients / intra schedule differ"
+        assert jf[hf["gen_off"]:hf["gen_off"] + 16 * hf["n_gen"]] == jl[hl["gen_off"]:hl["gen_off"] + 16 * hl["n_gen"]]
+        assert jf[hf["dbk_off"]:hf["dbk_off"] + 2 * hf["n_dbk"]] == jl[hl["dbk_off"]:hl["dbk_off"] + 2 * hl["n_dbk"]]
+        cf, cl = _copy_mbs(jf, hf), _copy_mbs(jl, hl)
+        assert not (cl & ~cf).any()
+        elided = cf & ~cl
+        truth = _tiles(dpb.decode(jf), hf["width_mbs"], hf["height_mbs"])
+        s = sim[hf["cur_slot"]]
+        s[~elided] = truth[~elided]
+        bad = np.nonzero((s != truth).any(axis=1))[0]
+        assert bad.size == 0, f"job {k}: {bad.size} elided tiles do not hold the picture's bytes, first macroblock {bad[0]}"
+        n_copy += int(cf.sum())
+        n_elided += int(elided.sum())
+    return n_copy, n_elided
+
+
+@pytest.mark.parametrize("name", STREAMS)
+def test_bundled_streams(built, name):
+    n_copy, n_elided = replay_with_elision(built, stream_bytes(name))
+    assert n_elided > 0.2 * n_copy                         # the point of it: 41 % of the copies of the 1080p stream
+    if name == "test_1920x1080":
+        assert (n_copy, n_elided) == (362795, 149207)
+
+
+def test_synthetic_streams(built):
+    total = [0, 0]
+    for name, cfg in CONFIGS.items():
+        c, e = replay_with_elision(built, StreamWriter(**cfg).build())
+        total[0] += c
+        total[1] += e
+    assert total[1] > 0
+
+
+def test_damaged_streams(built):
+    """multi-job pictures (ghost / redo jobs), concealment copies, stale macroblocks, rolled-back slices"""
+    total = [0, 0]
+    for name in dmg.NAMES:
+        try:
+            data = dmg.stream_of(name)
+        except pytest.skip.Exception:
+            continue
+        c, e = replay_with_elision(built, data)
+        total[0] += c
+        total[1] += e
+    assert total[0] > 0
+
+
+def test_off_in_capture_mode_by_default(built, captured):
+    """a captured frame job stays a pure function of its picture unless elision is asked for"""
+    jobs, _, _ = captured("test_640x360")
+    again, _, _ = built.capture_stream(stream_bytes("test_640x360"), copy_elision=False)
+    assert [bytes(j) for j in jobs] == [bytes(j) for j in again]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", STREAMS)
+def test_gpu_replay_of_elided_jobs(built, golden, name):
+    """the bench's form: elided jobs replayed in order onto persistent frames, picture by picture, two laps (the second
+    lap finds the frames of the first in the buffers), every picture of every stream against the reference's checksum"""
+    jobs, _, _ = built.capture_stream(stream_bytes(name), copy_elision=True)
+    heads = [built.job_header(j) for j in jobs]
+    assert sum(h["n_copy_mbs"] for h in heads) < sum(built.job_header(j)["n_copy_mbs"] for j in built.capture_stream(stream_bytes(name))[0])
+    g = golden[name]["frame_checksum64"]
+    rep = built.Replay(jobs, n_streams=3)
+    try:
+        for lap in range(2):
+            for i in range(len(jobs)):
+                rep.run(i, 1)
+                sums = rep.checksums(heads[i]["cur_slot"])
+                assert [int(x) for x in sums] == [g[i]] * 3, (lap, i)
+    finally:
+        rep.close()
+
+
+@pytest.mark.gpu
+def test_gpu_desynchronised_replay_of_elided_jobs(built, golden):
+    """streams that start in mid-sequence decode garbage until their first IDR picture — and nothing an elided job relies
+    on is older than the last IDR picture, so after a lap every stream's last picture is right"""
+    name = "test_640x360"
+    jobs, _, _ = built.capture_stream(stream_bytes(name), copy_elision=True)
+    heads = [built.job_header(j) for j in jobs]
+    g = golden[name]["frame_checksum64"]
+    n, S = len(jobs), 23
+    offsets = [(s * n) // S for s in range(S)]
+    rep = built.Replay(jobs, n_streams=S, offsets=offsets, heavy_lanes=2, heavy_delay=3, groups=4)
+    try:
+        for lap in range(3):
+            rep.run()
+            rep.sync()
+            sums = {slot: rep.checksums(slot) for slot in set(h["cur_slot"] for h in heads)}
+            for s in range(S):
+                last = (offsets[s] - 1) % n
+                assert int(sums[heads[last]["cur_slot"]][s]) == g[last], (lap, s, last)
+    finally:
+        rep.close()
