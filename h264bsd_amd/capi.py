@@ -356,7 +356,7 @@ def job_header(blob):
     import struct
     (magic, total, wmb, hmb, n_mbs, cur, is_idr, n_slots, any_dbk, rec_off, mv_off, lvl_off, idx_off, coef_off,
      n_intra, n_levels, n_coef, n_inter, pic_seq, copy_off, n_copy, gen_off, n_gen, dbk_off, n_dbk, n_gen_uniform, ghost,
-     dbk_only) = struct.unpack_from("<IIHHIBBBBIIIIIIIIIIIIIIIIIII", blob, 0)
+     dbk_only, _down, n_gen_quad) = struct.unpack_from("<IIHHIBBBBIIIIIIIIIIIIIIIIIIIII", blob, 0)
     if magic != 0x314A4648:
         raise ValueError("not a frame job")
     # FjCopy entries are 8 bytes {u16 mb, u8 slot, u8 count, i16 dx, i16 dy}: macroblocks moved by k_copy
@@ -366,7 +366,7 @@ def job_header(blob):
                 idx_off=idx_off, coef_off=coef_off, n_intra=n_intra, n_intra_levels=n_levels,
                 n_coef_blocks=n_coef, n_inter=n_inter, pic_seq=pic_seq, copy_off=copy_off, n_copy=n_copy,
                 gen_off=gen_off, n_gen=n_gen, dbk_off=dbk_off, n_dbk=n_dbk, n_copy_mbs=n_copy_mbs,
-                n_gen_uniform=n_gen_uniform, ghost=ghost, dbk_only=dbk_only)
+                n_gen_uniform=n_gen_uniform, n_gen_quad=n_gen_quad, ghost=ghost, dbk_only=dbk_only)
 
 
 def capture_stream(data, copy_elision=False):

@@ -7,7 +7,8 @@
  * through the DPB; pictures of different streams never do).  A tick of N pictures is SIX launches (launch_tick):
  *     k_copy            grid (32, N)          x 256  whole-sample copy macroblocks, one run of <= 8 tiles per wavefront
  *     k_recon_inter<0>  grid (n_uni/4, N)     x 256  inter macroblocks with one motion vector, one wavefront each
- *     k_recon_inter<1>  grid (n_part/4, N)    x 256  partitioned inter macroblocks
+ *     k_recon_inter<1>  grid (n_quad/4, N)    x 256  inter macroblocks with one motion vector per 8x8 quadrant
+ *     k_recon_inter<2>  grid (n_rest/4, N)    x 256  finer partitions
  *     k_dbk             grid (32, N)          x 256  boundary strengths from metadata; on a second HIP stream, next to the three above
  *     k_frame_intra     grid (N)              x 768  one workgroup per picture: intra macroblocks, dataflow-scheduled in LDS
  *     k_frame_dbk       grid (N)              x 768  one workgroup per picture: in-loop filter, dataflow-scheduled in LDS
@@ -323,7 +324,7 @@ static uint32_t *tickets_for(hipStream_t st)
 /* ---- launch of one tick ---- */
 struct TickShape {
     uint32_t n_frames = 0, max_mbs = 0;
-    uint32_t max_copy = 0, max_gen = 0, max_gen_uni = 0, max_gen_rest = 0, max_dbk = 0, max_levels = 0, max_w = 0, max_h = 0;
+    uint32_t max_copy = 0, max_gen = 0, max_gen_uni = 0, max_gen_quad = 0, max_gen_rest = 0, max_dbk = 0, max_levels = 0, max_w = 0, max_h = 0;
     bool any_tail = false, any_deblock = false;
     uint32_t dbk_waves = 0;          /* wavefronts per workgroup of k_frame_dbk; 0 = the configured default (launch_tick) */
     /* row bands of the two per-picture kernels: most bands a light / a heavy picture of the tick wants, for k_frame_dbk [0]
@@ -348,6 +349,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     d.n_copy = h->n_copy;
     d.n_gen = h->n_gen;
     d.n_gen_uni = h->n_gen_uniform;
+    d.n_gen_quad = h->n_gen_quad;
     d.dbki = reinterpret_cast<const uint16_t *>(dev_blob + h->dbk_off);
     d.n_dbk = h->n_dbk;
     d.dbk = dev_dbk;
@@ -374,7 +376,8 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
         shape->max_copy = std::max(shape->max_copy, h->n_copy);
         shape->max_gen = std::max(shape->max_gen, h->n_gen);
         shape->max_gen_uni = std::max(shape->max_gen_uni, h->n_gen_uniform);
-        shape->max_gen_rest = std::max(shape->max_gen_rest, h->n_gen - h->n_gen_uniform);
+        shape->max_gen_quad = std::max(shape->max_gen_quad, h->n_gen_quad);
+        shape->max_gen_rest = std::max(shape->max_gen_rest, h->n_gen - h->n_gen_uniform - h->n_gen_quad);
         shape->max_dbk = std::max(shape->max_dbk, h->n_dbk);
         shape->any_deblock |= h->any_deblock != 0;
         shape->max_levels = std::max(shape->max_levels, h->n_intra_levels);
@@ -434,7 +437,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     if (EV_NEEDED(1)) HIP_TRY(hipEventRecord(tt->ev[1], st));
     if ((stages & 1u) && s.max_gen) {
         if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_inter<0>, dim3((s.max_gen_uni + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
-        if (s.max_gen_rest) hipLaunchKernelGGL(h264k::k_recon_inter<1>, dim3((s.max_gen_rest + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
+        if (s.max_gen_quad) hipLaunchKernelGGL(h264k::k_recon_inter<1>, dim3((s.max_gen_quad + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
+        if (s.max_gen_rest) hipLaunchKernelGGL(h264k::k_recon_inter<2>, dim3((s.max_gen_rest + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[1]++;
     }
     if (EV_NEEDED(2)) HIP_TRY(hipEventRecord(tt->ev[2], st));

@@ -133,7 +133,9 @@ typedef struct FjHeader {
     uint32_t intra_down_deps; /* 1: the intra schedule holds concealed macroblocks, which may wait for the macroblock BELOW them
                                  (FJ_NEED_D) and read all four neighbours: the picture's intra reconstruction must not be split
                                  into row bands (k_frame_intra) */
-    uint32_t reserved[7];
+    uint32_t n_gen_quad;      /* of the partitioned entries behind the first n_gen_uniform, the first n_gen_quad have one motion vector
+                                 per 8x8 quadrant (FjGen.uniform == 2: 16x8, 8x16, 8x8 partitions), the rest finer partitions */
+    uint32_t reserved[6];
 } FjHeader;                   /* 128 bytes */
 
 /* An inter macroblock with no coefficients whose 16 motion vectors are equal and whole-sample for

@@ -348,13 +348,15 @@ deblock_index:
     h->total_bytes = fj_align32(h->dbk_off + n_dbk * 2u);
     if (h->total_bytes > cap) return -1;
     memcpy(job + h->copy_off, copy_tmp, (size_t)n_copy * 8u);
-    {   /* general-inter list: the entries with one motion vector per macroblock first (k_recon_inter<0>), then the
-         * partitioned ones (k_recon_inter<1>); both parts keep raster order */
+    {   /* general-inter list: the entries with one motion vector per macroblock first (k_recon_inter<0>), then those with
+         * one per 8x8 quadrant (<1>), then the finer partitions (<2>); every part keeps raster order */
         FjGen *dst = (FjGen *)(job + h->gen_off);
         uint32_t k = 0;
         for (uint32_t i = 0; i < n_gen; i++) if (gen_tmp[i].uniform == 1) dst[k++] = gen_tmp[i];
         h->n_gen_uniform = k;
-        for (uint32_t i = 0; i < n_gen; i++) if (gen_tmp[i].uniform != 1) dst[k++] = gen_tmp[i];
+        for (uint32_t i = 0; i < n_gen; i++) if (gen_tmp[i].uniform == 2) dst[k++] = gen_tmp[i];
+        h->n_gen_quad = k - h->n_gen_uniform;
+        for (uint32_t i = 0; i < n_gen; i++) if (gen_tmp[i].uniform == 0) dst[k++] = gen_tmp[i];
     }
     memcpy(job + h->dbk_off, dbk_tmp, (size_t)n_dbk * 2u);
     {   /* intra schedule: the scheduled MB addresses sorted by dependency level, ascending address inside a level */

@@ -53,6 +53,7 @@ struct FrameDesc {
     uint8_t        *cur;          /* slot that receives the picture */
     uint32_t        n_mbs, n_levels, n_copy, n_gen, n_dbk;
     uint32_t        n_gen_uni;    /* the first n_gen_uni entries of gen have one motion vector for the whole macroblock */
+    uint32_t        n_gen_quad;   /* the next n_gen_quad one motion vector per 8x8 quadrant, the rest finer partitions */
     uint16_t        wmb, hmb;
     uint32_t        any_deblock;
     uint16_t        dbk_bands, intra_bands;   /* row bands (= workgroups) the per-picture kernels may split this picture into (>= 1; the launch caps it) */
@@ -750,9 +751,10 @@ constexpr int INTER_WAVE_LDS = 2688;                 /* max(21 * IW_STRIDE + 2 *
 #ifndef INTER_OCC
 #define INTER_OCC 8      /* macroblock-tile layout: 8 waves per SIMD (64 VGPRs, more spills) beat 7 / 6 / 5: 50.4 vs 54.4 / 58.9 / 59.2 ms per step — the kernel hides latency with wavefronts */
 #endif
-/* Two instantiations share the list: PATH 0 reconstructs the entries with one motion vector per macroblock (82 % of
- * them), PATH 1 the partitioned ones.  Compiled separately, each gets the registers its own path needs — the common
- * case no longer pays (in spills at 8 waves per SIMD) for the per-lane window code of the rare one. */
+/* Three instantiations share the list: PATH 0 reconstructs the entries with one motion vector per macroblock (82 % of
+ * them in the bundled 1080p stream), PATH 1 those with one per 8x8 quadrant (16x8, 8x16, 8x8 partitions: all the others
+ * of that stream), PATH 2 the finer partitions.  Compiled separately, each gets the registers its own path needs — the
+ * common cases do not pay (in spills at 8 waves per SIMD) for the per-lane window code of the rare one. */
 #ifndef INTER_OCC_PART
 #define INTER_OCC_PART INTER_OCC
 #endif
@@ -763,8 +765,8 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
     const FrameDesc &fd = FD_REF(frames, blockIdx.y);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform: the list entry, the record and
                                                                                  everything derived live in scalar registers */
-    const uint32_t gi = (PATH == 0 ? 0u : fd.n_gen_uni) + blockIdx.x * 4 + wave;
-    if (gi >= (PATH == 0 ? fd.n_gen_uni : fd.n_gen)) return;
+    const uint32_t gi = (PATH == 0 ? 0u : PATH == 1 ? fd.n_gen_uni : fd.n_gen_uni + fd.n_gen_quad) + blockIdx.x * 4 + wave;
+    if (gi >= (PATH == 0 ? fd.n_gen_uni : PATH == 1 ? fd.n_gen_uni + fd.n_gen_quad : fd.n_gen)) return;
     /* list entry and record as whole dwords from a wave-uniform address in read-only memory: scalar loads (there is no scalar
      * byte load: a struct copy would fetch the byte-sized members with vector loads and wait for them) */
     FjGen ge;
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
     const int16_t *coef = (const int16_t *)((const H264K_CONST int16_t *)fd.coefs + 16 * (size_t)ge.coef_idx);
     H264K_GLOBAL uint8_t *cur = (H264K_GLOBAL uint8_t *)fd.cur;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
-    const bool uniform = PATH == 0, quadwise = PATH == 1 && ge.uniform == 2;
+    const bool uniform = PATH == 0, quadwise = PATH == 1;
     uint32_t refs = ge.slot * 0x01010101u, mv_mine = 0;
     const uint32_t mv0 = (uint32_t)(uint16_t)ge.mvx | ((uint32_t)(uint16_t)ge.mvy << 16);
     if (!uniform) {

@@ -52,7 +52,11 @@ def test_lists_cover_exactly_what_the_records_reconstruct(built, name):
         assert len(listed) == len(set(listed)), "a macroblock is scheduled twice"
         assert set(listed) == recon, (sorted(set(listed) ^ recon), h["ghost"], h["dbk_only"])
         assert all(kind[a] in (INTER, CONCEAL_P) for a in copied + gen)
-        assert h["n_gen_uniform"] <= h["n_gen"]
+        assert h["n_gen_uniform"] + h["n_gen_quad"] <= h["n_gen"]
+        # the three parts of the general-inter list (k_recon_inter<0/1/2> each walk one): one motion vector per macroblock,
+        # one per 8x8 quadrant, finer partitions
+        kinds = [j[h["gen_off"] + 16 * i + 2] for i in range(h["n_gen"])]
+        assert kinds == [1] * h["n_gen_uniform"] + [2] * h["n_gen_quad"] + [0] * (h["n_gen"] - h["n_gen_uniform"] - h["n_gen_quad"])
         lvl = struct.unpack_from(f"<{h['n_intra_levels'] + 1}I", j, h["lvl_off"]) if h["n_intra"] else (0,)
         assert list(lvl) == sorted(lvl) and lvl[0] == 0 and lvl[-1] == h["n_intra"]
         dbk = [struct.unpack_from("<H", j, h["dbk_off"] + 2 * i)[0] for i in range(h["n_dbk"])]

@@ -1,12 +1,11 @@
 #!/bin/bash
-# GPU box: kernel parity (random jobs + bundled streams), then one lock-step timing
+# GPU box: kernel parity (TESTS, default: random jobs + bundled + synthetic streams), then lock-step timings
 set -u
 out=gpurun_out/quick; rm -rf $out; mkdir -p $out
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random_jobs.py -x -q -m gpu > $out/tests.log 2>&1
+timeout 1500 python -m pytest ${TESTS:-tests/test_gpu_parity.py tests/test_gpu_random_jobs.py tests/test_synth_streams.py} -x -q -m gpu > $out/tests.log 2>&1
 tail -3 $out/tests.log
-for i in 1 2 3; do
-if [ $i = 3 ]; then export H264BSDMI_NO_AHEAD=1; echo "no ahead:"; fi
-timeout 300 python bench.py --steps 3 --warmup 1 --ramp-seconds 2 --no-cpu-baseline --no-staggered --no-desync --no-argb --no-end-to-end --no-groups-variant ${BENCH_EXTRA:-} 2> $out/err.log | tail -1 > $out/b.json
+for i in 1 2; do
+timeout 300 python bench.py --steps 5 --warmup 1 --ramp-seconds 2 --no-cpu-baseline --no-staggered --no-desync --no-argb --no-end-to-end --no-groups-variant ${BENCH_EXTRA:-} 2> $out/err.log | tail -1 > $out/b.json
 python - <<'P'
 import json
 try:
