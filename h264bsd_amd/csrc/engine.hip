@@ -254,7 +254,7 @@ Engine *engine_get(int device = -1)
         hipEventCreateWithFlags(&e->side.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->side.join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->side.join_copy, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc((void **)&e->d_err, 256) != hipSuccess || hipMemset(e->d_err, 0, 256) != hipSuccess ||
+        hipMalloc((void **)&e->d_err, 256) != hipSuccess || hipMemset(e->d_err, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||   /* (hipMemset returns before the fill has run) */
         hipHostMalloc((void **)&e->h_err, 64, hipHostMallocDefault) != hipSuccess) { delete e; return nullptr; }
     *e->h_err = 0;
     g_engines[device] = e;
@@ -315,8 +315,11 @@ static uint32_t *tickets_for(hipStream_t st)
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
     std::lock_guard<std::mutex> lk(g_ticket_mu);
     for (auto &p : g_tickets[dev]) if (p.first == st) return p.second;
+    /* zeroed ON the stream whose kernels count in it: hipMemset() on device memory returns before the fill has run, on the
+     * null stream, which the (non-blocking) lane streams do not wait for — a fill that landed in the middle of the first
+     * banded launch handed out tickets twice and left a band of a picture without a workgroup (rare, under load only) */
     uint32_t *d = nullptr;
-    if (hipMalloc((void **)&d, 64) != hipSuccess || hipMemset(d, 0, 64) != hipSuccess) return nullptr;
+    if (hipMalloc((void **)&d, 64) != hipSuccess || hipMemsetAsync(d, 0, 64, st) != hipSuccess) return nullptr;
     g_tickets[dev].emplace_back(st, d);
     return d;
 }
@@ -1534,6 +1537,7 @@ int h264bsdmiDebugTailProfile(int enable, unsigned long long *out)
     if (enable) {
         if (!e->tail_prof) HIP_TRY(hipMalloc((void **)&e->tail_prof, (16 * 16 + 16 * 8) * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(e->tail_prof, 0, (16 * 16 + 16 * 8) * sizeof(unsigned long long)));
+        HIP_TRY(hipDeviceSynchronize());
     } else if (e->tail_prof) {
         if (out) HIP_TRY(hipMemcpy(out, e->tail_prof, (16 * 16 + 16 * 8) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         HIP_TRY(hipFree(e->tail_prof));

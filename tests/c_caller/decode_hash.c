@@ -81,6 +81,12 @@ static void decode_content(Job *job)
         u8 *strm = content;
         u32 len = (u32)job->size, read_bytes = 0, pic_id, is_idr, n_err;
         int pics = 0;
+        FILE *dump = NULL;                            /* DH_DUMP=dir: the frames of every decoder, for diagnosing a wrong digest */
+        if (getenv("DH_DUMP")) {
+            char path[512];
+            snprintf(path, sizeof(path), "%s/dec%d_pass%d.yuv", getenv("DH_DUMP"), job->id, pass);
+            dump = fopen(path, "wb");
+        }
         while (len > 0 && !job->failed) {
             const u32 result = h264bsdDecode(&dec, strm, len, 0, &read_bytes);
             len -= read_bytes;
@@ -89,6 +95,7 @@ static void decode_content(Job *job)
                 const u8 *pic;
                 while ((pic = h264bsdNextOutputPicture(&dec, &pic_id, &is_idr, &n_err)) != NULL) {
                     sha_update(&sha, pic, (size_t)h264bsdPicWidth(&dec) * h264bsdPicHeight(&dec) * 384u);
+                    if (dump) fwrite(pic, 1, (size_t)h264bsdPicWidth(&dec) * h264bsdPicHeight(&dec) * 384u, dump);
                     pics++;
                 }
             } else if (result == H264BSD_ERROR || result == H264BSD_PARAM_SET_ERROR || result == H264BSD_MEMALLOC_ERROR) {
@@ -97,6 +104,7 @@ static void decode_content(Job *job)
             }
         }
         h264bsdShutdown(&dec);
+        if (dump) fclose(dump);
         sha_hex(&sha, job->digest);
         job->pictures = pics;
         printf("decoder %d pass %d: %d pictures sha256 %s\n", job->id, pass, pics, job->digest);

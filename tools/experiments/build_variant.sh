@@ -1,0 +1,10 @@
+#!/bin/bash
+# build_variant.sh <name> <extra hipcc flags...>: the product library with other kernel flags into h264bsd_amd/lib_<name>/
+set -e
+name=$1; shift
+cd "$(dirname "$0")/../../h264bsd_amd/csrc"
+mkdir -p build_$name ../lib_$name
+/opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-value "$@" -c engine.hip -o build_$name/engine.o
+objs=$(ls build/hd_*.o build/api.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -Wl,--version-script=exports.map -o ../lib_$name/libh264bsd_mi355x.so $objs build_$name/engine.o -lpthread
+echo built ../lib_$name
