@@ -29,7 +29,9 @@ for l in body.splitlines():
 # 384 bytes in and 384 bytes out per copied macroblock, as contiguous 16-byte-per-lane pieces of macroblock tiles.
 sys.path.insert(0, root)
 import h264bsd_amd
-jobs, _, _ = h264bsd_amd.capture_stream(open(os.path.join(root, "tests", "golden", "test_1920x1080.h264"), "rb").read())
+# (the same capture as the bench line's: with copy elision the jobs list fewer copies)
+elide = bool(json.loads(line).get("config", {}).get("copy_elision", {}).get("on", False))
+jobs, _, _ = h264bsd_amd.capture_stream(open(os.path.join(root, "tests", "golden", "test_1920x1080.h264"), "rb").read(), copy_elision=elide)
 heads = [h264bsd_amd.job_header(j) for j in jobs]
 ticks_with_copies = sum(1 for h in heads if h["n_copy"])
 copy_alg = sum(h["n_copy_mbs"] for h in heads) * 384 * 256 / ticks_with_copies          # bytes per dispatch, each direction
