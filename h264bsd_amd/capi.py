@@ -14,6 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "lib", "libh264bsd_mi355x.so")                  # the product: what a C application links
 BENCH_LIB_PATH = os.path.join(HERE, "lib", "libh264bsd_mi355x_bench.so")      # same objects + the harness exports; what
                                                                               # this mirror loads (Replay, job tools)
+if os.environ.get("H264BSD_VARIANT"):      # A/B experiments: a library built with other kernel flags (tools/experiments/build_variant.sh)
+    BENCH_LIB_PATH = os.path.join(HERE, "lib_" + os.environ["H264BSD_VARIANT"], "libh264bsd_mi355x_bench.so")
 
 (H264BSD_RDY, H264BSD_PIC_RDY, H264BSD_HDRS_RDY, H264BSD_ERROR, H264BSD_PARAM_SET_ERROR,
  H264BSD_MEMALLOC_ERROR) = range(6)
