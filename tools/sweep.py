@@ -22,6 +22,7 @@ ap.add_argument("--sizes", default="", help="WMIN-WMAX,HMIN-HMAX: override the p
 ap.add_argument("--concat", type=int, default=1, help="N > 1: every case is N different random streams one after the other (new SPS "
                 "/ PPS with the same ids, other picture and DPB sizes: re-activation, possibly in the middle of damage)")
 ap.add_argument("--no-output-reordering", type=int, default=-1, help="h264bsdInit's flag: 0 / 1; default: seed parity for intact streams, 0 for damaged ones")
+ap.add_argument("--still", type=float, default=0.0, help="writer options p_skip = this, p_intra_in_p = 0.02: long skip runs, i.e. static regions — where the product's copy elision leaves macroblocks out")
 ap.add_argument("--backend", default="oracle", choices=("oracle", "gpu"), help="gpu = the product through the C ABI (needs an MI355X)")
 args = ap.parse_args()
 os.dup2(os.open(os.devnull, os.O_WRONLY), 2)      # the reference is built with _ERROR_PRINT
@@ -44,6 +45,7 @@ for seed in range(args.first, args.first + args.count):
                 if not args.keep_redundant: cfg["redundant"] = False
             if args.overflow: cfg["overflow"] = args.overflow; cfg["max_qp"] = max(cfg["max_qp"], 40)
             if args.huge_mv: cfg["p_huge_mv"] = args.huge_mv
+            if args.still: cfg["p_skip"] = args.still; cfg["p_intra_in_p"] = 0.02
             if args.long:
                 cfg["n_pics"] = 40 + sub % 31
             w = h264writer.StreamWriter(**cfg)
