@@ -820,7 +820,9 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
          * `if` make the wavefront wait for that load before it issues the next one.)  Lanes without a piece load the first
          * bytes of the reference frame and drop them. */
         const int lr = (lane * 43) >> 7, lk = lane - 3 * lr, lx = xs + 16 * lk;          /* lane / 3, lane % 3 */
-        const bool l_on = lfast && lane < 63 && lx < W;
+        /* (the window's 21 columns reach into the third tile only when they start in the last four columns of the first:
+         * in three cases out of four that tile is not requested at all — nothing reads the bytes it would have filled) */
+        const bool l_on = lfast && lane < 63 && lx < W && (lk < 2 || xi - xs >= 12);
         const uint4 vl = ld16g(ref + (l_on ? luma_at(wmb, lx, yi + lr) : (size_t)0));
         const int cp = lane >= 18, rem = cp ? lane - 18 : lane, cr = rem >> 1, ck = rem & 1, cx = cxs + 8 * ck;
         const bool c_on = cfast && lane < 36 && cx < CW;
