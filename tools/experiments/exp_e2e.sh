@@ -1,7 +1,6 @@
 #!/bin/bash
-# end-to-end throughput against parser threads and pinning policy (host-side experiment, GPU box)
-cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-lscpu | grep -E 'NUMA|Socket|Model name' | head -8
-for pin in 2 1 0; do for t in 16 32 64; do
-  echo -n "pin $pin threads $t: "; H264BSDMI_PIN=$pin timeout 120 python tools/e2e_bench.py --native --threads $t 2>&1 | tail -n 1 | cut -c1-200
-done; done
+set -u
+for i in 1 2; do
+for v in 1 0; do echo "async enqueue thread $v:"; H264BSDMI_ASYNC_ENQUEUE=$v timeout 200 python tools/experiments/e2e_split.py 16 2>&1 | grep -v amdgpu; done
+done
+timeout 900 python -m pytest tests/test_gpu_api.py tests/test_parse_pool.py -x -q -m gpu 2>&1 | tail -2
