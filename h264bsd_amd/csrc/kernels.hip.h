@@ -1870,7 +1870,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
     /* debug accounting (h264bsdmiDebugTailProfile, second half of the buffer): band 0 of picture 0, per wavefront:
      * [0] cycles with nothing ready, [1] cycles reconstructing, [2] cycles waiting for stores + release, [3] MBs */
     unsigned long long *tp = (prof && ticket == 0) ? prof + 256 + wave * 8 : nullptr;
-    unsigned long long t_idle = 0, t_work = 0, t_rel = 0, n_done = 0, t_mark = tp ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long t_idle = 0, t_work = 0, t_rel = 0, t_rec = 0, n_done = 0, t_mark = tp ? __builtin_readcyclecounter() : 0ull;
     /* Pull model: a free wavefront takes up to FOUR ready macroblocks at once.  Each is prepared by the whole wavefront
      * in turn (neighbours, residual, chroma; Intra16x16 / I_PCM / concealed macroblocks completely); the luma of the
      * Intra4x4 ones among them — 10 dependent steps with at most two blocks each — is then predicted jointly, one quarter
@@ -1937,6 +1937,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
             rec_lds[lane] = reinterpret_cast<const uint32_t *>(&fd.recs[mbj])[lane & 7];
         }
         wave_sync();
+        if (tp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); t_rec += t - t_mark; }
         /* first row of the band: the row above comes from another workgroup; last row: the band below reads this one */
         const int cross_lo = has_up ? lo : -1, cross_hi = has_up ? lo + wmb : -1, wt_lo = has_down ? hi - wmb : 0x7FFFFFFF;
         /* software pipeline over the group: the loads of macroblock j + 1 are in flight while macroblock j is reconstructed */
@@ -1980,7 +1981,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc
         }
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_rel += t - t_mark; t_mark = t; }
     }
-    if (tp && lane == 0) { tp[0] += t_idle; tp[1] += t_work; tp[2] += t_rel; tp[3] += n_done; }
+    if (tp && lane == 0) { tp[0] += t_idle; tp[1] += t_work; tp[2] += t_rel; tp[3] += n_done; tp[4] += t_rec; }
     /* the last band of the picture to leave zeroes the done bytes for the next picture of this stream */
     if (BANDED && nb > 1) {
         __syncthreads();

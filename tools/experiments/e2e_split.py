@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import h264bsd_amd as h
 L = h.lib()
 data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden", "test_1920x1080.h264"), "rb").read()
-streams, laps = 256, 2
+streams, laps = (int(sys.argv[2]) if len(sys.argv) > 2 else 256), (int(sys.argv[3]) if len(sys.argv) > 3 else 2)
 threads = L.h264bsdmiSetParserThreads(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 decs = [h.Decoder() for _ in range(streams)]
 drv = h.BatchDriver(decs, [data * (laps + 1)] * streams)
