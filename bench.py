@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=4.0, help="untimed load before the warm-up steps (device clock ramp)")
     ap.add_argument("--time-all-kernels", action="store_true", help="bracket all five kernels with events in the timed steps too (A/B of the event overhead)")
     ap.add_argument("--no-copy-elision", action="store_true", help="capture the replayed frame jobs without copy elision (the product's default with a device is ON: copies that would rewrite what the destination frame holds are left out, include/h264bsd_mi355x.h)")
+    ap.add_argument("--no-full-copies-variant", action="store_true", help="skip the lock-step measurement without copy elision (reported next to `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-groups-variant", action="store_true", help="skip the lock-step measurement with 4 stream groups")
     ap.add_argument("--no-desync", action="store_true", help="skip the fully desynchronised variants (reported next to the lock-step value)")
@@ -250,7 +251,7 @@ def main():
     kernels = h264bsd_amd.Replay.KERNELS
     golden_sums = golden["frame_checksum64"]
 
-    def run_variant(odd_offset, steps):
+    def run_variant(odd_offset, steps, jobs=jobs, main=True):
         """Verify, warm up and time one variant of the workload.  odd_offset = 0: lock-step (every stream on
         the same picture index: two all-IDR ticks per step, the worst case); otherwise odd streams start at the
         second IDR (SURVEY.md §8d config 4 "staggered").  Returns (elapsed s, kernel ms, launches, device ms, job bytes)."""
@@ -305,7 +306,7 @@ def main():
         elapsed = time.perf_counter() - t0
         # the same lock-step work with the streams split into 4 groups that run their ticks on their own HIP streams
         # (the per-picture kernels of one group overlap with the other groups' work); reported next to `value`
-        if odd_offset == 0 and args.groups == 1 and args.streams >= 8 and not args.no_groups_variant:
+        if main and odd_offset == 0 and args.groups == 1 and args.streams >= 8 and not args.no_groups_variant:
             rep.set_groups(4)
             rep.run(); rep.sync()
             barrier()
@@ -331,6 +332,12 @@ def main():
         return elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local, extra
 
     elapsed, k_ms, k_n, dev_total_ms, job_bytes, dom, breakdown, local_elapsed, lock_extra = run_variant(0, args.steps)
+    # the same lock-step work with EVERY copy macroblock copied (no copy elision): what the number is without that
+    # optimisation of the parser, on the same line
+    full_copies = None
+    if elide and not args.no_full_copies_variant:
+        fc_elapsed, _, _, fc_dev_ms, _, _, fc_breakdown, _, _ = run_variant(0, side_steps, jobs=h264bsd_amd.capture_stream(data)[0], main=False)
+        full_copies = dict(elapsed=fc_elapsed, breakdown=fc_breakdown, dev_ms=fc_dev_ms)
     staggered = None
     if not args.no_staggered and args.streams > 1:
         idr = [i for i, h in enumerate(heads) if h["is_idr"] and i > 0]
@@ -514,6 +521,12 @@ def main():
             out["lock_step_4_stream_groups"] = {"value": n_pics * args.streams * n_mbs * side_steps / ge, "unit": "macroblocks/s",
                                                 "ms_per_step": ge * 1e3 / side_steps, "steps": side_steps,
                                                 "note": "rank 0's own clock; same work as `value`, streams split into 4 groups on 4 HIP streams"}
+        if full_copies is not None:
+            out["lock_step_without_copy_elision"] = {
+                "value": pics_per_step * n_mbs * side_steps / full_copies["elapsed"], "unit": "macroblocks/s",
+                "ms_per_step": full_copies["elapsed"] * 1e3 / side_steps, "steps": side_steps,
+                "device_ms_per_step": dict({k: full_copies["breakdown"][k][0] for k in kernels}, total=full_copies["dev_ms"] / side_steps),
+                "note": "frame jobs captured with h264bsdmiSetCopyElision(0): every copy macroblock is copied; verified on device like `value`"}
         if staggered is not None:
             # same work per step, odd streams start at the second IDR: I pictures never fill a whole tick
             side_mbs = pics_per_step * n_mbs * side_steps

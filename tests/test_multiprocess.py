@@ -68,7 +68,7 @@ def test_gpu_bench_two_ranks_on_one_box(built):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--streams", "32", "--steps", "1", "--warmup", "0", "--ramp-seconds", "0",
-                          "--no-staggered", "--no-desync", "--no-argb"],
+                          "--no-staggered", "--no-desync", "--no-argb", "--no-full-copies-variant"],
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -86,7 +86,7 @@ def test_gpu_bench_starts_its_own_ranks(built):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "32", "--steps", "1", "--warmup", "0",
-                          "--ramp-seconds", "0", "--no-staggered", "--no-desync", "--no-argb"],
+                          "--ramp-seconds", "0", "--no-staggered", "--no-desync", "--no-argb", "--no-full-copies-variant"],
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, "\n".join(l for l in out.stderr.splitlines() if "socket.cpp" not in l and "amdgpu.ids" not in l)[-6000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

@@ -4,7 +4,7 @@ out=gpurun_out/desync; rm -rf $out; mkdir -p $out
 run() {
   name=$1; shift
   echo -n "$name: "
-  env "$@" timeout 600 python bench.py --steps 10 --warmup 1 --ramp-seconds 1 --no-cpu-baseline --no-argb --no-end-to-end --no-groups-variant 2> $out/err_$name.log | tail -1 > $out/b_$name.json
+  env "$@" timeout 600 python bench.py --steps 10 --warmup 1 --ramp-seconds 1 --no-cpu-baseline --no-argb --no-end-to-end --no-groups-variant --no-full-copies-variant 2> $out/err_$name.log | tail -1 > $out/b_$name.json
   python - "$out/b_$name.json" <<'P'
 import sys, json
 try:

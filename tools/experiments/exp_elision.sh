@@ -6,7 +6,7 @@ timeout 1200 python -m pytest tests/test_copy_elision.py tests/test_gpu_api.py t
 tail -3 $out/tests.log
 for v in on off on off; do
 extra=""; [ $v = off ] && extra="--no-copy-elision"
-timeout 300 python bench.py --steps 5 --warmup 1 --ramp-seconds 2 --no-cpu-baseline --no-staggered --no-desync --no-argb --no-end-to-end --no-groups-variant $extra 2> $out/err_$v.log | tail -1 > $out/b_$v.json
+timeout 300 python bench.py --steps 5 --warmup 1 --ramp-seconds 2 --no-cpu-baseline --no-staggered --no-desync --no-argb --no-end-to-end --no-groups-variant --no-full-copies-variant $extra 2> $out/err_$v.log | tail -1 > $out/b_$v.json
 python - $v <<'P'
 import json, sys
 try:

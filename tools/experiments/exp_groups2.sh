@@ -5,7 +5,7 @@ out=gpurun_out/groups2; rm -rf $out; mkdir -p $out
 run() {  # name, env..., -- bench args
   name=$1; shift
   echo "== $name"
-  env "$@" timeout 300 python bench.py --steps 3 --warmup 1 --ramp-seconds 2 --no-cpu-baseline --no-staggered --no-desync --no-argb --no-end-to-end --no-groups-variant $EXTRA 2> $out/err_$name.log | tail -1 > $out/b_$name.json
+  env "$@" timeout 300 python bench.py --steps 3 --warmup 1 --ramp-seconds 2 --no-cpu-baseline --no-staggered --no-desync --no-argb --no-end-to-end --no-groups-variant --no-full-copies-variant $EXTRA 2> $out/err_$name.log | tail -1 > $out/b_$name.json
   python - "$out/b_$name.json" <<'P'
 import sys, json
 try:

@@ -5,7 +5,7 @@ out=gpurun_out/quick; rm -rf $out; mkdir -p $out
 timeout 1500 python -m pytest ${TESTS:-tests/test_gpu_parity.py tests/test_gpu_random_jobs.py tests/test_synth_streams.py} -x -q -m gpu > $out/tests.log 2>&1
 tail -3 $out/tests.log
 for i in 1 2; do
-timeout 300 python bench.py --steps 5 --warmup 1 --ramp-seconds 2 --no-cpu-baseline --no-staggered --no-desync --no-argb --no-end-to-end --no-groups-variant ${BENCH_EXTRA:-} 2> $out/err.log | tail -1 > $out/b.json
+timeout 300 python bench.py --steps 5 --warmup 1 --ramp-seconds 2 --no-cpu-baseline --no-staggered --no-desync --no-argb --no-end-to-end --no-groups-variant --no-full-copies-variant ${BENCH_EXTRA:-} 2> $out/err.log | tail -1 > $out/b.json
 python - <<'P'
 import json
 try:

@@ -5,7 +5,7 @@ out=gpurun_out/small; rm -rf $out; mkdir -p $out
 for n in 4 16 32 64 128; do
   for b in 320 0; do
     echo -n "streams $n band budget $b: "
-    H264BSDMI_BAND_BUDGET=$b timeout 300 python bench.py --streams $n --steps 5 --warmup 1 --ramp-seconds 1 --no-cpu-baseline --no-staggered --no-desync --no-argb --no-end-to-end --no-groups-variant 2> $out/err.log | tail -1 > $out/b.json
+    H264BSDMI_BAND_BUDGET=$b timeout 300 python bench.py --streams $n --steps 5 --warmup 1 --ramp-seconds 1 --no-cpu-baseline --no-staggered --no-desync --no-argb --no-end-to-end --no-groups-variant --no-full-copies-variant 2> $out/err.log | tail -1 > $out/b.json
     python - <<'P'
 import json
 try:

@@ -3,7 +3,7 @@
 set -u
 out=gpurun_out/variants; rm -rf $out; mkdir -p $out
 one() {
-  H264BSD_VARIANT=$1 timeout 300 python bench.py --steps ${STEPS:-5} --warmup 1 --ramp-seconds 2 --no-cpu-baseline --no-staggered ${EXTRA:---no-desync} --no-argb --no-end-to-end --no-groups-variant 2> $out/err_$1.log | tail -1 > $out/b.json
+  H264BSD_VARIANT=$1 timeout 300 python bench.py --steps ${STEPS:-5} --warmup 1 --ramp-seconds 2 --no-cpu-baseline --no-staggered ${EXTRA:---no-desync} --no-argb --no-end-to-end --no-groups-variant --no-full-copies-variant 2> $out/err_$1.log | tail -1 > $out/b.json
   python - "$1" <<'P'
 import json, sys
 try:
