@@ -126,6 +126,7 @@ static void cavlc_build_tables(void)
 {
     const char *t = getenv("HD_TRACE");
     hd_trace = t && *t && *t != '0';
+    { const char *f = getenv("HD_NO_FAST_SKIP"); hd_no_fast_skip = f && *f && *f != '0'; }
     for (int t = 0; t < 3; t++) vlc_build(&vlc_ct[t], ct_len[t], ct_code[t], 68);
     vlc_build(&vlc_cdc, cdc_len, cdc_code, 20);
     for (int t = 0; t < 15; t++) vlc_build(&vlc_tz[t], tz_len[t], tz_code[t], 16);

@@ -162,7 +162,8 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
          * has its coefficient blocks inside the section (a parser bug must end in a failed decode, not in a kernel
          * reading past the job) */
         if (recon && (r->kind == FJ_MB_INTER || r->kind == FJ_MB_I4x4 || r->kind == FJ_MB_I16x16 || r->kind == FJ_MB_IPCM)) {
-            const uint32_t nb = r->kind == FJ_MB_IPCM ? 12u : (uint32_t)__builtin_popcount(r->coded & 0x03FFFFFFu);
+            const uint32_t cm = r->coded & 0x03FFFFFFu;         /* (most macroblocks have none: no population count for them) */
+            const uint32_t nb = r->kind == FJ_MB_IPCM ? 12u : cm ? (uint32_t)__builtin_popcount(cm) : 0u;
             if (nb && (r->coef_idx > coef_blocks || nb > coef_blocks - r->coef_idx)) {
                 if (hd_trace) fprintf(stderr, "TRACE fj_finalize: mb %u kind %u pred %#x needs blocks %u..%u of %u (ghost %u dbk_only %u)\n", a, r->kind, r->pred, r->coef_idx, r->coef_idx + nb, coef_blocks, h->ghost, h->dbk_only);
                 return -1;

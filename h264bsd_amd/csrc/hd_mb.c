@@ -640,8 +640,80 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
 
 /* Coefficient blocks of a macroblock that failed are given back: nothing refers to them (no record was written, or
  * an inert one), and a hostile stream must not be able to grow the section by repeating broken slices. */
+/* P_Skip, the common case (6 of 10 macroblocks of the bundled 1080p stream) without the generality of decode_mb_body: first
+ * decode of the macroblock in this picture, nothing set aside for it, reference 0 present, motion vector in range — i.e. no
+ * error path can be reached.  Writes exactly what decode_mb_body writes for such a macroblock (MbInfo, record, vectors,
+ * counters: tests/test_parser_fast_paths.py compares the frame jobs of whole streams with and without it); returns 0 when it
+ * declined and the general path has to run. */
+int hd_no_fast_skip;         /* HD_NO_FAST_SKIP in the environment (read with HD_TRACE): the general path for everything */
+static int decode_skip_fast(HostDec *d, const SliceHdr *sh, const Pps *pps, uint32_t addr, int qp)
+{
+    if (d->mb_decoded[addr] || d->mb_rec_sid[addr] || (d->mb_redone && d->mb_redone[addr])) return 0;
+    const int slot = hd_dpb_ref_slot(&d->dpb, 0);
+    if (slot < 0) return 0;
+    MbCtx c;                                          /* only what the motion vector prediction looks at */
+    const uint32_t sid = d->slice_id, w = d->width_mbs, mbx = addr % w, mby = addr / w;
+    MbInfo *m = c.cur = &d->mb[addr];
+    c.done = 0;
+    c.A = mbx ? usable(d, addr - 1, sid) : NULL;
+    c.B = mby ? usable(d, addr - w, sid) : NULL;
+    c.C = (mby && mbx + 1 < w) ? usable(d, addr - w + 1, sid) : NULL;
+    c.D = (mby && mbx) ? usable(d, addr - w - 1, sid) : NULL;
+    int16_t mv[2] = { 0, 0 };
+    {
+        const Nb a = nb_from(c.A, 3, 0), b = nb_from(c.B, 0, 3);
+        if (a.avail && b.avail && !(a.ref == 0 && a.mx == 0 && a.my == 0) && !(b.ref == 0 && b.mx == 0 && b.my == 0)) {
+            predict_mv(&c, 0, 0, 4, 0, 0, mv);
+            if ((uint32_t)(mv[0] + 8192) >= 16384u || (uint32_t)(mv[1] + 2048) >= 4096u) return 0;
+        }
+    }
+    FjHeader *hdr = (FjHeader *)d->job;
+    FjMbRec *recs = (FjMbRec *)(d->job + hdr->rec_off);
+    uint8_t *mvdst = d->job + hdr->mv_off + (size_t)addr * 64u;
+    /* MbInfo */
+    m->dbk_idc = (uint8_t)sh->disable_deblocking_filter_idc;
+    m->mb_type = 0;
+    m->kind = FJ_MB_INTER;
+    memset(m->ref_idx, 0, 4);
+    memset(m->ref_slot, slot, 4);
+    uint32_t one;
+    memcpy(&one, mv, 4);
+    const uint64_t two = (uint64_t)one << 32 | one;
+    uint8_t *mdst = (uint8_t *)m->mv;                 /* 4-byte aligned only */
+    for (int i = 0; i < 8; i++) { memcpy(mdst + 8 * i, &two, 8); memcpy(mvdst + 8 * i, &two, 8); }
+    memset(m->tc, 0, sizeof(m->tc));
+    m->qp = (uint8_t)qp;
+    d->mb_decoded[addr] = 1;
+    /* record */
+    FjMbRec rec;
+    memset(&rec, 0, sizeof(rec));
+    rec.kind = FJ_MB_INTER;
+    rec.qp_y = (uint8_t)qp;
+    {
+        int qi = qp + pps->chroma_qp_index_offset;
+        qi = qi < 0 ? 0 : qi > 51 ? 51 : qi;
+        rec.qp_c = qpc_table[qi];
+    }
+    rec.pred = (uint8_t)((FJ_PARTS_16x16 << FJ_PRED_PARTS_SHIFT) | FJ_PRED_UNIFORM_MV);
+    if (sh->disable_deblocking_filter_idc != 1) {
+        rec.dbk = FJ_DBK_INNER;
+        if (mbx && (sh->disable_deblocking_filter_idc != 2 || c.A)) rec.dbk |= FJ_DBK_LEFT;
+        if (mby && (sh->disable_deblocking_filter_idc != 2 || c.B)) rec.dbk |= FJ_DBK_TOP;
+    }
+    rec.alpha_off = (int8_t)sh->alpha_off;
+    rec.beta_off = (int8_t)sh->beta_off;
+    rec.coef_idx = d->coef_blocks;
+    memset(rec.ref_slot, slot, 4);
+    rec.cqp_off = (int8_t)pps->chroma_qp_index_offset;
+    recs[addr] = rec;
+    d->mb_rec_sid[addr] = sid;
+    d->n_inter++;
+    return 1;
+}
+
 static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *pps, uint32_t addr, int skipped, int *qp)
 {
+    if (skipped && !hd_no_fast_skip && decode_skip_fast(d, sh, pps, addr, *qp)) return 0;
     const uint32_t coef_start = d->coef_blocks;
     const int rc = decode_mb_body(d, br, sh, pps, addr, skipped, qp);
     if (rc) d->coef_blocks = coef_start;

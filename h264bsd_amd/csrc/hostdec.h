@@ -364,6 +364,7 @@ int  hd_dpb_mark_current(Dpb *dpb, const SliceHdr *sh, int is_ref, int is_idr, i
 void hd_dpb_flush(Dpb *dpb);
 const OutPic *hd_dpb_next_output(Dpb *dpb);
 /* hd_cavlc.c */
+extern int hd_no_fast_skip;   /* HD_NO_FAST_SKIP in the environment: hd_mb.c takes the general path for every macroblock (A/B of the fast paths) */
 extern int hd_trace;   /* HD_TRACE in the environment, read once by hd_cavlc_init() (debugging aid) */
 void hd_cavlc_init(void);
 /* Decodes one residual block.  coef[] (raster 4x4 via zig-zag, or plain order for chroma DC) must
