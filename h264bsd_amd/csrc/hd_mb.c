@@ -645,7 +645,6 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
  * error path can be reached.  Writes exactly what decode_mb_body writes for such a macroblock (MbInfo, record, vectors,
  * counters: tests/test_parser_fast_paths.py compares the frame jobs of whole streams with and without it); returns 0 when it
  * declined and the general path has to run. */
-int hd_no_fast_skip;         /* HD_NO_FAST_SKIP in the environment (read with HD_TRACE): the general path for everything */
 static int decode_skip_fast(HostDec *d, const SliceHdr *sh, const Pps *pps, uint32_t addr, int qp)
 {
     if (d->mb_decoded[addr] || d->mb_rec_sid[addr] || (d->mb_redone && d->mb_redone[addr])) return 0;
