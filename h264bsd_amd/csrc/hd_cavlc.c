@@ -189,17 +189,6 @@ static inline int bw_done(const BitWin *w, BitReader *br)
 int hd_cavlc_block_sum(BitReader *br, int nc, int max_coeff, int16_t *coef, int *spill, uint32_t *abs_sum)
 {
     if (spill) *spill = 0;
-    /* An empty block — the commonest outcome inside a coded 8x8 — is the shortest code of its table (Table 9-5: "1", "11",
-     * "1111" for nC 0-1, 2-3, 4-7; "01" for chroma DC): seen in the next four bits, before a bit window is set up.  (Away from
-     * the end of the data only: there the general code decides what an overrun means.) */
-    if (nc < 8 && br->pos + 8u <= br->size_bits) {
-        const uint8_t *p = br->buf + (br->pos >> 3);
-        const uint32_t t = ((((uint32_t)p[0] << 8) | p[1]) >> (12 - (br->pos & 7))) & 15u;     /* the next four bits */
-        if (nc < 0) { if ((t >> 2) == 1u) { br->pos += 2; return 0; } }
-        else if (nc < 2) { if (t >> 3) { br->pos += 1; return 0; } }
-        else if (nc < 4) { if ((t >> 2) == 3u) { br->pos += 2; return 0; } }
-        else if (t == 15u) { br->pos += 4; return 0; }
-    }
     BitWin bw = { br->buf, 0, br->pos, br->size_bits, 0 };
     int sym;
     if (nc < 0) sym = bw_vlc(&vlc_cdc, &bw);
