@@ -484,6 +484,7 @@ int hd_job_finish(HostDec *d, int is_idr, int single_job)
     d->n_elided = 0;
     if (d->tile_ver && d->tile_mbs == h->n_mbs && cur < d->tile_slots) {
         if (d->tile_uncommitted) tiles_forget(d);             /* the previous picture never reached the sink */
+        if (d->tile_serial > 0xFFFF0000u) { d->tile_serial = 0; tiles_forget(d); }    /* (numbers are compared for equality: no wrap-around) */
         /* An IDR picture starts a sequence that must be decodable on its own — replay sets start there — so nothing that
          * the other slots held before it is relied on afterwards */
         if (is_idr) for (uint32_t s = 0; s < d->tile_slots; s++) if (s != cur) tiles_fresh_slot(d, s);
