@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Dependency chains of the deblocking filter of the bundled 1080p stream, on the CPU: boundary strengths from the frame
+jobs (8.7.2.1, as k_dbk computes them), the macroblock flags of k_frame_dbk (ANY / LEFT / TOP / INNER), and the longest
+dependency path of every picture under
+  (a) the rule k_frame_dbk uses (kernels.hip.h: a macroblock waits for (x-1,y), (x,y-1), (x+1,y-1) only where a sample
+      they share can still change), one task per macroblock;
+  (b) macroblock-granular dependencies without that refinement (every filtered neighbour counts);
+  (c) TWO tasks per macroblock — V (vertical edges) and H (horizontal edges) — with the dependencies the samples impose:
+      V(x,y) after H(x-1,y) if the left edge is active; H(x,y) after V(x,y), after H(x,y-1) if the upper edge is active and
+      after V(x+1,y-1) if that macroblock's left edge is active (its V pass rewrites the columns of (x,y-1) that H(x,y)
+      reads).  A path is then measured in half steps;
+  (d) one task per macroblock as in (a), but a macroblock releases the one below-left of it after its V pass.
+What a shorter path is worth: k_frame_dbk's P pictures are bound by links x ~12-15 k cycles.
+usage: dbk_chains.py [first picture] [count]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import h264bsd_amd as h
+
+data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "test_1920x1080.h264"), "rb").read()
+jobs, _, _ = h.capture_stream(data)
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else len(jobs)
+Zx = [0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3]; Zy = [0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3]
+zof = np.zeros((4, 4), int)
+for z in range(16): zof[Zy[z], Zx[z]] = z
+INTRA_KINDS = (1, 2, 3, 5, 6, 7)      # framejob.h: everything that is filtered as intra (is_intra_kind)
+
+
+def flags_of(j):
+    hd = h.job_header(j); n, w, hh = hd["n_mbs"], hd["width_mbs"], hd["height_mbs"]
+    rec = np.frombuffer(j, dtype=np.uint8, count=n * 32, offset=hd["rec_off"]).reshape(n, 32)
+    kind, dbk, pred = rec[:, 0], rec[:, 5], rec[:, 4]
+    coded = np.frombuffer(rec[:, 8:12].tobytes(), dtype=np.uint32)
+    refs = rec[:, 16:20]
+    mv = np.frombuffer(j, dtype=np.int16, count=n * 32, offset=hd["mv_off"]).reshape(n, 4, 4, 2)
+    intra = np.isin(kind, INTRA_KINDS)
+    cb = np.zeros((n, 4, 4), bool); rb = np.zeros((n, 4, 4), int)
+    for y in range(4):
+        for x in range(4):
+            cb[:, y, x] = (coded >> zof[y, x]) & 1
+            rb[:, y, x] = refs[:, (y >> 1) * 2 + (x >> 1)]
+    g = lambda a: a.reshape(hh, w, 4, 4).transpose(0, 2, 1, 3).reshape(hh * 4, w * 4)
+    CB, RB = g(cb), g(rb)
+    MV = mv.reshape(hh, w, 4, 4, 2).transpose(0, 2, 1, 3, 4).reshape(hh * 4, w * 4, 2).astype(int)
+    IN = np.repeat(np.repeat(intra.reshape(hh, w), 4, 0), 4, 1)
+    H, W = hh * 4, w * 4
+    def bs(p, q): return IN[p] | IN[q] | CB[p] | CB[q] | (RB[p] != RB[q]) | (np.abs(MV[p] - MV[q]).max(-1) >= 4)
+    v = np.zeros((H, W), bool); v[:, 1:] = bs((slice(None), slice(0, W - 1)), (slice(None), slice(1, W)))     # edge on the left of block x
+    hz = np.zeros((H, W), bool); hz[1:, :] = bs((slice(0, H - 1), slice(None)), (slice(1, H), slice(None)))
+    # motion is compared inside a macroblock only across the partition boundaries its type has: the writer of the jobs gives all
+    # blocks of a partition one vector, so the comparison above says the same
+    D = dbk.reshape(hh, w)
+    on = D != 0
+    vb = v.reshape(hh, 4, w, 4); hb = hz.reshape(hh, 4, w, 4)
+    left = vb[:, :, :, 0].any(axis=1) & ((D & 1) != 0)            # FJ_DBK_LEFT = 1, FJ_DBK_TOP = 2 (framejob.h)
+    top = hb[:, 0, :, :].any(axis=2) & ((D & 2) != 0)
+    inner = (vb[:, :, :, 1:].any(axis=(1, 3)) | hb[:, 1:, :, :].any(axis=(1, 3))) & on
+    left &= on; top &= on
+    return hh, w, left, top, inner, (left | top | inner)
+
+
+def longest(hh, w, left, top, inner, any_, rule):
+    if rule == "d":
+        # one task per macroblock as in (a), but (x+1,y-1) releases the macroblock below-left of it after its V pass: the
+        # macroblock waits for the END of its left and upper neighbours and for the MIDDLE of the upper-right one
+        L = np.zeros((hh, w), int)
+        for y in range(hh):
+            for x in range(w):
+                if not any_[y, x]: continue
+                d = 0
+                if x and left[y, x] and (inner[y, x - 1] or top[y, x - 1]): d = max(d, L[y, x - 1])
+                if y and top[y, x] and (inner[y - 1, x] or left[y - 1, x]): d = max(d, L[y - 1, x])
+                if y and x + 1 < w and top[y, x] and left[y - 1, x + 1]: d = max(d, L[y - 1, x + 1] - 1)
+                L[y, x] = d + 2
+        return int(L.max())
+    if rule in ("a", "b"):
+        L = np.zeros((hh, w), int)
+        for y in range(hh):
+            for x in range(w):
+                if not any_[y, x]: continue
+                d = 0
+                if rule == "a":
+                    if x and left[y, x] and (inner[y, x - 1] or top[y, x - 1]): d = max(d, L[y, x - 1])
+                    if y and top[y, x] and (inner[y - 1, x] or left[y - 1, x]): d = max(d, L[y - 1, x])
+                    if y and x + 1 < w and top[y, x] and left[y - 1, x + 1]: d = max(d, L[y - 1, x + 1])
+                else:
+                    if x and any_[y, x - 1]: d = max(d, L[y, x - 1])
+                    if y and any_[y - 1, x]: d = max(d, L[y - 1, x])
+                    if y and x + 1 < w and any_[y - 1, x + 1]: d = max(d, L[y - 1, x + 1])
+                L[y, x] = d + 2                                  # a macroblock = two half steps
+        return int(L.max())
+    V = np.zeros((hh, w), int); Hh = np.zeros((hh, w), int)
+    for y in range(hh):
+        for x in range(w):
+            if not any_[y, x]: continue
+            dv = Hh[y, x - 1] if (x and left[y, x] and any_[y, x - 1]) else 0
+            V[y, x] = dv + 1
+            dh = V[y, x]
+            if y and top[y, x] and any_[y - 1, x]: dh = max(dh, Hh[y - 1, x])
+            if y and x + 1 < w and top[y, x] and left[y - 1, x + 1]: dh = max(dh, V[y - 1, x + 1])
+            Hh[y, x] = dh + 1
+    return int(max(V.max(), Hh.max()))
+
+
+tot = {"a": 0, "b": 0, "c": 0, "d": 0}
+for i in range(first, min(first + count, len(jobs))):
+    hh, w, left, top, inner, any_ = flags_of(jobs[i])
+    r = {k: longest(hh, w, left, top, inner, any_, k) for k in ("a", "b", "c", "d")}
+    for k in r: tot[k] += r[k]
+    if count <= 12: print(f"picture {i}: filtered {int(any_.sum())}, half steps on the longest path: current rule {r['a']}, plain macroblock rule {r['b']}, V/H tasks {r['c']}")
+print(f"pictures {first}..{first + count - 1}: half steps on the longest paths, summed: current rule {tot['a']} (= {tot['a'] // 2} links), plain macroblock rule {tot['b']}, V/H tasks {tot['c']}, early release of the macroblock below-left after the V pass {tot['d']}")
