@@ -110,3 +110,47 @@ for i in range(first, min(first + count, len(jobs))):
     for k in r: tot[k] += r[k]
     if count <= 12: print(f"picture {i}: filtered {int(any_.sum())}, half steps on the longest path: current rule {r['a']}, plain macroblock rule {r['b']}, V/H tasks {r['c']}")
 print(f"pictures {first}..{first + count - 1}: half steps on the longest paths, summed: current rule {tot['a']} (= {tot['a'] // 2} links), plain macroblock rule {tot['b']}, V/H tasks {tot['c']}, early release of the macroblock below-left after the V pass {tot['d']}")
+
+
+# ---- a model of k_frame_dbk's scheduler: W wavefronts, a free one takes up to 4 ready macroblocks (its share of the ready
+# list when that is short), a step costs `step` cycles whatever it holds, dependants are released at its end ----
+def simulate(hh, w, left, top, inner, any_, waves=12, step=12000, per_mb=4):
+    import heapq
+    n = hh * w
+    dep = np.zeros(n, int); succ = [[] for _ in range(n)]
+    A = any_.reshape(-1); Lf = left.reshape(-1); Tp = top.reshape(-1); In = inner.reshape(-1)
+    for y in range(hh):
+        for x in range(w):
+            i = y * w + x
+            if not A[i]: continue
+            if x and Lf[i] and A[i - 1] and (In[i - 1] or Tp[i - 1]): dep[i] += 1; succ[i - 1].append(i)
+            if y and Tp[i] and A[i - w] and (In[i - w] or Lf[i - w]): dep[i] += 1; succ[i - w].append(i)
+            if y and x + 1 < w and Tp[i] and A[i - w + 1] and Lf[i - w + 1]: dep[i] += 1; succ[i - w + 1].append(i)
+    ready = [i for i in range(n) if A[i] and dep[i] == 0]
+    t, free, running, done, busy = 0, waves, [], 0, 0
+    total = int(A.sum())
+    while done < total:
+        while free and ready:
+            k = max(1, min(per_mb, len(ready) // max(1, free)))
+            batch, ready = ready[:k], ready[k:]
+            heapq.heappush(running, (t + step, batch)); free -= 1; busy += step
+        t, batch = heapq.heappop(running)
+        free += 1
+        for i in batch:
+            done += 1
+            for s_ in succ[i]:
+                dep[s_] -= 1
+                if dep[s_] == 0: ready.append(s_)
+    return t, busy
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "simulate":
+    GHZ = 2.3
+    for waves, step, per_mb in ((12, 12000, 4), (8, 12000, 4), (16, 12000, 4), (12, 12000, 2), (12, 9000, 4), (24, 12000, 4)):
+        cyc = busy = 0
+        for i in range(first, min(first + count, len(jobs))):
+            hh, w, left, top, inner, any_ = flags_of(jobs[i])
+            t, b = simulate(hh, w, left, top, inner, any_, waves, step, per_mb)
+            cyc += t; busy += b
+        print(f"model: {waves} wavefronts, {step} cycles per step, up to {per_mb} macroblocks per step: {cyc / GHZ / 1e6:.1f} ms per pass of these pictures, "
+              f"wavefronts busy {busy / (cyc * waves):.0%}")
