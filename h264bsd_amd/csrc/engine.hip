@@ -333,6 +333,10 @@ struct TickShape {
     /* row bands of the two per-picture kernels: most bands a light / a heavy picture of the tick wants, for k_frame_dbk [0]
      * and k_frame_intra [1]; number of heavy pictures (more than a quarter of the macroblocks intra coded) */
     uint32_t want_light[2] = { 1, 1 }, want_heavy[2] = { 1, 1 }, n_heavy = 0;
+    /* a picture of the tick whose intra schedule may wait for macroblocks BELOW (concealment, FjHeader.intra_down_deps) must
+     * stay in ONE band of k_frame_intra: the launch's rows-per-band cap (which the kernel applies to every picture) must
+     * then cover a whole picture, whatever the other pictures of the tick want */
+    bool intra_whole = false;
     uint32_t load = 0;               /* pictures the device works on at the same time as this tick (other lanes' ticks included): the
                                         band budget is shared between them; 0 = this tick only */
 };
@@ -390,6 +394,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
         shape->n_heavy += d.heavy;
         if (h->any_deblock) (d.heavy ? shape->want_heavy : shape->want_light)[0] = std::max<uint32_t>((d.heavy ? shape->want_heavy : shape->want_light)[0], d.dbk_bands);
         if (h->n_intra_levels) (d.heavy ? shape->want_heavy : shape->want_light)[1] = std::max<uint32_t>((d.heavy ? shape->want_heavy : shape->want_light)[1], d.intra_bands);
+        if (h->n_intra_levels && h->intra_down_deps) shape->intra_whole = true;
     }
 }
 
@@ -476,7 +481,10 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         const uint32_t eff_l = std::min(s.want_light[which], light_cap), eff_h = std::min(s.want_heavy[which], heavy_cap);
         /* rows a band can have: the picture with the fewest bands decides (all pictures of a tick have the tick's size in
          * practice; max_h / fewest bands is the bound) */
-        const uint32_t fewest = s.n_heavy >= s.n_frames ? eff_h : s.n_heavy ? std::min(eff_l, eff_h) : eff_l;
+        uint32_t fewest = s.n_heavy >= s.n_frames ? eff_h : s.n_heavy ? std::min(eff_l, eff_h) : eff_l;
+        /* (band_split() clamps a picture's rows per band to this cap: a picture that wants ONE band gets it only if the cap is
+         * the picture's height — for k_frame_intra that is a matter of correctness, see TickShape::intra_whole) */
+        if (which == 1 && s.intra_whole) fewest = 1;
         uint32_t rows = (s.max_h + fewest - 1) / std::max<uint32_t>(1u, fewest);
         rows = std::max<uint32_t>(1u, std::min<uint32_t>(rows, s.max_h));
         while (may_shorten && lds_bytes(waves, s.max_w, rows) > LDS_BUDGET && rows > 1) rows = (rows + 1) / 2;      /* (rows is a cap the kernel applies to every picture) */

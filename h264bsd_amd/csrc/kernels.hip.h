@@ -1782,8 +1782,11 @@ __host__ __device__ inline size_t intra_lds_bytes(uint32_t waves, uint32_t wmb, 
 }
 /* BANDED = false: the launch gives every picture one workgroup (max_bands == 1, blockIdx.x = picture): no tickets, no
  * hand-over code in the loop. */
+#ifndef INTRA_OCC
+#define INTRA_OCC 3
+#endif
 template <bool BANDED>
-__global__ __launch_bounds__(64 * TAIL_WAVES) void k_frame_intra(const FrameDesc *__restrict__ frames, unsigned long long *prof,
+__global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(const FrameDesc *__restrict__ frames, unsigned long long *prof,
                                                                  uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap, uint32_t light_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -2033,8 +2036,11 @@ __host__ __device__ inline size_t dbk_lds_bytes(uint32_t waves, uint32_t wmb, ui
     const size_t n_loc16 = (((size_t)band_rows + 1) * wmb + 15) & ~(size_t)15, nq8 = ((size_t)band_rows * wmb + 7) & ~(size_t)7;
     return (size_t)waves * 4 * WORKER_LDS + 2 * n_loc16 + 2 * nq8 + 32 + 4 * ((((size_t)wmb + 31) / 32 + 3) & ~(size_t)3) + 384;
 }
+#ifndef DBK_OCC
+#define DBK_OCC 3
+#endif
 template <bool BANDED>
-__global__ __launch_bounds__(64 * DBK_WAVES) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof,
+__global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof,
                                                               uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap, uint32_t light_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
