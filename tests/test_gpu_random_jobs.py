@@ -96,3 +96,38 @@ def test_huge_picture_in_row_bands(built, tail):
     lib = built.lib()
     jobs = [build_job(lib, rng, 256, 144, 0, 2, []), build_job(lib, rng, 256, 144, 1, 2, [0], p_inter=0.9, mv_range=300)]
     _run(built, jobs, n_streams=1)
+
+
+@pytest.mark.parametrize("name", ["damaged_41", "damaged_29", "damaged_32"])
+def test_concealed_picture_next_to_a_banded_heavy_picture(built, tail, name):
+    """one tick holds an I picture with concealed macroblocks (they may wait for the macroblock BELOW them:
+    FjHeader.intra_down_deps, the picture must stay in ONE band of k_frame_intra) and an intact intra picture that wants
+    a band per macroblock row.  The launch's rows-per-band cap used to follow the picture that wanted the most bands, so
+    the concealed picture was split as well and read tiles below a band boundary before they were reconstructed."""
+    import struct
+    import h264bsd_amd
+    from damage import damage
+    from h264writer import StreamWriter
+    from synth_configs import DAMAGED
+    cfg, dmg = DAMAGED[name]
+    jobs, _, _ = h264bsd_amd.capture_stream(damage(StreamWriter(**cfg).build(), **dmg))
+    conc = jobs[0]
+    h = pyoracle.blob_header(conc)
+    assert struct.unpack_from("<I", bytes(conc), 96)[0] == 1 and h["n_intra_levels"] > 0, "fixture no longer has downward dependencies"
+    wmb, hmb, n_slots = h["width_mbs"], h["height_mbs"], h["n_slots"]
+    rng = np.random.default_rng(77)
+    intact = build_job(built.lib(), rng, wmb, hmb, (h["cur_slot"] + 1) % n_slots, n_slots, [])
+    want = {}
+    for job in (conc, intact):
+        want[pyoracle.blob_header(job)["cur_slot"]] = pyoracle.OracleDpb(job).decode(job)
+    tail(1, 1, 4, 1, 1, 4, 1 << 20)                      # a band per macroblock row for whoever may be split
+    for rep_no in range(4):
+        rep = built.Replay([intact, conc], n_streams=2, offsets=[0, 1])
+        try:
+            rep.run(0, 2)                                # tick 0: stream 0 intact + stream 1 concealed; tick 1: the other way round
+            for s in range(2):
+                for slot, w in want.items():
+                    got = rep.fetch(s, slot)
+                    assert np.array_equal(got, w), f"run {rep_no} stream {s} slot {slot}: {np.count_nonzero(got != w)} bytes differ"
+        finally:
+            rep.close()
