@@ -266,7 +266,7 @@ Engine *engine_get(int device = -1)
  * workgroup, and a cap on the bands of one launch.  H264BSDMI_TAIL="dbk_rows_light,dbk_rows_heavy,dbk_waves,intra_rows_light,
  * intra_rows_heavy,intra_waves" overrides the defaults (0 rows = one band); h264bsdmiDebugSetTail() does the same for tests. */
 struct TailConfig {
-    uint32_t dbk_rows_light = 17, dbk_rows_heavy = 9, dbk_waves = 12;
+    uint32_t dbk_rows_light = 17, dbk_rows_heavy = 9, dbk_waves = 8;
     uint32_t intra_rows_light = 0, intra_rows_heavy = 9, intra_waves = 12;
     /* A picture is only split where that puts idle compute units to work: a launch gets at most band_budget workgroups
      * (bands per picture <= band_budget / pictures of the tick, at least 1).  256 pictures in lock-step: one workgroup per
@@ -423,7 +423,8 @@ static int launch_kdbk_aside(const SideLane *side, int parity, const FrameDesc *
 struct AheadDbk { const FrameDesc *next_desc; const TickShape *next_shape; TickTimers *next_tt; int parity; };
 
 int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5],
-                unsigned stages = 7u, const SideLane *side = nullptr, unsigned long long *prof = nullptr, const AheadDbk *ahead = nullptr)
+                unsigned stages = 7u, const SideLane *side = nullptr, unsigned long long *prof = nullptr, const AheadDbk *ahead = nullptr,
+                hipEvent_t after_lists = nullptr)       /* recorded behind the list-driven kernels (copy, inter, strengths): the stream groups' ring */
 {
     const bool timed = tt && tt->on;
     const unsigned tmask = timed ? tt->mask : 0u;
@@ -461,6 +462,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         if (launches) launches[2]++;
     }
     if (EV_NEEDED(3)) HIP_TRY(hipEventRecord(tt->ev[3], st));
+    if (after_lists) HIP_TRY(hipEventRecord(after_lists, st));
     /* The two per-picture kernels keep per-macroblock scheduling state in LDS next to their wavefronts' tiles: for
      * pictures that leave less than 16 wavefronts' worth of tile space in the 160 KB of a CU, fewer wavefronts run. */
     constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
@@ -1038,6 +1040,8 @@ struct h264bsdmi_replay {
     uint32_t n_groups;
     hipStream_t gstream[8];
     hipEvent_t gdone[8];
+    hipEvent_t gring[8];            /* ring of the stream groups: group g has finished the list-driven kernels of its current tick */
+    bool group_ring = true;
     bool overlap_dbk = true;
     bool dbk_ahead = false;           /* lock-step / staggered sets: k_dbk of tick i+1 next to the per-picture kernels of tick i (AheadDbk) */
     unsigned timed_mask = 31u;
@@ -1275,7 +1279,8 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
     r->dbk_ahead = getenv("H264BSDMI_AHEAD") != nullptr;       /* measured: 128.2 vs 126.4 ms per step — it moves k_dbk's instructions from one
                                                                     instruction-bound phase into another (kept as an experiment) */
     r->n_groups = 1;
-    for (int g = 0; g < 8; g++) { r->gstream[g] = nullptr; r->gdone[g] = nullptr; }
+    for (int g = 0; g < 8; g++) { r->gstream[g] = nullptr; r->gdone[g] = nullptr; r->gring[g] = nullptr; }
+    r->group_ring = !(getenv("H264BSDMI_GROUP_RING") && atoi(getenv("H264BSDMI_GROUP_RING")) == 0);
     if (!ok) {
         fprintf(stderr, "h264bsd-mi355x: h264bsdmiReplayCreate failed (%s)\n", hipGetErrorString(hipGetLastError()));
         if (r->d_blobs) hipFree(r->d_blobs);
@@ -1300,7 +1305,7 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     if (r->d_planar) hipFree(r->d_planar);
     for (auto &t : r->timers) for (auto &ev : t.ev) hipEventDestroy(ev);
     hipEventDestroy(r->ev_begin); hipEventDestroy(r->ev_end); if (r->gdone_any) hipEventDestroy(r->gdone_any);
-    for (int g = 0; g < 8; g++) { if (r->gstream[g]) hipStreamDestroy(r->gstream[g]); if (r->gdone[g]) hipEventDestroy(r->gdone[g]); }
+    for (int g = 0; g < 8; g++) { if (r->gstream[g]) hipStreamDestroy(r->gstream[g]); if (r->gdone[g]) hipEventDestroy(r->gdone[g]); if (r->gring[g]) hipEventDestroy(r->gring[g]); }
     for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
     for (auto &ev : r->cev) hipEventDestroy(ev);
     for (auto &st : r->lanes) if (st) hipStreamDestroy(st);
@@ -1375,9 +1380,14 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
                 sh.load = r->n_streams;
                 TickTimers &tt = r->timers[(size_t)g * r->n_pics + i];
                 tt.on = true; tt.mask = r->timed_mask;
-                /* de-phase the groups once: group g starts when group g-1 has entered its first tail */
-                if (i == first && g > 0) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->timers[(size_t)(g - 1) * r->n_pics + i].ev[3], 0));
-                if (launch_tick(r->gstream[g], r->d_desc + (size_t)i * r->n_streams + s0, sh, &tt, r->launches, r->stages)) return -1;
+                /* The groups take turns at the list-driven kernels (copy, inter, strengths: bound by instruction issue, they gain
+                 * nothing from running side by side) and overlap in the per-picture kernels (bound by the latency of their dependency
+                 * chains, with half of the vector pipe to spare): group g starts its lists when group g-1 has finished the lists of
+                 * the same tick (group 0: the last group's lists of the tick before).  Left to themselves the groups stay in phase —
+                 * all of them in their list kernels, then all of them in their chains — and the split buys nothing. */
+                if (r->group_ring && (g > 0 || i > first)) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->gring[g > 0 ? g - 1 : G - 1], 0));
+                else if (!r->group_ring && i == first && g > 0) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->timers[(size_t)(g - 1) * r->n_pics + i].ev[3], 0));
+                if (launch_tick(r->gstream[g], r->d_desc + (size_t)i * r->n_streams + s0, sh, &tt, r->launches, r->stages, nullptr, nullptr, nullptr, r->group_ring ? r->gring[g] : nullptr)) return -1;
             }
         }
         for (u32 g = 0; g < G; g++) {
@@ -1402,6 +1412,7 @@ int h264bsdmiReplaySetGroups(h264bsdmi_replay *r, u32 n_groups)
     for (u32 g = 0; g < n_groups; g++) {
         if (!r->gstream[g]) HIP_TRY(hipStreamCreateWithFlags(&r->gstream[g], hipStreamNonBlocking));
         if (!r->gdone[g]) HIP_TRY(hipEventCreateWithFlags(&r->gdone[g], hipEventDisableTiming));
+        if (!r->gring[g]) HIP_TRY(hipEventCreateWithFlags(&r->gring[g], hipEventDisableTiming));
     }
     r->n_groups = n_groups;
     return 0;

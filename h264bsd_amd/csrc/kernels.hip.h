@@ -69,12 +69,15 @@ struct FrameDesc {
 #define DEVERR_INTRA_SCHED    2u  /* k_frame_intra gave up waiting for a ready macroblock (scheduling bug)          */
 #define DEVERR_DBK_SCHED      4u  /* k_frame_dbk did                                                               */
 
-/* Deblocking record of one macroblock (32 bytes), written by the reconstruction of that MB:
- *   bytes 0..15  boundary strengths, one nibble per (dir, edge e, segment k): n = 16*dir + 4*e + k
- *   bytes 16..21 indexA, bytes 22..27 indexB for the classes luma{left,top,inner}, chroma{left,top,inner}
- *   byte 28 FJ_DBK_* flags, byte 29 "any strength non-zero"
- * followed (at dbk + 32*n_mbs) by one byte per MB: 1 = at least one non-zero strength.           */
-#define DBK_REC_BYTES 32
+/* Deblocking record of one macroblock (48 bytes), written by k_dbk, read by k_frame_dbk:
+ *   bytes 0..15  boundary strengths, one nibble per (dir, edge e, segment k): n = 16*dir + 4*e + k (byte n >> 1, low nibble first)
+ *   bytes 16..39 six dwords, one per threshold class c = luma{left,top,inner}, chroma{left,top,inner}:
+ *                byte 0 alpha, byte 1 beta, byte 2 tc0 for bS 1, byte 3 tc0 for bS 2 — the VALUES of Tables 8-16 / 8-17, looked up once
+ *                per macroblock here instead of once per edge and lane in the filter
+ *   bytes 40..45 tc0 for bS 3 of the six classes
+ *   byte 46 FJ_DBK_* flags (LEFT / TOP only where that neighbour exists), byte 47 "any strength non-zero"
+ * followed (at dbk + 48*n_mbs) by one flag byte per MB (DBKF_*). */
+#define DBK_REC_BYTES 48
 /* the per-macroblock flag byte behind the records */
 #define DBKF_ANY  1u   /* at least one non-zero strength: the macroblock is filtered                         */
 #define DBKF_LEFT 2u   /* its left macroblock edge has a non-zero strength: it reads and rewrites the last columns of (x-1,y) */
@@ -532,6 +535,16 @@ __device__ __forceinline__ void wave_sync()
 #endif
 __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frames)
 {
+    /* Tables 8-16 / 8-17 in LDS (alpha[64] | beta[64] | tc0[64] as dwords {bS 1, bS 2, bS 3, 0}): a lane-indexed __constant__
+     * lookup is a global load */
+    __shared__ uint32_t s_tab[32 + 64];
+    if (threadIdx.x < 64) {
+        const uint32_t t = threadIdx.x, ok = t < 52;
+        reinterpret_cast<uint8_t *>(s_tab)[t] = ok ? c_alpha[t] : 0;
+        reinterpret_cast<uint8_t *>(s_tab)[64 + t] = ok ? c_beta[t] : 0;
+        s_tab[32 + t] = ok ? (uint32_t)c_tc0[t][0] | ((uint32_t)c_tc0[t][1] << 8) | ((uint32_t)c_tc0[t][2] << 16) : 0u;
+    }
+    __syncthreads();
     const FrameDesc &fd = FD_REF(frames, blockIdx.y);
     /* One macroblock per 16 lanes, four per wavefront: lane m of a group owns byte m of the 16-byte strength array, i.e. the
      * two segments k = 2*kh, 2*kh+1 of edge (dir, e) — m = 8*dir + 2*e + kh.  (Two macroblocks per wavefront with one segment
@@ -582,10 +595,12 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
     uint8_t *out = fd.dbk + (size_t)mb * DBK_REC_BYTES;
     uint8_t *any_out = fd.dbk + (size_t)fd.n_mbs * DBK_REC_BYTES + mb;
     const bool filtered = live && q.dbk && q.kind != FJ_MB_ABSENT;
-    if (live && !filtered && m == 0) { *reinterpret_cast<uint32_t *>(out + 28) = 0; *any_out = 0; }
+    if (live && !filtered && m == 0) { *reinterpret_cast<uint16_t *>(out + 46) = 0; *any_out = 0; }
     uint32_t bs2 = 0;                                              /* the lane's two strengths: low and high nibble of byte m */
+    /* k_frame_dbk relies on it for its addresses: a left / upper macroblock edge is only ever active where that neighbour exists
+     * (the host never says otherwise: GetMbFilteringFlags, deblocking.c:289-320 — enforced here for hand-built jobs) */
+    const bool f_left = (q.dbk & FJ_DBK_LEFT) && mb % (uint32_t)wmb, f_top = (q.dbk & FJ_DBK_TOP) && mb >= (uint32_t)wmb;
     if (filtered) {
-        const bool f_left = q.dbk & FJ_DBK_LEFT, f_top = q.dbk & FJ_DBK_TOP;
         const bool edge_on = e ? true : (dir ? f_top : f_left);
         if (edge_on) {
             const int p_kind = e ? q.kind : (dir ? pt.kind : pl.kind);
@@ -627,10 +642,10 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
                            ((bal16 & 0xFCFCu) ? DBKF_INNER : 0u);
     if (filtered) {
         if ((m & 3) == 0) *reinterpret_cast<uint32_t *>(out + m) = v;
-        /* threshold indices: lane m < 12 computes ONE of them — indexA (m < 6) or indexB of class m % 6 (luma left / top / inner,
-         * chroma left / top / inner) — and stores its byte (one lane doing all twelve costs the wavefront six times the instructions) */
-        if (m < 12) {
-            const int c = m < 6 ? m : m - 6;                           /* class */
+        /* thresholds: lane m < 6 computes indexA and indexB of class m (luma left / top / inner, chroma left / top / inner), looks
+         * alpha, beta and the three tc0 up and stores the class's dword and its bS-3 byte */
+        if (m < 6) {
+            const int c = m;                                           /* class */
             const int side = c % 3;                                    /* 0: across the left edge, 1: across the upper edge, 2: inside */
             const int pqp = side == 0 ? (int)pl.qp_y : side == 1 ? (int)pt.qp_y : (int)q.qp_y;
             int a = (int)q.qp_y, b = pqp;
@@ -639,10 +654,14 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
                 b = qpc_of(clip3(0, 51, b + q.cqp_off));
             }
             const int qpav = (a + b + 1) >> 1;
-            out[16 + m] = (uint8_t)clip3(0, 51, qpav + (m < 6 ? q.alpha_off : q.beta_off));
+            const int ia = clip3(0, 51, qpav + q.alpha_off), ib = clip3(0, 51, qpav + q.beta_off);
+            const uint32_t t = s_tab[32 + ia];
+            *reinterpret_cast<uint32_t *>(out + 16 + 4 * c) = (uint32_t)reinterpret_cast<const uint8_t *>(s_tab)[ia] |
+                ((uint32_t)reinterpret_cast<const uint8_t *>(s_tab)[64 + ib] << 8) | ((t & 0xFFFFu) << 16);
+            out[40 + c] = (uint8_t)(t >> 16);
         }
         if (m == 12) {
-            *reinterpret_cast<uint32_t *>(out + 28) = (uint32_t)q.dbk | (any ? 0x100u : 0u);
+            *reinterpret_cast<uint16_t *>(out + 46) = (uint16_t)((f_left ? FJ_DBK_LEFT : 0u) | (f_top ? FJ_DBK_TOP : 0u) | (q.dbk & FJ_DBK_INNER) | (any ? 0x100u : 0u));
             *any_out = (uint8_t)sched;
         }
     }
@@ -1447,36 +1466,73 @@ __device__ __forceinline__ void intra4_joint(const FrameDesc &fd, int my_mb, int
 }
 
 /* ------------------------------------------------------------------ deblocking */
-struct EdgeThr { int alpha, beta, ia; };
-__device__ __forceinline__ EdgeThr thr_of(uint32_t ia, uint32_t ib)
+/* A deblocking WORKER is an eighth of a wavefront: 8 lanes per macroblock, up to eight macroblocks per wavefront step.
+ * Lane l of a worker owns, in the vertical-edge pass, luma rows 2l, 2l+1 and then chroma rows 2(l&3), 2(l&3)+1 of plane l>>2;
+ * in the horizontal-edge pass luma columns 2l, 2l+1 and then chroma columns 2(l&3), 2(l&3)+1 of plane l>>2 — two sample
+ * lines per register (packed 16-bit), the four luma edges and then the two chroma edges of a direction one after the
+ * other.  (Round 3 gave a macroblock 16 lanes, half of them chroma lanes that idled through two of the four edge slots, and
+ * paid the per-step overhead — claim, addresses, record decode, release — once per FOUR macroblocks; the picture's compute
+ * unit is bound by VALU issue, so what counts is wave instructions per macroblock.)
+ * The worker's LDS tile is only the transposition medium between the two passes: the vertical pass takes its rows from the
+ * registers the macroblock was loaded into and writes single bytes (ds_write_b8 / _d16_hi: no VALU packing), the horizontal
+ * pass reads single bytes into register halves (ds_read_u8_d16 / _d16_hi: no VALU unpacking) and writes back what its
+ * active edges changed. */
+constexpr int LS = 48, LX = 16;                      /* deblock luma tile: 20 rows (4 above + 16) of LS bytes; the macroblock's columns at bytes LX .. LX+15 (16-byte
+                                                        aligned: a row is one ds_read / ds_write_b128), the four columns to its left at LX-4 .. LX-1 */
+constexpr int CS = 16, CX = 8;                       /* deblock chroma tiles: 2 planes x 10 rows (2 above + 8) of CS bytes; columns at CX .. CX+7, left strip at CX-4 .. CX-1 */
+constexpr int WORKER_LDS = 20 * LS + 2 * 10 * CS + 16;   /* 1296 bytes = 324 dwords: the eight workers of a wavefront start four banks apart */
+constexpr int DBK_LANES = 8;                         /* lanes per worker */
+
+/* ---- single bytes from the HALVES of a register to LDS (ds_write_b8 / ds_write_b8_d16_hi): a packed pair of samples that
+ * belong to different rows (or columns) of the tile leaves as two LDS instructions and no VALU work.  Left to itself the
+ * compiler fuses neighbouring byte stores into 16-bit ones and spends three or four VALU instructions per pair building them
+ * — on the pipe this kernel is bound by.  (The other direction does not exist here: with SRAM ECC a d16 LOAD clears the other
+ * half of its register instead of keeping it — tried, every even column came back 0 — so the horizontal pass reads 16-bit
+ * pairs and spreads them with one v_perm_b32 each.)  The compiler does not see the LDS traffic of an asm statement: the
+ * statements are volatile and clobber "memory", which keeps them in order with its own LDS accesses; LDS instructions of one
+ * wavefront execute in order. */
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const H264K_LDS uint8_t *)p; }
+template <int OFF_LO, int OFF_HI>
+__device__ __forceinline__ void lds_st_pair(uint32_t addr, s2 v)
 {
-    EdgeThr t;
-    t.ia = (int)ia; t.alpha = c_alpha[ia]; t.beta = c_beta[ib];
-    return t;
+    asm volatile("ds_write_b8 %0, %1 offset:%2\n\tds_write_b8_d16_hi %0, %1 offset:%3" :: "v"(addr), "v"(v), "n"(OFF_LO), "n"(OFF_HI) : "memory");
+}
+/* lds[addr + FIRST + i * STEP] = low byte of px[i].x, lds[addr + FIRST + i * STEP + PAIR] = low byte of px[i].y, i = 0 .. N-1 */
+template <int N, int FIRST, int STEP, int PAIR, int I = 0>
+__device__ __forceinline__ void lds_st_pairs(uint32_t addr, const s2 *px)
+{
+    if constexpr (I < N) { lds_st_pair<FIRST + I * STEP, FIRST + I * STEP + PAIR>(addr, px[I]); lds_st_pairs<N, FIRST, STEP, PAIR, I + 1>(addr, px); }
 }
 
-constexpr int LS = 36;                               /* deblock luma tile: 20 rows x 20 cols; 9-dword stride = no bank conflicts for row-per-lane reads */
-constexpr int CS = 20;                               /* deblock chroma tiles: 10 rows x 12 cols, 5-dword stride */
-constexpr int WORKER_LDS = 1280;                     /* LDS per deblocking worker (= a quarter wavefront) */
+__device__ __forceinline__ s2 pk_splat_byte(uint32_t w, int byte)   /* (byte, byte) as two 16-bit halves: one v_perm_b32 */
+{
+    return as_s2(perm(w, w, byte == 0 ? 0x0C000C00u : byte == 1 ? 0x0C010C01u : byte == 2 ? 0x0C020C02u : 0x0C030C03u));
+}
 
-/* ---- packed edge filter: TWO lines per lane (v_pk_*_i16) ----
- * A lane owns two adjacent sample rows (vertical edges) or columns (horizontal edges); every register holds the
- * same sample position of both lines as two 16-bit halves.  The two lines lie in the same 4-sample segment of the
- * edge, so they share bS, alpha, beta and tc0.  Conditions become 0 / -1 half-word masks ((a - b) >> 15), selection
- * is bitwise (v_bfi).  Same arithmetic as 8.7.2.3 / 8.7.2.4, same result as filter_edge8. */
-__device__ __forceinline__ void filter_edge8_pk(s2 v[8], int bs, int alpha, int beta, int tc0, bool chroma)
+/* ---- packed edge filters: TWO lines per lane (v_pk_*_i16), every register holds the same sample position of both lines.
+ * The two lines lie in one 4-sample segment of the edge: they share bS, alpha, beta and tc0.  Conditions are sign bits
+ * (x - threshold < 0), combined with AND and spread by one arithmetic shift; selection is bitwise.  8.7.2.3 / 8.7.2.4,
+ * reference FilterVerLumaEdge / FilterHorLuma / FilterVerChromaEdge ... src/h264bsd_deblocking.c:643-1180.
+ * bs = 0 switches the lane off (alpha 0: |p0 - q0| < 0 never holds). */
+__device__ __forceinline__ s2 pk_absdiff(s2 a, s2 b) { return __builtin_elementwise_max(a - b, b - a); }
+
+__device__ __forceinline__ void filter_luma_pk(s2 v[8], int bs, s2 A, s2 B, int tc0, s2 one)
 {
     const s2 p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
-    const s2 B = pk(beta), zero = pk(0);
-    const s2 on = pk(bs != 0 ? -1 : 0), lum = pk(chroma ? 0 : -1);
-    const s2 d0 = pk_abs(p0 - q0);
-    const s2 fs = on & pk_lt(d0, pk(alpha)) & pk_lt(pk_abs(p1 - p0), B) & pk_lt(pk_abs(q1 - q0), B);
-    const s2 ap = lum & pk_lt(pk_abs(p2 - p0), B), aq = lum & pk_lt(pk_abs(q2 - q0), B);
+    const s2 zero = pk(0);
+    const s2 Aon = bs != 0 ? A : zero;
+    const s2 d0 = pk_absdiff(p0, q0);
+    s2 fs = ((d0 - Aon) & (pk_absdiff(p1, p0) - B) & (pk_absdiff(q1, q0) - B)) >> pk(15);
+    s2 ap = (pk_absdiff(p2, p0) - B) >> pk(15), aq = (pk_absdiff(q2, q0) - B) >> pk(15);      /* -1 where true */
+    /* (masks of unknown origin: a select on a spread sign bit is turned into a 16-bit compare and a v_cndmask per HALF, nine
+     * instructions for one v_bfi) */
+    asm("" : "+v"(fs), "+v"(ap), "+v"(aq));
     /* bS < 4 */
     const s2 t0 = pk(tc0);
-    const s2 tc = chroma ? t0 + pk(1) : t0 - ap - aq;                     /* masks are -1 where true */
+    const s2 tc = t0 - ap - aq;
     const s2 d = pk_clip(-tc, tc, (((q0 - p0) << pk(2)) + (p1 - q1) + pk(4)) >> pk(3));
-    const s2 avg = (p0 + q0 + pk(1)) >> pk(1);
+    const s2 avg = (p0 + q0 + one) >> pk(1);            /* (`one` comes in a register: written as + 1 the compiler matches a rounding
+                                                           average, which it then takes apart into seven 16-bit instructions) */
     s2 r_p0 = pk_clip(zero, pk(255), p0 + d), r_q0 = pk_clip(zero, pk(255), q0 - d);
     s2 r_p1 = p1 + pk_clip(-t0, t0, (p2 + avg - (p1 << pk(1))) >> pk(1));
     s2 r_q1 = q1 + pk_clip(-t0, t0, (q2 + avg - (q1 << pk(1))) >> pk(1));
@@ -1484,7 +1540,8 @@ __device__ __forceinline__ void filter_edge8_pk(s2 v[8], int bs, int alpha, int 
     s2 m_p1 = ap, m_q1 = aq, m_p2 = zero, m_q2 = zero;
     const bool strong = bs == 4;
     if (__ballot(strong)) {                              /* wave-uniform: intra edges only */
-        const s2 sm = pk_lt(d0, pk((alpha >> 2) + 2));
+        s2 sm = (d0 - ((A >> pk(2)) + pk(2))) >> pk(15);                                    /* |p0 - q0| < (alpha >> 2) + 2 */
+        asm("" : "+v"(sm));
         const s2 sp = sm & ap, sq = sm & aq;
         const s2 p0q0 = p0 + q0;
         const s2 s_p0 = pk_sel(sp, (p2 + ((p1 + p0q0) << pk(1)) + q1 + pk(4)) >> pk(3), ((p1 << pk(1)) + p0 + q1 + pk(2)) >> pk(2));
@@ -1505,208 +1562,276 @@ __device__ __forceinline__ void filter_edge8_pk(s2 v[8], int bs, int alpha, int 
     v[6] = pk_sel(fs & m_q2, r_q2, q2);
 }
 
-/* Everything a worker can fetch about a macroblock BEFORE its neighbours are final: the deblocking
- * record and the macroblock's own (still un-filtered) samples.  Issued one slot ahead.
- * A worker is a QUARTER of a wavefront (16 lanes, ql = lane & 15). */
-struct DbkPrefetch { uint4 y; uint2 c; uint32_t bsb; uint4 thr; uint32_t s_ly, s_ty, s_lc, s_tc; };
+/* chroma (chromaEdgeFlag = 1): only p0 and q0 change; v = p1, p0, q0, q1 */
+__device__ __forceinline__ void filter_chroma_pk(s2 v[4], int bs, s2 A, s2 B, int tc0)
+{
+    const s2 p1 = v[0], p0 = v[1], q0 = v[2], q1 = v[3];
+    const s2 zero = pk(0);
+    const s2 Aon = bs != 0 ? A : zero;
+    s2 fs = ((pk_absdiff(p0, q0) - Aon) & (pk_absdiff(p1, p0) - B) & (pk_absdiff(q1, q0) - B)) >> pk(15);
+    asm("" : "+v"(fs));
+    const s2 tc = pk(tc0 + 1);
+    const s2 d = pk_clip(-tc, tc, (((q0 - p0) << pk(2)) + (p1 - q1) + pk(4)) >> pk(3));
+    s2 r_p0 = pk_clip(zero, pk(255), p0 + d), r_q0 = pk_clip(zero, pk(255), q0 - d);
+    const bool strong = bs == 4;
+    if (__ballot(strong)) {
+        const s2 s_p0 = ((p1 << pk(1)) + p0 + q1 + pk(2)) >> pk(2), s_q0 = ((q1 << pk(1)) + q0 + p1 + pk(2)) >> pk(2);
+        if (strong) { r_p0 = s_p0; r_q0 = s_q0; }
+    }
+    v[1] = pk_sel(fs, r_p0, p0);
+    v[2] = pk_sel(fs, r_q0, q0);
+}
 
-/* cross: the macroblock lies in the first row of a row band (k_frame_dbk): the tile above belongs to another workgroup, its
- * last rows are read past the L1 (ld_agent_u32) — and only when this macroblock's upper edge is filtered at all (want_top),
- * because an unconditional load could run ahead of the other band's stores. */
-__device__ __forceinline__ void dbk_prefetch(const FrameDesc &fd, int mb, int ql, DbkPrefetch &p, bool cross = false, bool want_top = true)
+/* Everything a macroblock's worker loads, all of it requested before the first use (one memory round trip per step): the
+ * macroblock's own samples, the strips of the left and upper neighbour that its two macroblock edges work on (whether they
+ * are needed is in the record that is still in flight) and its 48-byte record.  Addresses are 32-bit offsets from wave-uniform
+ * bases (global_load with an SGPR base). */
+struct DbkLoads {
+    uint4 y0, y1, c;               /* luma rows 2l, 2l+1 (32 contiguous bytes of the tile); chroma rows 2(l&3), 2(l&3)+1 of plane l>>2 (16 contiguous bytes) */
+    uint32_t ly0, ly1, lc0, lc1;   /* the last four columns of the tile to the left, same rows                           */
+    uint2 ty; uint32_t tc;         /* this lane's share of the last four luma rows (dwords 2l, 2l+1 of 16) and of the last two
+                                      chroma rows of both planes (dword l of 8) of the tile above                         */
+    uint4 r0, r1, r2;              /* the record                                                                          */
+};
+
+/* cross: the macroblock lies in the first row of a row band: the tile above belongs to another workgroup, its last rows are
+ * read past the L1 (ld_agent_u32) — and only when this macroblock's upper edge is filtered at all (want_top), because an
+ * unconditional load could run ahead of the other band's stores. */
+__device__ __forceinline__ void dbk_load(const FrameDesc &fd, int mb, int l, DbkLoads &p, bool cross, bool want_top)
 {
     if (mb < 0) return;
-    const int wmb = fd.wmb;
-    const int mbx = mb % wmb, mby = mb / wmb;
-    const uint8_t *T = fd.cur + (size_t)mb * TILE;               /* this macroblock's tile: three cache lines */
-    p.y = *reinterpret_cast<const uint4 *>(T + ql * 16);         /* luma row ql */
-    const int plane = ql >> 3, r = ql & 7;                       /* one 8-byte chroma row */
-    const uint8_t *P = T + T_CB + plane * 64;
-    p.c = *reinterpret_cast<const uint2 *>(P + r * 8);
-    const uint8_t *rec = fd.dbk + (size_t)mb * DBK_REC_BYTES;
-    p.bsb = rec[ql];                                            /* strengths: byte ql = nibbles 2ql, 2ql+1 */
-    p.thr = *reinterpret_cast<const uint4 *>(rec + 16);
-    /* The strips of the left / upper neighbour (final by now: this macroblock was only published after them).
-     * Whether they are needed is in the record that is still in flight, so they are fetched unconditionally —
-     * one memory round trip per macroblock instead of two.  Left strip: the last 4 columns of the tile to the left
-     * (2 lines); upper strip: the last 4 rows of the tile above (64 contiguous bytes). */
-    p.s_ly = p.s_ty = p.s_lc = p.s_tc = 0;
-    if (mbx > 0) {
-        p.s_ly = *reinterpret_cast<const uint32_t *>(T - TILE + ql * 16 + 12);
-        p.s_lc = *reinterpret_cast<const uint32_t *>(P - TILE + r * 8 + 4);
-    }
-    if (mby > 0) {
-        const uint8_t *U = T - (size_t)wmb * TILE;
-        const uint8_t *uy = U + (12 + (ql >> 2)) * 16 + 4 * (ql & 3), *uc = U + T_CB + (ql >> 2) * 64 + (6 + ((ql >> 1) & 1)) * 8 + 4 * (ql & 1);
-        if (!cross) {
-            p.s_ty = *reinterpret_cast<const uint32_t *>(uy);
-            if (ql < 8) p.s_tc = *reinterpret_cast<const uint32_t *>(uc);
-        } else if (want_top) {
-            p.s_ty = ld_agent_u32(uy);
-            if (ql < 8) p.s_tc = ld_agent_u32(uc);
-        }
+    const H264K_GLOBAL uint8_t *cur = (const H264K_GLOBAL uint8_t *)fd.cur;
+    const H264K_GLOBAL uint8_t *recs = (const H264K_GLOBAL uint8_t *)fd.dbk;
+    const uint32_t umb = (uint32_t)mb, wmb = fd.wmb;
+    const uint32_t t = umb * TILE, tl = (umb ? umb - 1u : 0u) * TILE, tu = (umb >= wmb ? umb - wmb : umb) * TILE;     /* stand-ins where there is no neighbour: never used (k_dbk: LEFT / TOP only where it exists) */
+    const uint32_t ro = umb * DBK_REC_BYTES;
+    p.y0 = ld16g(cur + t + 32u * l);
+    p.y1 = ld16g(cur + t + 32u * l + 16u);
+    p.c = ld16g(cur + t + T_CB + 16u * l);
+    p.r0 = ld16g(recs + ro);
+    p.r1 = ld16g(recs + ro + 16u);
+    p.r2 = ld16g(recs + ro + 32u);
+    p.ly0 = *(const H264K_GLOBAL uint32_t *)(cur + tl + 32u * l + 12u);
+    p.ly1 = *(const H264K_GLOBAL uint32_t *)(cur + tl + 32u * l + 28u);
+    p.lc0 = *(const H264K_GLOBAL uint32_t *)(cur + tl + T_CB + 16u * l + 4u);
+    p.lc1 = *(const H264K_GLOBAL uint32_t *)(cur + tl + T_CB + 16u * l + 12u);
+    const uint32_t uy = tu + 192u + 8u * l, uc = tu + T_CB + 64u * (l >> 2) + 48u + 4u * (l & 3);
+    p.ty = make_uint2(0u, 0u); p.tc = 0u;
+    if (!cross) {
+        p.ty = ld8g(cur + uy);
+        p.tc = *(const H264K_GLOBAL uint32_t *)(cur + uc);
+    } else if (want_top) {
+        p.ty = make_uint2(ld_agent_u32(fd.cur + uy), ld_agent_u32(fd.cur + uy + 4));
+        p.tc = ld_agent_u32(fd.cur + uc);
     }
 }
 
-/* In-loop filter of one macroblock by one worker = 16 lanes: vertical edges, then horizontal edges (8.7).
- * mb < 0: this quarter of the wavefront idles.  w = worker-private LDS.  q16 = 16 * (quarter index). */
-/* inner: the macroblock has an active inner edge (DBKF_INNER).  Without one it STORES only what its two macroblock edges can
+/* the lane's strength at edge slot e (luma edges 0..3; chroma slots 0, 1 = luma edges 0, 2) of a direction whose eight strength
+ * bytes are w0 | w1, already shifted right by 4 * (segment of the lane): nibble n = 4 * e + k sits at bit 16 * (e & 1) of dword e >> 1 */
+__device__ __forceinline__ int bs_of(uint32_t w0s, uint32_t w1s, int e) { return (int)(((e & 2 ? w1s : w0s) >> (16 * (e & 1))) & 15u); }
+/* tc0 of a class for strength bs: t4 = { 0, tc0(1), tc0(2), tc0(3) } as bytes; bs 0 and 4 give 0 */
+__device__ __forceinline__ int tc0_of(uint32_t t4, int bs) { return (int)((t4 >> (8 * (bs & 3))) & 255u); }
+
+/* In-loop filter of one macroblock by one worker = 8 lanes: vertical edges, then horizontal edges (8.7).
+ * mb < 0: this eighth of the wavefront idles.  w = worker-private LDS.
+ * inner: the macroblock has an active inner edge (DBKF_INNER).  Without one it STORES only what its two macroblock edges can
  * have changed — rows 0..2 (upper edge) and columns 0..3 (left edge) of its own tile — because the macroblocks to its right
  * and below it no longer wait for it unless those very samples concern them (k_frame_dbk, dependency rule) and may be
- * rewriting the rest of its tile at the same time. */
-__device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int ql, int q16, const DbkPrefetch &p, uint8_t *w,
-                                           int nxt, DbkPrefetch &nxt_pf, const uint8_t *tabs, bool wt, bool inner, unsigned long long *tp = nullptr)
+ * rewriting the rest of its tile at the same time.
+ * wt: the macroblock lies in the last row of a row band, the band below reads what it writes: everything goes write-through. */
+template <bool BANDED>
+__device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, const DbkLoads &p, uint8_t *w, bool wt, bool inner, unsigned long long *tp = nullptr)
 {
 #define DTICK() (tp ? __builtin_readcyclecounter() : 0ull)
     const unsigned long long d0 = DTICK();
-    /* threshold tables in LDS (tabs: alpha[64] | beta[64] | tc0[64][4]): a lane-indexed __constant__ lookup is a
-     * global load, and these sit on the critical path of every edge */
-    uint8_t *lt = w, *ct0 = w + 20 * LS, *bs_s = w + 20 * LS + 2 * 10 * CS;
+    w = static_cast<uint8_t *>(__builtin_assume_aligned(w, 16));
+    uint8_t *lt = w, *ct = w + 20 * LS + (l >> 2) * 10 * CS;      /* luma tile; this lane's chroma plane */
     const bool act = mb >= 0;
-    const int wmb = fd.wmb;
-    uint8_t *Y = fd.cur + (size_t)(act ? mb : 0) * TILE;          /* the macroblock's tile */
-    /* lane ql holds strength byte ql: bytes 0..7 = vertical edges (0,1 = left MB edge), 8..15 = horizontal edges
-     * (8,9 = top MB edge).  The neighbours are touched only if that macroblock edge has a non-zero strength. */
-    const bool nz = act && p.bsb != 0;
-    const uint32_t mine = (uint32_t)(__ballot(nz) >> q16) & 0xFFFFu;
-    const bool any_v = __ballot(nz && ql < 8) != 0ull, any_h = __ballot(nz && ql >= 8) != 0ull;   /* wave-wide phase skips */
-    const bool f_left = (p.thr.w & FJ_DBK_LEFT) && (mine & 0x0003u);
-    const bool f_top = (p.thr.w & FJ_DBK_TOP) && (mine & 0x0300u);
+    const int c4 = l & 3;                                          /* chroma line pair of this lane */
+    /* the record: strengths (dir 0 = vertical edges: r0.x, r0.y; dir 1: r0.z, r0.w), class dwords r1.x .. r2.y, bS-3 bytes and flags r2.z, r2.w */
+    const uint32_t flags = p.r2.w >> 16;                          /* byte 46: FJ_DBK_*, byte 47: any */
+    const bool f_left = act && (flags & FJ_DBK_LEFT) && (p.r0.x & 0xFFFFu), f_top = act && (flags & FJ_DBK_TOP) && (p.r0.z & 0xFFFFu);
+    const bool any_v = __ballot(act && (p.r0.x | p.r0.y)) != 0ull, any_h = __ballot(act && (p.r0.z | p.r0.w)) != 0ull;   /* wave-wide phase skips */
+    /* thresholds per class: A / B = alpha / beta in both halves, t4 = { 0, tc0(1), tc0(2), tc0(3) } */
+    const uint32_t w_ll = p.r1.x, w_lt = p.r1.y, w_li = p.r1.z, w_cl = p.r1.w, w_ctp = p.r2.x, w_ci = p.r2.y;
+    const uint32_t t3a = p.r2.z, t3b = p.r2.w;                    /* bytes 40..43, 44..47 */
+    s2 one = pk(1);
+    asm volatile("" : "+v"(one));
 
-    /* neighbour strips (the only samples that depend on earlier macroblocks): issued first; then the NEXT slot's
-     * prefetch goes out behind them so that it flies during the filter */
-    const uint32_t s_ly = f_left ? p.s_ly : 0u, s_lc = f_left ? p.s_lc : 0u, s_ty = f_top ? p.s_ty : 0u, s_tc = f_top ? p.s_tc : 0u;
-    dbk_prefetch(fd, nxt, ql, nxt_pf);
+    /* ---- staging: what the horizontal pass needs and the vertical pass does not produce — the upper strips ---- */
     if (act) {
-        *reinterpret_cast<uint32_t *>(&lt[(4 + ql) * LS]) = s_ly;                                        /* left 4 columns  */
-        *reinterpret_cast<uint32_t *>(&lt[(ql >> 2) * LS + 4 + 4 * (ql & 3)]) = s_ty;                    /* upper 4 rows    */
-        *reinterpret_cast<uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS]) = s_lc;
-        if (ql < 8) *reinterpret_cast<uint32_t *>(&ct0[(ql >> 2) * 10 * CS + ((ql >> 1) & 1) * CS + 4 + 4 * (ql & 1)]) = s_tc;
-        /* own samples (prefetched) and boundary strengths */
-        {
-            uint32_t *ydst = reinterpret_cast<uint32_t *>(&lt[(4 + ql) * LS + 4]);
-            ydst[0] = p.y.x; ydst[1] = p.y.y; ydst[2] = p.y.z; ydst[3] = p.y.w;
-        }
-        {   /* (tile rows are 20 bytes apart: dword accesses only) */
-            uint32_t *cdst = reinterpret_cast<uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS + 4]);
-            cdst[0] = p.c.x; cdst[1] = p.c.y;
-        }
-        bs_s[2 * ql] = (uint8_t)(p.bsb & 15u);
-        bs_s[2 * ql + 1] = (uint8_t)((p.bsb >> 4) & 15u);
+        *reinterpret_cast<uint2 *>(&lt[(l >> 1) * LS + LX + 8 * (l & 1)]) = p.ty;                          /* strip dwords 2l, 2l+1: row l >> 1, columns 8 * (l & 1) .. + 7 */
+        *reinterpret_cast<uint32_t *>(&ct[(c4 >> 1) * CS + CX + 4 * (c4 & 1)]) = p.tc;                     /* strip dword l: plane l >> 2, row (l & 3) >> 1, columns 4 * (l & 1) .. + 3 */
+        *reinterpret_cast<uint32_t *>(&ct[(2 + 2 * c4) * CS + CX - 4]) = p.lc0;                            /* the left chroma strip: the vertical pass only rewrites its last byte */
+        *reinterpret_cast<uint32_t *>(&ct[(3 + 2 * c4) * CS + CX - 4]) = p.lc1;
     }
-    /* thresholds: classes luma left/top/inner = 0,1,2 ; chroma left/top/inner = 3,4,5 */
-    const uint4 r1 = p.thr;
-    const bool chroma = ql >= 8;
-    const uint32_t ia_in = chroma ? (r1.y >> 8) & 255u : (r1.x >> 16) & 255u, ib_in = chroma ? (r1.z >> 24) & 255u : r1.z & 255u;
-    const uint32_t ia_l = chroma ? (r1.x >> 24) & 255u : r1.x & 255u, ib_l = chroma ? (r1.z >> 8) & 255u : (r1.y >> 16) & 255u;
-    const uint32_t ia_t = chroma ? r1.y & 255u : (r1.x >> 8) & 255u, ib_t = chroma ? (r1.z >> 16) & 255u : (r1.y >> 24) & 255u;
-    const int al_in = tabs[ia_in & 63u], be_in = tabs[64 + (ib_in & 63u)];
-    const int al_l = tabs[ia_l & 63u], be_l = tabs[64 + (ib_l & 63u)];
-    const int al_t = tabs[ia_t & 63u], be_t = tabs[64 + (ib_t & 63u)];
-    wave_sync();
+
+    if (tp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long d1 = DTICK();
-
-    /* Lanes 0..7 own luma line pairs (2ql, 2ql+1), lanes 8..15 chroma line pairs of plane (ql-8)>>2; both lines of a
-     * pair lie in edge segment kseg, chroma tiles are 12 bytes wide / 10 rows high with their edges on luma edges 0, 2 */
-    const int cplane = (ql - 8) >> 2, cpair = (ql - 8) & 3;
-    const int kseg = chroma ? cpair : (ql >> 1);
-
-    /* ---- vertical edges: a lane owns two sample rows across all edges ---- */
-    if (act && any_v) {
-        uint8_t *rowp = chroma ? &ct0[cplane * 10 * CS + (2 + 2 * cpair) * CS] : &lt[(4 + 2 * ql) * LS];
-        const int rstride = chroma ? CS : LS;
+    /* ---- vertical edges, luma: rows 2l (low halves) and 2l+1 (high halves) across all four edges ---- */
+    {
         s2 px[20];
+        px[0] = as_s2(perm(p.ly1, p.ly0, 0x0C040C00u)); px[1] = as_s2(perm(p.ly1, p.ly0, 0x0C050C01u));
+        px[2] = as_s2(perm(p.ly1, p.ly0, 0x0C060C02u)); px[3] = as_s2(perm(p.ly1, p.ly0, 0x0C070C03u));
+        const uint32_t ra[4] = { p.y0.x, p.y0.y, p.y0.z, p.y0.w }, rb[4] = { p.y1.x, p.y1.y, p.y1.z, p.y1.w };
 #pragma unroll
-        for (int w4 = 0; w4 < 5; w4++) {
-            const bool have = w4 < 3 || !chroma;
-            const uint32_t a = have ? *reinterpret_cast<const uint32_t *>(rowp + 4 * w4) : 0u;
-            const uint32_t b = have ? *reinterpret_cast<const uint32_t *>(rowp + rstride + 4 * w4) : 0u;
-            px[4 * w4 + 0] = as_s2(perm(b, a, 0x0C040C00u));
-            px[4 * w4 + 1] = as_s2(perm(b, a, 0x0C050C01u));
-            px[4 * w4 + 2] = as_s2(perm(b, a, 0x0C060C02u));
-            px[4 * w4 + 3] = as_s2(perm(b, a, 0x0C070C03u));
+        for (int w4 = 0; w4 < 4; w4++) {
+            px[4 + 4 * w4 + 0] = as_s2(perm(rb[w4], ra[w4], 0x0C040C00u));
+            px[4 + 4 * w4 + 1] = as_s2(perm(rb[w4], ra[w4], 0x0C050C01u));
+            px[4 + 4 * w4 + 2] = as_s2(perm(rb[w4], ra[w4], 0x0C060C02u));
+            px[4 + 4 * w4 + 3] = as_s2(perm(rb[w4], ra[w4], 0x0C070C03u));
         }
-        /* strengths and tc0 of the four edges up front: two rounds of independent LDS reads instead of eight dependent ones */
-        int bsv[4], tcv[4];
+        if (any_v) {
+            const int k = l >> 1;                                  /* both rows lie in segment k of every vertical edge */
+            const uint32_t w0s = p.r0.x >> (4 * k), w1s = p.r0.y >> (4 * k);
+            const s2 A_l = pk_splat_byte(w_ll, 0), B_l = pk_splat_byte(w_ll, 1), A_i = pk_splat_byte(w_li, 0), B_i = pk_splat_byte(w_li, 1);
+            const uint32_t t4_l = perm(t3a, w_ll, 0x0403020Cu), t4_i = perm(t3a, w_li, 0x0603020Cu);    /* { 0, tc0(1), tc0(2), tc0(3) } */
 #pragma unroll
-        for (int e = 0; e < 4; e++) bsv[e] = chroma ? (e < 2 ? bs_s[8 * e + kseg] : 0) : bs_s[4 * e + kseg];
-#pragma unroll
-        for (int e = 0; e < 4; e++) tcv[e] = tabs[128 + 4 * ((e ? ia_in : ia_l) & 63u) + ((bsv[e] - 1) & 3)];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int bs = bsv[e];
-            if (__ballot(bs != 0)) filter_edge8_pk(px + 4 * e, bs, e ? al_in : al_l, e ? be_in : be_l, bs > 0 && bs < 4 ? tcv[e] : 0, chroma);
-        }
-#pragma unroll
-        for (int w4 = 0; w4 < 5; w4++)
-            if (w4 < 3 || !chroma) {
-                const uint32_t x0 = as_u32(px[4 * w4]), x1 = as_u32(px[4 * w4 + 1]), x2 = as_u32(px[4 * w4 + 2]), x3 = as_u32(px[4 * w4 + 3]);
-                /* row A = low halves, row B = high halves */
-                *reinterpret_cast<uint32_t *>(rowp + 4 * w4) = perm(x1, x0, 0x0C0C0400u) | perm(x3, x2, 0x04000C0Cu);
-                *reinterpret_cast<uint32_t *>(rowp + rstride + 4 * w4) = perm(x1, x0, 0x0C0C0602u) | perm(x3, x2, 0x06020C0Cu);
+            for (int e = 0; e < 4; e++) {
+                const int bs = act ? bs_of(w0s, w1s, e) : 0;
+                if (__ballot(bs != 0)) filter_luma_pk(px + 4 * e, bs, e ? A_i : A_l, e ? B_i : B_l, tc0_of(e ? t4_i : t4_l, bs), one);
             }
+        }
+        if (act) {
+            /* back to rows: four packed pairs -> one dword of row 2l and one of row 2l+1 (samples are < 256: two pairs merge with a
+             * shift-or, the rows come apart with a byte permute each) */
+            uint32_t ra[5], rb[5];
+#pragma unroll
+            for (int g = 0; g < 5; g++) {
+                const uint32_t t01 = as_u32(px[4 * g]) | (as_u32(px[4 * g + 1]) << 8), t23 = as_u32(px[4 * g + 2]) | (as_u32(px[4 * g + 3]) << 8);
+                ra[g] = perm(t23, t01, 0x05040100u); rb[g] = perm(t23, t01, 0x07060302u);
+            }
+            uint8_t *rowa = &lt[(4 + 2 * l) * LS];
+            *reinterpret_cast<uint32_t *>(rowa + LX - 4) = ra[0]; *reinterpret_cast<uint32_t *>(rowa + LS + LX - 4) = rb[0];
+            *reinterpret_cast<uint4 *>(rowa + LX) = make_uint4(ra[1], ra[2], ra[3], ra[4]);
+            *reinterpret_cast<uint4 *>(rowa + LS + LX) = make_uint4(rb[1], rb[2], rb[3], rb[4]);
+        }
+    }
+    /* ---- vertical edges, chroma: rows 2 c4, 2 c4 + 1 of plane l >> 2; edges at columns 0 and 4 = luma edges 0 and 2 ---- */
+    {
+        s2 px[12];
+        px[2] = as_s2(perm(p.lc1, p.lc0, 0x0C060C02u)); px[3] = as_s2(perm(p.lc1, p.lc0, 0x0C070C03u));
+        px[4] = as_s2(perm(p.c.z, p.c.x, 0x0C040C00u)); px[5] = as_s2(perm(p.c.z, p.c.x, 0x0C050C01u));
+        px[6] = as_s2(perm(p.c.z, p.c.x, 0x0C060C02u)); px[7] = as_s2(perm(p.c.z, p.c.x, 0x0C070C03u));
+        px[8] = as_s2(perm(p.c.w, p.c.y, 0x0C040C00u)); px[9] = as_s2(perm(p.c.w, p.c.y, 0x0C050C01u));
+        px[10] = as_s2(perm(p.c.w, p.c.y, 0x0C060C02u)); px[11] = as_s2(perm(p.c.w, p.c.y, 0x0C070C03u));
+        if (any_v) {
+            const uint32_t w0s = p.r0.x >> (4 * c4), w1s = p.r0.y >> (4 * c4);     /* chroma rows 2 c4, 2 c4 + 1 = luma rows 4 c4 .. 4 c4 + 3: segment c4 */
+            const int bs0 = act ? (int)(w0s & 15u) : 0, bs1 = act ? (int)(w1s & 15u) : 0;
+            if (__ballot(bs0 != 0))
+                filter_chroma_pk(px + 2, bs0, pk_splat_byte(w_cl, 0), pk_splat_byte(w_cl, 1), tc0_of(perm(t3a, w_cl, 0x0703020Cu), bs0));
+            if (__ballot(bs1 != 0))
+                filter_chroma_pk(px + 6, bs1, pk_splat_byte(w_ci, 0), pk_splat_byte(w_ci, 1), tc0_of(perm(t3b, w_ci, 0x0503020Cu), bs1));
+        }
+        if (act) {
+            uint8_t *rowa = &ct[(2 + 2 * c4) * CS];
+            uint32_t ra[2], rb[2];
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const uint32_t t01 = as_u32(px[4 + 4 * g]) | (as_u32(px[5 + 4 * g]) << 8), t23 = as_u32(px[6 + 4 * g]) | (as_u32(px[7 + 4 * g]) << 8);
+                ra[g] = perm(t23, t01, 0x05040100u); rb[g] = perm(t23, t01, 0x07060302u);
+            }
+            lds_st_pair<CX - 1, CS + CX - 1>(lds_addr(rowa), px[3]);                   /* p0 of the left edge: the last byte of the strip */
+            *reinterpret_cast<uint2 *>(rowa + CX) = make_uint2(ra[0], ra[1]);
+            *reinterpret_cast<uint2 *>(rowa + CS + CX) = make_uint2(rb[0], rb[1]);
+        }
     }
     wave_sync();
     const unsigned long long d2 = DTICK();
 
-    /* ---- horizontal edges: a lane owns two adjacent sample columns; chroma columns (10 rows) sit at px[2..11] so
-     * that their edges (rows 2 and 6 of the tile) fall on px[4] and px[8] like the first two luma edges ---- */
-    if (act && any_h) {
-        uint8_t *colp = chroma ? &ct0[cplane * 10 * CS + 4 + 2 * cpair] : &lt[4 + 2 * ql];
+    /* ---- horizontal edges, luma: columns 2l (low halves), 2l+1 (high halves); tile rows 0..3 = the strip above ---- */
+    if (any_h) {
+        const uint8_t *colp = &lt[LX + 2 * l];
         s2 px[20];
 #pragma unroll
-        for (int r = 0; r < 20; r++) {
-            uint32_t v = 0;
-            if (!chroma) v = *reinterpret_cast<const uint16_t *>(colp + r * LS);
-            else if (r >= 2 && r < 12) v = *reinterpret_cast<const uint16_t *>(colp + (r - 2) * CS);
-            px[r] = as_s2(perm(0u, v, 0x0C010C00u));
-        }
-        int bsv[4], tcv[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) bsv[e] = chroma ? (e < 2 ? bs_s[16 + 8 * e + kseg] : 0) : bs_s[16 + 4 * e + kseg];
-#pragma unroll
-        for (int e = 0; e < 4; e++) tcv[e] = tabs[128 + 4 * ((e ? ia_in : ia_t) & 63u) + ((bsv[e] - 1) & 3)];
+        for (int r = 0; r < 20; r++) px[r] = as_s2(perm(0u, *reinterpret_cast<const uint16_t *>(colp + r * LS), 0x0C010C00u));
+        const int k = l >> 1;
+        const uint32_t w0s = p.r0.z >> (4 * k), w1s = p.r0.w >> (4 * k);
+        const s2 A_t = pk_splat_byte(w_lt, 0), B_t = pk_splat_byte(w_lt, 1), A_i = pk_splat_byte(w_li, 0), B_i = pk_splat_byte(w_li, 1);
+        const uint32_t t4_t = perm(t3a, w_lt, 0x0503020Cu), t4_i = perm(t3a, w_li, 0x0603020Cu);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const int bs = bsv[e];
-            if (__ballot(bs != 0)) filter_edge8_pk(px + 4 * e, bs, e ? al_in : al_t, e ? be_in : be_t, bs > 0 && bs < 4 ? tcv[e] : 0, chroma);
-        }
+            const int bs = act ? bs_of(w0s, w1s, e) : 0;
+            if (__ballot(bs != 0)) {
+                filter_luma_pk(px + 4 * e, bs, e ? A_i : A_t, e ? B_i : B_t, tc0_of(e ? t4_i : t4_t, bs), one);
+                if (act) {
 #pragma unroll
-        for (int r = 1; r < 20; r++) {
-            const uint16_t o = (uint16_t)perm(0u, as_u32(px[r]), 0x0C0C0200u);
-            if (!chroma) *reinterpret_cast<uint16_t *>(colp + r * LS) = o;
-            else if (r >= 3 && r < 12) *reinterpret_cast<uint16_t *>(colp + (r - 2) * CS) = o;
+                    for (int r = 4 * e + 1; r < 4 * e + 7; r++) *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + r * LS) = (uint16_t)perm(0u, as_u32(px[r]), 0x0C0C0200u);
+                }
+            }
+        }
+    }
+    /* ---- horizontal edges, chroma: columns 2 c4, 2 c4 + 1 of plane l >> 2; tile rows 0, 1 = the strip above; edges at rows 2 and 6 ---- */
+    if (any_h) {
+        const uint8_t *colp = &ct[CX + 2 * c4];
+        s2 px[10];
+#pragma unroll
+        for (int r = 0; r < 10; r++) px[r] = as_s2(perm(0u, *reinterpret_cast<const uint16_t *>(colp + r * CS), 0x0C010C00u));
+        const uint32_t w0s = p.r0.z >> (4 * c4), w1s = p.r0.w >> (4 * c4);
+        const int bs0 = act ? (int)(w0s & 15u) : 0, bs1 = act ? (int)(w1s & 15u) : 0;
+        if (__ballot(bs0 != 0)) {
+            filter_chroma_pk(px + 0, bs0, pk_splat_byte(w_ctp, 0), pk_splat_byte(w_ctp, 1), tc0_of(perm(t3b, w_ctp, 0x0403020Cu), bs0));
+            if (act) { *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + 1 * CS) = (uint16_t)perm(0u, as_u32(px[1]), 0x0C0C0200u); *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + 2 * CS) = (uint16_t)perm(0u, as_u32(px[2]), 0x0C0C0200u); }
+        }
+        if (__ballot(bs1 != 0)) {
+            filter_chroma_pk(px + 4, bs1, pk_splat_byte(w_ci, 0), pk_splat_byte(w_ci, 1), tc0_of(perm(t3b, w_ci, 0x0503020Cu), bs1));
+            if (act) { *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + 5 * CS) = (uint16_t)perm(0u, as_u32(px[5]), 0x0C0C0200u); *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + 6 * CS) = (uint16_t)perm(0u, as_u32(px[6]), 0x0C0C0200u); }
         }
     }
     wave_sync();
     const unsigned long long d3 = DTICK();
 
-    /* ---- store: own macroblock, the 3 (1) columns of the left and rows of the upper neighbour.  wt: the macroblock lies in
-     * the last row of a row band, the band below reads its last rows: everything it writes goes write-through ---- */
+    /* ---- store: own macroblock (whole, or what its two macroblock edges can have changed), the last 3 (1) columns of the left
+     * and rows of the upper neighbour ---- */
     if (act) {
-        {
-            const uint32_t *ysrc = reinterpret_cast<const uint32_t *>(&lt[(4 + ql) * LS + 4]);
-            if (inner || (f_top && ql < 3)) put16(Y + ql * 16, make_uint4(ysrc[0], ysrc[1], ysrc[2], ysrc[3]), wt);
-            else if (f_left) put4(Y + ql * 16, ysrc[0], wt);
+        const uint32_t t = (uint32_t)mb * TILE;
+        uint8_t *cur = fd.cur;
+        H264K_GLOBAL uint8_t *curg = (H264K_GLOBAL uint8_t *)fd.cur;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                              /* luma rows 2l, 2l+1 */
+            const int row = 2 * l + h;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&lt[(4 + row) * LS + LX]);
+            const uint32_t o = t + 16u * row;
+            if (inner || (f_top && row < 3)) {
+                const uint4 v4 = *reinterpret_cast<const uint4 *>(src);
+                if (BANDED && wt) put16(cur + o, v4, true); else st16g(curg + o, v4);
+            } else if (f_left) {
+                if (BANDED && wt) put4(cur + o, src[0], true); else *(H264K_GLOBAL uint32_t *)(curg + o) = src[0];
+            }
         }
-        uint8_t *PCq = Y + T_CB + (ql >> 3) * 64;                 /* this lane's chroma plane inside the tile */
-        {
-            const uint32_t *csrc = reinterpret_cast<const uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS + 4]);
-            if (inner || (f_top && (ql & 7) == 0)) put8(PCq + (ql & 7) * 8, make_uint2(csrc[0], csrc[1]), wt);
-            else if (f_left) put4(PCq + (ql & 7) * 8, csrc[0], wt);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                              /* chroma rows 2 c4, 2 c4 + 1 of plane l >> 2 */
+            const int row = 2 * c4 + h;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&ct[(2 + row) * CS + CX]);
+            const uint32_t o = t + T_CB + 64u * (l >> 2) + 8u * row;
+            if (inner || (f_top && row == 0)) {
+                const uint2 v2 = *reinterpret_cast<const uint2 *>(src);
+                if (BANDED && wt) put8(cur + o, v2, true); else *(H264K_GLOBAL u32x2 *)(curg + o) = (u32x2){ v2.x, v2.y };
+            } else if (f_left) {
+                if (BANDED && wt) put4(cur + o, src[0], true); else *(H264K_GLOBAL uint32_t *)(curg + o) = src[0];
+            }
         }
         if (f_left) {
-            put4(Y - TILE + ql * 16 + 12, *reinterpret_cast<const uint32_t *>(&lt[(4 + ql) * LS]), wt);
-            put4(PCq - TILE + (ql & 7) * 8 + 4, *reinterpret_cast<const uint32_t *>(&ct0[(ql >> 3) * 10 * CS + (2 + (ql & 7)) * CS]), wt);
+            const uint32_t tl = t - TILE;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t vy = *reinterpret_cast<const uint32_t *>(&lt[(4 + 2 * l + h) * LS + LX - 4]), vc = *reinterpret_cast<const uint32_t *>(&ct[(2 + 2 * c4 + h) * CS + CX - 4]);
+                const uint32_t oy = tl + 16u * (2 * l + h) + 12u, oc = tl + T_CB + 64u * (l >> 2) + 8u * (2 * c4 + h) + 4u;
+                if (BANDED && wt) { put4(cur + oy, vy, true); put4(cur + oc, vc, true); }
+                else { *(H264K_GLOBAL uint32_t *)(curg + oy) = vy; *(H264K_GLOBAL uint32_t *)(curg + oc) = vc; }
+            }
         }
         if (f_top) {
-            uint8_t *U = Y - (size_t)wmb * TILE;                  /* the tile above */
-            if (ql < 12) {
-                const int r = 1 + ql / 4, cw2 = ql % 4;                /* tile rows 1..3 = rows 13..15 of the macroblock above */
-                put4(U + (12 + r) * 16 + 4 * cw2, *reinterpret_cast<const uint32_t *>(&lt[r * LS + 4 + 4 * cw2]), wt);
-            } else {
-                const int i = ql - 12, plane = i >> 1, cw2 = i & 1;    /* chroma tile row 1 of both planes = row 7 above */
-                put4(U + T_CB + plane * 64 + 7 * 8 + 4 * cw2, *reinterpret_cast<const uint32_t *>(&ct0[plane * 10 * CS + 1 * CS + 4 + 4 * cw2]), wt);
+            const uint32_t tu = t - (uint32_t)fd.wmb * TILE;
+            if (l >= 2) {                                          /* luma strip rows 1..3 (row 0 = p3 never changes): dwords 2l, 2l+1 of the strip */
+                const uint2 v2 = *reinterpret_cast<const uint2 *>(&lt[(l >> 1) * LS + LX + 8 * (l & 1)]);
+                const uint32_t o = tu + 192u + 8u * l;
+                if (BANDED && wt) put8(cur + o, v2, true); else *(H264K_GLOBAL u32x2 *)(curg + o) = (u32x2){ v2.x, v2.y };
+            }
+            if (c4 >= 2) {                                         /* chroma strip row 1 (row 0 = p1 never changes) */
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(&ct[1 * CS + CX + 4 * (c4 & 1)]);
+                const uint32_t o = tu + T_CB + 64u * (l >> 2) + 56u + 4u * (c4 & 1);
+                if (BANDED && wt) put4(cur + o, v, true); else *(H264K_GLOBAL uint32_t *)(curg + o) = v;
             }
         }
     }
@@ -1726,11 +1851,8 @@ constexpr int TAIL_WAVES = TAIL_WAVES_N;
 #ifndef DBK_WAVES_N
 #define DBK_WAVES_N 12
 #endif
-constexpr int DBK_WAVES = DBK_WAVES_N;              /* wavefronts of k_frame_dbk.  With planar frames the per-CU cache-line request rate
-                                                        bounded a picture and the count did not matter (4..16 wavefronts: 85-90 ms per
-                                                        step); with macroblock tiles it does: 4: 72.9, 6: 62.5, 8: 56.8, 12: 54.9 ms, 16: 67.6
-                                                        (a 1024-thread workgroup caps the kernel at 128 VGPRs: spills) */
-constexpr int TAIL_WORKERS = 4 * DBK_WAVES;       /* deblocking workers = quarter wavefronts */
+constexpr int DBK_WAVES = DBK_WAVES_N;              /* most wavefronts of k_frame_dbk (the launch chooses: TailConfig.dbk_waves); a wavefront
+                                                        is eight workers (deblock_mb) */
 
 /* Which picture and which row band a workgroup of the two per-picture kernels works on.  Workgroups take a ticket when they
  * start (one device-scope atomic): ticket t = band t % max_bands of picture t / max_bands.  A band only ever waits for the
@@ -2030,11 +2152,11 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
  * three dependants (x+1,y), (x,y+1), (x-1,y+1).  No level barriers; ready macroblocks are packed into as few
  * wavefronts as possible because the loop is instruction-issue bound (a step costs the same with one busy quarter as
  * with four).  Same-CU visibility of the stores needs only s_waitcnt vmcnt(0) before the LDS release.
- * Dynamic LDS: workers x WORKER_LDS tiles | anyf | dep | queue u16 | counters | seen bits | threshold tables (dbk_lds_bytes). */
+ * Dynamic LDS: workers x WORKER_LDS tiles | anyf | dep | queue u16 | counters | seen bits (dbk_lds_bytes). */
 __host__ __device__ inline size_t dbk_lds_bytes(uint32_t waves, uint32_t wmb, uint32_t band_rows)
 {
     const size_t n_loc16 = (((size_t)band_rows + 1) * wmb + 15) & ~(size_t)15, nq8 = ((size_t)band_rows * wmb + 7) & ~(size_t)7;
-    return (size_t)waves * 4 * WORKER_LDS + 2 * n_loc16 + 2 * nq8 + 32 + 4 * ((((size_t)wmb + 31) / 32 + 3) & ~(size_t)3) + 384;
+    return (((size_t)waves * (64 / DBK_LANES) * WORKER_LDS + 15) & ~(size_t)15) + 2 * n_loc16 + 2 * nq8 + 32 + 4 * ((((size_t)wmb + 31) / 32 + 3) & ~(size_t)3);
 }
 #ifndef DBK_OCC
 #define DBK_OCC 3
@@ -2051,7 +2173,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
     const uint32_t ticket = BANDED ? take_ticket(tickets, &s_misc[0]) : blockIdx.x;
     const uint32_t pic = BANDED ? ticket / max_bands : ticket, band = BANDED ? ticket - pic * max_bands : 0u;
     const FrameDesc &fd = FD_REF(frames, pic);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, quarter = lane >> 4, ql = lane & 15, q16 = 16 * quarter;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane / DBK_LANES, l = lane % DBK_LANES;
     const int wmb = fd.wmb, hmb = fd.hmb, n_mbs = (int)fd.n_mbs;
     int R = hmb, nb = 1;
     if (BANDED) band_split(hmb, fd.dbk_bands, fd.heavy, max_bands, light_cap, rows_cap, R, nb);
@@ -2060,13 +2182,12 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
     const int base = (r0 - 1) * wmb;                        /* band-local index of macroblock mb: mb - base (row r0-1 first) */
     const int n_loc = (R + 1) * wmb, n_loc16 = (n_loc + 15) & ~15, nq8 = (R * wmb + 7) & ~7;
     const bool has_up = BANDED && band > 0, has_down = BANDED && r1 < hmb;
-    uint8_t *anyf = lds + (blockDim.x >> 4) * WORKER_LDS;   /* 4 workers per launched wavefront */
+    uint8_t *anyf = lds + (((blockDim.x / DBK_LANES) * WORKER_LDS + 15) & ~15);   /* 8 workers per launched wavefront */
     uint8_t *dep = anyf + n_loc16;
     uint16_t *queue = reinterpret_cast<uint16_t *>(dep + n_loc16);
     uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + nq8);   /* [0] head, [1] tail, [2] total, [3] producers awaited, [4] producers seen, [5] poll lock */
     uint32_t *seen = ctr + 8;                                    /* one bit per column: the done byte of (x, r0-1) has been seen */
-    uint8_t *tabs = reinterpret_cast<uint8_t *>(seen + ((((wmb + 31) >> 5) + 3) & ~3));   /* alpha[64] | beta[64] | tc0[64][4] */
-    uint8_t *wlds = lds + (wave * 4 + quarter) * WORKER_LDS;
+    uint8_t *wlds = lds + (wave * (64 / DBK_LANES) + grp) * WORKER_LDS;
     uint8_t *flags_g = scratch_flags(fd), *done_g = scratch_done(fd, 0);
     /* debug accounting (h264bsdmiDebugTailProfile): band 0 of picture 0 only, per wavefront: [0] cycles with nothing ready,
      * [1] cycles filtering, [2] cycles waiting for own stores, [3] macroblocks filtered (both halves), [4] total */
@@ -2089,12 +2210,6 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
         for (int i = tid; i < nq8 / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;
         if (tid < 8) ctr[tid] = 0;
         for (int i = tid; i < (wmb + 31) >> 5; i += blockDim.x) seen[i] = 0;
-        if (tid < 64) {
-            tabs[tid] = tid < 52 ? c_alpha[tid] : 0;
-            tabs[64 + tid] = tid < 52 ? c_beta[tid] : 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) tabs[128 + 4 * tid + k] = tid < 52 ? c_tc0[tid][k] : 0;
-        }
     }
     __syncthreads();
     /* Dependencies at edge granularity.  A filtered macroblock waits for
@@ -2111,14 +2226,16 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
      * (deblocking.c:604-638); the longest chain of the bundled 1080p stream shrinks by 21 % (9562 -> 7512 steps).
      * For the band's first row the macroblocks above belong to the band above: they count like any other and are
      * released by the poller (below) instead of by the wavefront that filtered them. */
+    /* (k_dbk sets DBKF_LEFT / DBKF_TOP only where that neighbour exists: a macroblock in column 0 never has LEFT — so the
+     * macroblock "to the left" of it, the last one of the row above, is never counted, and neither is the first one of the next
+     * row as the right-hand neighbour of the last column: no division by the picture width anywhere in this kernel) */
     for (int mb = r0 * wmb + tid; mb < r1 * wmb; mb += blockDim.x) {
         const int li = mb - base;
         const uint32_t f = anyf[li];
         if (!(f & DBKF_ANY)) continue;
-        const int x = mb % wmb, y = mb / wmb;
-        const int d = (x > 0 && (f & DBKF_LEFT) && (anyf[li - 1] & (DBKF_INNER | DBKF_TOP)) ? 1 : 0) +
-                      (y > 0 && (f & DBKF_TOP) && (anyf[li - wmb] & (DBKF_INNER | DBKF_LEFT)) ? 1 : 0) +
-                      (y > 0 && x + 1 < wmb && (f & DBKF_TOP) && (anyf[li - wmb + 1] & DBKF_LEFT) ? 1 : 0);
+        const int d = ((f & DBKF_LEFT) && (anyf[li - 1] & (DBKF_INNER | DBKF_TOP)) ? 1 : 0) +
+                      ((f & DBKF_TOP) && (anyf[li - wmb] & (DBKF_INNER | DBKF_LEFT)) ? 1 : 0) +
+                      ((f & DBKF_TOP) && (anyf[li - wmb + 1] & DBKF_LEFT) ? 1 : 0);
         dep[li] = (uint8_t)d;
         atomicAdd(&ctr[2], 1u);
         if (d == 0) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)mb;
@@ -2149,7 +2266,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
         if (lane == 0) {
             const uint32_t h = vctr[0], t = vctr[1];
             if (t > h) {
-                k = t - h < 4u ? t - h : 4u;
+                k = t - h < 8u ? t - h : 8u;
                 if (atomicCAS(&ctr[0], h, h + k) != h) k = 0;       /* lost the race: look again */
                 cbase = h;
             } else if (h >= total) {
@@ -2194,40 +2311,37 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
         }
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
         int run = -1;
-        if ((uint32_t)quarter < k) {
+        if ((uint32_t)grp < k) {
             int v;
-            do { v = vq[cbase + quarter]; } while (v == 0xFFFF);     /* the publisher bumps the cursor, then writes the slot */
+            do { v = vq[cbase + grp]; } while (v == 0xFFFF);         /* the publisher bumps the cursor, then writes the slot */
             run = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int ry = run >= 0 ? run / wmb : -1;
-        const bool cross = has_up && ry == r0;                      /* the tile above belongs to the band above */
-        const bool wt = has_down && ry == r1 - 1;                   /* the band below reads what this macroblock writes */
+        const int lo_mb = r0 * wmb, hi_mb = r1 * wmb;                /* the band's own macroblocks */
+        const bool cross = has_up && run >= 0 && run < lo_mb + wmb;  /* first row: the tile above belongs to the band above */
+        const bool wt = has_down && run >= hi_mb - wmb;              /* last row: the band below reads what this macroblock writes */
+        const uint32_t fm = run >= 0 ? anyf[run - base] : 0u;
         bool want_top = true;
-        if (__ballot(cross) != 0ull) want_top = !cross || (anyf[run - base] & DBKF_TOP);
-        DbkPrefetch cp = {}, np = {};
-        dbk_prefetch(fd, run, ql, cp, cross, want_top);
-        const bool inner = run >= 0 && (anyf[run - base] & DBKF_INNER);
-        deblock_mb(fd, run, ql, q16, cp, wlds, -1, np, tabs, wt, inner, (tp && lane == 0) ? tp : nullptr);
-        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && ql == 0)); n_steps++; }
+        if (BANDED && __ballot(cross) != 0ull) want_top = !cross || (fm & DBKF_TOP);
+        DbkLoads cp;
+        dbk_load(fd, run, l, cp, BANDED && cross, want_top);
+        deblock_mb<BANDED>(fd, run, l, cp, wlds, wt, (fm & DBKF_INNER) != 0u, (tp && lane == 0) ? tp : nullptr);
+        if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && l == 0)); n_steps++; }
         /* release: stores done -> dependants */
         __builtin_amdgcn_s_waitcnt(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             /* (the compiler may drop the builtin in front of an agent-scope store) */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (wt && ql == 3) st_agent_u8(done_g + run, 1u);            /* hand-over to the band below */
-        if (run >= 0 && ql < 3) {
-            const int x = run % wmb, y = ry;
-            int dmb = -1;
-            if (ql == 0) { if (x + 1 < wmb) dmb = run + 1; }
-            else if (ql == 1) { if (y + 1 < r1) dmb = run + wmb; }
-            else { if (y + 1 < r1 && x > 0) dmb = run + wmb - 1; }
-            /* the mirror image of the dependency rule above */
+        if (BANDED && wt && l == 3) st_agent_u8(done_g + run, 1u);   /* hand-over to the band below */
+        if (run >= 0 && l < 3) {
+            /* dependants: l = 0: (x+1, y), l = 1: (x, y+1), l = 2: (x-1, y+1) — the mirror image of the dependency rule above.  The
+             * "neighbours" of the first / last column that lie in another row never qualify: a macroblock of column 0 has no LEFT */
+            const int dmb = l == 0 ? run + 1 : l == 1 ? run + wmb : run + wmb - 1;
             bool waits = false;
-            if (dmb >= 0) {
-                const uint32_t fd_ = anyf[dmb - base], fm = anyf[run - base];
-                waits = (fd_ & DBKF_ANY) && (ql == 0 ? ((fd_ & DBKF_LEFT) != 0u && (fm & (DBKF_INNER | DBKF_TOP)) != 0u)
-                                                   : ql == 1 ? ((fd_ & DBKF_TOP) != 0u && (fm & (DBKF_INNER | DBKF_LEFT)) != 0u)
-                                                             : ((fd_ & DBKF_TOP) != 0u && (fm & DBKF_LEFT) != 0u));
+            if (dmb < hi_mb) {
+                const uint32_t fd_ = anyf[dmb - base];
+                waits = (fd_ & DBKF_ANY) && (l == 0 ? ((fd_ & DBKF_LEFT) != 0u && (fm & (DBKF_INNER | DBKF_TOP)) != 0u)
+                                                  : l == 1 ? ((fd_ & DBKF_TOP) != 0u && (fm & (DBKF_INNER | DBKF_LEFT)) != 0u)
+                                                           : ((fd_ & DBKF_TOP) != 0u && (fm & DBKF_LEFT) != 0u));
             }
             if (waits) release(dmb - base);
         }

@@ -144,6 +144,56 @@ def simulate(hh, w, left, top, inner, any_, waves=12, step=12000, per_mb=4):
     return t, busy
 
 
+# ---- the same model with the step cost depending on what the step holds (round 4: eight macroblocks per step, and a question:
+# what if macroblocks WITHOUT an active inner edge — they only need the first edge slot of each direction — were claimed apart
+# from the others, so that their steps are short?) ----
+def simulate2(hh, w, left, top, inner, any_, waves, per_mb, cost_full, cost_light, split):
+    import heapq
+    n = hh * w
+    dep = np.zeros(n, int); succ = [[] for _ in range(n)]
+    A = any_.reshape(-1); Lf = left.reshape(-1); Tp = top.reshape(-1); In = inner.reshape(-1)
+    for y in range(hh):
+        for x in range(w):
+            i = y * w + x
+            if not A[i]: continue
+            if x and Lf[i] and A[i - 1] and (In[i - 1] or Tp[i - 1]): dep[i] += 1; succ[i - 1].append(i)
+            if y and Tp[i] and A[i - w] and (In[i - w] or Lf[i - w]): dep[i] += 1; succ[i - w].append(i)
+            if y and x + 1 < w and Tp[i] and A[i - w + 1] and Lf[i - w + 1]: dep[i] += 1; succ[i - w + 1].append(i)
+    ready = [[], []]
+    def push(i): ready[1 if (split and not In[i]) else 0].append(i)
+    for i in range(n):
+        if A[i] and dep[i] == 0: push(i)
+    t, free, running, done, busy, steps = 0, waves, [], 0, 0, 0
+    total = int(A.sum())
+    while done < total:
+        while free and (ready[0] or ready[1]):
+            q = 1 if len(ready[1]) >= len(ready[0]) and ready[1] else (0 if ready[0] else 1)
+            batch, ready[q] = ready[q][:per_mb], ready[q][per_mb:]
+            light = all(not In[i] for i in batch)
+            c = cost_light if light else cost_full
+            heapq.heappush(running, (t + c, batch)); free -= 1; busy += c; steps += 1
+        t, batch = heapq.heappop(running)
+        free += 1
+        for i in batch:
+            done += 1
+            for s_ in succ[i]:
+                dep[s_] -= 1
+                if dep[s_] == 0: push(s_)
+    return t, busy, steps, total
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "simulate2":
+    GHZ = 2.4
+    for waves, per_mb, cf, cl, split in ((8, 8, 11500, 11500, 0), (8, 8, 11500, 4500, 0), (8, 8, 11500, 4500, 1), (12, 8, 11500, 4500, 1), (8, 8, 11500, 6000, 1), (8, 8, 9000, 4500, 1),
+                                         (8, 4, 8000, 8000, 0), (12, 4, 8000, 8000, 0), (12, 4, 8000, 3500, 1)):
+        cyc = busy = steps = mbs = 0
+        for i in range(first, min(first + count, len(jobs))):
+            hh, w, left, top, inner, any_ = flags_of(jobs[i])
+            t, b, st, tot_ = simulate2(hh, w, left, top, inner, any_, waves, per_mb, cf, cl, split)
+            cyc += t; busy += b; steps += st; mbs += tot_
+        print(f"model: {waves} wavefronts, up to {per_mb} per step, {cf} cycles per step ({cl} when no macroblock of it has an inner edge), {'two ready lists' if split else 'one ready list'}: "
+              f"{cyc / GHZ / 1e6:.1f} ms per pass, wavefronts busy {busy / (cyc * waves):.0%}, {mbs / steps:.2f} macroblocks per step")
+
 if len(sys.argv) > 3 and sys.argv[3] == "simulate":
     GHZ = 2.3
     for waves, step, per_mb in ((12, 12000, 4), (8, 12000, 4), (16, 12000, 4), (12, 12000, 2), (12, 9000, 4), (24, 12000, 4)):
