@@ -364,6 +364,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     d.n_mbs = h->n_mbs;
     d.n_levels = h->n_intra_levels;
     d.wmb = h->width_mbs;
+    d.wmb_magic = (uint32_t)(0x100000000ull / (h->width_mbs ? h->width_mbs : 1u)) + 1u;
     d.hmb = h->height_mbs;
     d.any_deblock = h->any_deblock;
     {

@@ -55,6 +55,8 @@ struct FrameDesc {
     uint32_t        n_gen_uni;    /* the first n_gen_uni entries of gen have one motion vector for the whole macroblock */
     uint32_t        n_gen_quad;   /* the next n_gen_quad one motion vector per 8x8 quadrant, the rest finer partitions */
     uint16_t        wmb, hmb;
+    uint32_t        wmb_magic;    /* floor(2^32 / wmb) + 1: mb / wmb = mulhi(mb, wmb_magic) for every macroblock address (< 2^16) — a scalar
+                                     multiply where the compiler's division by a run-time value is a dozen vector instructions */
     uint32_t        any_deblock;
     uint16_t        dbk_bands, intra_bands;   /* row bands (= workgroups) the per-picture kernels may split this picture into (>= 1; the launch caps it) */
     uint16_t        heavy;                    /* 1: mostly intra coded — several times the work of the other pictures of its tick */
@@ -492,6 +494,87 @@ __device__ __forceinline__ void luma_from_window(const uint32_t rw[6][3], int fx
 #undef RND5
 }
 
+/* The same prediction for a lane whose window lies in LDS (k_recon_inter, staged windows): src = window row 0 at the dword that
+ * holds window column 0, sh = 8 * (byte of that column in its dword).  The interpolation class is wave-uniform (one motion
+ * vector per wavefront or quadrant... per lane in the quadrant path, still few classes per wavefront) and every class reads
+ * only the window rows and dwords it uses — whole-sample: one row, two dwords; horizontal: one row; vertical: six rows of two
+ * dwords; only the centre classes need all 6 x 3 — instead of 24 LDS dwords and 18 funnel shifts for every macroblock.
+ * Result: the four samples as two packed pairs (o01, o23), 0..255 each. */
+__device__ __forceinline__ void luma_pred_lds(const uint8_t *src, int stride, int sh, int fx, int fy, s2 &o01, s2 &o23)
+{
+    uint32_t rw[6][3];
+    auto row = [&](int r, int nd) {                  /* dwords 0 .. nd-1 of window row r */
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(src + r * stride);   /* 4-byte aligned only */
+        uint32_t d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k <= nd) d[k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (k < nd) rw[r][k] = (uint32_t)(((unsigned long long)d[k + 1] << 32 | d[k]) >> sh);
+    };
+#define CP(r, c) as_s2(perm(rw[(r)][((c) + 1) >> 2], rw[(r)][(c) >> 2], \
+                      0x0C000C00u | (uint32_t)((c) & 3) | ((uint32_t)(((((c) + 1) >> 2) != ((c) >> 2)) ? 4 + (((c) + 1) & 3) : (((c) + 1) & 3)) << 16)))
+#define HT2(r, i) (CP(r, i) + CP(r, (i) + 5) - pk(5) * (CP(r, (i) + 1) + CP(r, (i) + 4)) + pk(20) * (CP(r, (i) + 2) + CP(r, (i) + 3)))
+#define VT2(c) (CP(0, c) + CP(5, c) - pk(5) * (CP(1, c) + CP(4, c)) + pk(20) * (CP(2, c) + CP(3, c)))
+#define RND5(x) pk_clip(pk(0), pk(255), ((x) + pk(16)) >> pk(5))
+#define GW(r, c) ((int)((rw[(r)][(c) >> 2] >> (8 * ((c) & 3))) & 255u))
+    if ((fx | fy) == 0) {                            /* G: whole-sample */
+        row(2, 2);
+        o01 = CP(2, 2); o23 = CP(2, 4);
+        return;
+    }
+    if (fy == 0) {                                   /* a, b, c: horizontal only (window row 2) */
+        row(2, 3);
+        o01 = RND5(HT2(2, 0)); o23 = RND5(HT2(2, 2));
+        if (fx == 1) { o01 = (o01 + CP(2, 2) + pk(1)) >> pk(1); o23 = (o23 + CP(2, 4) + pk(1)) >> pk(1); }
+        else if (fx == 3) { o01 = (o01 + CP(2, 3) + pk(1)) >> pk(1); o23 = (o23 + CP(2, 5) + pk(1)) >> pk(1); }
+        return;
+    }
+    if (fx == 0) {                                   /* d, h, n: vertical only (columns 2..5) */
+        row(0, 2); row(1, 2); row(2, 2); row(3, 2); row(4, 2); row(5, 2);
+        o01 = RND5(VT2(2)); o23 = RND5(VT2(4));
+        if (fy == 1) { o01 = (o01 + CP(2, 2) + pk(1)) >> pk(1); o23 = (o23 + CP(2, 4) + pk(1)) >> pk(1); }
+        else if (fy == 3) { o01 = (o01 + CP(3, 2) + pk(1)) >> pk(1); o23 = (o23 + CP(3, 4) + pk(1)) >> pk(1); }
+        return;
+    }
+    if (fx != 2 && fy != 2) {                        /* e, g, p, r: average of the nearest horizontal and vertical half samples */
+        row(0, 2); row(1, 2); row(4, 2); row(5, 2);
+        s2 b01, b23, h01, h23;
+        if (fy == 1) { row(2, 3); row(3, 2); b01 = HT2(2, 0); b23 = HT2(2, 2); } else { row(2, 2); row(3, 3); b01 = HT2(3, 0); b23 = HT2(3, 2); }
+        if (fx == 1) { h01 = VT2(2); h23 = VT2(4); } else { h01 = VT2(3); h23 = VT2(5); }
+        o01 = (RND5(b01) + RND5(h01) + pk(1)) >> pk(1); o23 = (RND5(b23) + RND5(h23) + pk(1)) >> pk(1);
+        return;
+    }
+    /* j, f, q, i, k: the 6-tap filter over un-rounded intermediate sums — over the vertical sums of nine columns (8.4.2.2.1: both
+     * orders are equal): 9 + 4 filters instead of 24 + 4, and the vertical sums are exactly what i / k need */
+    row(0, 3); row(1, 3); row(2, 3); row(3, 3); row(4, 3); row(5, 3);
+#define VH1(c) tap6(GW(0, c), GW(1, c), GW(2, c), GW(3, c), GW(4, c), GW(5, c))
+#define HB1(r, i) tap6(GW(r, i), GW(r, (i) + 1), GW(r, (i) + 2), GW(r, (i) + 3), GW(r, (i) + 4), GW(r, (i) + 5))
+    int v1[9], out[4];
+#pragma unroll
+    for (int c = 0; c < 9; c++) v1[c] = VH1(c);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = clip255((tap6(v1[i], v1[i + 1], v1[i + 2], v1[i + 3], v1[i + 4], v1[i + 5]) + 512) >> 10);
+        int v = j;
+        if (fy != 2) {                               /* f / q: with b (row y) or s (row y+1) */
+            const int b = clip255(((fy == 1 ? HB1(2, i) : HB1(3, i)) + 16) >> 5);
+            v = (j + b + 1) >> 1;
+        } else if (fx != 2) {                        /* i / k: with h (col x) or m (col x+1) */
+            const int hh = clip255(((fx == 1 ? v1[i + 2] : v1[i + 3]) + 16) >> 5);
+            v = (j + hh + 1) >> 1;
+        }
+        out[i] = v;
+    }
+    o01 = as_s2((uint32_t)out[0] | ((uint32_t)out[1] << 16)); o23 = as_s2((uint32_t)out[2] | ((uint32_t)out[3] << 16));
+#undef VH1
+#undef HB1
+#undef GW
+#undef CP
+#undef HT2
+#undef VT2
+#undef RND5
+}
+
 /* 2 chroma samples from the two rows a[0..2], b[0..2] at eighth-sample fraction (fx,fy), 8.4.2.2.2 */
 __device__ __forceinline__ void chroma_from_rows(const int a[3], const int b[3], int fx, int fy, int out[2])
 {
@@ -803,7 +886,7 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
     const int lane = threadIdx.x & 63;
     uint8_t *lw = lds + wave * INTER_WAVE_LDS, *lc = lw + 21 * IW_STRIDE;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
-    const int mbx = mb % wmb, mby = mb / wmb;
+    const int mby = wmb == 1 ? (int)mb : (int)__umulhi(mb, fd.wmb_magic), mbx = (int)mb - mby * wmb;     /* scalar: FrameDesc.wmb_magic */
     /* (address spaces spelled out once: the loads below become global_load / s_load instead of flat_load) */
     const int16_t *mvs = (const int16_t *)((const H264K_CONST int16_t *)fd.mvs + 32 * (size_t)mb);
     const int16_t *coef = (const int16_t *)((const H264K_CONST int16_t *)fd.coefs + 16 * (size_t)ge.coef_idx);
@@ -821,7 +904,8 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
      * first) and consumed after the prediction */
     ResidRows rrows;
     if (!uniform) rrows = mb_residual_fetch(ge.coded, coef, lane);
-    int pl[4], pc[4] = { 0, 0, 0, 0 };
+    s2 pl01 = pk(0), pl23 = pk(0);               /* the lane's four luma prediction samples, two packed pairs */
+    int pc[4] = { 0, 0, 0, 0 };
     if (uniform) {
         const int mvx = (int16_t)(mv0 & 0xFFFFu), mvy = (int32_t)mv0 >> 16;
         const H264K_GLOBAL uint8_t *ref = (const H264K_GLOBAL uint8_t *)slot_ptr(fd, refs & 255u);
@@ -871,17 +955,7 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
         /* ---- luma: window rows (4*by+row)..+5, bytes o..o+11 with o = (xi-xs) + 4*bx ---- */
         {
             const int o = (xi - xs) + 4 * bx, sh = 8 * (o & 3);
-            const uint8_t *src = lw + (4 * by + row) * IW_STRIDE + (o & ~3);
-            uint32_t rw[6][3];
-#pragma unroll
-            for (int r = 0; r < 6; r++) {
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(src + r * IW_STRIDE);   /* 4-byte aligned only */
-                const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                rw[r][0] = (uint32_t)(((unsigned long long)q1 << 32 | q0) >> sh);
-                rw[r][1] = (uint32_t)(((unsigned long long)q2 << 32 | q1) >> sh);
-                rw[r][2] = (uint32_t)(((unsigned long long)q3 << 32 | q2) >> sh);
-            }
-            luma_from_window(rw, mvx & 3, mvy & 3, pl);
+            luma_pred_lds(lw + (4 * by + row) * IW_STRIDE + (o & ~3), IW_STRIDE, sh, mvx & 3, mvy & 3, pl01, pl23);
         }
         /* ---- chroma: lanes 0..31, 4 samples of one row = two pairs ---- */
         if (lane < 32) {
@@ -990,17 +1064,7 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
             const int mvx = (int16_t)(mv_mine & 0xFFFFu), mvy = (int32_t)mv_mine >> 16;
             const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2;
             const int o = (xi & 15) + 4 * (bx & 1), sh = 8 * (o & 3);
-            const uint8_t *src = lq + q * 13 * QW_STRIDE + (4 * (by & 1) + row) * QW_STRIDE + (o & ~3);
-            uint32_t rw[6][3];
-#pragma unroll
-            for (int r = 0; r < 6; r++) {
-                const uint32_t *qq = reinterpret_cast<const uint32_t *>(src + r * QW_STRIDE);
-                const uint32_t q0 = qq[0], q1 = qq[1], q2 = qq[2], q3 = qq[3];
-                rw[r][0] = (uint32_t)(((unsigned long long)q1 << 32 | q0) >> sh);
-                rw[r][1] = (uint32_t)(((unsigned long long)q2 << 32 | q1) >> sh);
-                rw[r][2] = (uint32_t)(((unsigned long long)q3 << 32 | q2) >> sh);
-            }
-            luma_from_window(rw, mvx & 3, mvy & 3, pl);
+            luma_pred_lds(lq + q * 13 * QW_STRIDE + (4 * (by & 1) + row) * QW_STRIDE + (o & ~3), QW_STRIDE, sh, mvx & 3, mvy & 3, pl01, pl23);
         }
         if (lane < 32) {
             const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
@@ -1021,6 +1085,7 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
             const int mvx = (int16_t)(mv_mine & 0xFFFFu), mvy = (int32_t)mv_mine >> 16;
             const uint8_t *ref = slot_ptr(fd, (refs >> (8 * ((by >> 1) * 2 + (bx >> 1)))) & 255u);
             const int x = mbx * 16 + bx * 4 + (mvx >> 2), y = mby * 16 + by * 4 + row + (mvy >> 2);
+            int pl[4];
             if (((mvx | mvy) & 3) == 0 && x >= 0 && x + 3 < W && y >= 0 && y < H) {
                 const uint32_t v = luma4_at(ref, wmb, x, y);
                 pl[0] = v & 255; pl[1] = (v >> 8) & 255; pl[2] = (v >> 16) & 255; pl[3] = v >> 24;
@@ -1029,6 +1094,7 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
                 luma_window_global(ref, wmb, W, H, x, y, rw);
                 luma_from_window(rw, mvx & 3, mvy & 3, pl);
             }
+            pl01 = as_s2((uint32_t)pl[0] | ((uint32_t)pl[1] << 16)); pl23 = as_s2((uint32_t)pl[2] | ((uint32_t)pl[3] << 16));
         }
         if (lane < 32) {
             const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
@@ -1047,18 +1113,25 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
     /* (an unconditional use of the coefficient rows here — they arrived long ago — keeps the compiler from sinking their loads
      * into the residual code, where every coded macroblock would wait for a second memory round trip) */
     asm volatile("" :: "v"(rrows.y.x), "v"(rrows.y.y), "v"(rrows.c.x), "v"(rrows.c.y), "v"(rrows.cdc.x), "v"(rrows.cdc.y));
-    int ry[4], rc[4];
-    report_residual_range(fd, mb_residual_compute<false>(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc), lane);
     /* ---- residual add, clip, store.  Lane (block, row) holds 4 samples of row 4*by+row at column 4*bx: the 64 dwords of the
      * wavefront ARE the 256 luma bytes of the tile (each group of 16 lanes one 64-byte piece), the 32 chroma dwords its third
-     * line — two coalesced stores, no detour through LDS ---- */
+     * line — two coalesced stores, no detour through LDS.  A macroblock without coefficients (55 % of this list in the bundled
+     * stream) stores its prediction as it is: no unpacking, no residual, no clipping ---- */
     H264K_GLOBAL uint8_t *T = cur + (size_t)mb * TILE;
-    *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + (by * 4 + row) * 16 + bx * 4) =
-        pack4(clip255(pl[0] + ry[0]), clip255(pl[1] + ry[1]), clip255(pl[2] + ry[2]), clip255(pl[3] + ry[3]));
+    uint32_t luma_dw, chroma_dw;
+    if ((ge.coded & 0x03FFFFFFu) == 0u) {                        /* wave-uniform */
+        luma_dw = perm(as_u32(pl23), as_u32(pl01), 0x06040200u);
+        chroma_dw = pack4(pc[0], pc[1], pc[2], pc[3]);
+    } else {
+        int ry[4], rc[4];
+        report_residual_range(fd, mb_residual_compute<false>(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc), lane);
+        luma_dw = pack4(clip255(pl01.x + ry[0]), clip255(pl01.y + ry[1]), clip255(pl23.x + ry[2]), clip255(pl23.y + ry[3]));
+        chroma_dw = pack4(clip255(pc[0] + rc[0]), clip255(pc[1] + rc[1]), clip255(pc[2] + rc[2]), clip255(pc[3] + rc[3]));
+    }
+    *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + (by * 4 + row) * 16 + bx * 4) = luma_dw;
     if (lane < 32) {
         const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
-        *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + T_CB + plane * 64 + (cby * 4 + row) * 8 + cbx * 4) =
-            pack4(clip255(pc[0] + rc[0]), clip255(pc[1] + rc[1]), clip255(pc[2] + rc[2]), clip255(pc[3] + rc[3]));
+        *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + T_CB + plane * 64 + (cby * 4 + row) * 8 + cbx * 4) = chroma_dw;
     }
 }
 
