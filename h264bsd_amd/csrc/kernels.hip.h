@@ -1712,9 +1712,12 @@ __device__ __forceinline__ int tc0_of(uint32_t t4, int bs) { return (int)((t4 >>
  * and below it no longer wait for it unless those very samples concern them (k_frame_dbk, dependency rule) and may be
  * rewriting the rest of its tile at the same time.
  * wt: the macroblock lies in the last row of a row band, the band below reads what it writes: everything goes write-through. */
-template <bool BANDED>
+/* SLOTS = 4: every edge.  SLOTS = 1: none of the wavefront's macroblocks has an active inner edge (DBKF_INNER clear: the step was
+ * claimed from the second ready list, k_frame_dbk) — only the left and the upper macroblock edge exist: a third of the work. */
+template <bool BANDED, int SLOTS>
 __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, const DbkLoads &p, uint8_t *w, bool wt, bool inner, unsigned long long *tp = nullptr)
 {
+    constexpr int NG = SLOTS == 4 ? 5 : 2;                         /* groups of four sample positions a luma pass touches */
 #define DTICK() (tp ? __builtin_readcyclecounter() : 0ull)
     const unsigned long long d0 = DTICK();
     w = static_cast<uint8_t *>(__builtin_assume_aligned(w, 16));
@@ -1724,7 +1727,8 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
     /* the record: strengths (dir 0 = vertical edges: r0.x, r0.y; dir 1: r0.z, r0.w), class dwords r1.x .. r2.y, bS-3 bytes and flags r2.z, r2.w */
     const uint32_t flags = p.r2.w >> 16;                          /* byte 46: FJ_DBK_*, byte 47: any */
     const bool f_left = act && (flags & FJ_DBK_LEFT) && (p.r0.x & 0xFFFFu), f_top = act && (flags & FJ_DBK_TOP) && (p.r0.z & 0xFFFFu);
-    const bool any_v = __ballot(act && (p.r0.x | p.r0.y)) != 0ull, any_h = __ballot(act && (p.r0.z | p.r0.w)) != 0ull;   /* wave-wide phase skips */
+    const bool any_v = __ballot(act && (SLOTS == 4 ? (p.r0.x | p.r0.y) : (p.r0.x & 0xFFFFu))) != 0ull;   /* wave-wide phase skips */
+    const bool any_h = __ballot(act && (SLOTS == 4 ? (p.r0.z | p.r0.w) : (p.r0.z & 0xFFFFu))) != 0ull;
     /* thresholds per class: A / B = alpha / beta in both halves, t4 = { 0, tc0(1), tc0(2), tc0(3) } */
     const uint32_t w_ll = p.r1.x, w_lt = p.r1.y, w_li = p.r1.z, w_cl = p.r1.w, w_ctp = p.r2.x, w_ci = p.r2.y;
     const uint32_t t3a = p.r2.z, t3b = p.r2.w;                    /* bytes 40..43, 44..47 */
@@ -1743,12 +1747,12 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
     const unsigned long long d1 = DTICK();
     /* ---- vertical edges, luma: rows 2l (low halves) and 2l+1 (high halves) across all four edges ---- */
     {
-        s2 px[20];
+        s2 px[4 * NG];
         px[0] = as_s2(perm(p.ly1, p.ly0, 0x0C040C00u)); px[1] = as_s2(perm(p.ly1, p.ly0, 0x0C050C01u));
         px[2] = as_s2(perm(p.ly1, p.ly0, 0x0C060C02u)); px[3] = as_s2(perm(p.ly1, p.ly0, 0x0C070C03u));
         const uint32_t ra[4] = { p.y0.x, p.y0.y, p.y0.z, p.y0.w }, rb[4] = { p.y1.x, p.y1.y, p.y1.z, p.y1.w };
 #pragma unroll
-        for (int w4 = 0; w4 < 4; w4++) {
+        for (int w4 = 0; w4 < NG - 1; w4++) {
             px[4 + 4 * w4 + 0] = as_s2(perm(rb[w4], ra[w4], 0x0C040C00u));
             px[4 + 4 * w4 + 1] = as_s2(perm(rb[w4], ra[w4], 0x0C050C01u));
             px[4 + 4 * w4 + 2] = as_s2(perm(rb[w4], ra[w4], 0x0C060C02u));
@@ -1760,24 +1764,24 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
             const s2 A_l = pk_splat_byte(w_ll, 0), B_l = pk_splat_byte(w_ll, 1), A_i = pk_splat_byte(w_li, 0), B_i = pk_splat_byte(w_li, 1);
             const uint32_t t4_l = perm(t3a, w_ll, 0x0403020Cu), t4_i = perm(t3a, w_li, 0x0603020Cu);    /* { 0, tc0(1), tc0(2), tc0(3) } */
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
+            for (int e = 0; e < SLOTS; e++) {
                 const int bs = act ? bs_of(w0s, w1s, e) : 0;
                 if (__ballot(bs != 0)) filter_luma_pk(px + 4 * e, bs, e ? A_i : A_l, e ? B_i : B_l, tc0_of(e ? t4_i : t4_l, bs), one);
             }
         }
         if (act) {
             /* back to rows: four packed pairs -> one dword of row 2l and one of row 2l+1 (samples are < 256: two pairs merge with a
-             * shift-or, the rows come apart with a byte permute each) */
-            uint32_t ra[5], rb[5];
+             * shift-or, the rows come apart with a byte permute each); the columns a pass did not touch go as they came */
+            uint32_t na[5] = { 0u, ra[0], ra[1], ra[2], ra[3] }, nb[5] = { 0u, rb[0], rb[1], rb[2], rb[3] };
 #pragma unroll
-            for (int g = 0; g < 5; g++) {
+            for (int g = 0; g < NG; g++) {
                 const uint32_t t01 = as_u32(px[4 * g]) | (as_u32(px[4 * g + 1]) << 8), t23 = as_u32(px[4 * g + 2]) | (as_u32(px[4 * g + 3]) << 8);
-                ra[g] = perm(t23, t01, 0x05040100u); rb[g] = perm(t23, t01, 0x07060302u);
+                na[g] = perm(t23, t01, 0x05040100u); nb[g] = perm(t23, t01, 0x07060302u);
             }
             uint8_t *rowa = &lt[(4 + 2 * l) * LS];
-            *reinterpret_cast<uint32_t *>(rowa + LX - 4) = ra[0]; *reinterpret_cast<uint32_t *>(rowa + LS + LX - 4) = rb[0];
-            *reinterpret_cast<uint4 *>(rowa + LX) = make_uint4(ra[1], ra[2], ra[3], ra[4]);
-            *reinterpret_cast<uint4 *>(rowa + LS + LX) = make_uint4(rb[1], rb[2], rb[3], rb[4]);
+            *reinterpret_cast<uint32_t *>(rowa + LX - 4) = na[0]; *reinterpret_cast<uint32_t *>(rowa + LS + LX - 4) = nb[0];
+            *reinterpret_cast<uint4 *>(rowa + LX) = make_uint4(na[1], na[2], na[3], na[4]);
+            *reinterpret_cast<uint4 *>(rowa + LS + LX) = make_uint4(nb[1], nb[2], nb[3], nb[4]);
         }
     }
     /* ---- vertical edges, chroma: rows 2 c4, 2 c4 + 1 of plane l >> 2; edges at columns 0 and 4 = luma edges 0 and 2 ---- */
@@ -1786,21 +1790,23 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
         px[2] = as_s2(perm(p.lc1, p.lc0, 0x0C060C02u)); px[3] = as_s2(perm(p.lc1, p.lc0, 0x0C070C03u));
         px[4] = as_s2(perm(p.c.z, p.c.x, 0x0C040C00u)); px[5] = as_s2(perm(p.c.z, p.c.x, 0x0C050C01u));
         px[6] = as_s2(perm(p.c.z, p.c.x, 0x0C060C02u)); px[7] = as_s2(perm(p.c.z, p.c.x, 0x0C070C03u));
-        px[8] = as_s2(perm(p.c.w, p.c.y, 0x0C040C00u)); px[9] = as_s2(perm(p.c.w, p.c.y, 0x0C050C01u));
-        px[10] = as_s2(perm(p.c.w, p.c.y, 0x0C060C02u)); px[11] = as_s2(perm(p.c.w, p.c.y, 0x0C070C03u));
+        if (SLOTS == 4) {
+            px[8] = as_s2(perm(p.c.w, p.c.y, 0x0C040C00u)); px[9] = as_s2(perm(p.c.w, p.c.y, 0x0C050C01u));
+            px[10] = as_s2(perm(p.c.w, p.c.y, 0x0C060C02u)); px[11] = as_s2(perm(p.c.w, p.c.y, 0x0C070C03u));
+        }
         if (any_v) {
             const uint32_t w0s = p.r0.x >> (4 * c4), w1s = p.r0.y >> (4 * c4);     /* chroma rows 2 c4, 2 c4 + 1 = luma rows 4 c4 .. 4 c4 + 3: segment c4 */
             const int bs0 = act ? (int)(w0s & 15u) : 0, bs1 = act ? (int)(w1s & 15u) : 0;
             if (__ballot(bs0 != 0))
                 filter_chroma_pk(px + 2, bs0, pk_splat_byte(w_cl, 0), pk_splat_byte(w_cl, 1), tc0_of(perm(t3a, w_cl, 0x0703020Cu), bs0));
-            if (__ballot(bs1 != 0))
+            if constexpr (SLOTS == 4) if (__ballot(bs1 != 0))
                 filter_chroma_pk(px + 6, bs1, pk_splat_byte(w_ci, 0), pk_splat_byte(w_ci, 1), tc0_of(perm(t3b, w_ci, 0x0503020Cu), bs1));
         }
         if (act) {
             uint8_t *rowa = &ct[(2 + 2 * c4) * CS];
-            uint32_t ra[2], rb[2];
+            uint32_t ra[2] = { 0u, p.c.y }, rb[2] = { 0u, p.c.w };
 #pragma unroll
-            for (int g = 0; g < 2; g++) {
+            for (int g = 0; g < (SLOTS == 4 ? 2 : 1); g++) {
                 const uint32_t t01 = as_u32(px[4 + 4 * g]) | (as_u32(px[5 + 4 * g]) << 8), t23 = as_u32(px[6 + 4 * g]) | (as_u32(px[7 + 4 * g]) << 8);
                 ra[g] = perm(t23, t01, 0x05040100u); rb[g] = perm(t23, t01, 0x07060302u);
             }
@@ -1815,15 +1821,15 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
     /* ---- horizontal edges, luma: columns 2l (low halves), 2l+1 (high halves); tile rows 0..3 = the strip above ---- */
     if (any_h) {
         const uint8_t *colp = &lt[LX + 2 * l];
-        s2 px[20];
+        s2 px[4 * NG];
 #pragma unroll
-        for (int r = 0; r < 20; r++) px[r] = as_s2(perm(0u, *reinterpret_cast<const uint16_t *>(colp + r * LS), 0x0C010C00u));
+        for (int r = 0; r < 4 * NG; r++) px[r] = as_s2(perm(0u, *reinterpret_cast<const uint16_t *>(colp + r * LS), 0x0C010C00u));
         const int k = l >> 1;
         const uint32_t w0s = p.r0.z >> (4 * k), w1s = p.r0.w >> (4 * k);
         const s2 A_t = pk_splat_byte(w_lt, 0), B_t = pk_splat_byte(w_lt, 1), A_i = pk_splat_byte(w_li, 0), B_i = pk_splat_byte(w_li, 1);
         const uint32_t t4_t = perm(t3a, w_lt, 0x0503020Cu), t4_i = perm(t3a, w_li, 0x0603020Cu);
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+        for (int e = 0; e < SLOTS; e++) {
             const int bs = act ? bs_of(w0s, w1s, e) : 0;
             if (__ballot(bs != 0)) {
                 filter_luma_pk(px + 4 * e, bs, e ? A_i : A_t, e ? B_i : B_t, tc0_of(e ? t4_i : t4_t, bs), one);
@@ -1837,16 +1843,16 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
     /* ---- horizontal edges, chroma: columns 2 c4, 2 c4 + 1 of plane l >> 2; tile rows 0, 1 = the strip above; edges at rows 2 and 6 ---- */
     if (any_h) {
         const uint8_t *colp = &ct[CX + 2 * c4];
-        s2 px[10];
+        s2 px[SLOTS == 4 ? 10 : 4];
 #pragma unroll
-        for (int r = 0; r < 10; r++) px[r] = as_s2(perm(0u, *reinterpret_cast<const uint16_t *>(colp + r * CS), 0x0C010C00u));
+        for (int r = 0; r < (SLOTS == 4 ? 10 : 4); r++) px[r] = as_s2(perm(0u, *reinterpret_cast<const uint16_t *>(colp + r * CS), 0x0C010C00u));
         const uint32_t w0s = p.r0.z >> (4 * c4), w1s = p.r0.w >> (4 * c4);
         const int bs0 = act ? (int)(w0s & 15u) : 0, bs1 = act ? (int)(w1s & 15u) : 0;
         if (__ballot(bs0 != 0)) {
             filter_chroma_pk(px + 0, bs0, pk_splat_byte(w_ctp, 0), pk_splat_byte(w_ctp, 1), tc0_of(perm(t3b, w_ctp, 0x0403020Cu), bs0));
             if (act) { *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + 1 * CS) = (uint16_t)perm(0u, as_u32(px[1]), 0x0C0C0200u); *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + 2 * CS) = (uint16_t)perm(0u, as_u32(px[2]), 0x0C0C0200u); }
         }
-        if (__ballot(bs1 != 0)) {
+        if constexpr (SLOTS == 4) if (__ballot(bs1 != 0)) {
             filter_chroma_pk(px + 4, bs1, pk_splat_byte(w_ci, 0), pk_splat_byte(w_ci, 1), tc0_of(perm(t3b, w_ci, 0x0503020Cu), bs1));
             if (act) { *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + 5 * CS) = (uint16_t)perm(0u, as_u32(px[5]), 0x0C0C0200u); *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + 6 * CS) = (uint16_t)perm(0u, as_u32(px[6]), 0x0C0C0200u); }
         }
@@ -2299,6 +2305,15 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
      * (deblocking.c:604-638); the longest chain of the bundled 1080p stream shrinks by 21 % (9562 -> 7512 steps).
      * For the band's first row the macroblocks above belong to the band above: they count like any other and are
      * released by the poller (below) instead of by the wavefront that filtered them. */
+    /* TWO ready lists in one array: macroblocks with an active inner edge are published from the front (cursors ctr[0] / ctr[1]),
+     * those without — only the left and / or upper macroblock edge: a third of the work — from the back (ctr[6] / ctr[7]).  A
+     * wavefront claims from ONE list, so that a step of edge-only macroblocks runs the short instruction stream (deblock_mb,
+     * SLOTS = 1): in a P picture a step is a link of a dependency chain and its length is what the picture's time is made of. */
+    const int nq_last = nq8 - 1;
+    auto push = [&](int mb, uint32_t flags) {
+        if (flags & DBKF_INNER) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)mb;
+        else queue[nq_last - (int)atomicAdd(&ctr[7], 1u)] = (uint16_t)mb;
+    };
     /* (k_dbk sets DBKF_LEFT / DBKF_TOP only where that neighbour exists: a macroblock in column 0 never has LEFT — so the
      * macroblock "to the left" of it, the last one of the row above, is never counted, and neither is the first one of the next
      * row as the right-hand neighbour of the last column: no division by the picture width anywhere in this kernel) */
@@ -2311,7 +2326,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
                       ((f & DBKF_TOP) && (anyf[li - wmb + 1] & DBKF_LEFT) ? 1 : 0);
         dep[li] = (uint8_t)d;
         atomicAdd(&ctr[2], 1u);
-        if (d == 0) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)mb;
+        if (d == 0) push(mb, f);
     }
     if (has_up)
         for (int x = tid; x < wmb; x += blockDim.x)
@@ -2326,7 +2341,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
         uint32_t *w = reinterpret_cast<uint32_t *>(dep + (li & ~3));
         const uint32_t sh = 8u * (li & 3);
         const uint32_t old = atomicSub(w, 1u << sh);
-        if (((old >> sh) & 255u) == 1u) queue[atomicAdd(&ctr[1], 1u)] = (uint16_t)(li + base);
+        if (((old >> sh) & 255u) == 1u) push(li + base, anyf[li]);
     };
 
     /* Pull model: a free wavefront takes up to four READY macroblocks at once (one per quarter).  Ready macroblocks
@@ -2335,18 +2350,21 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
     uint32_t spins = 0;                  /* safety net: a scheduling bug must end in a reported error (DEVERR_*), never in a hung GPU */
     volatile H264K_LDS uint32_t *vctr = (volatile H264K_LDS uint32_t *)ctr;
     for (;;) {
-        uint32_t cbase = 0, k = 0;
+        uint32_t cbase = 0, k = 0, cls = 0;
         if (lane == 0) {
-            const uint32_t h = vctr[0], t = vctr[1];
-            if (t > h) {
-                k = t - h < 8u ? t - h : 8u;
-                if (atomicCAS(&ctr[0], h, h + k) != h) k = 0;       /* lost the race: look again */
+            const uint32_t h0 = vctr[0], t0 = vctr[1], h1 = vctr[6], t1 = vctr[7];
+            const uint32_t a0 = t0 - h0, a1 = t1 - h1;
+            if (a0 | a1) {
+                cls = a1 >= a0 ? 1u : 0u;                            /* the longer list; the cheaper one when they tie */
+                const uint32_t h = cls ? h1 : h0, a = cls ? a1 : a0;
+                k = a < 8u ? a : 8u;
+                if (atomicCAS(&ctr[cls ? 6 : 0], h, h + k) != h) k = 0;       /* lost the race: look again */
                 cbase = h;
-            } else if (h >= total) {
+            } else if (h0 + h1 >= total) {
                 k = 0xFFFFFFFFu;                                    /* everything has been claimed */
             }
         }
-        cbase = __shfl(cbase, 0); k = __shfl(k, 0);
+        cbase = __shfl(cbase, 0); k = __shfl(k, 0); cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(cls, 0));
         if (k == 0xFFFFFFFFu) break;
         if (++spins > (1u << 24)) { if (lane == 0) atomicOr(fd.err, DEVERR_DBK_SCHED); break; }
         if (k == 0) {
@@ -2386,7 +2404,8 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
         int run = -1;
         if ((uint32_t)grp < k) {
             int v;
-            do { v = vq[cbase + grp]; } while (v == 0xFFFF);         /* the publisher bumps the cursor, then writes the slot */
+            const int slot = cls ? nq_last - (int)(cbase + grp) : (int)(cbase + grp);
+            do { v = vq[slot]; } while (v == 0xFFFF);                /* the publisher bumps the cursor, then writes the slot */
             run = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2398,7 +2417,8 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
         if (BANDED && __ballot(cross) != 0ull) want_top = !cross || (fm & DBKF_TOP);
         DbkLoads cp;
         dbk_load(fd, run, l, cp, BANDED && cross, want_top);
-        deblock_mb<BANDED>(fd, run, l, cp, wlds, wt, (fm & DBKF_INNER) != 0u, (tp && lane == 0) ? tp : nullptr);
+        if (cls) deblock_mb<BANDED, 1>(fd, run, l, cp, wlds, wt, false, (tp && lane == 0) ? tp : nullptr);
+        else deblock_mb<BANDED, 4>(fd, run, l, cp, wlds, wt, (fm & DBKF_INNER) != 0u, (tp && lane == 0) ? tp : nullptr);
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && l == 0)); n_steps++; }
         /* release: stores done -> dependants */
         __builtin_amdgcn_s_waitcnt(0);
