@@ -435,18 +435,29 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     const bool do_copy = (stages & 1u) && s.max_copy;
     const bool use_ahead = ahead && side && side->stream;        /* this tick's k_dbk was launched by the tick before it (or the caller) */
     const bool aside = !use_ahead && side && side->stream && do_dbk;
+    static const bool copy_aside_env = getenv("H264BSDMI_COPY_ASIDE") && atoi(getenv("H264BSDMI_COPY_ASIDE")) != 0;
+    const bool copy_aside = copy_aside_env && aside && do_copy;       /* experiment: k_copy (bound by HBM) next to k_recon_inter (bound by issue and latency) */
     if (aside) {
         HIP_TRY(hipEventRecord(side->fork, st));                 /* after the previous tick's k_frame_dbk: the records are free */
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        if (copy_aside) {
+            hipLaunchKernelGGL(h264k::k_copy, dim3(std::min<uint32_t>((s.max_copy + 3) / 4, COPY_WGS), s.n_frames), dim3(256), 0, side->stream, d_desc);
+            if (launches) launches[0]++;
+            HIP_TRY(hipEventRecord(side->join_copy, side->stream));
+        }
         if (launch_kdbk_aside(side, 0, d_desc, s, tt, launches, stages)) return -1;
     }
-    if (do_copy) {
+    if (do_copy && !copy_aside) {
         hipLaunchKernelGGL(h264k::k_copy, dim3(std::min<uint32_t>((s.max_copy + 3) / 4, COPY_WGS), s.n_frames), dim3(256), 0, st, d_desc);   /* COPY_WGS workgroups per picture walk its run list */
         if (launches) launches[0]++;
     }
     if (EV_NEEDED(1)) HIP_TRY(hipEventRecord(tt->ev[1], st));
     if ((stages & 1u) && s.max_gen) {
+#if INTER_NMB > 1
+        if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_uni, dim3((s.max_gen_uni + 4 * INTER_NMB - 1) / (4 * INTER_NMB), s.n_frames), dim3(256), 0, st, d_desc);
+#else
         if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_inter<0>, dim3((s.max_gen_uni + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
+#endif
         if (s.max_gen_quad) hipLaunchKernelGGL(h264k::k_recon_inter<1>, dim3((s.max_gen_quad + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
         if (s.max_gen_rest) hipLaunchKernelGGL(h264k::k_recon_inter<2>, dim3((s.max_gen_rest + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[1]++;
@@ -462,6 +473,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 15) / 16, DBK_WGS), s.n_frames), dim3(256), 0, st, d_desc);
         if (launches) launches[2]++;
     }
+    if (copy_aside) HIP_TRY(hipStreamWaitEvent(st, side->join_copy, 0));      /* intra prediction reads copied neighbours */
     if (EV_NEEDED(3)) HIP_TRY(hipEventRecord(tt->ev[3], st));
     if (after_lists) HIP_TRY(hipEventRecord(after_lists, st));
     /* The two per-picture kernels keep per-macroblock scheduling state in LDS next to their wavefronts' tiles: for

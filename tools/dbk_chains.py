@@ -182,6 +182,60 @@ def simulate2(hh, w, left, top, inner, any_, waves, per_mb, cost_full, cost_ligh
     return t, busy, steps, total
 
 
+# ---- chain following: a worker whose macroblock was the last thing (x+1, y) waited for goes on with that macroblock itself —
+# no store wait, no release, no claim, no load of the strip between them (it is in the worker's LDS tile) ----
+def simulate3(hh, w, left, top, inner, any_, waves, per_mb, cost_full, cost_light, follow_full, follow_light):
+    import heapq
+    n = hh * w
+    dep = np.zeros(n, int); succ = [[] for _ in range(n)]
+    A = any_.reshape(-1); Lf = left.reshape(-1); Tp = top.reshape(-1); In = inner.reshape(-1)
+    for y in range(hh):
+        for x in range(w):
+            i = y * w + x
+            if not A[i]: continue
+            if x and Lf[i] and A[i - 1] and (In[i - 1] or Tp[i - 1]): dep[i] += 1; succ[i - 1].append(i)
+            if y and Tp[i] and A[i - w] and (In[i - w] or Lf[i - w]): dep[i] += 1; succ[i - w].append(i)
+            if y and x + 1 < w and Tp[i] and A[i - w + 1] and Lf[i - w + 1]: dep[i] += 1; succ[i - w + 1].append(i)
+    ready = [[], []]
+    def push(i): ready[1 if not In[i] else 0].append(i)
+    for i in range(n):
+        if A[i] and dep[i] == 0: push(i)
+    t, free, running, done, busy, steps, followed = 0, waves, [], 0, 0, 0, 0
+    total = int(A.sum())
+    seq = 0
+    while done < total:
+        while free and (ready[0] or ready[1]):
+            q = 1 if len(ready[1]) >= len(ready[0]) and ready[1] else (0 if ready[0] else 1)
+            batch, ready[q] = ready[q][:per_mb], ready[q][per_mb:]
+            c = cost_light if all(not In[i] for i in batch) else cost_full
+            seq += 1; heapq.heappush(running, (t + c, seq, batch)); free -= 1; busy += c; steps += 1
+        t, _, batch = heapq.heappop(running)
+        nxt = []
+        for i in batch:
+            done += 1
+            for s_ in succ[i]:
+                dep[s_] -= 1
+                if dep[s_] == 0:
+                    if s_ == i + 1 and follow_full: nxt.append(s_)
+                    else: push(s_)
+        if nxt:
+            c = follow_light if all(not In[i] for i in nxt) else follow_full
+            seq += 1; heapq.heappush(running, (t + c, seq, nxt)); busy += c; steps += 1; followed += len(nxt)
+        else: free += 1
+    return t, busy, steps, total, followed
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "simulate3":
+    GHZ = 2.4
+    for waves, per_mb, cf, cl, ff, fl in ((8, 8, 11000, 6500, 0, 0), (8, 8, 11000, 6500, 7500, 3500), (8, 8, 11000, 6500, 6500, 3000), (12, 8, 11000, 6500, 7500, 3500)):
+        cyc = busy = steps = mbs = fol = 0
+        for i in range(first, min(first + count, len(jobs))):
+            hh, w, left, top, inner, any_ = flags_of(jobs[i])
+            t, b, st, tot_, f_ = simulate3(hh, w, left, top, inner, any_, waves, per_mb, cf, cl, ff, fl)
+            cyc += t; busy += b; steps += st; mbs += tot_; fol += f_
+        print(f"model: {waves} wavefronts, up to {per_mb} per step, {cf} / {cl} cycles per full / edge-only step, a followed step {ff} / {fl}: "
+              f"{cyc / GHZ / 1e6:.1f} ms per pass, {mbs / steps:.2f} macroblocks per step, {100.0 * fol / mbs:.0f} % of the macroblocks followed")
+
 if len(sys.argv) > 3 and sys.argv[3] == "simulate2":
     GHZ = 2.4
     for waves, per_mb, cf, cl, split in ((8, 8, 11500, 11500, 0), (8, 8, 11500, 4500, 0), (8, 8, 11500, 4500, 1), (12, 8, 11500, 4500, 1), (8, 8, 11500, 6000, 1), (8, 8, 9000, 4500, 1),
