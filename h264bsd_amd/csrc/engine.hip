@@ -69,6 +69,9 @@ struct StreamCtx {
 /* k_dbk (boundary strengths) needs only the frame job, not pixels: it runs on a second HIP stream next to the
  * reconstruction kernels of the same tick and joins before k_frame_dbk (measured: 245.2 -> 237.5 ms per step).
  * Putting k_copy there as well was tried and lost (it competes with k_recon_inter for the memory system). */
+#ifndef DBK_AT_INTRA_DEFAULT
+#define DBK_AT_INTRA_DEFAULT false
+#endif
 struct SideLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join_copy = nullptr; };
 
 /* A lane = one HIP stream that runs ticks one after the other, with its own device arena for the frame jobs of a tick
@@ -250,7 +253,13 @@ Engine *engine_get(int device = -1)
     if (hipSetDevice(e->device) != hipSuccess) { delete e; return nullptr; }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return nullptr; }
     if (hipEventCreateWithFlags(&e->inflight_done, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->side.stream, hipStreamNonBlocking) != hipSuccess ||
+        [&] {   /* the side stream (k_dbk next to the copy and inter kernels) gets the highest priority the device has: its few workgroups
+                  * must not queue behind the hundred thousand of k_recon_inter (H264BSDMI_SIDE_PRIO=0: default priority) */
+            int lo = 0, hi = 0;
+            const bool prio = !(getenv("H264BSDMI_SIDE_PRIO") && atoi(getenv("H264BSDMI_SIDE_PRIO")) == 0);
+            if (!prio || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(&e->side.stream, hipStreamNonBlocking);
+            return hipStreamCreateWithPriority(&e->side.stream, hipStreamNonBlocking, hi);
+        }() != hipSuccess ||
         hipEventCreateWithFlags(&e->side.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->side.join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->side.join_copy, hipEventDisableTiming) != hipSuccess ||
@@ -409,7 +418,7 @@ static int launch_kdbk_aside(const SideLane *side, int parity, const FrameDesc *
     const bool timed = tt && tt->on && (tt->mask & 4u);
     if (timed && tt->sev[1]) HIP_TRY(hipEventRecord(tt->sev[1], side->stream));
     if (do_dbk) {
-        hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 15) / 16, DBK_WGS), s.n_frames), dim3(256), 0, side->stream, d_desc);
+        hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 4 * DBK_WG_WAVES - 1) / (4 * DBK_WG_WAVES), DBK_WGS * 4 / DBK_WG_WAVES), s.n_frames), dim3(64 * DBK_WG_WAVES), 0, side->stream, d_desc);
         if (launches) launches[2]++;
     }
     if (timed && tt->sev[2]) HIP_TRY(hipEventRecord(tt->sev[2], side->stream));
@@ -437,7 +446,10 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     const bool aside = !use_ahead && side && side->stream && do_dbk;
     static const bool copy_aside_env = getenv("H264BSDMI_COPY_ASIDE") && atoi(getenv("H264BSDMI_COPY_ASIDE")) != 0;
     const bool copy_aside = copy_aside_env && aside && do_copy;       /* experiment: k_copy (bound by HBM) next to k_recon_inter (bound by issue and latency) */
-    if (aside) {
+    /* where k_dbk runs: "lists" = next to the copy and inter kernels from the start of the tick (rounds 1-3), "intra" = next to
+     * k_frame_intra (whose P-picture ticks leave the device nearly idle), forked behind the inter kernels.  H264BSDMI_DBK_AT */
+    static const bool dbk_late = [] { const char *v = getenv("H264BSDMI_DBK_AT"); return v ? !strcmp(v, "intra") : DBK_AT_INTRA_DEFAULT; }();
+    if (aside && !dbk_late) {
         HIP_TRY(hipEventRecord(side->fork, st));                 /* after the previous tick's k_frame_dbk: the records are free */
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
         if (copy_aside) {
@@ -456,11 +468,16 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
 #if INTER_NMB > 1
         if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_uni, dim3((s.max_gen_uni + 4 * INTER_NMB - 1) / (4 * INTER_NMB), s.n_frames), dim3(256), 0, st, d_desc);
 #else
-        if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_inter<0>, dim3((s.max_gen_uni + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
+        if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_inter<0>, dim3((s.max_gen_uni + INTER_WG_WAVES - 1) / INTER_WG_WAVES, s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
 #endif
-        if (s.max_gen_quad) hipLaunchKernelGGL(h264k::k_recon_inter<1>, dim3((s.max_gen_quad + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
-        if (s.max_gen_rest) hipLaunchKernelGGL(h264k::k_recon_inter<2>, dim3((s.max_gen_rest + 3) / 4, s.n_frames), dim3(256), 0, st, d_desc);
+        if (s.max_gen_quad) hipLaunchKernelGGL(h264k::k_recon_inter<1>, dim3((s.max_gen_quad + INTER_WG_WAVES - 1) / INTER_WG_WAVES, s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
+        if (s.max_gen_rest) hipLaunchKernelGGL(h264k::k_recon_inter<2>, dim3((s.max_gen_rest + INTER_WG_WAVES - 1) / INTER_WG_WAVES, s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
         if (launches) launches[1]++;
+    }
+    if (aside && dbk_late) {
+        HIP_TRY(hipEventRecord(side->fork, st));
+        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        if (launch_kdbk_aside(side, 0, d_desc, s, tt, launches, stages)) return -1;
     }
     if (EV_NEEDED(2)) HIP_TRY(hipEventRecord(tt->ev[2], st));
     if (use_ahead && ahead->next_desc) {
@@ -470,7 +487,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         if (launch_kdbk_aside(side, ahead->parity ^ 1, ahead->next_desc, *ahead->next_shape, ahead->next_tt, launches, stages)) return -1;
     }
     if (do_dbk && !aside && !use_ahead) {
-        hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 15) / 16, DBK_WGS), s.n_frames), dim3(256), 0, st, d_desc);
+        hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 4 * DBK_WG_WAVES - 1) / (4 * DBK_WG_WAVES), DBK_WGS * 4 / DBK_WG_WAVES), s.n_frames), dim3(64 * DBK_WG_WAVES), 0, st, d_desc);
         if (launches) launches[2]++;
     }
     if (copy_aside) HIP_TRY(hipStreamWaitEvent(st, side->join_copy, 0));      /* intra prediction reads copied neighbours */

@@ -616,7 +616,10 @@ __device__ __forceinline__ void wave_sync()
 #ifndef DBK_WGS
 #define DBK_WGS 32           /* workgroups per picture: each walks the picture's index list with stride 8 * DBK_WGS */
 #endif
-__global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frames)
+#ifndef DBK_WG_WAVES
+#define DBK_WG_WAVES 4       /* wavefronts per workgroup of k_dbk (four macroblocks each) */
+#endif
+__global__ __launch_bounds__(64 * DBK_WG_WAVES) void k_dbk(const FrameDesc *__restrict__ frames)
 {
     /* Tables 8-16 / 8-17 in LDS (alpha[64] | beta[64] | tc0[64] as dwords {bS 1, bS 2, bS 3, 0}): a lane-indexed __constant__
      * lookup is a global load */
@@ -640,13 +643,13 @@ __global__ __launch_bounds__(256) void k_dbk(const FrameDesc *__restrict__ frame
      * the current macroblock is worked on, and everything a macroblock needs — its record, the records of its left and
      * upper neighbours, the motion vectors on both sides of the lane's segments — is requested TOGETHER, whether the flags in
      * the record (still in flight) will want it or not: two dependent memory round trips per macroblock. */
-    uint32_t di = blockIdx.x * 16 + (threadIdx.x >> 4);
+    uint32_t di = blockIdx.x * (4 * DBK_WG_WAVES) + (threadIdx.x >> 4);
     const bool live0 = di < n_dbk;
     if (__ballot(live0) == 0ull) return;
     uint32_t mb = live0 ? fd.dbki[di] : 0u;
     bool live = live0;
   for (;;) {
-    const uint32_t ndi = di + 16u * gridDim.x;
+    const uint32_t ndi = di + (4u * DBK_WG_WAVES) * gridDim.x;
     uint32_t nmb = mb;
     const bool nlive = live && ndi < n_dbk;
     if (nlive) nmb = fd.dbki[ndi];
@@ -860,10 +863,16 @@ constexpr int INTER_WAVE_LDS = 2688;                 /* max(21 * IW_STRIDE + 2 *
 #ifndef INTER_OCC_PART
 #define INTER_OCC_PART INTER_OCC
 #endif
+#ifndef INTER_WG_WAVES
+#define INTER_WG_WAVES 1     /* wavefronts (= macroblocks) per workgroup.  The wavefronts of this kernel share nothing, and a workgroup of four
+                                needs a free slot on each of the four SIMDs of one CU at the same moment: 1 / 2 / 4 / 8 / 16 wavefronts per
+                                workgroup take 34.0 / 35.8 / 38.8 / 42.9 / 48.9 ms per step (the average occupancy, not the instruction
+                                count, was what held the kernel back: -10 % instructions had changed nothing) */
+#endif
 template <int PATH>
-__global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k_recon_inter(const FrameDesc *__restrict__ frames)
+__global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC * 4 / INTER_WG_WAVES : INTER_OCC_PART * 4 / INTER_WG_WAVES) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * INTER_WAVE_LDS];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[INTER_WG_WAVES * INTER_WAVE_LDS];
     const FrameDesc &fd = FD_REF(frames, blockIdx.y);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform: the list entry, the record and
                                                                                  everything derived live in scalar registers */
@@ -876,7 +885,7 @@ __global__ __launch_bounds__(256, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k
 #else
     const uint32_t bx_ = blockIdx.x;
 #endif
-    const uint32_t gi = (PATH == 0 ? 0u : PATH == 1 ? fd.n_gen_uni : fd.n_gen_uni + fd.n_gen_quad) + bx_ * 4 + wave;
+    const uint32_t gi = (PATH == 0 ? 0u : PATH == 1 ? fd.n_gen_uni : fd.n_gen_uni + fd.n_gen_quad) + bx_ * INTER_WG_WAVES + wave;
     if (gi >= (PATH == 0 ? fd.n_gen_uni : PATH == 1 ? fd.n_gen_uni + fd.n_gen_quad : fd.n_gen)) return;
     /* list entry and record as whole dwords from a wave-uniform address in read-only memory: scalar loads (there is no scalar
      * byte load: a struct copy would fetch the byte-sized members with vector loads and wait for them) */
