@@ -915,7 +915,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC * 4 / IN
     const uint32_t mv0 = (uint32_t)(uint16_t)ge.mvx | ((uint32_t)(uint16_t)ge.mvy << 16);
     if (!uniform) {
         __builtin_memcpy(&refs, rec.ref_slot, 4);
-        mv_mine = *reinterpret_cast<const uint32_t *>(mvs + 2 * blk);
+        if (!quadwise) mv_mine = *reinterpret_cast<const uint32_t *>(mvs + 2 * blk);
     }
 
     /* the coefficient rows are requested right behind the reference windows (whose loads come first: they are needed
@@ -988,90 +988,70 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC * 4 / IN
         }
     } else if (quadwise) {
         /* ---- one motion vector per 8x8 quadrant (16x8, 8x16, 8x8 partitions): four 13x13 luma and four 5x5 (x2 planes)
-         * chroma windows staged in LDS with row-wide dword loads, then the same register-window arithmetic ---- */
+         * chroma windows staged in LDS, then the same window arithmetic per lane.  Staging: per quadrant 13 luma rows x 2
+         * tiles (26 aligned 16-byte pieces: lanes 0..25) and 2 planes x 5 chroma rows x 2 tiles (20 aligned 8-byte pieces:
+         * lanes 26..45) — which piece a lane fetches is the same in every quadrant, what differs between the quadrants (motion
+         * vector, reference, window origin, whether the window lies inside the picture) is wave-uniform: scalar registers.
+         * All four quadrants are requested before the first is consumed (one memory round trip).  (Round 3 let every lane
+         * derive quadrant, row and tile of TWO pieces from its lane number with divisions, and load its quadrant's motion
+         * vector from memory: 627 vector instructions per macroblock against 290 on the one-vector path.) ---- */
         uint8_t *lq = lw, *cq = lw + 4 * 13 * QW_STRIDE;
-        {
-            /* staging: per quadrant 13 luma rows x 2 tiles (104 aligned 16-byte loads: two per lane) and 2 planes x 5 chroma
-             * rows x 2 tiles (80 aligned 8-byte loads), all four requested before the first is consumed (one memory round
-             * trip); a window that leaves the picture is gathered sample by sample afterwards */
-            uint4 lv[2]; uint2 cv[2];
-            uint32_t *ldst[2], *cdst[2];
-            bool lon[2], con[2];
+        const H264K_CONST uint32_t *mvc = (const H264K_CONST uint32_t *)fd.mvs + 16 * (size_t)mb;       /* (x | y << 16) per 4x4 block, raster */
+        const bool is_l = lane < 26, is_c = lane >= 26 && lane < 46;
+        const int e = lane - 26, pp = e >= 10, e2 = pp ? e - 10 : e;
+        const int pr = is_l ? lane >> 1 : e2 >> 1, pk2 = (is_l ? lane : e2) & 1;          /* the piece's row in the window, its tile (0 / 1) */
+        uint32_t mvq[4];
+        uint4 pv[4];
+        bool pon[4], lfast[4], cfast[4];
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int idx = min(lane + 64 * j, 103);
-                const int q = idx / 26, rem = idx - 26 * q, r = rem >> 1, k = rem & 1;
-                const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
-                const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
-                const H264K_GLOBAL uint8_t *ref = (const H264K_GLOBAL uint8_t *)slot_ptr(fd, (refs >> (8 * q)) & 255u);
+        for (int q = 0; q < 4; q++) {
+            mvq[q] = mvc[(q >> 1) * 8 + (q & 1) * 2];
+            const int mvx = (int16_t)(mvq[q] & 0xFFFFu), mvy = (int32_t)mvq[q] >> 16;
+            const H264K_GLOBAL uint8_t *ref = (const H264K_GLOBAL uint8_t *)slot_ptr(fd, (refs >> (8 * q)) & 255u);
+            const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
+            const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
+            lfast[q] = xi >= 0 && xi + 13 <= W && yi >= 0 && yi + 13 <= H;
+            cfast[q] = cxi >= 0 && cxi + 5 <= CW && cyi >= 0 && cyi + 5 <= CH;
+            const int xs = ((xi >> 4) << 4) + 16 * pk2, cxs = ((cxi >> 3) << 3) + 8 * pk2;
+            pon[q] = is_l ? (lfast[q] && xs < W) : (is_c && cfast[q] && cxs < CW);
+            const size_t off = !pon[q] ? (size_t)0 : is_l ? luma_at(wmb, xs, yi + pr) : chroma_at(wmb, pp, cxs, cyi + pr);
+            pv[q] = ld16g(ref + off);        /* (no branch around a load: its end would wait for it.  Chroma lanes use the first 8 of the 16 bytes;
+                                                 the rest is the plane's next row, or the first bytes of what follows the tile) */
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (pon[q]) {
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(is_l ? lq + q * 13 * QW_STRIDE + pr * QW_STRIDE + 16 * pk2
+                                                                  : cq + (q * 2 + pp) * 5 * QC_STRIDE + pr * QC_STRIDE + 8 * pk2);
+                d32[0] = pv[q].x; d32[1] = pv[q].y;
+                if (is_l) { d32[2] = pv[q].z; d32[3] = pv[q].w; }
+            }
+            /* windows that leave the picture (h264bsdFillBlock, reconstruct.c:2244): gathered sample by sample, clamped */
+            if (!lfast[q] || !cfast[q]) {                            /* wave-uniform */
+                const int mvx = (int16_t)(mvq[q] & 0xFFFFu), mvy = (int32_t)mvq[q] >> 16;
+                const uint8_t *ref = slot_ptr(fd, (refs >> (8 * q)) & 255u);
                 const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
-                const int xs = ((xi >> 4) << 4) + 16 * k;
-                ldst[j] = reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + r * QW_STRIDE + 16 * k);
-                lon[j] = lane + 64 * j < 104 && xi >= 0 && xi + 13 <= W && yi >= 0 && yi + 13 <= H && xs < W;
-                lv[j] = ld16g(ref + (lon[j] ? luma_at(wmb, xs, yi + r) : (size_t)0));
-            }
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int idx = min(lane + 64 * j, 79);
-                const int q = idx / 20, rem = idx - 20 * q, pp = rem >= 10, e2 = pp ? rem - 10 : rem, r = e2 >> 1, k = e2 & 1;
-                const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
-                const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
-                const H264K_GLOBAL uint8_t *ref = (const H264K_GLOBAL uint8_t *)slot_ptr(fd, (refs >> (8 * q)) & 255u);
                 const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
-                const int cxs = ((cxi >> 3) << 3) + 8 * k;
-                cdst[j] = reinterpret_cast<uint32_t *>(cq + (q * 2 + pp) * 5 * QC_STRIDE + r * QC_STRIDE + 8 * k);
-                con[j] = lane + 64 * j < 80 && cxi >= 0 && cxi + 5 <= CW && cyi >= 0 && cyi + 5 <= CH && cxs < CW;
-                cv[j] = ld8g(ref + (con[j] ? chroma_at(wmb, pp, cxs, cyi + r) : (size_t)0));
-            }
+                if (!lfast[q] && is_l) {
+                    const int xs = ((xi >> 4) << 4) + 16 * pk2, yy = clip3(0, H - 1, yi + pr);
+                    uint32_t *d32 = reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + pr * QW_STRIDE + 16 * pk2);
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                if (lon[j]) { ldst[j][0] = lv[j].x; ldst[j][1] = lv[j].y; ldst[j][2] = lv[j].z; ldst[j][3] = lv[j].w; }
-                if (con[j]) { cdst[j][0] = cv[j].x; cdst[j][1] = cv[j].y; }
-            }
-            /* windows that leave the picture (h264bsdFillBlock, reconstruct.c:2244) */
+                    for (int c = 0; c < 4; c++) {
+                        uint32_t v = 0;
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int idx = lane + 64 * j;
-                if (idx < 104) {
-                    const int q = idx / 26, rem = idx - 26 * q, r = rem >> 1, k = rem & 1;
-                    const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
-                    const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
-                    const uint8_t *ref = slot_ptr(fd, (refs >> (8 * q)) & 255u);
-                    const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2, yi = mby * 16 + 8 * (q >> 1) + (mvy >> 2) - 2;
-                    const int xs = ((xi >> 4) << 4) + 16 * k;
-                    uint32_t *d32 = reinterpret_cast<uint32_t *>(lq + q * 13 * QW_STRIDE + r * QW_STRIDE + 16 * k);
-                    if (!(xi >= 0 && xi + 13 <= W && yi >= 0 && yi + 13 <= H)) {
-                        const int yy = clip3(0, H - 1, yi + r);
-#pragma unroll
-                        for (int c = 0; c < 4; c++) {
-                            uint32_t v = 0;
-#pragma unroll
-                            for (int i = 0; i < 4; i++) v |= (uint32_t)ref[luma_at(wmb, clip3(0, W - 1, xs + 4 * c + i), yy)] << (8 * i);
-                            d32[c] = v;
-                        }
+                        for (int i = 0; i < 4; i++) v |= (uint32_t)ref[luma_at(wmb, clip3(0, W - 1, xs + 4 * c + i), yy)] << (8 * i);
+                        d32[c] = v;
                     }
                 }
-            }
+                if (!cfast[q] && is_c) {
+                    const int cxs = ((cxi >> 3) << 3) + 8 * pk2, yy = clip3(0, CH - 1, cyi + pr);
+                    uint32_t *d32 = reinterpret_cast<uint32_t *>(cq + (q * 2 + pp) * 5 * QC_STRIDE + pr * QC_STRIDE + 8 * pk2);
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int idx = lane + 64 * j;
-                if (idx < 80) {
-                    const int q = idx / 20, rem = idx - 20 * q, pp = rem >= 10, e2 = pp ? rem - 10 : rem, r = e2 >> 1, k = e2 & 1;
-                    const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
-                    const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
-                    const uint8_t *ref = slot_ptr(fd, (refs >> (8 * q)) & 255u);
-                    const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3), cyi = mby * 8 + 4 * (q >> 1) + (mvy >> 3);
-                    const int cxs = ((cxi >> 3) << 3) + 8 * k;
-                    uint32_t *d32 = reinterpret_cast<uint32_t *>(cq + (q * 2 + pp) * 5 * QC_STRIDE + r * QC_STRIDE + 8 * k);
-                    if (!(cxi >= 0 && cxi + 5 <= CW && cyi >= 0 && cyi + 5 <= CH)) {
-                        const int yy = clip3(0, CH - 1, cyi + r);
+                    for (int c = 0; c < 2; c++) {
+                        uint32_t v = 0;
 #pragma unroll
-                        for (int c = 0; c < 2; c++) {
-                            uint32_t v = 0;
-#pragma unroll
-                            for (int i = 0; i < 4; i++) v |= (uint32_t)ref[chroma_at(wmb, pp, clip3(0, CW - 1, cxs + 4 * c + i), yy)] << (8 * i);
-                            d32[c] = v;
-                        }
+                        for (int i = 0; i < 4; i++) v |= (uint32_t)ref[chroma_at(wmb, pp, clip3(0, CW - 1, cxs + 4 * c + i), yy)] << (8 * i);
+                        d32[c] = v;
                     }
                 }
             }
@@ -1079,7 +1059,8 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC * 4 / IN
         wave_sync();
         {
             const int q = (by >> 1) * 2 + (bx >> 1);
-            const int mvx = (int16_t)(mv_mine & 0xFFFFu), mvy = (int32_t)mv_mine >> 16;
+            const uint32_t mvm = q == 0 ? mvq[0] : q == 1 ? mvq[1] : q == 2 ? mvq[2] : mvq[3];          /* the lane's quadrant's vector: three selects */
+            const int mvx = (int16_t)(mvm & 0xFFFFu), mvy = (int32_t)mvm >> 16;
             const int xi = mbx * 16 + 8 * (q & 1) + (mvx >> 2) - 2;
             const int o = (xi & 15) + 4 * (bx & 1), sh = 8 * (o & 3);
             luma_pred_lds(lq + q * 13 * QW_STRIDE + (4 * (by & 1) + row) * QW_STRIDE + (o & ~3), QW_STRIDE, sh, mvx & 3, mvy & 3, pl01, pl23);
@@ -1087,8 +1068,8 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC * 4 / IN
         if (lane < 32) {
             const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
             const int q = cby * 2 + cbx;                             /* a 4x4 chroma block = one luma quadrant */
-            const uint32_t mvq = *reinterpret_cast<const uint32_t *>(mvs + 2 * ((q >> 1) * 8 + (q & 1) * 2));
-            const int mvx = (int16_t)(mvq & 0xFFFFu), mvy = (int32_t)mvq >> 16;
+            const uint32_t mvm = q == 0 ? mvq[0] : q == 1 ? mvq[1] : q == 2 ? mvq[2] : mvq[3];
+            const int mvx = (int16_t)(mvm & 0xFFFFu), mvy = (int32_t)mvm >> 16;
             const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3);
             const uint8_t *s0 = cq + (q * 2 + plane) * 5 * QC_STRIDE + row * QC_STRIDE + (cxi & 7), *s1 = s0 + QC_STRIDE;
             int a[5], b[5];
