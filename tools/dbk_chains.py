@@ -225,6 +225,93 @@ def simulate3(hh, w, left, top, inner, any_, waves, per_mb, cost_full, cost_ligh
     return t, busy, steps, total, followed
 
 
+# ---- intra prediction and deblocking of a picture in ONE dataflow kernel?  Today k_frame_intra runs to its end before
+# k_frame_dbk starts (a macroblock's filtering rewrites samples its neighbours' intra prediction still needs: 8.3 predicts from
+# UNFILTERED samples), and in a P picture both are dependency chains that leave the device idle.  Fused, a macroblock's filtering
+# waits for the intra macroblocks among itself and its eight neighbours only.  The model: W wavefronts; an intra step takes one
+# macroblock (cost ci), a deblocking step up to 8 of one class (cost cf / cl); intra first. ----
+def intra_graph(j):
+    hd = h.job_header(j); n, w = hd["n_mbs"], hd["width_mbs"]
+    rec = np.frombuffer(j, dtype=np.uint8, count=n * 32, offset=hd["rec_off"]).reshape(n, 32)
+    idx = np.frombuffer(j, dtype=np.uint16, count=hd["n_intra"], offset=hd["idx_off"]).astype(int)
+    sched = np.zeros(n, bool); sched[idx] = True
+    need = rec[:, 16]
+    D = [(-1, 0), (-1, -1), (0, -1), (1, -1), (1, 0), (1, 1), (0, 1), (-1, 1)]
+    hh = n // w
+    deps = {}
+    for i in idx:
+        x, y = i % w, i // w
+        ds = []
+        for b in range(8):
+            if (need[i] >> b) & 1:
+                nx, ny = x + D[b][0], y + D[b][1]
+                if 0 <= nx < w and 0 <= ny < hh and sched[ny * w + nx]: ds.append(ny * w + nx)
+        deps[int(i)] = ds
+    return deps, sched
+
+
+def simulate_fused(j, waves, ci, cf, cl, fused):
+    import heapq
+    hh, w, left, top, inner, any_ = flags_of(j)
+    n = hh * w
+    A = any_.reshape(-1); Lf = left.reshape(-1); Tp = top.reshape(-1); In = inner.reshape(-1)
+    ideps, sched = intra_graph(j)
+    # task ids: intra i -> i, deblock i -> n + i
+    dep = {}; succ = {}
+    def add(a, b): succ.setdefault(a, []).append(b); dep[b] = dep.get(b, 0) + 1
+    for i, ds in ideps.items():
+        dep.setdefault(i, 0)
+        for d in ds: add(d, i)
+    for y in range(hh):
+        for x in range(w):
+            i = y * w + x
+            if not A[i]: continue
+            t = n + i; dep.setdefault(t, 0)
+            if x and Lf[i] and A[i - 1] and (In[i - 1] or Tp[i - 1]): add(n + i - 1, t)
+            if y and Tp[i] and A[i - w] and (In[i - w] or Lf[i - w]): add(n + i - w, t)
+            if y and x + 1 < w and Tp[i] and A[i - w + 1] and Lf[i - w + 1]: add(n + i - w + 1, t)
+            if fused:
+                for dy in (-1, 0, 1):
+                    for dx in (-1, 0, 1):
+                        nx, ny = x + dx, y + dy
+                        if 0 <= nx < w and 0 <= ny < hh and sched[ny * w + nx]: add(ny * w + nx, t)
+    def run(tasks_filter):
+        d = {k: v for k, v in dep.items() if tasks_filter(k)}
+        ready = [[], [], []]                      # intra, inner, edge-only
+        def push(k): ready[0 if k < n else (1 if In[k - n] else 2)].append(k)
+        for k, v in d.items():
+            if v == 0: push(k)
+        t, free, running, done, seq = 0, waves, [], 0, 0
+        total = len(d)
+        while done < total:
+            while free and (ready[0] or ready[1] or ready[2]):
+                if ready[0]: batch, ready[0] = ready[0][:1], ready[0][1:]; c = ci
+                else:
+                    q = 2 if len(ready[2]) >= len(ready[1]) and ready[2] else (1 if ready[1] else 2)
+                    batch, ready[q] = ready[q][:8], ready[q][8:]; c = cl if q == 2 else cf
+                seq += 1; heapq.heappush(running, (t + c, seq, batch)); free -= 1
+            t, _, batch = heapq.heappop(running); free += 1
+            for k in batch:
+                done += 1
+                for s_ in succ.get(k, []):
+                    if s_ in d:
+                        d[s_] -= 1
+                        if d[s_] == 0: push(s_)
+        return t
+    if fused: return run(lambda k: True)
+    # separate kernels: the deblocking graph without the cross edges, after the intra graph
+    return run(lambda k: k < n) + run(lambda k: k >= n)
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "fused":
+    GHZ = 2.4
+    for waves in (8, 12):
+        sep = fus = 0
+        for i in range(first, min(first + count, len(jobs))):
+            sep += simulate_fused(jobs[i], waves, 9500, 11000, 6500, False)
+            fus += simulate_fused(jobs[i], waves, 9500, 11000, 6500, True)
+        print(f"model, {waves} wavefronts: k_frame_intra then k_frame_dbk {sep / GHZ / 1e6:.1f} ms per pass, one fused dataflow kernel {fus / GHZ / 1e6:.1f} ms")
+
 if len(sys.argv) > 3 and sys.argv[3] == "simulate3":
     GHZ = 2.4
     for waves, per_mb, cf, cl, ff, fl in ((8, 8, 11000, 6500, 0, 0), (8, 8, 11000, 6500, 7500, 3500), (8, 8, 11000, 6500, 6500, 3000), (12, 8, 11000, 6500, 7500, 3500)):
