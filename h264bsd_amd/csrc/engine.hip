@@ -836,6 +836,13 @@ int sink_submit(void *user, const uint8_t *blob, uint32_t bytes)
     return 0;
 }
 
+/* the engine's sticky error bits as last folded in (poll_errors runs wherever the host waits for the device): no wait here */
+uint32_t sink_errors(void *user)
+{
+    SinkUser *u = static_cast<SinkUser *>(user);
+    return __atomic_load_n(&u->e->errors, __ATOMIC_RELAXED);
+}
+
 uint8_t *sink_fetch(void *user, uint32_t slot)
 {
     SinkUser *u = static_cast<SinkUser *>(user);
@@ -935,6 +942,7 @@ int eng_attach(JobSink *sink)
     sink->fetch_converted = sink_fetch_converted;
     sink->fetch_device = sink_fetch_device;
     sink->close = sink_close;
+    sink->errors = sink_errors;
     return 0;
 }
 

@@ -484,13 +484,19 @@ int hd_job_finish(HostDec *d, int is_idr, int single_job)
     d->n_elided = 0;
     if (d->tile_ver && d->tile_mbs == h->n_mbs && cur < d->tile_slots) {
         if (d->tile_uncommitted) tiles_forget(d);             /* the previous picture never reached the sink */
+        /* submit() succeeding only means "queued": if the device has since reported an error (a tripwire of the kernels, a
+         * scheduler that gave up), some picture was not produced as its job said — nothing the buffers hold is relied on any
+         * more, for the rest of this decoder's life */
+        if (d->copy_elision && d->sink.errors && d->sink.errors(d->sink.user)) { d->copy_elision = 0; tiles_forget(d); }
         if (d->tile_serial > 0xFFFF0000u) { d->tile_serial = 0; tiles_forget(d); }    /* (numbers are compared for equality: no wrap-around) */
         /* An IDR picture starts a sequence that must be decodable on its own — replay sets start there — so nothing that
          * the other slots held before it is relied on afterwards */
         if (is_idr) for (uint32_t s = 0; s < d->tile_slots; s++) if (s != cur) tiles_fresh_slot(d, s);
         el.ver = d->tile_ver; el.n_slots = d->tile_slots; el.cur_slot = cur; el.serial = ++d->tile_serial;
         el.out = d->tile_pending; el.n_elided = 0;
-        if (d->copy_elision && single_job && !h->dbk_only && !h->ghost) elide = &el;
+        /* (the reconstruction-only job that conceals a whole lost picture into the spare buffer, hd_decode: frame_num gap, is a
+         * single job too and is elided like any other: the engine executes it like any other, and its tiles are committed) */
+        if (d->copy_elision && single_job && !h->dbk_only) elide = &el;
         else for (uint32_t a = 0; a < d->tile_mbs; a++) d->tile_pending[a] = el.serial;
         d->tile_pending_slot = cur;
         d->tile_uncommitted = 1;

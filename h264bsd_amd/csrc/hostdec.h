@@ -233,6 +233,10 @@ typedef struct JobSink {
     /* slot (cropped to x0,y0,w,h; fmt 0..2 converted, 3 = I420) as a DEVICE pointer; *stream = the HIP stream used */
     void *(*fetch_device)(void *user, uint32_t slot, int fmt, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void **stream);
     void (*close)(void *user);
+    /* optional: the sink's sticky error bits as far as it knows them without waiting (the engine's device error word, folded in
+     * wherever the host waits for the device anyway).  Non-zero = pictures may not have been produced as submitted: the
+     * parser stops relying on what the frame buffers hold (copy elision, hd_job_finish) */
+    uint32_t (*errors)(void *user);
 } JobSink;
 
 /* ---------------------------------------------------------------- decoder instance */

@@ -861,7 +861,8 @@ constexpr int INTER_WAVE_LDS = 2688;                 /* max(21 * IW_STRIDE + 2 *
  * of that stream), PATH 2 the finer partitions.  Compiled separately, each gets the registers its own path needs — the
  * common cases do not pay (in spills at 8 waves per SIMD) for the per-lane window code of the rare one. */
 #ifndef INTER_OCC_PART
-#define INTER_OCC_PART INTER_OCC
+#define INTER_OCC_PART 6     /* the partitioned paths: a hint of 6 lets the quadrant path take the 100 scalar registers it wants (60 VGPRs: it still runs
+                                8 waves per SIMD); at a hint of 8 it spills 32 scalar registers into vector lanes */
 #endif
 #ifndef INTER_WG_WAVES
 #define INTER_WG_WAVES 1     /* wavefronts (= macroblocks) per workgroup.  The wavefronts of this kernel share nothing, and a workgroup of four
@@ -870,7 +871,7 @@ constexpr int INTER_WAVE_LDS = 2688;                 /* max(21 * IW_STRIDE + 2 *
                                 count, was what held the kernel back: -10 % instructions had changed nothing) */
 #endif
 template <int PATH>
-__global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC * 4 / INTER_WG_WAVES : INTER_OCC_PART * 4 / INTER_WG_WAVES) void k_recon_inter(const FrameDesc *__restrict__ frames)
+__global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[INTER_WG_WAVES * INTER_WAVE_LDS];
     const FrameDesc &fd = FD_REF(frames, blockIdx.y);
