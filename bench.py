@@ -484,6 +484,36 @@ def main():
                 traffic_note = f"{tname}: FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes of this command, calibrated on k_copy's known byte count"
         except (OSError, KeyError, ValueError, IndexError):
             pass
+        # the other roofline: wave-level vector instructions.  Counts per launch come from separate rocprofv3 --pmc passes
+        # (tools/sq_profile.sh -> profiles/rNN_sq_counters.json, valid for these kernel sources only), the cost of an instruction
+        # from tools/probes/valu_rate_probe.hip, the launch durations from THIS run (warm-up pass, all kernels bracketed)
+        valu = None
+        try:
+            import glob
+            vpath = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")))[-1]
+            vfile = json.load(open(vpath))
+            from h264bsd_amd.srchash import kernel_source_sha256
+            if vfile.get("kernel_source_sha256") != kernel_source_sha256(ROOT):
+                valu = {"note": f"{os.path.relpath(vpath, ROOT)} was measured with other kernel sources: stale, not reported (rerun tools/sq_profile.sh)"}
+            else:
+                cyc = float(vfile["cycles_per_wave_instruction"])
+                peak = 1024 * 2.4e9 / cyc                                     # 256 CUs x 4 SIMDs, wave64 instructions per second
+                scale = args.streams / float(vfile.get("streams", 256))
+                per = {}
+                for k in kernels:
+                    if k in vfile["kernels"] and breakdown[k][1]:
+                        n_i = vfile["kernels"][k]["valu_wave_instr_per_launch"] * scale
+                        t_s = breakdown[k][0] * 1e-3 / breakdown[k][1]
+                        per[k] = {"wave_instr_per_launch": n_i, "avg_launch_us": t_s * 1e6, "achieved": n_i / t_s, "frac": n_i / t_s / peak,
+                                  "wave_instr_per_macroblock": n_i / (n_mbs * args.streams)}
+                tot_i = sum(v["wave_instr_per_launch"] for v in per.values())
+                valu = {"peak_wave_instr_per_s": peak, "cycles_per_wave_instruction": cyc, "source": os.path.relpath(vpath, ROOT),
+                        "per_kernel": per, "whole_path": {"wave_instr_per_tick": tot_i, "achieved": tot_i * n_pics * args.steps / (dev_total_ms * 1e-3),
+                                                          "frac": tot_i * n_pics * args.steps / (dev_total_ms * 1e-3) / peak,
+                                                          "note": "every kernel runs once per tick; k_dbk runs next to the others, its time is not in the total"}}
+        except (OSError, KeyError, ValueError, IndexError, ZeroDivisionError):
+            pass
+        moved_per_mb = alg_per_mb - 768.0 * (copy_mbs_full - copy_mbs) / (n_mbs * n_pics)
         out = {
             "metric": "1080p macroblocks/s", "value": mbs / elapsed, "unit": "macroblocks/s",
             "fps": pics_per_step * args.steps / elapsed,
@@ -510,6 +540,8 @@ def main():
                          "mbs_per_launch": units_per_launch,
                          "avg_launch_us": avg_launch_us, "launches": launches,
                          "whole_path_GBs": path_gbs, "whole_path_frac": path_gbs / HBM_PEAK_GBS,
+                         "whole_path_GBs_moved": path_gbs * moved_per_mb / alg_per_mb, "whole_path_frac_moved": path_gbs * moved_per_mb / alg_per_mb / HBM_PEAK_GBS,
+                         "valu": valu,
                          "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
                          "whole_path_frac_of_copy_ceiling": path_gbs / copy_gbs,
                          "device_ms_per_step": dict({k: breakdown[k][0] for k in kernels}, total=dev_total_ms / args.steps,
@@ -537,6 +569,7 @@ def main():
                                 "odd_stream_offset_pictures": staggered["odd_stream_offset"],
                                 "vs_lock_step": side_mbs / staggered["elapsed"] / (mbs / elapsed),
                                 "whole_path_GBs": st_gbs, "whole_path_frac": st_gbs / HBM_PEAK_GBS / world,
+                                "whole_path_frac_moved": st_gbs * moved_per_mb / alg_per_mb / HBM_PEAK_GBS / world,
                                 "device_ms_per_step": dict({k: staggered["breakdown"][k][0] for k in kernels},
                                                            total=staggered["dev_ms"] / side_steps)}
         if argb is not None:
@@ -559,6 +592,7 @@ def main():
                 if isinstance(d, dict):
                     d["whole_path_GBs"] = alg_bytes_stream * args.streams * world / (d["ms_per_step"] * 1e-3) / 1e9
                     d["whole_path_frac"] = d["whole_path_GBs"] / HBM_PEAK_GBS / world
+                    d["whole_path_frac_moved"] = d["whole_path_frac"] * moved_per_mb / alg_per_mb      # (the copies that elision leaves out do not move)
                     d["vs_lock_step"] = d["value"] / (mbs / elapsed)
             out["desynchronised"] = desync
         if world == 1 and not args.no_end_to_end:

@@ -71,9 +71,9 @@ def replay_with_elision(built, data):
 @pytest.mark.parametrize("name", STREAMS)
 def test_bundled_streams(built, name):
     n_copy, n_elided = replay_with_elision(built, stream_bytes(name))
-    assert n_elided > 0.2 * n_copy                         # the point of it: 41 % of the copies of the 1080p stream
+    assert n_elided > 0.2 * n_copy                         # the point of it: 46 % of the copies of the 1080p stream (41 % before the host proved strength-free edges against coded / partitioned neighbours)
     if name == "test_1920x1080":
-        assert (n_copy, n_elided) == (362795, 149207)
+        assert (n_copy, n_elided) == (362795, 165648)
 
 
 def test_synthetic_streams(built):

@@ -19,13 +19,14 @@ for f in sorted(glob.glob(os.path.join(src, "pass*.txt"))):
 bl = json.loads(open(os.path.join(src, "bench_line.json")).read())
 ms = bl["roofline"]["device_ms_per_step"]
 ticks = 73
-GHZ = 2.3
+GHZ = 2.4
+VALU_CYC = 4.3            # cycles a SIMD spends per wave64 VOP3 / VOP3P instruction (profiles/r04_valu_rate_probe.txt; rounds 1-3 assumed 4)
 order = ["k_copy", "k_recon_inter", "k_dbk", "k_frame_intra", "k_frame_dbk"]
 out = ["# SQ / TCC counters of the lock-step bench (256 x 1080p streams), " + tag + "; one rocprofv3 --pmc pass per group, no runtime traces:"]
 out += ["#   " + c[2:] for c in cmds]
 out += ["# per dispatch (= one tick of 256 pictures; values of the two instantiations of a templated kernel added).  SQ_WAVE_CYCLES / SQ_WAIT_* /",
         "# SQ_ACTIVE_* count quad-cycles summed over wavefronts (MI355X_MICROARCH.md); WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES.",
-        f"# 'valu pipe' = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time per tick from the un-profiled bench line of the same build x {GHZ} GHz).",
+        f"# 'valu pipe' = SQ_INSTS_VALU x {VALU_CYC} cycles (measured: tools/probes/valu_rate_probe.hip) / (1024 SIMDs x kernel time per tick from the un-profiled bench line of the same build x {GHZ} GHz).",
         f"# bench line of this build: {bl['value'] / 1e6:.1f} M MB/s, device ms per step " + json.dumps({k: round(v, 1) for k, v in ms.items() if isinstance(v, (int, float))}),
         "kernel           dispatches  VALU instr  SALU instr   LDS instr  VMEM rd/wr   parked  issue-stall  issuing  LDS-stall  bank-confl  L2 hit  valu pipe"]
 for k in order:
@@ -34,7 +35,7 @@ for k in order:
         continue
     wc = v.get("SQ_WAVE_CYCLES", 0) or 1
     t_us = ms[k] * 1e3 / ticks
-    pipe = v.get("SQ_INSTS_VALU", 0) * 4 / (1024 * t_us * 1e-6 * GHZ * 1e9)
+    pipe = v.get("SQ_INSTS_VALU", 0) * VALU_CYC / (1024 * t_us * 1e-6 * GHZ * 1e9)
     hit = v.get("TCC_HIT_sum", 0) / max(1.0, v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0))
     n = max(c for _, c in vals[k].values())
     out.append(f"{k:16s} {n:10d}  {v.get('SQ_INSTS_VALU', 0):10.3e}  {v.get('SQ_INSTS_SALU', 0):10.3e}  {v.get('SQ_INSTS_LDS', 0):10.3e}  "
@@ -47,4 +48,18 @@ for k in order:
         t, c = vals[k][n]
         out.append(f"{k:16s} {n:24s} {t / c:.4g}")
 open(os.path.join(root, "profiles", f"{tag}_sq_counters.txt"), "w").write("\n".join(out) + "\n")
+# the table bench.py reads for roofline.valu: wave-level instruction counts per launch (= per tick of 256 pictures), tied to the
+# kernel sources like the traffic table
+sys.path.insert(0, root)
+from h264bsd_amd.srchash import kernel_source_sha256
+table = {"source": f"profiles/{tag}_sq_counters.txt (separate rocprofv3 --pmc passes of the lock-step bench, 256 x 1080p streams)",
+         "kernel_source_sha256": kernel_source_sha256(root), "cycles_per_wave_instruction": VALU_CYC,
+         "cycles_source": "tools/probes/valu_rate_probe.hip: 4.2-4.5 cycles per wave64 VOP3 / VOP3P instruction on one SIMD (v_pk_*_i16, v_perm_b32, v_mad_*, v_dot4)",
+         "streams": 256, "kernels": {}}
+for k in order:
+    v = {n: (t / c if c else 0.0) for n, (t, c) in vals.get(k, {}).items()}
+    if v:
+        table["kernels"][k] = {"valu_wave_instr_per_launch": v.get("SQ_INSTS_VALU", 0.0), "salu_wave_instr_per_launch": v.get("SQ_INSTS_SALU", 0.0),
+                               "lds_wave_instr_per_launch": v.get("SQ_INSTS_LDS", 0.0), "active_lanes_per_valu_instr": (v.get("SQ_THREAD_CYCLES_VALU", 0.0) / v["SQ_INSTS_VALU"] / 4.0) if v.get("SQ_INSTS_VALU") else None}
+json.dump(table, open(os.path.join(root, "profiles", f"{tag}_sq_counters.json"), "w"), indent=1)
 print("\n".join(out[:24]))
