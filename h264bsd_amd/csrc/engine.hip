@@ -1079,7 +1079,7 @@ struct h264bsdmi_replay {
     hipStream_t gstream[8];
     hipEvent_t gdone[8];
     hipEvent_t gring[8];            /* ring of the stream groups: group g has finished the list-driven kernels of its current tick */
-    bool group_ring = true;
+    bool group_ring = false;
     bool overlap_dbk = true;
     bool dbk_ahead = false;           /* lock-step / staggered sets: k_dbk of tick i+1 next to the per-picture kernels of tick i (AheadDbk) */
     unsigned timed_mask = 31u;
@@ -1318,7 +1318,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
                                                                     instruction-bound phase into another (kept as an experiment) */
     r->n_groups = 1;
     for (int g = 0; g < 8; g++) { r->gstream[g] = nullptr; r->gdone[g] = nullptr; r->gring[g] = nullptr; }
-    r->group_ring = !(getenv("H264BSDMI_GROUP_RING") && atoi(getenv("H264BSDMI_GROUP_RING")) == 0);
+    r->group_ring = getenv("H264BSDMI_GROUP_RING") && atoi(getenv("H264BSDMI_GROUP_RING")) != 0;     /* measured: the ring loses (1388 / 1416 vs 1435 / 1484 M MB/s with 2 / 4 groups): off unless asked for */
     if (!ok) {
         fprintf(stderr, "h264bsd-mi355x: h264bsdmiReplayCreate failed (%s)\n", hipGetErrorString(hipGetLastError()));
         if (r->d_blobs) hipFree(r->d_blobs);

@@ -2204,7 +2204,12 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
     uint32_t spins = 0;                  /* safety net: a scheduling bug must end in a reported error (DEVERR_*), never in a hung GPU */
     /* debug accounting (h264bsdmiDebugTailProfile, second half of the buffer): band 0 of picture 0, per wavefront:
      * [0] cycles with nothing ready, [1] cycles reconstructing, [2] cycles waiting for stores + release, [3] MBs */
+#ifdef H264K_TAIL_PROFILE
     unsigned long long *tp = (prof && ticket == 0) ? prof + 256 + wave * 8 : nullptr;
+#else
+    unsigned long long *const tp = nullptr;        /* (the cycle accounting costs registers in a loop that has none to spare: -DH264K_TAIL_PROFILE builds it, tools/prof_tail.py) */
+    (void)prof;
+#endif
     unsigned long long t_idle = 0, t_work = 0, t_rel = 0, t_rec = 0, n_done = 0, t_mark = tp ? __builtin_readcyclecounter() : 0ull;
     /* Pull model: a free wavefront takes up to FOUR ready macroblocks at once.  Each is prepared by the whole wavefront
      * in turn (neighbours, residual, chroma; Intra16x16 / I_PCM / concealed macroblocks completely); the luma of the
@@ -2401,7 +2406,12 @@ __global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const Fra
     uint8_t *flags_g = scratch_flags(fd), *done_g = scratch_done(fd, 0);
     /* debug accounting (h264bsdmiDebugTailProfile): band 0 of picture 0 only, per wavefront: [0] cycles with nothing ready,
      * [1] cycles filtering, [2] cycles waiting for own stores, [3] macroblocks filtered (both halves), [4] total */
+#ifdef H264K_TAIL_PROFILE
     unsigned long long *tp = (prof && ticket == 0) ? prof + wave * 16 : nullptr;
+#else
+    unsigned long long *const tp = nullptr;
+    (void)prof;
+#endif
     unsigned long long t_idle = 0, t_work = 0, t_store = 0, n_done = 0, n_steps = 0;
     const unsigned long long t_begin = tp ? __builtin_readcyclecounter() : 0ull;
     unsigned long long t_mark = t_begin;

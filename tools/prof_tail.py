@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Cycle accounting of k_frame_dbk's dataflow loop (workgroup 0 = stream 0, per wavefront) for a few ticks of the
+"""(needs a library built with -DH264K_TAIL_PROFILE: tools/experiments/build_variant.sh prof -DH264K_TAIL_PROFILE, then H264BSD_VARIANT=prof)
+Cycle accounting of k_frame_dbk's dataflow loop (workgroup 0 = stream 0, per wavefront) for a few ticks of the
 256-stream 1080p replay: how much of a wave's life is spent with nothing ready / filtering / waiting for stores."""
 import sys, os, ctypes, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
