@@ -201,7 +201,7 @@ static int streams_run_concurrently(Engine *e)
         ok = ok && hipEventSynchronize(ev[1]) == hipSuccess && hipEventElapsedTime(&all, ev[0], ev[1]) == hipSuccess;
         for (auto &d : done) if (d) hipEventDestroy(d);
     }
-    for (auto &s : st) if (s) hipStreamDestroy(s);
+    for (auto &s : st) if (s) hipStreamDestroy(s);     /* (probe streams never launch banded kernels: no ticket counters) */
     for (auto &v : ev) if (v) hipEventDestroy(v);
     if (getenv("H264BSDMI_TRACE_LANES")) fprintf(stderr, "h264bsd-mi355x: stream probe: one %.3f ms, eight %.3f ms, ok %d\n", one, all, ok);
     return ok && one > 0 && all < 1.7f * one;       /* measured: 16 hardware queues 1.24 x, 4 queues 3.1 x */
@@ -331,6 +331,22 @@ static uint32_t *tickets_for(hipStream_t st)
     if (hipMalloc((void **)&d, 64) != hipSuccess || hipMemsetAsync(d, 0, 64, st) != hipSuccess) return nullptr;
     g_tickets[dev].emplace_back(st, d);
     return d;
+}
+/* a stream is about to be destroyed: its counters go with it (a later stream may get the same handle and must not inherit them) */
+static void tickets_release(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    for (auto &v : g_tickets)
+        for (size_t i = 0; i < v.size();)
+            if (v[i].first == st) { hipFree(v[i].second); v.erase(v.begin() + (long)i); } else i++;
+}
+/* a banded launch that ended early (a scheduler gave up: DEVERR_*_SCHED) leaves its ticket counters non-zero, and every later
+ * banded launch on that stream would map tickets to the wrong picture and band: after a device error all of them start over */
+static void tickets_rezero(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    if (dev < 0 || dev >= MAX_DEVICES) return;
+    for (auto &p : g_tickets[dev]) (void)hipMemsetAsync(p.second, 0, 64, p.first);
 }
 
 /* ---- launch of one tick ---- */
@@ -598,6 +614,7 @@ int poll_errors(Engine *e)
                 (fresh & DEVERR_RESIDUAL_RANGE) ? " residual outside [-512,511] reached the kernels (host check missed it)" : "",
                 (fresh & DEVERR_INTRA_SCHED) ? " k_frame_intra scheduler gave up" : "", (fresh & DEVERR_DBK_SCHED) ? " k_frame_dbk scheduler gave up" : "");
         e->errors |= fresh;
+        tickets_rezero(e->device);
     }
     return 0;
 }
@@ -1343,10 +1360,10 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     if (r->d_planar) hipFree(r->d_planar);
     for (auto &t : r->timers) for (auto &ev : t.ev) hipEventDestroy(ev);
     hipEventDestroy(r->ev_begin); hipEventDestroy(r->ev_end); if (r->gdone_any) hipEventDestroy(r->gdone_any);
-    for (int g = 0; g < 8; g++) { if (r->gstream[g]) hipStreamDestroy(r->gstream[g]); if (r->gdone[g]) hipEventDestroy(r->gdone[g]); if (r->gring[g]) hipEventDestroy(r->gring[g]); }
+    for (int g = 0; g < 8; g++) { if (r->gstream[g]) { tickets_release(r->gstream[g]); hipStreamDestroy(r->gstream[g]); } if (r->gdone[g]) hipEventDestroy(r->gdone[g]); if (r->gring[g]) hipEventDestroy(r->gring[g]); }
     for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
     for (auto &ev : r->cev) hipEventDestroy(ev);
-    for (auto &st : r->lanes) if (st) hipStreamDestroy(st);
+    for (auto &st : r->lanes) if (st) { tickets_release(st); hipStreamDestroy(st); }
     for (auto &sl : r->lane_side) { if (sl.stream) hipStreamDestroy(sl.stream); if (sl.fork) hipEventDestroy(sl.fork); if (sl.join) hipEventDestroy(sl.join); }
     delete r;
 }

@@ -9,29 +9,30 @@
  *                   block of count x 384 bytes, 16 bytes per lane per access, every load before the first store.
  *                       reference: the P_Skip / integer-mv path of src/h264bsd_inter_prediction.c:361-482,
  *                                  h264bsdFillBlock src/h264bsd_reconstruct.c:2244, src/h264bsd_image.c:81
- *   k_recon_inter : every other inter macroblock, one wavefront each (4 per 256-thread workgroup), list-driven.
+ *   k_recon_inter : every other inter macroblock, one wavefront each (= one workgroup: the wavefronts share nothing), list-driven.
  *                   Reference windows staged in LDS tile row by tile row (aligned 16-byte loads), 6-tap luma on packed
  *                   sample pairs / bilinear chroma, dequant + 4x4 inverse transform with DPP quad transposes, residual
  *                   add; the macroblock leaves as its tile (24 x 16 bytes).
  *                       reference: src/h264bsd_reconstruct.c, src/h264bsd_inter_prediction.c:361-482,
  *                                  src/h264bsd_transform.c, src/h264bsd_image.c:172
- *   k_dbk         : boundary strengths + threshold indices of every macroblock the host could not prove strength-free
- *                   (metadata only, two MBs per wavefront) -> 32-byte deblocking records + one flag byte per MB
- *                   (DBKF_*: filtered at all / touches the left / the upper neighbour).
+ *   k_dbk         : boundary strengths + alpha / beta / tc0 VALUES of every macroblock the host could not prove strength-free
+ *                   (metadata only, four MBs per wavefront) -> 48-byte deblocking records + one flag byte per MB
+ *                   (DBKF_*: filtered at all / touches the left / the upper neighbour / has an active inner edge).
  *                       reference: src/h264bsd_deblocking.c:1187-1541
  *   k_frame_intra : ONE workgroup per picture (a picture never leaves its CU): intra and concealed macroblocks,
  *                   dataflow-scheduled in LDS (dependency counters + ready queue, a free wavefront takes one ready MB).
  *                       reference: src/h264bsd_intra_prediction.c, src/h264bsd_conceal.c
  *   k_frame_dbk   : ONE workgroup per picture: the in-loop filter, dataflow-scheduled in LDS at macroblock-EDGE
- *                   granularity (a macroblock waits only for the neighbours whose samples it really shares), quarter-
- *                   wavefront workers, packed 16-bit arithmetic.
+ *                   granularity (a macroblock waits only for the neighbours whose samples it really shares), eight-lane
+ *                   workers (up to eight macroblocks per wavefront step), two ready lists, packed 16-bit arithmetic.
  *                       reference: src/h264bsd_deblocking.c:575-1745
  *   k_convert / k_output / k_detile : YUV420 -> RGBA / BGRA / YCbCrA, cropped windows, tiles -> planar I420.
  *                       reference: src/h264bsd_decoder.c:1163-1370, :970-1001
  *   k_checksum    : position-weighted 64-bit checksum of a frame in planar order (on-device verification).
  *
- * Everything is integer arithmetic on u8 samples / i16 levels / i32 intermediates: there is no dense
- * contraction on this path, hence no MFMA.
+ * Everything is integer arithmetic on u8 samples / i16 levels / i32 intermediates.  The one contraction on the path — the 6-tap
+ * filter, a Toeplitz product — is a fifth of k_recon_inter's vector instructions, and an i8 MFMA would take over half of THAT
+ * only for the one-dimensional classes ("the matrix pipe"): no MFMA.
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -2361,12 +2362,15 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
  *   dep[mb]   number of filtered macroblocks among those three that are not finished yet
  *   queue[]   ready list: every filtered macroblock is pushed exactly once, when its dep reaches 0
  *   head/tail claim / publish cursors (LDS atomics)
- * A worker is a QUARTER wavefront (16 lanes, two sample lines per lane, packed 16-bit arithmetic).  A
- * free wavefront pulls up to four READY macroblocks at once (compare-and-swap on head), one per quarter, fetches their
+ * A worker is an EIGHTH of a wavefront (8 lanes, two sample lines per lane, packed 16-bit arithmetic, luma and then chroma:
+ * deblock_mb).  A free wavefront pulls up to eight READY macroblocks of ONE of the two ready lists at once (compare-and-swap on
+ * that list's head: macroblocks with an active inner edge / with macroblock edges only), one per worker, fetches their
  * samples, records and neighbour strips in one memory round trip, filters, waits for its stores, then releases the
- * three dependants (x+1,y), (x,y+1), (x-1,y+1).  No level barriers; ready macroblocks are packed into as few
- * wavefronts as possible because the loop is instruction-issue bound (a step costs the same with one busy quarter as
- * with four).  Same-CU visibility of the stores needs only s_waitcnt vmcnt(0) before the LDS release.
+ * three dependants (x+1,y), (x,y+1), (x-1,y+1).  No level barriers.  What a P picture costs is the LATENCY of its ~100
+ * dependent steps (a step is ~9.5 k cycles: claim 0.5, one memory round trip 1.5, the two passes 2.4 + 2.4, stores 1.2, their
+ * completion and the release 0.8; the wavefronts find nothing ready 40-60 % of the time, the vector pipe is 45 % busy), which is
+ * why edge-only macroblocks have their own list and their own short instruction stream.  Same-CU visibility of the stores needs
+ * only s_waitcnt vmcnt(0) before the LDS release.
  * Dynamic LDS: workers x WORKER_LDS tiles | anyf | dep | queue u16 | counters | seen bits (dbk_lds_bytes). */
 __host__ __device__ inline size_t dbk_lds_bytes(uint32_t waves, uint32_t wmb, uint32_t band_rows)
 {
@@ -2374,10 +2378,10 @@ __host__ __device__ inline size_t dbk_lds_bytes(uint32_t waves, uint32_t wmb, ui
     return (((size_t)waves * (64 / DBK_LANES) * WORKER_LDS + 15) & ~(size_t)15) + 2 * n_loc16 + 2 * nq8 + 32 + 4 * ((((size_t)wmb + 31) / 32 + 3) & ~(size_t)3);
 }
 #ifndef DBK_OCC
-#define DBK_OCC 3
+#define DBK_OCC 4            /* 127 VGPRs, nothing spilled (cycle accounting compiled out): a SIMD could hold four of these wavefronts */
 #endif
 template <bool BANDED>
-__global__ __launch_bounds__(64 * DBK_WAVES, DBK_OCC) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof,
+__global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof,
                                                               uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap, uint32_t light_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
