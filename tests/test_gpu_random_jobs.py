@@ -62,7 +62,7 @@ def test_no_deblocking_at_all(built):
 
 # ---- row bands of the two per-picture kernels (k_frame_dbk / k_frame_intra, kernels.hip.h): a picture split over several
 # workgroups with the hand-over through HBM must give the same samples as one workgroup ----
-DEFAULT_TAIL = (17, 9, 12, 0, 9, 12, 320)      # engine.hip TailConfig
+DEFAULT_TAIL = (17, 9, 8, 0, 9, 12, 320)       # engine.hip TailConfig
 
 
 @pytest.fixture
