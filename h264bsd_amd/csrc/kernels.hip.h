@@ -145,6 +145,24 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
  * the band below therefore travel write-through: relaxed agent-scope stores (global_store ... sc1: the line leaves the
  * producer's L2) and relaxed agent-scope loads (global_load ... sc1: past the L1) on the consumer's side, the "done" byte
  * stored after s_waitcnt vmcnt(0) the same way.  No fences: a release fence writes back the whole L2 of the XCD. */
+/* ---- hand-over inside a workgroup (the per-picture schedulers) ----
+ * A wavefront that has stored a macroblock tells its dependants through LDS.  All wavefronts of a workgroup run on one CU
+ * and share its vector L1, and the CU's memory pipeline keeps vector memory instructions in issue order: a load issued by
+ * another wavefront of the workgroup after it has seen the LDS release observes the stores issued before that release.  That
+ * is the architecture's contract, not an observation: for a workgroup-scope release in front of global stores the compiler
+ * emits no s_waitcnt vmcnt(0) on gfx950 (it does under -mtgsplit, where a workgroup may span CUs; this code is never built
+ * that way).  So the release does not wait for the stores to be acknowledged by the L2 — several hundred cycles that used
+ * to sit on every link of a dependency chain.  Only a macroblock that another WORKGROUP will read (the last row of a band)
+ * still waits: its "done" byte must not pass its samples on the way to the other CU. */
+#ifndef H264K_RELEASE_WAITS
+#define H264K_RELEASE_WAITS 0                                /* 1: the conservative form (wait for every store) for A/B runs */
+#endif
+__device__ __forceinline__ void release_stores(bool leaves_the_workgroup)
+{
+    if (H264K_RELEASE_WAITS || __ballot(leaves_the_workgroup) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
 #define H264K_GLOBAL __attribute__((address_space(1)))      /* HBM pointers: global_load / global_store instead of flat */
 #define H264K_LDS    __attribute__((address_space(3)))
 #define H264K_CONST  __attribute__((address_space(4)))      /* frame-job sections: nothing writes them while kernels run, so a load
@@ -2308,9 +2326,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
         if (__ballot(joint_mb >= 0) != 0ull) intra4_joint(fd, joint_mb, lane, my, i4tab, BANDED && joint_mb >= wt_lo);
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += k; }
         /* release: stores done -> the neighbours that wait for these macroblocks (lanes 16j + b: neighbour b of macroblock j) */
-        __builtin_amdgcn_s_waitcnt(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             /* (the compiler may drop the builtin in front of an agent-scope store) */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        release_stores(BANDED && v >= wt_lo && (uint32_t)lane < k);
         {
             const int j = lane >> 4, b = lane & 15;
             const int mbj = __shfl(v, j);
@@ -2365,12 +2381,12 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
  * A worker is an EIGHTH of a wavefront (8 lanes, two sample lines per lane, packed 16-bit arithmetic, luma and then chroma:
  * deblock_mb).  A free wavefront pulls up to eight READY macroblocks of ONE of the two ready lists at once (compare-and-swap on
  * that list's head: macroblocks with an active inner edge / with macroblock edges only), one per worker, fetches their
- * samples, records and neighbour strips in one memory round trip, filters, waits for its stores, then releases the
+ * samples, records and neighbour strips in one memory round trip, filters, stores, then releases the
  * three dependants (x+1,y), (x,y+1), (x-1,y+1).  No level barriers.  What a P picture costs is the LATENCY of its ~100
  * dependent steps (a step is ~9.5 k cycles: claim 0.5, one memory round trip 1.5, the two passes 2.4 + 2.4, stores 1.2, their
  * completion and the release 0.8; the wavefronts find nothing ready 40-60 % of the time, the vector pipe is 45 % busy), which is
  * why edge-only macroblocks have their own list and their own short instruction stream.  Same-CU visibility of the stores needs
- * only s_waitcnt vmcnt(0) before the LDS release.
+ * no wait at all (release_stores above); rounds 1-3 waited for the stores' acknowledgement on every step.
  * Dynamic LDS: workers x WORKER_LDS tiles | anyf | dep | queue u16 | counters | seen bits (dbk_lds_bytes). */
 __host__ __device__ inline size_t dbk_lds_bytes(uint32_t waves, uint32_t wmb, uint32_t band_rows)
 {
@@ -2566,9 +2582,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
         else deblock_mb<BANDED, 4>(fd, run, l, cp, wlds, wt, (fm & DBKF_INNER) != 0u, (tp && lane == 0) ? tp : nullptr);
         if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && l == 0)); n_steps++; }
         /* release: stores done -> dependants */
-        __builtin_amdgcn_s_waitcnt(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             /* (the compiler may drop the builtin in front of an agent-scope store) */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        release_stores(BANDED && wt && run >= 0);
         if (BANDED && wt && l == 3) st_agent_u8(done_g + run, 1u);   /* hand-over to the band below */
         if (run >= 0 && l < 3) {
             /* dependants: l = 0: (x+1, y), l = 1: (x, y+1), l = 2: (x-1, y+1) — the mirror image of the dependency rule above.  The
