@@ -358,7 +358,7 @@ def job_header(blob):
     import struct
     (magic, total, wmb, hmb, n_mbs, cur, is_idr, n_slots, any_dbk, rec_off, mv_off, lvl_off, idx_off, coef_off,
      n_intra, n_levels, n_coef, n_inter, pic_seq, copy_off, n_copy, gen_off, n_gen, dbk_off, n_dbk, n_gen_uniform, ghost,
-     dbk_only, _down, n_gen_quad) = struct.unpack_from("<IIHHIBBBBIIIIIIIIIIIIIIIIIIIII", blob, 0)
+     dbk_only, _down, n_gen_quad, mvx_off, n_mvx) = struct.unpack_from("<IIHHIBBBBIIIIIIIIIIIIIIIIIIIIIII", blob, 0)
     if magic != 0x314A4648:
         raise ValueError("not a frame job")
     # FjCopy entries are 8 bytes {u16 mb, u8 slot, u8 count, i16 dx, i16 dy}: macroblocks moved by k_copy
@@ -368,7 +368,26 @@ def job_header(blob):
                 idx_off=idx_off, coef_off=coef_off, n_intra=n_intra, n_intra_levels=n_levels,
                 n_coef_blocks=n_coef, n_inter=n_inter, pic_seq=pic_seq, copy_off=copy_off, n_copy=n_copy,
                 gen_off=gen_off, n_gen=n_gen, dbk_off=dbk_off, n_dbk=n_dbk, n_copy_mbs=n_copy_mbs,
-                n_gen_uniform=n_gen_uniform, n_gen_quad=n_gen_quad, ghost=ghost, dbk_only=dbk_only)
+                n_gen_uniform=n_gen_uniform, n_gen_quad=n_gen_quad, ghost=ghost, dbk_only=dbk_only, mvx_off=mvx_off, n_mvx=n_mvx)
+
+
+def job_mvs(blob):
+    """The motion vectors of a FINISHED frame job as a dense int16 array [n_mbs][16][2] (raster 4x4 order, quarter samples):
+    a macroblock with FJ_PRED_UNIFORM_MV (pred bit 6) carries its one vector in the record (bytes 24..27), the other inter
+    macroblocks have sixteen in the sparse section at mvx_off, entry = u32 at bytes 28..31 of the record (framejob.h)."""
+    h = job_header(blob)
+    n = h["n_mbs"]
+    rec = np.frombuffer(blob, dtype=np.uint8, count=n * 32, offset=h["rec_off"]).reshape(n, 32)
+    mvx = np.frombuffer(blob, dtype=np.int16, count=h["n_mvx"] * 32, offset=h["mvx_off"]).reshape(h["n_mvx"], 16, 2)
+    out = np.zeros((n, 16, 2), dtype=np.int16)
+    inter = rec[:, 0] == 0
+    one = inter & ((rec[:, 4] & 0x40) != 0)
+    mv1 = np.frombuffer(rec[:, 24:28].tobytes(), dtype=np.int16).reshape(n, 2)
+    idx = np.frombuffer(rec[:, 28:32].tobytes(), dtype=np.uint32)
+    out[one] = mv1[one][:, None, :]
+    many = inter & ~one
+    out[many] = mvx[idx[many]]
+    return out
 
 
 def capture_stream(data, copy_elision=False):

@@ -372,7 +372,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
 {
     const FjHeader *h = reinterpret_cast<const FjHeader *>(host_blob);
     d.recs = reinterpret_cast<const FjMbRec *>(dev_blob + h->rec_off);
-    d.mvs = reinterpret_cast<const int16_t *>(dev_blob + h->mv_off);
+    d.mvx = reinterpret_cast<const int16_t *>(dev_blob + h->mvx_off);
     d.coefs = reinterpret_cast<const int16_t *>(dev_blob + h->coef_off);
     d.lvl = reinterpret_cast<const uint32_t *>(dev_blob + h->lvl_off);
     d.idx = reinterpret_cast<const uint16_t *>(dev_blob + h->idx_off);

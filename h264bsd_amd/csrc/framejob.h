@@ -63,9 +63,11 @@
 #define FJ_PRED_PHASE2 0x80u  /* in a deblock-only job (FjHeader.dbk_only): this macroblock is nevertheless reconstructed, on top of
                                  the pixels of the job before — it replaced pixels that other macroblocks had already predicted
                                  from (concealment of, or a later slice over, a macroblock that a failed redundant slice un-decoded) */
-#define FJ_PRED_UNIFORM_MV 0x40u /* inter macroblocks: a hint of the parser to fj_finalize() — the 16 motion vectors were written as 16 copies of
-                                  one vector and the four references are equal (P_Skip, P_L0_16x16): no need to compare them.  A job
-                                  built elsewhere may leave it clear. */
+#define FJ_PRED_UNIFORM_MV 0x40u /* inter macroblocks: the 16 motion vectors are 16 copies of one vector and the four references are equal.
+                                  Before fj_finalize() it is a hint of the parser (P_Skip, P_L0_16x16: no need to compare them; a job
+                                  built elsewhere may leave it clear); fj_finalize() sets it wherever it holds, and in a FINISHED job
+                                  it says where the vectors are: set -> FjMbRec.mv is the macroblock's one vector, clear -> the 16
+                                  vectors are entry FjMbRec.mvx of the sparse section at FjHeader.mvx_off. */
 #define FJ_PRED_PARTS_SHIFT 4  /* inter macroblocks, pred bits 4-5: where the macroblock TYPE allows motion to differ inside it — the
                                  deblocking filter compares motion vectors / references only there (reference
                                  deblocking.c:1266-1345) */
@@ -108,7 +110,9 @@ typedef struct FjHeader {
     uint8_t  n_slots;         /* DPB slots of the owning decoder (dpbSize+1)                  */
     uint8_t  any_deblock;     /* 0: no MB of the picture is filtered (idc==1 everywhere)      */
     uint32_t rec_off;         /* FjMbRec[n_mbs]                                               */
-    uint32_t mv_off;          /* int16 mv[n_mbs][16][2]  (x,y) quarter-pel, raster 4x4 order  */
+    uint32_t mv_off;          /* INPUT of fj_finalize(), host only: int16 mv[n_mbs][16][2] (x,y) quarter-pel, raster 4x4 order — the dense
+                                 array the parser writes.  The parser keeps it behind everything else in the job buffer, past
+                                 total_bytes: it is never transferred.  Finished jobs carry vectors as FjMbRec.mv / mvx_off. */
     uint32_t lvl_off;         /* uint32 lvl_start[n_intra_levels+1]  (indices into intra_idx) */
     uint32_t idx_off;         /* uint16 intra_idx[n_intra]  MB addresses sorted by level      */
     uint32_t coef_off;        /* int16 coef[n_coef_blocks][16]                                */
@@ -135,7 +139,11 @@ typedef struct FjHeader {
                                  into row bands (k_frame_intra) */
     uint32_t n_gen_quad;      /* of the partitioned entries behind the first n_gen_uniform, the first n_gen_quad have one motion vector
                                  per 8x8 quadrant (FjGen.uniform == 2: 16x8, 8x16, 8x8 partitions), the rest finer partitions */
-    uint32_t reserved[6];
+    uint32_t mvx_off;         /* int16 mvx[n_mvx][16][2]: the vectors of the inter macroblocks that have more than one (raster 4x4
+                                 order), in macroblock address order; FjMbRec.mvx is the entry's index.  64 bytes for one macroblock
+                                 in six of the bundled 1080p stream instead of 64 bytes for every macroblock */
+    uint32_t n_mvx;
+    uint32_t reserved[4];
 } FjHeader;                   /* 128 bytes */
 
 /* An inter macroblock with no coefficients whose 16 motion vectors are equal and whole-sample for
@@ -184,7 +192,13 @@ typedef struct FjMbRec {
     int8_t   cqp_off;         /* chroma_qp_index_offset of the MB's PPS (deblock QPc)         */
     uint8_t  dbk_trivial;     /* 1: every boundary strength of this MB is zero by construction (host-proved) */
     uint16_t intra_level;     /* dependency level among intra MBs of the picture              */
-    uint8_t  i4mode[8];       /* 16 nibbles: Intra4x4PredMode of block z (H.264 block order)  */
+    union {
+        uint8_t  i4mode[8];   /* Intra4x4: 16 nibbles, Intra4x4PredMode of block z (H.264 block order) */
+        struct {              /* inter macroblocks, written by fj_finalize():                          */
+            int16_t  mv[2];   /*   the vector of block 0 = THE vector when FJ_PRED_UNIFORM_MV          */
+            uint32_t mvx;     /*   else: index of the macroblock's 16 vectors in the section at mvx_off */
+        };
+    };
 } FjMbRec;                    /* 32 bytes */
 
 /* Order of a macroblock's coefficient blocks starting at coef_idx:

@@ -60,14 +60,18 @@ void hd_destroy(HostDec *d)
 }
 
 /* ---------------------------------------------------------------- frame job */
+/* the parser's dense motion-vector array (FjHeader.mv_off): the tail of the job buffer, never part of the finished job */
+static uint32_t job_dense_mv_bytes(uint32_t n_mbs) { return n_mbs * 64u + 32u; }
+
 static uint32_t job_capacity(uint32_t n_mbs)
 {
     /* coefficients: 27 blocks per macroblock (16 luma, Intra16x16 DC, 2 chroma DC sharing one, 8 chroma AC) + 2, and room
      * for one more macroblock: a redundant slice that decodes the last macroblock of a full picture again parses its
      * blocks into the section before it gives them back */
-    return 128u + n_mbs * (32u + 64u) + (n_mbs * 27u + 2u + 27u) * 32u
+    return 128u + n_mbs * 32u + (n_mbs * 27u + 2u + 27u) * 32u
            + (n_mbs + 2u) * 4u /* level starts */ + fj_align32(n_mbs * 2u) /* intra index */
-           + n_mbs * 16u /* copy list + general list */ + fj_align32(n_mbs * 2u) /* deblocking index */ + 512u;
+           + n_mbs * 16u /* copy list + general list */ + fj_align32(n_mbs * 2u) /* deblocking index */ + 512u
+           + n_mbs * 64u /* sparse vectors, at worst all of them */ + job_dense_mv_bytes(n_mbs);
 }
 
 int hd_job_begin(HostDec *d)
@@ -92,8 +96,8 @@ int hd_job_begin(HostDec *d)
     h->height_mbs = (uint16_t)d->height_mbs;
     h->n_mbs = n;
     h->rec_off = 128;
-    h->mv_off = h->rec_off + n * 32u;
-    h->coef_off = h->mv_off + n * 64u;
+    h->coef_off = h->rec_off + n * 32u;
+    h->mv_off = (cap - n * 64u) & ~31u;             /* host only, behind everything the finished job can hold (job_capacity) */
     /* records and motion vectors are NOT pre-initialised: every decoded macroblock writes both, and
      * hd_job_finish() fills in the macroblocks no slice covered (saves two passes over 0.8 MB per 1080p picture) */
     d->coef_blocks = 0;
@@ -130,7 +134,7 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
     FjMbRec *recs = (FjMbRec *)(job + h->rec_off);
     const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(job + h->mv_off);
     {
-        const size_t need_bytes = (size_t)n * (1 + 8 + 16 + 2 + 2) + ((size_t)n + 2) * 4 + 64;
+        const size_t need_bytes = (size_t)n * (1 + 8 + 16 + 2 + 2 + 2) + ((size_t)n + 2) * 4 + 64;
         if (tl_scratch_cap < need_bytes) {
             free(tl_scratch);
             tl_scratch = (uint8_t *)malloc(need_bytes);
@@ -144,8 +148,9 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
     uint32_t *hist = (uint32_t *)(copy_tmp + n);                 /* intra MBs per level */
     uint16_t *dbk_tmp = (uint16_t *)(hist + n + 2);
     uint16_t *ilist = dbk_tmp + n;                               /* intra-schedule MBs in raster order */
-    uint8_t *cls = (uint8_t *)(ilist + n);
-    uint32_t max_level = 0, n_intra = 0, n_absent = 0, n_conceal = 0, n_copy = 0, n_gen = 0, n_dbk = 0;
+    uint16_t *mvx_list = ilist + n;                              /* inter macroblocks with more than one vector, raster order */
+    uint8_t *cls = (uint8_t *)(mvx_list + n);
+    uint32_t max_level = 0, n_intra = 0, n_absent = 0, n_conceal = 0, n_copy = 0, n_gen = 0, n_dbk = 0, n_mvx = 0;
     uint8_t any_dbk = 0;
     memset(hist, 0, ((size_t)n + 2) * 4);
 
@@ -235,6 +240,10 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
                 for (int k = 0; k < 8; k++) acc |= w[k] ^ two;
                 same_mv = acc == 0;
             }
+            /* where the finished job keeps the vectors: one in the record, or sixteen in the sparse section (framejob.h) */
+            r->mv[0] = m0[0]; r->mv[1] = m0[1];
+            if (same_mv) { r->pred |= FJ_PRED_UNIFORM_MV; r->mvx = 0; }
+            else { r->pred &= (uint8_t)~FJ_PRED_UNIFORM_MV; r->mvx = n_mvx; mvx_list[n_mvx++] = (uint16_t)a; }
             const int uni = same_mv && r->coded == 0;
             cls[a] = (uint8_t)(uni ? (((m0[0] | m0[1]) & 7) == 0 ? 3 : 1) : 0);
             if (recon && !(cls[a] & 2)) {
@@ -251,6 +260,7 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
                 }
                 gi->mb = (uint16_t)a; gi->uniform = (uint8_t)(same_mv ? 1 : quad ? 2 : 0); gi->slot = r->ref_slot[0];
                 gi->mvx = m0[0]; gi->mvy = m0[1]; gi->coef_idx = r->coef_idx; gi->coded = r->coded;
+                if (!same_mv) memcpy(&gi->mvx, &r->mvx, 4);      /* partitioned: the two fields hold the index of its sixteen vectors */
             }
         }
 deblock_index:
@@ -360,8 +370,13 @@ deblock_index:
     h->gen_off = fj_align32(h->copy_off + n_copy * 8u);
     h->dbk_off = fj_align32(h->gen_off + n_gen * 16u);
     h->n_dbk = n_dbk;
-    h->total_bytes = fj_align32(h->dbk_off + n_dbk * 2u);
+    h->mvx_off = fj_align32(h->dbk_off + n_dbk * 2u);
+    h->n_mvx = n_mvx;
+    h->total_bytes = fj_align32(h->mvx_off + n_mvx * 64u);
     if (h->total_bytes > cap) return -1;
+    /* the dense vectors are read below: they lie in front of the coefficients (hand-built jobs) or behind everything (the parser) */
+    if (h->mv_off >= h->coef_off && h->mv_off < h->total_bytes) return -1;
+    for (uint32_t i = 0; i < n_mvx; i++) memcpy(job + h->mvx_off + (size_t)i * 64u, mvs[mvx_list[i]], 64);
     memcpy(job + h->copy_off, copy_tmp, (size_t)n_copy * 8u);
     {   /* general-inter list: the entries with one motion vector per macroblock first (k_recon_inter<0>), then those with
          * one per 8x8 quadrant (<1>), then the finer partitions (<2>); every part keeps raster order */
@@ -391,7 +406,7 @@ deblock_index:
         const uint32_t ends[6] = { h->coef_off + coef_blocks * 32u, h->lvl_off + (n_levels + 1) * 4u,
                                    h->idx_off + n_intra * 2u, h->copy_off + h->n_copy * 8u, h->gen_off + h->n_gen * 16u,
                                    h->dbk_off + h->n_dbk * 2u };
-        const uint32_t nexts[6] = { h->lvl_off, h->idx_off, h->copy_off, h->gen_off, h->dbk_off, h->total_bytes };
+        const uint32_t nexts[6] = { h->lvl_off, h->idx_off, h->copy_off, h->gen_off, h->dbk_off, h->mvx_off };
         for (int i = 0; i < 6; i++) if (nexts[i] > ends[i]) memset(job + ends[i], 0, nexts[i] - ends[i]);
     }
     h->n_intra = n_intra;
@@ -900,6 +915,7 @@ static uint8_t *redo_split(HostDec *d, uint8_t **between)
     uint8_t *blob = (uint8_t *)malloc(d->job_cap);
     if (!blob) return NULL;
     memcpy(blob, d->job, used);
+    memcpy(blob + h->mv_off, d->job + h->mv_off, (size_t)n * 64u);        /* the dense vectors live at the tail of the buffer */
     FjHeader *gh = (FjHeader *)blob;
     FjMbRec *grecs = (FjMbRec *)(blob + gh->rec_off);
     for (uint32_t i = 0; i < d->n_redo; i++) {
@@ -912,6 +928,7 @@ static uint8_t *redo_split(HostDec *d, uint8_t **between)
         uint8_t *mid = (uint8_t *)malloc(d->job_cap);
         if (!mid) { free(blob); return NULL; }
         memcpy(mid, d->job, used);
+        memcpy(mid + h->mv_off, d->job + h->mv_off, (size_t)n * 64u);
         FjHeader *mh = (FjHeader *)mid;
         FjMbRec *mrecs = (FjMbRec *)(mid + mh->rec_off);
         for (uint32_t a = 0; a < n; a++) { mrecs[a].pred &= (uint8_t)~FJ_PRED_PHASE2; mrecs[a].dbk = 0; }

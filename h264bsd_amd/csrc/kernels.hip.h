@@ -43,7 +43,7 @@
  * dependent load: blob header -> section pointers). */
 struct FrameDesc {
     const FjMbRec  *recs;
-    const int16_t  *mvs;
+    const int16_t  *mvx;          /* the sparse vector section (FjHeader.mvx_off): 16 x (x, y) per macroblock that has more than one vector */
     const int16_t  *coefs;
     const uint32_t *lvl;          /* lvl_start[n_levels+1] */
     const uint16_t *idx;          /* intra MB addresses sorted by level */
@@ -660,8 +660,8 @@ __global__ __launch_bounds__(64 * DBK_WG_WAVES) void k_dbk(const FrameDesc *__re
     const uint32_t n_dbk = fd.n_dbk;
     /* A fixed number of workgroups per picture walks the index list with a stride; the next index is requested while
      * the current macroblock is worked on, and everything a macroblock needs — its record, the records of its left and
-     * upper neighbours, the motion vectors on both sides of the lane's segments — is requested TOGETHER, whether the flags in
-     * the record (still in flight) will want it or not: two dependent memory round trips per macroblock. */
+     * upper neighbours — is requested TOGETHER, whether the flags in the record (still in flight) will want it or not: two
+     * dependent memory round trips per macroblock, a third for the vectors of partitioned macroblocks. */
     uint32_t di = blockIdx.x * (4 * DBK_WG_WAVES) + (threadIdx.x >> 4);
     const bool live0 = di < n_dbk;
     if (__ballot(live0) == 0ull) return;
@@ -675,9 +675,14 @@ __global__ __launch_bounds__(64 * DBK_WG_WAVES) void k_dbk(const FrameDesc *__re
     const uint32_t mbl = mb % (uint32_t)wmb ? mb - 1 : mb, mbt = mb >= (uint32_t)wmb ? mb - wmb : mb;    /* in-picture stand-ins */
     FjMbRec q, pl, pt;
     const int dir = m >> 3, e = (m >> 1) & 3, kh = m & 1;
-    const uint32_t pmb = e ? mb : (dir ? mbt : mbl);
     int qx[2], qy[2], px[2], py[2];
     uint32_t mva[2], mvb[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+        const int k = 2 * kh + kk;
+        qx[kk] = dir ? k : e; qy[kk] = dir ? e : k;
+        px[kk] = dir ? k : (e ? e - 1 : 3); py[kk] = dir ? (e ? e - 1 : 3) : k;
+    }
     {
         /* the three records as whole 16-byte pieces, the motion vectors of both sides — all requested before anything is
          * looked at (a struct copy lets the compiler fetch member by member where each is used: five dependent round trips) */
@@ -685,17 +690,23 @@ __global__ __launch_bounds__(64 * DBK_WG_WAVES) void k_dbk(const FrameDesc *__re
                                    *rt = (const H264K_GLOBAL uint8_t *)(fd.recs + mbt);
         uint4 w[6] = { ld16g(rq), ld16g(rq + 16), ld16g(rl), ld16g(rl + 16), ld16g(rt), ld16g(rt + 16) };
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            const int k = 2 * kh + kk;
-            qx[kk] = dir ? k : e; qy[kk] = dir ? e : k;
-            px[kk] = dir ? k : (e ? e - 1 : 3); py[kk] = dir ? (e ? e - 1 : 3) : k;
-            mva[kk] = *(const H264K_GLOBAL uint32_t *)(fd.mvs + 32 * (size_t)mb + 2 * (4 * qy[kk] + qx[kk]));
-            mvb[kk] = *(const H264K_GLOBAL uint32_t *)(fd.mvs + 32 * (size_t)pmb + 2 * (4 * py[kk] + px[kk]));
-        }
-#pragma unroll
         for (int i = 0; i < 6; i++) asm volatile("" : "+v"(w[i].x), "+v"(w[i].y), "+v"(w[i].z), "+v"(w[i].w));
-        asm volatile("" : "+v"(mva[0]), "+v"(mvb[0]), "+v"(mva[1]), "+v"(mvb[1]));
         __builtin_memcpy(&q, &w[0], 32); __builtin_memcpy(&pl, &w[2], 32); __builtin_memcpy(&pt, &w[4], 32);
+    }
+    {
+        /* motion vectors on both sides of the lane's two segments.  A macroblock with ONE vector carries it in its record
+         * (FJ_PRED_UNIFORM_MV: five of six — nothing more to fetch); the others have their sixteen in the sparse section, one
+         * more dependent round trip for the lanes that look at such a macroblock */
+        const FjMbRec &pr = e ? q : (dir ? pt : pl);
+        const bool q_one = (q.pred & FJ_PRED_UNIFORM_MV) || q.kind != FJ_MB_INTER, p_one = (pr.pred & FJ_PRED_UNIFORM_MV) || pr.kind != FJ_MB_INTER;
+        const uint32_t q_mv = q.kind == FJ_MB_INTER ? (uint32_t)(uint16_t)q.mv[0] | ((uint32_t)(uint16_t)q.mv[1] << 16) : 0u;
+        const uint32_t p_mv = pr.kind == FJ_MB_INTER ? (uint32_t)(uint16_t)pr.mv[0] | ((uint32_t)(uint16_t)pr.mv[1] << 16) : 0u;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            mva[kk] = q_mv; mvb[kk] = p_mv;
+            if (!q_one) mva[kk] = *(const H264K_GLOBAL uint32_t *)(fd.mvx + 32 * (size_t)q.mvx + 2 * (4 * qy[kk] + qx[kk]));
+            if (!p_one) mvb[kk] = *(const H264K_GLOBAL uint32_t *)(fd.mvx + 32 * (size_t)pr.mvx + 2 * (4 * py[kk] + px[kk]));
+        }
     }
     uint8_t *out = fd.dbk + (size_t)mb * DBK_REC_BYTES;
     uint8_t *any_out = fd.dbk + (size_t)fd.n_mbs * DBK_REC_BYTES + mb;
@@ -926,7 +937,9 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mby = wmb == 1 ? (int)mb : (int)__umulhi(mb, fd.wmb_magic), mbx = (int)mb - mby * wmb;     /* scalar: FrameDesc.wmb_magic */
     /* (address spaces spelled out once: the loads below become global_load / s_load instead of flat_load) */
-    const int16_t *mvs = (const int16_t *)((const H264K_CONST int16_t *)fd.mvs + 32 * (size_t)mb);
+    /* partitioned macroblocks: the list entry's vector fields hold the index of their sixteen vectors in the sparse section */
+    const uint32_t mvx_idx = PATH == 0 ? 0u : (uint32_t)(uint16_t)ge.mvx | ((uint32_t)(uint16_t)ge.mvy << 16);
+    const int16_t *mvs = (const int16_t *)((const H264K_CONST int16_t *)fd.mvx + 32 * (size_t)mvx_idx);
     const int16_t *coef = (const int16_t *)((const H264K_CONST int16_t *)fd.coefs + 16 * (size_t)ge.coef_idx);
     H264K_GLOBAL uint8_t *cur = (H264K_GLOBAL uint8_t *)fd.cur;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
@@ -1016,7 +1029,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
          * derive quadrant, row and tile of TWO pieces from its lane number with divisions, and load its quadrant's motion
          * vector from memory: 627 vector instructions per macroblock against 290 on the one-vector path.) ---- */
         uint8_t *lq = lw, *cq = lw + 4 * 13 * QW_STRIDE;
-        const H264K_CONST uint32_t *mvc = (const H264K_CONST uint32_t *)fd.mvs + 16 * (size_t)mb;       /* (x | y << 16) per 4x4 block, raster */
+        const H264K_CONST uint32_t *mvc = (const H264K_CONST uint32_t *)fd.mvx + 16 * (size_t)mvx_idx;   /* (x | y << 16) per 4x4 block, raster */
         const bool is_l = lane < 26, is_c = lane >= 26 && lane < 46;
         const int e = lane - 26, pp = e >= 10, e2 = pp ? e - 10 : e;
         const int pr = is_l ? lane >> 1 : e2 >> 1, pk2 = (is_l ? lane : e2) & 1;          /* the piece's row in the window, its tile (0 / 1) */

@@ -413,6 +413,25 @@ static int check_blob(const uint8_t *blob)
     return h->magic == FJ_MAGIC ? 0 : -1;
 }
 
+/* The motion vectors of a finished frame job as a dense array [n_mbs][16][2] (raster 4x4 order), malloc'ed: a macroblock with
+ * FJ_PRED_UNIFORM_MV carries its one vector in the record, the others have sixteen in the sparse section at mvx_off
+ * (framejob.h); macroblocks that are not inter coded have none (zeros). */
+static int16_t (*dense_mvs(const uint8_t *blob))[16][2]
+{
+    const FjHeader *h = (const FjHeader *)blob;
+    const FjMbRec *recs = (const FjMbRec *)(blob + h->rec_off);
+    const int16_t (*mvx)[16][2] = (const int16_t (*)[16][2])(blob + h->mvx_off);
+    int16_t (*mvs)[16][2] = (int16_t (*)[16][2])calloc((size_t)h->n_mbs + 1, 64);
+    if (!mvs) return NULL;
+    for (uint32_t a = 0; a < h->n_mbs; a++) {
+        const FjMbRec *r = &recs[a];
+        if (r->kind != FJ_MB_INTER) continue;
+        if (r->pred & FJ_PRED_UNIFORM_MV) for (int b = 0; b < 16; b++) { mvs[a][b][0] = r->mv[0]; mvs[a][b][1] = r->mv[1]; }
+        else if (r->mvx < h->n_mvx) memcpy(mvs[a], mvx[r->mvx], 64);
+    }
+    return mvs;
+}
+
 /* un-deblocked picture into slots[cur_slot]; macroblocks are processed in raster order, which
  * satisfies every dependency (the reference decodes in slice order; pixels do not depend on it) */
 /* ------------------------------------------------------------------ concealment of lost macroblocks */
@@ -492,7 +511,8 @@ int oracle_recon(const uint8_t *blob, uint8_t *const *slots)
     if (check_blob(blob)) return -1;
     const FjHeader *h = (const FjHeader *)blob;
     const FjMbRec *recs = (const FjMbRec *)(blob + h->rec_off);
-    const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(blob + h->mv_off);
+    int16_t (*mvs)[16][2] = dense_mvs(blob);
+    if (!mvs) return -1;
     const int16_t *coefs = (const int16_t *)(blob + h->coef_off);
     Frame f = frame_view(slots[h->cur_slot], h->width_mbs, h->height_mbs);
     int res_y[256], res_c[128];
@@ -524,13 +544,13 @@ int oracle_recon(const uint8_t *blob, uint8_t *const *slots)
     /* lost macroblocks, in the order the reference's concealment loop visits them (FjMbRec.coef_idx) */
     if (n_conceal) {
         uint32_t *ord = (uint32_t *)malloc(sizeof(uint32_t) * h->n_mbs);
-        if (!ord) return -1;
+        if (!ord) { free(mvs); return -1; }
         for (uint32_t i = 0; i < h->n_mbs; i++) ord[i] = 0xFFFFFFFFu;
         for (uint32_t a = 0; a < h->n_mbs; a++) {
             const FjMbRec *r = &recs[a];
             if (r->kind != FJ_MB_CONCEAL_I && r->kind != FJ_MB_CONCEAL_P) continue;
             if (h->dbk_only && !(r->pred & FJ_PRED_PHASE2)) continue;
-            if (r->coef_idx >= h->n_mbs || ord[r->coef_idx] != 0xFFFFFFFFu) { free(ord); return -1; }
+            if (r->coef_idx >= h->n_mbs || ord[r->coef_idx] != 0xFFFFFFFFu) { free(ord); free(mvs); return -1; }
             ord[r->coef_idx] = a;
         }
         for (uint32_t i = 0; i < h->n_mbs; i++) {
@@ -540,6 +560,7 @@ int oracle_recon(const uint8_t *blob, uint8_t *const *slots)
         }
         free(ord);
     }
+    free(mvs);
     return 0;
 }
 
@@ -632,7 +653,8 @@ int oracle_deblock(const uint8_t *blob, uint8_t *frame)
     if (check_blob(blob)) return -1;
     const FjHeader *h = (const FjHeader *)blob;
     const FjMbRec *recs = (const FjMbRec *)(blob + h->rec_off);
-    const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(blob + h->mv_off);
+    int16_t (*mvs)[16][2] = dense_mvs(blob);
+    if (!mvs) return -1;
     Frame f = frame_view(frame, h->width_mbs, h->height_mbs);
     const int W = f.w, CW = f.w / 2;
     for (uint32_t a = 0; a < h->n_mbs; a++) {
@@ -678,6 +700,7 @@ int oracle_deblock(const uint8_t *blob, uint8_t *frame)
             }
         }
     }
+    free(mvs);
     return 0;
 }
 
@@ -717,7 +740,8 @@ int oracle_strengths(const uint8_t *blob, uint8_t *out)
     if (check_blob(blob)) return -1;
     const FjHeader *h = (const FjHeader *)blob;
     const FjMbRec *recs = (const FjMbRec *)(blob + h->rec_off);
-    const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(blob + h->mv_off);
+    int16_t (*mvs)[16][2] = dense_mvs(blob);
+    if (!mvs) return -1;
     memset(out, 0, (size_t)h->n_mbs * 32u);
     for (uint32_t a = 0; a < h->n_mbs; a++) {
         const FjMbRec *q = &recs[a];
@@ -735,5 +759,6 @@ int oracle_strengths(const uint8_t *blob, uint8_t *out)
                 }
             }
     }
+    free(mvs);
     return 0;
 }

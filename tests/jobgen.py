@@ -57,12 +57,14 @@ def _coef_block(rng, ac_only=False, density=0.3, amp=12):
     return c
 
 
-def build_job(lib, rng, wmb, hmb, cur_slot, n_slots, ref_slots, *, p_inter=0.6, p_pcm=0.03, mv_range=None, any_deblock=True):
-    """One random picture.  ref_slots: slots holding valid pictures (empty -> intra only)."""
+def build_job(lib, rng, wmb, hmb, cur_slot, n_slots, ref_slots, *, p_inter=0.6, p_pcm=0.03, mv_range=None, any_deblock=True, patch=None):
+    """One random picture.  ref_slots: slots holding valid pictures (empty -> intra only).
+    patch(recs, mvs): called on the records [n][32] and the dense vectors [n][16][2] before the job is finished — a finished
+    job carries its vectors in the records and the sparse section (framejob.h), the dense array here is only h264bsdmiJobFinalize's input."""
     n = wmb * hmb
     rec_off, mv_off = 128, 128 + n * 32
     coef_off = mv_off + n * 64
-    cap = coef_off + (n * 27 + 2) * 32 + (n + 2) * 4 + n * 2 + n * 16 + n * 2 + 4096
+    cap = coef_off + (n * 27 + 2) * 32 + (n + 2) * 4 + n * 2 + n * 16 + n * 2 + n * 64 + 4096
     buf = np.zeros(cap, dtype=np.uint8)
     recs = buf[rec_off:rec_off + n * 32].reshape(n, 32)
     mvs = buf[mv_off:mv_off + n * 64].view(np.int16).reshape(n, 16, 2)
@@ -148,6 +150,8 @@ def build_job(lib, rng, wmb, hmb, cur_slot, n_slots, ref_slots, *, p_inter=0.6, 
                     if rng.random() < 0.3:
                         coefs[16 * nblk:16 * nblk + 16] = _coef_block(rng, ac_only=True); nblk += 1; coded |= 1 << (16 + k)
         struct.pack_into("<I", r, 8, coded)
+    if patch is not None:
+        patch(recs, mvs)
     struct.pack_into("<IIHHIBBBBIII", buf, 0, 0x314A4648, 0, wmb, hmb, n, cur_slot, 0, n_slots, 0, rec_off, mv_off, 0)
     struct.pack_into("<I", buf, 36, coef_off)
     rc = lib.h264bsdmiJobFinalize(ctypes.c_void_p(buf.ctypes.data), cap, nblk)

@@ -20,6 +20,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle
+import h264bsd_amd
 from jobgen import QPC, Z_X, Z_Y, _i4_modes, build_job
 
 
@@ -203,14 +204,12 @@ def test_intra_prediction_matches_the_reference_functions(ref, built, avail):
 
 
 # ------------------------------------------------------------------ deblocking
-def _patch_partitions(blob, rng):
-    """give every inter macroblock of a jobgen picture a macroblock type (Skip / 16x16 / 16x8 / 8x16 / 8x8) with motion and
-    references to match, and the FJ_PARTS_* hint the parser would set; returns (blob, types)"""
-    h = pyoracle.blob_header(blob)
-    n = h["n_mbs"]
-    b = bytearray(blob)
-    recs = np.frombuffer(b, dtype=np.uint8, count=n * 32, offset=h["rec_off"]).reshape(n, 32)
-    mvs = np.frombuffer(b, dtype=np.int16, count=n * 32, offset=h["mv_off"]).reshape(n, 4, 4, 2)      # [mb][by][bx][xy], raster
+def _patch_partitions(recs, mvs16, rng):
+    """give every inter macroblock of a jobgen picture (records and dense vectors, before the job is finished) a macroblock
+    type (Skip / 16x16 / 16x8 / 8x16 / 8x8) with motion and references to match, and the FJ_PARTS_* hint the parser would
+    set; returns the types"""
+    n = recs.shape[0]
+    mvs = mvs16.reshape(n, 4, 4, 2)                                   # [mb][by][bx][xy], raster
     types = []
     for a in range(n):
         if recs[a, 0] != 0:
@@ -231,9 +230,9 @@ def _patch_partitions(blob, rng):
                 for bx in range(4): mvs[a, by, bx] = small()
             parts = 0
         recs[a, 16:20] = refs
-        recs[a, 4] = (int(recs[a, 4]) & 0xCF) | (parts << 4)
+        recs[a, 4] = (int(recs[a, 4]) & 0x8F) | (parts << 4)
         types.append(t)
-    return bytes(b), types
+    return types
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -242,11 +241,12 @@ def test_deblocking_matches_h264bsdFilterPicture(ref, built, seed):
     rng = np.random.default_rng(5000 + seed)
     wmb, hmb = int(rng.integers(1, 7)), int(rng.integers(1, 6))
     n = wmb * hmb
-    blob = build_job(built.lib(), rng, wmb, hmb, 3, 4, [0, 1, 2], p_inter=0.75 if seed % 4 else 0.3, p_pcm=0.02)
-    blob, types = _patch_partitions(blob, rng)
+    types = []
+    blob = build_job(built.lib(), rng, wmb, hmb, 3, 4, [0, 1, 2], p_inter=0.75 if seed % 4 else 0.3, p_pcm=0.02,
+                     patch=lambda recs_, mvs_: types.extend(_patch_partitions(recs_, mvs_, rng)))
     h = pyoracle.blob_header(blob)
     recs = np.frombuffer(blob, dtype=np.uint8, count=n * 32, offset=h["rec_off"]).reshape(n, 32)
-    mvs = np.frombuffer(blob, dtype=np.int16, count=n * 32, offset=h["mv_off"]).reshape(n, 16, 2)
+    mvs = h264bsd_amd.job_mvs(blob)
     W, H = wmb * 16, hmb * 16
     start = rng.integers(0, 256, W * H * 3 // 2, dtype=np.uint8)
     if seed % 3 == 0:                                                 # smooth content: the filters switch on far more often

@@ -33,7 +33,7 @@ def flags_of(j):
     kind, dbk, pred = rec[:, 0], rec[:, 5], rec[:, 4]
     coded = np.frombuffer(rec[:, 8:12].tobytes(), dtype=np.uint32)
     refs = rec[:, 16:20]
-    mv = np.frombuffer(j, dtype=np.int16, count=n * 32, offset=hd["mv_off"]).reshape(n, 4, 4, 2)
+    mv = h.job_mvs(j).reshape(n, 4, 4, 2)
     intra = np.isin(kind, INTRA_KINDS)
     cb = np.zeros((n, 4, 4), bool); rb = np.zeros((n, 4, 4), int)
     for y in range(4):
@@ -302,6 +302,67 @@ def simulate_fused(j, waves, ci, cf, cl, fused):
     # separate kernels: the deblocking graph without the cross edges, after the intra graph
     return run(lambda k: k < n) + run(lambda k: k >= n)
 
+
+
+# ---- luma and chroma as TWO tasks per macroblock: the chroma filter of a macroblock depends on chroma samples only, the luma
+# filter on luma samples only — two independent graphs of the same shape, whose steps are shorter than a joint one (the fixed
+# part of a step — claim, one memory round trip, stores, release — is paid twice) ----
+def simulate4(hh, w, left, top, inner, any_, waves, per_mb, fixed, pass_full, pass_light, luma_full, luma_light, split_planes):
+    import heapq
+    n = hh * w
+    dep0 = np.zeros(n, int); succ = [[] for _ in range(n)]
+    A = any_.reshape(-1); Lf = left.reshape(-1); Tp = top.reshape(-1); In = inner.reshape(-1)
+    for y in range(hh):
+        for x in range(w):
+            i = y * w + x
+            if not A[i]: continue
+            if x and Lf[i] and A[i - 1] and (In[i - 1] or Tp[i - 1]): dep0[i] += 1; succ[i - 1].append(i)
+            if y and Tp[i] and A[i - w] and (In[i - w] or Lf[i - w]): dep0[i] += 1; succ[i - w].append(i)
+            if y and x + 1 < w and Tp[i] and A[i - w + 1] and Lf[i - w + 1]: dep0[i] += 1; succ[i - w + 1].append(i)
+    parts = 2 if split_planes else 1
+    dep = [dep0.copy() for _ in range(parts)]
+    ready = [[] for _ in range(2 * parts)]          # [part][inner / edge-only]
+    cost = {}
+    if split_planes:
+        cost = {0: fixed + pass_full * luma_full, 1: fixed + pass_light * luma_light,
+                2: fixed + pass_full * (1 - luma_full), 3: fixed + pass_light * (1 - luma_light)}
+    else:
+        cost = {0: fixed + pass_full, 1: fixed + pass_light}
+    def push(part, i): ready[2 * part + (0 if In[i] else 1)].append(i)
+    for part in range(parts):
+        for i in range(n):
+            if A[i] and dep[part][i] == 0: push(part, i)
+    t, free, running, done, busy, seq = 0, waves, [], 0, 0, 0
+    total = int(A.sum()) * parts
+    while done < total:
+        while free and any(ready):
+            # luma lists first (the long chain), the longer of the two; chroma when no luma is ready
+            cand = [q for q in (0, 1) if ready[q]] or [q for q in range(2, 2 * parts) if ready[q]]
+            q = max(cand, key=lambda q_: (len(ready[q_]), q_))
+            batch, ready[q] = ready[q][:per_mb], ready[q][per_mb:]
+            c = cost[q]
+            seq += 1; heapq.heappush(running, (t + c, seq, q >> 1, batch)); free -= 1; busy += c
+        t, _, part, batch = heapq.heappop(running)
+        free += 1
+        for i in batch:
+            done += 1
+            for s_ in succ[i]:
+                dep[part][s_] -= 1
+                if dep[part][s_] == 0: push(part, s_)
+    return t, busy
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "simulate4":
+    GHZ = 2.4
+    for waves, fixed, pf, pl, lf, ll, sp in ((8, 3500, 7500, 3000, 0.82, 0.67, 0), (8, 3500, 7500, 3000, 0.82, 0.67, 1), (12, 3500, 7500, 3000, 0.82, 0.67, 1),
+                                             (8, 3000, 6000, 2600, 0.82, 0.67, 0), (8, 3000, 6000, 2600, 0.82, 0.67, 1), (12, 3000, 6000, 2600, 0.82, 0.67, 1)):
+        cyc = busy = 0
+        for i in range(first, min(first + count, len(jobs))):
+            hh, w, left, top, inner, any_ = flags_of(jobs[i])
+            t, b = simulate4(hh, w, left, top, inner, any_, waves, 8, fixed, pf, pl, lf, ll, sp)
+            cyc += t; busy += b
+        print(f"model: {waves} wavefronts, fixed {fixed} + passes {pf} / {pl} cycles per step, {'luma and chroma apart' if sp else 'one task per macroblock'}: "
+              f"{cyc / GHZ / 1e6:.1f} ms per pass, wavefronts busy {busy / (cyc * waves):.0%}")
 
 if len(sys.argv) > 3 and sys.argv[3] == "fused":
     GHZ = 2.4
