@@ -226,12 +226,14 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
         } else if (r->kind == FJ_MB_INTER) {
             /* cls bit0: uniform (16 equal mvs, one reference, no coefficients); bit1: additionally whole-sample for
              * luma and chroma -> pure copy */
-            const int16_t *m0 = mvs[a][0];
+            /* the parser's hint: one vector, already in the record, the macroblock's dense entry was never written (framejob.h) */
+            const int hinted = (r->pred & FJ_PRED_UNIFORM_MV) != 0;
+            const int16_t *m0 = hinted ? r->mv : mvs[a][0];
             uint32_t refs;
             memcpy(&refs, r->ref_slot, 4);
             const int one_ref = refs == (refs & 255u) * 0x01010101u;
-            int same_mv = one_ref;
-            if (same_mv && !(r->pred & FJ_PRED_UNIFORM_MV)) {   /* 16 equal vectors: eight 64-bit words equal to the doubled first */
+            int same_mv = one_ref || hinted;
+            if (same_mv && !hinted) {                           /* 16 equal vectors: eight 64-bit words equal to the doubled first */
                 uint64_t w[8], acc = 0;
                 uint32_t first;
                 memcpy(w, mvs[a], 64);
@@ -241,7 +243,7 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
                 same_mv = acc == 0;
             }
             /* where the finished job keeps the vectors: one in the record, or sixteen in the sparse section (framejob.h) */
-            r->mv[0] = m0[0]; r->mv[1] = m0[1];
+            if (!hinted) { r->mv[0] = m0[0]; r->mv[1] = m0[1]; }
             if (same_mv) { r->pred |= FJ_PRED_UNIFORM_MV; r->mvx = 0; }
             else { r->pred &= (uint8_t)~FJ_PRED_UNIFORM_MV; r->mvx = n_mvx; mvx_list[n_mvx++] = (uint16_t)a; }
             const int uni = same_mv && r->coded == 0;
@@ -276,7 +278,7 @@ deblock_index:
                     if (!want[k]) continue;
                     const uint32_t p = nb[k];
                     if (cls[p] & 1) {
-                        const int dx = mvs[a][0][0] - mvs[p][0][0], dy = mvs[a][0][1] - mvs[p][0][1];
+                        const int dx = r->mv[0] - recs[p].mv[0], dy = r->mv[1] - recs[p].mv[1];
                         trivial = recs[p].ref_slot[0] == r->ref_slot[0] && dx > -4 && dx < 4 && dy > -4 && dy < 4;
                     } else if (recs[p].kind == FJ_MB_INTER) {
                         /* a coded or partitioned inter neighbour: the four 4x4 blocks of it that touch the edge decide (8.7.2.1: a
@@ -285,8 +287,8 @@ deblock_index:
                         for (int i = 0; i < 4 && trivial; i++) {
                             const int bx = k ? i : 3, by = k ? 3 : i;
                             const int z = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1);
-                            const int16_t *pm = mvs[p][4 * by + bx];
-                            const int dx = mvs[a][0][0] - pm[0], dy = mvs[a][0][1] - pm[1];
+                            const int16_t *pm = (recs[p].pred & FJ_PRED_UNIFORM_MV) ? recs[p].mv : mvs[p][4 * by + bx];
+                            const int dx = r->mv[0] - pm[0], dy = r->mv[1] - pm[1];
                             trivial = !((recs[p].coded >> z) & 1u) && recs[p].ref_slot[(by >> 1) * 2 + (bx >> 1)] == r->ref_slot[0] &&
                                       dx > -4 && dx < 4 && dy > -4 && dy < 4;
                         }
@@ -308,7 +310,7 @@ deblock_index:
         const FjMbRec *r = &recs[a];
         if (elide) elide->out[a] = elide->serial;
         if (!(RECON(r) && (cls[a] & 2))) continue;
-        const int16_t *m0 = mvs[a][0];
+        const int16_t *m0 = r->mv;
         if (elide && (m0[0] | m0[1]) == 0 && r->ref_slot[0] < elide->n_slots && r->ref_slot[0] != elide->cur_slot && r->dbk_trivial &&
             ((a + 1) % w == 0 || recs[a + 1].dbk_trivial) && (a + w >= n || recs[a + w].dbk_trivial)) {
             const uint32_t v = elide->ver[(size_t)r->ref_slot[0] * n + a];
@@ -433,7 +435,6 @@ static void fill_undecoded(HostDec *d)
         if (!d->mb_decoded[a] && !(complete && d->mb_rec_sid[a])) {
             memset(&recs[a], 0, sizeof(FjMbRec));
             recs[a].kind = FJ_MB_ABSENT;
-            memset(d->job + h->mv_off + (size_t)a * 64u, 0, 64);
             if (!complete) continue;                   /* (an incomplete picture is concealed: every macroblock gets a record) */
             /* Counter-complete picture, macroblock never decoded: nothing writes its pixels, but h264bsdFilterPicture filters
              * every macroblock with what its mbStorage_t holds (src/h264bsd_deblocking.c:236-275 and :575-640) — type, QP,
@@ -739,6 +740,16 @@ static int store_pps(HostDec *d, Pps *p)
  * stay decoded too: intra prediction inside the slice reads them) is copied into a side store, and if at the end of
  * the picture a stale macroblock sits on such pixels the stored slices are submitted as reconstruction-only frame jobs
  * (FjHeader.ghost) in front of the picture's own job, into the same DPB slot.  Costs nothing on intact streams. */
+/* The sixteen vectors (raster 4x4 order) a record stands for while a picture is being parsed: an inter macroblock with the
+ * parser's FJ_PRED_UNIFORM_MV hint has ONE, in the record, and its entry of the dense array was never written; any other inter
+ * macroblock has them in the dense array; everything else has none. */
+void hd_dense_mv_read(const FjMbRec *r, const int16_t *dense, int16_t out[32])
+{
+    if (r->kind != FJ_MB_INTER) memset(out, 0, 64);
+    else if (r->pred & FJ_PRED_UNIFORM_MV) for (int b = 0; b < 16; b++) { out[2 * b] = r->mv[0]; out[2 * b + 1] = r->mv[1]; }
+    else memcpy(out, dense, 64);
+}
+
 static int makes_pixels(int kind)
 {
     return kind == FJ_MB_INTER || kind == FJ_MB_I4x4 || kind == FJ_MB_I16x16 || kind == FJ_MB_IPCM;
@@ -801,7 +812,8 @@ static void ghost_store_slice(HostDec *d, uint32_t sid)
         GhostMb g;
         g.addr = a; g.n_blocks = rec_blocks(r); g.rec = *r;
         g.rec.pred &= (uint8_t)~FJ_PRED_PHASE2;
-        if (f) memcpy(g.mv, f->mv, 64); else memcpy(g.mv, d->job + h->mv_off + (size_t)a * 64u, 64);
+        if (f) memcpy(g.mv, f->mv, 64); else hd_dense_mv_read(r, (const int16_t *)(d->job + h->mv_off + (size_t)a * 64u), g.mv);
+        g.rec.pred &= (uint8_t)~FJ_PRED_UNIFORM_MV;       /* (the copy is sixteen vectors: fj_finalize looks again) */
         memcpy(p, &g, sizeof(g)); p += sizeof(g);
         memcpy(p, d->job + h->coef_off + (size_t)r->coef_idx * 32u, (size_t)g.n_blocks * 32u);
         p += (size_t)g.n_blocks * 32u;
@@ -849,6 +861,7 @@ static int ghost_submit(HostDec *d)
 }
 
 /* ---- macroblocks decoded twice (redundant slices in a damaged picture; hostdec.h, RedoMb) ---- */
+/* mv: the macroblock's entry of the dense array (only valid where hd_dense_mv_read says so) */
 int hd_redo_keep_first(HostDec *d, uint32_t addr, const FjMbRec *rec, const int16_t *mv)
 {
     if (!d->mb_redone && !(d->mb_redone = (uint8_t *)calloc(d->pic_size_mbs, 1))) return -1;
@@ -869,7 +882,8 @@ int hd_redo_keep_first(HostDec *d, uint32_t addr, const FjMbRec *rec, const int1
             r = &d->redo2[d->n_redo2++];
         }
         r->addr = addr; r->rec = *rec;
-        memcpy(r->mv, mv, 64);
+        hd_dense_mv_read(rec, mv, r->mv);
+        r->rec.pred &= (uint8_t)~FJ_PRED_UNIFORM_MV;
         return 0;
     }
     if (d->n_redo == d->redo_cap) {
@@ -881,7 +895,8 @@ int hd_redo_keep_first(HostDec *d, uint32_t addr, const FjMbRec *rec, const int1
     struct RedoMb *r = &d->redo[d->n_redo++];
     if (hd_trace) fprintf(stderr, "TRACE redo first version: mb %u kind %u coef_idx %u rec_sid %u decoded %u\n", addr, rec->kind, rec->coef_idx, d->mb_rec_sid[addr], d->mb_decoded[addr]);
     r->addr = addr; r->rec = *rec;
-    memcpy(r->mv, mv, 64);
+    hd_dense_mv_read(rec, mv, r->mv);
+    r->rec.pred &= (uint8_t)~FJ_PRED_UNIFORM_MV;      /* (sixteen vectors from here on: fj_finalize looks again) */
     d->mb_redone[addr] = 1;
     return 0;
 }
@@ -1033,7 +1048,6 @@ static uint32_t plan_concealment(HostDec *d, int p_type)
          * have predicted from them; they are reconstructed first, the concealment replaces them afterwards (RedoMb) */ \
         const int over__ = d->mb_rec_sid[a__] && makes_pixels(r->kind) && !hd_redo_keep_first(d, a__, r, &mvs[a__][0][0]); \
         memset(r, 0, sizeof(*r)); \
-        memset(mvs[a__], 0, 64); \
         if (over__) r->pred = FJ_PRED_PHASE2; \
         d->mb_rec_sid[a__] = 0; \
         r->qp_y = 40; r->qp_c = 36;          /* QPc of QP 40 with chroma_qp_index_offset 0 */ \
@@ -1070,7 +1084,6 @@ static uint32_t plan_concealment(HostDec *d, int p_type)
             for (uint32_t a = 0; a < n; a++) {
                 FjMbRec *r = &recs[a];
                 memset(r, 0, sizeof(*r));
-                memset(mvs[a], 0, 64);
                 r->kind = FJ_MB_IPCM;
                 r->coef_idx = d->coef_blocks;
                 d->mb_decoded[a] = 1;

@@ -585,7 +585,6 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
             if (d->mb_rec_sid[addr] && keep.kind == FJ_MB_STALE && hd_redo_keep_first(d, addr, &recs[addr], &mvs[addr][0][0])) FAIL;
             if (!(d->mb_rec_sid[addr] && keep.kind == FJ_MB_ABSENT)) {
                 recs[addr] = keep;
-                memset(mvs[addr], 0, 64);
                 d->mb_rec_sid[addr] = sid;
             }
         }
@@ -618,7 +617,8 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
         int16_t (*dst)[2] = mvs[addr];
         /* (a redundant decode that failed while it reconstructed: m->mv / m->ref_slot are what the reference's
          * mbStorage_t holds, restore_unwritten) */
-        if (!c.p2err && ((rec.pred >> FJ_PRED_PARTS_SHIFT) & 3) == FJ_PARTS_16x16) { memcpy(dst, m->mv, 64); rec.pred |= FJ_PRED_UNIFORM_MV; }   /* 16 equal vectors: the order does not matter */
+        /* one vector: it travels in the record, the dense entry stays unwritten (framejob.h, FJ_PRED_UNIFORM_MV) */
+        if (!c.p2err && ((rec.pred >> FJ_PRED_PARTS_SHIFT) & 3) == FJ_PARTS_16x16) { rec.mv[0] = m->mv[0][0]; rec.mv[1] = m->mv[0][1]; rec.pred |= FJ_PRED_UNIFORM_MV; }
         else
         for (int z = 0; z < 16; z++) {
             const int r = 4 * Z_Y[z] + Z_X[z];
@@ -627,7 +627,6 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
         }
         d->n_inter += (uint32_t)first_decode;
     } else {
-        memset(mvs[addr], 0, 64);      /* the sections are not pre-zeroed: keep the job a pure function of the stream */
         d->n_intra += (uint32_t)first_decode;
     }
     recs[addr] = rec;
@@ -668,7 +667,6 @@ static int decode_skip_fast(HostDec *d, const SliceHdr *sh, const Pps *pps, uint
     }
     FjHeader *hdr = (FjHeader *)d->job;
     FjMbRec *recs = (FjMbRec *)(d->job + hdr->rec_off);
-    uint8_t *mvdst = d->job + hdr->mv_off + (size_t)addr * 64u;
     /* MbInfo */
     m->dbk_idc = (uint8_t)sh->disable_deblocking_filter_idc;
     m->mb_type = 0;
@@ -679,7 +677,7 @@ static int decode_skip_fast(HostDec *d, const SliceHdr *sh, const Pps *pps, uint
     memcpy(&one, mv, 4);
     const uint64_t two = (uint64_t)one << 32 | one;
     uint8_t *mdst = (uint8_t *)m->mv;                 /* 4-byte aligned only */
-    for (int i = 0; i < 8; i++) { memcpy(mdst + 8 * i, &two, 8); memcpy(mvdst + 8 * i, &two, 8); }
+    for (int i = 0; i < 8; i++) memcpy(mdst + 8 * i, &two, 8);
     memset(m->tc, 0, sizeof(m->tc));
     m->qp = (uint8_t)qp;
     d->mb_decoded[addr] = 1;
@@ -704,6 +702,7 @@ static int decode_skip_fast(HostDec *d, const SliceHdr *sh, const Pps *pps, uint
     rec.coef_idx = d->coef_blocks;
     memset(rec.ref_slot, slot, 4);
     rec.cqp_off = (int8_t)pps->chroma_qp_index_offset;
+    rec.mv[0] = mv[0]; rec.mv[1] = mv[1];             /* the one vector travels in the record (FJ_PRED_UNIFORM_MV) */
     recs[addr] = rec;
     d->mb_rec_sid[addr] = sid;
     d->n_inter++;

@@ -387,6 +387,7 @@ uint32_t hd_next_mb_in_group(const uint32_t *map, uint32_t n, uint32_t addr);
 int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_ref_idc);
 /* hd_core.c: set the first decode's record of a macroblock aside before a redundant slice's decode replaces it (0 = ok) */
 int hd_redo_keep_first(HostDec *d, uint32_t addr, const FjMbRec *rec, const int16_t *mv);
+void hd_dense_mv_read(const FjMbRec *r, const int16_t *dense, int16_t out[32]);
 /* hd_api.c helpers used across files */
 int  hd_job_begin(HostDec *d);
 int  hd_job_finish(HostDec *d, int is_idr, int single_job);
