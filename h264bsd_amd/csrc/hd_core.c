@@ -306,19 +306,19 @@ deblock_index:
      * clean copy makes the destination tile equal to the source tile, so its tile inherits the source's number, and when
      * the destination carried that number already the copy would write what is there — it is left out. ---- */
     if (elide && !recon_all) elide = NULL;                 /* (callers do not ask for it either) */
-    for (uint32_t a = 0; a < n; a++) {
+    for (uint32_t a = 0, x = 0; a < n; a++, x = x + 1 == w ? 0 : x + 1) {     /* x = a % w without the division */
         const FjMbRec *r = &recs[a];
         if (elide) elide->out[a] = elide->serial;
         if (!(RECON(r) && (cls[a] & 2))) continue;
         const int16_t *m0 = r->mv;
         if (elide && (m0[0] | m0[1]) == 0 && r->ref_slot[0] < elide->n_slots && r->ref_slot[0] != elide->cur_slot && r->dbk_trivial &&
-            ((a + 1) % w == 0 || recs[a + 1].dbk_trivial) && (a + w >= n || recs[a + w].dbk_trivial)) {
+            (x + 1 == w || recs[a + 1].dbk_trivial) && (a + w >= n || recs[a + w].dbk_trivial)) {
             const uint32_t v = elide->ver[(size_t)r->ref_slot[0] * n + a];
             elide->out[a] = v;
             if (elide->ver[(size_t)elide->cur_slot * n + a] == v) { elide->n_elided++; continue; }
         }
         FjCopy *last = n_copy ? &copy_tmp[n_copy - 1] : NULL;
-        if (last && last->count < FJ_COPY_RUN && (uint32_t)last->mb + last->count == a && (a % w != 0 || (m0[0] | m0[1]) == 0) &&
+        if (last && last->count < FJ_COPY_RUN && (uint32_t)last->mb + last->count == a && (x != 0 || (m0[0] | m0[1]) == 0) &&
             last->slot == r->ref_slot[0] && last->dx == (m0[0] >> 2) && last->dy == (m0[1] >> 2)) {
             last->count++;
         } else {
@@ -569,6 +569,7 @@ static void select_sps(HostDec *d, int pps_id)
     d->width_mbs = d->active_sps->width_mbs;
     d->height_mbs = d->active_sps->height_mbs;
     d->pic_size_mbs = d->width_mbs * d->height_mbs;
+    d->width_magic = d->pic_size_mbs < 65536u ? (uint32_t)(0x100000000ull / d->width_mbs) + 1u : 0u;
     d->pending_activation = 1;
 }
 

@@ -256,6 +256,8 @@ typedef struct HostDec {
     uint8_t input_readonly;         /* h264bsdmiSetInputReadOnly: never write to the caller's buffer (hd_extract_nal) */
 
     uint32_t pic_size_mbs, width_mbs, height_mbs;
+    uint32_t width_magic;           /* floor(2^32 / width_mbs) + 1 while pic_size_mbs < 2^16 (every level of the standard up to 5.2), else 0:
+                                       addr / width_mbs = (addr * width_magic) >> 32 — hd_mb_row() */
     MbInfo  *mb;
     uint32_t *slice_group_map;
     /* per-picture state that is reset for every picture lives in compact arrays of its own, not in MbInfo: the
@@ -330,6 +332,12 @@ typedef struct HostDec {
     uint32_t tile_slots, tile_mbs, tile_serial, tile_pending_slot;
     uint32_t n_elided;              /* macroblocks left out of the last job's copy list */
 } HostDec;
+
+/* the row of a macroblock address without a division (the parser derives it for every macroblock) */
+static inline uint32_t hd_mb_row(const HostDec *d, uint32_t addr)
+{
+    return d->width_magic ? (uint32_t)(((uint64_t)addr * d->width_magic) >> 32) : addr / d->width_mbs;
+}
 
 /* what fj_finalize_ex needs to leave copies out (NULL: a frame job is a pure function of records, vectors and coefficients) */
 typedef struct FjElide {
