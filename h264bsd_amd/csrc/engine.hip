@@ -45,7 +45,7 @@
 namespace {
 
 constexpr int MAX_DEVICES = 16;
-struct PendingJob { uint8_t *host; uint32_t bytes, cap; };
+struct PendingJob { uint8_t *host; uint32_t bytes, cap; const uint8_t *dev; };     /* dev: the device's address of the pinned buffer (k_h2d) */
 constexpr size_t MAX_QUEUED_PICTURES = 8;    /* per decoder instance, before sink_submit starts the device on its own */
 
 struct StreamCtx {
@@ -56,7 +56,7 @@ struct StreamCtx {
     uint32_t *h_conv = nullptr, *d_conv = nullptr;
     uint8_t *d_planar = nullptr;            /* a picture on its way out: tiles -> the reference's planar I420 (k_detile) */
     std::mutex qmu;                         /* guards pending / free_bufs (submit runs on the caller's threads) */
-    PendingJob acquired = { nullptr, 0, 0 };   /* staging buffer the parser is currently filling (sink_acquire) */
+    PendingJob acquired = { nullptr, 0, 0, nullptr };   /* staging buffer the parser is currently filling (sink_acquire) */
     std::deque<PendingJob> pending;
     std::vector<PendingJob> free_bufs;      /* recycled pinned staging buffers */
     /* lane scheduling (flush_locked): the light lane this instance belongs to, where its latest picture was launched
@@ -91,6 +91,7 @@ struct Lane {
     bool owns_stream = false;
     uint8_t *d_arena = nullptr; size_t arena_cap = 0;      /* device copies of the blobs of one tick */
     FrameDesc *d_desc = nullptr, *h_desc = nullptr; size_t desc_cap = 0;    /* h_desc: pinned staging, 2 halves */
+    h264k::H2dItem *h_items = nullptr, *dv_items = nullptr;                    /* pinned, 2 halves like h_desc: the tick's jobs for k_h2d (dv_: the device's view of it) */
     int flip = 0; unsigned ticks = 0;
     hipEvent_t desc_ev[2] = { nullptr, nullptr };
     static constexpr unsigned RING = 64;
@@ -656,15 +657,22 @@ static int lane_launch(Engine *e, unsigned lane_idx, const std::vector<StreamCtx
         HIP_TRY(hipStreamSynchronize(l.st));
         if (l.d_desc) HIP_TRY(hipFree(l.d_desc));
         if (l.h_desc) HIP_TRY(hipHostFree(l.h_desc));
+        if (l.h_items) HIP_TRY(hipHostFree(l.h_items));
         l.desc_cap = part.size() * 2;
         HIP_TRY(hipMalloc((void **)&l.d_desc, l.desc_cap * sizeof(FrameDesc)));
         HIP_TRY(hipHostMalloc((void **)&l.h_desc, 2 * l.desc_cap * sizeof(FrameDesc), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&l.h_items, 2 * l.desc_cap * sizeof(h264k::H2dItem), hipHostMallocDefault));
+        HIP_TRY(hipHostGetDevicePointer((void **)&l.dv_items, l.h_items, 0));
         l.flip = 0; l.ticks = 0;
     }
     /* descriptors are staged in pinned memory (two halves, alternating) so that the copy can be asynchronous;
      * before reusing a half, the tick that used it two ticks ago must have consumed it */
     if (l.ticks >= 2) HIP_TRY(hipEventSynchronize(l.desc_ev[l.flip]));
     FrameDesc *descs = l.h_desc + (size_t)l.flip * l.desc_cap;
+    h264k::H2dItem *items = l.h_items + (size_t)l.flip * l.desc_cap;
+    /* how the jobs reach the device: one k_h2d launch that reads the pinned staging buffers (default), or one hipMemcpyAsync
+     * per job (H264BSDMI_H2D=memcpy) */
+    static const bool h2d_kernel = [] { const char *v = getenv("H264BSDMI_H2D"); return !(v && !strcmp(v, "memcpy")); }();
     TickShape shape;
     size_t off = 0;
     std::vector<std::pair<int, unsigned long long>> waited;
@@ -679,13 +687,15 @@ static int lane_launch(Engine *e, unsigned lane_idx, const std::vector<StreamCtx
                 waited.push_back(key);
             }
         }
-        HIP_TRY(hipMemcpyAsync(l.d_arena + off, j.host, j.bytes, hipMemcpyHostToDevice, l.st));
+        if (h2d_kernel) items[i] = h264k::H2dItem{ j.dev, l.d_arena + off, j.bytes, 0u };
+        else HIP_TRY(hipMemcpyAsync(l.d_arena + off, j.host, j.bytes, hipMemcpyHostToDevice, l.st));
         make_desc(descs[i], j.host, l.d_arena + off, s->d_frames, s->frame_bytes, s->d_dbk, &shape, e->d_err);
         off += (j.bytes + 255u) & ~255u;
         e->inflight.emplace_back(s, j);
         e->inflight_recorded = false;
         s->last_lane = (int)lane_idx; s->last_launch = l.launches;
     }
+    if (h2d_kernel) hipLaunchKernelGGL(h264k::k_h2d, dim3(h264k::H2D_CHUNKS, (uint32_t)part.size()), dim3(256), 0, l.st, l.dv_items + (size_t)l.flip * l.desc_cap);
     HIP_TRY(hipMemcpyAsync(l.d_desc, descs, part.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, l.st));
     HIP_TRY(hipEventRecord(l.desc_ev[l.flip], l.st));
     l.flip ^= 1;
@@ -755,7 +765,7 @@ void stream_release(StreamCtx *s)
     for (auto &j : s->free_bufs) hipHostFree(j.host);
     s->free_bufs.clear();
     if (s->acquired.host) hipHostFree(s->acquired.host);
-    s->acquired = PendingJob{ nullptr, 0, 0 };
+    s->acquired = PendingJob{ nullptr, 0, 0, nullptr };
     if (s->d_frames) hipFree(s->d_frames);
     if (s->d_dbk) hipFree(s->d_dbk);
     s->d_dbk = nullptr;
@@ -788,7 +798,7 @@ int sink_configure(void *user, uint32_t wmb, uint32_t hmb, uint32_t n_slots)
 /* staging buffer for a frame job of up to `bytes`: recycled pinned memory of this stream, else a new allocation */
 static int take_buffer(SinkUser *u, uint32_t bytes, PendingJob *out)
 {
-    PendingJob j = { nullptr, 0, 0 };
+    PendingJob j = { nullptr, 0, 0, nullptr };
     {
         std::lock_guard<std::mutex> ql(u->s->qmu);
         for (size_t i = 0; i < u->s->free_bufs.size(); i++)
@@ -802,6 +812,7 @@ static int take_buffer(SinkUser *u, uint32_t bytes, PendingJob *out)
         HIP_TRY(hipSetDevice(u->e->device));
         j.cap = bytes + 65536;                              /* pinned: recycled across pictures */
         HIP_TRY(hipHostMalloc((void **)&j.host, j.cap, hipHostMallocDefault));
+        HIP_TRY(hipHostGetDevicePointer((void **)&j.dev, j.host, 0));
     }
     *out = j;
     return 0;
@@ -817,7 +828,7 @@ uint8_t *sink_acquire(void *user, uint32_t bytes)
     if (s->acquired.host) {
         std::lock_guard<std::mutex> ql(s->qmu);
         s->free_bufs.push_back(s->acquired);
-        s->acquired = PendingJob{ nullptr, 0, 0 };
+        s->acquired = PendingJob{ nullptr, 0, 0, nullptr };
     }
     if (take_buffer(u, bytes, &s->acquired)) return nullptr;
     return s->acquired.host;
@@ -831,7 +842,7 @@ int sink_submit(void *user, const uint8_t *blob, uint32_t bytes)
     PendingJob j;
     if (u->s->acquired.host && blob == u->s->acquired.host) {
         j = u->s->acquired;
-        u->s->acquired = PendingJob{ nullptr, 0, 0 };
+        u->s->acquired = PendingJob{ nullptr, 0, 0, nullptr };
     } else {
         if (take_buffer(u, bytes, &j)) return -1;
         memcpy(j.host, blob, bytes);

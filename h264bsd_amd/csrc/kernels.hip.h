@@ -2634,6 +2634,35 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
     if (BANDED) return_ticket(tickets);
 }
 
+/* ------------------------------------------------------------------ frame jobs entering the device */
+/* The frame jobs of one tick, fetched from the parser's pinned staging buffers by ONE launch: item i = one job (source in
+ * host memory, mapped into the device's address space; destination in the lane's arena).  The host used to enqueue one
+ * hipMemcpyAsync per job — 256 runtime calls per tick, 0.7 of the 0.9 ms the enqueueing thread spends between two rounds of
+ * parsing (the parser threads wait for it).  H2D_CHUNKS workgroups per job, 16 bytes per lane and trip; sizes are multiples
+ * of 32 (FjHeader.total_bytes). */
+struct H2dItem { const uint8_t *src; uint8_t *dst; uint32_t bytes, pad; };
+constexpr int H2D_CHUNKS = 8;
+__global__ __launch_bounds__(256) void k_h2d(const H2dItem *__restrict__ items)
+{
+    const H2dItem it = items[blockIdx.y];
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(it.src);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(it.dst);
+    const uint32_t n = it.bytes >> 4, stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += 4u * stride) {
+        /* four loads in flight per lane: the link's latency is microseconds */
+        const uint32_t i1 = i + stride, i2 = i1 + stride, i3 = i2 + stride;
+        const u32x4 a = __builtin_nontemporal_load(src + i);
+        u32x4 b = a, c = a, d = a;
+        if (i1 < n) b = __builtin_nontemporal_load(src + i1);
+        if (i2 < n) c = __builtin_nontemporal_load(src + i2);
+        if (i3 < n) d = __builtin_nontemporal_load(src + i3);
+        dst[i] = a;
+        if (i1 < n) dst[i1] = b;
+        if (i2 < n) dst[i2] = c;
+        if (i3 < n) dst[i3] = d;
+    }
+}
+
 /* ------------------------------------------------------------------ pictures leaving the device */
 /* The reference's output format is planar I420, uncropped (image.h:46-55).  Frames live in HBM as macroblock tiles,
  * so every path that hands a picture out reads tiles: k_detile (whole frame -> planar), k_output (cropped window ->
