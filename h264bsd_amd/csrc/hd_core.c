@@ -162,6 +162,19 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
         FjMbRec *r = &recs[a];
         const int recon = RECON(r);
         any_dbk |= r->dbk;
+        /* seven of ten macroblocks of a P picture: one vector (the parser's hint), one reference, no coefficients — nothing of
+         * the general path below applies to them but the classification and, off the whole-sample grid, a list entry */
+        if (r->kind == FJ_MB_INTER && (r->pred & FJ_PRED_UNIFORM_MV) && r->coded == 0) {
+            const int whole = ((r->mv[0] | r->mv[1]) & 7) == 0;
+            cls[a] = whole ? 3 : 1;
+            r->mvx = 0;
+            if (recon && !whole) {
+                FjGen *gi = &gen_tmp[n_gen++];
+                gi->mb = (uint16_t)a; gi->uniform = 1; gi->slot = r->ref_slot[0];
+                gi->mvx = r->mv[0]; gi->mvy = r->mv[1]; gi->coef_idx = r->coef_idx; gi->coded = 0;
+            }
+            goto deblock_index;
+        }
         cls[a] = 0;
         /* invariant of the job format, checked where the kernels' lists are made: a macroblock that will be reconstructed
          * has its coefficient blocks inside the section (a parser bug must end in a failed decode, not in a kernel

@@ -647,10 +647,10 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
  * error path can be reached.  Writes exactly what decode_mb_body writes for such a macroblock (MbInfo, record, vectors,
  * counters: tests/test_parser_fast_paths.py compares the frame jobs of whole streams with and without it); returns 0 when it
  * declined and the general path has to run. */
-static int decode_skip_fast(HostDec *d, const SliceHdr *sh, const Pps *pps, uint32_t addr, int qp)
+static int decode_skip_fast(HostDec *d, const SliceHdr *sh, const Pps *pps, uint32_t addr, int qp, int slot)
 {
+    /* slot: the frame buffer behind RefPicList0[0], the same for every macroblock of the slice (hd_decode_slice_data) */
     if (d->mb_decoded[addr] || d->mb_rec_sid[addr] || (d->mb_redone && d->mb_redone[addr])) return 0;
-    const int slot = hd_dpb_ref_slot(&d->dpb, 0);
     if (slot < 0) return 0;
     MbCtx c;                                          /* only what the motion vector prediction looks at */
     const uint32_t sid = d->slice_id, w = d->width_mbs, mby = hd_mb_row(d, addr), mbx = addr - mby * w;
@@ -711,9 +711,9 @@ static int decode_skip_fast(HostDec *d, const SliceHdr *sh, const Pps *pps, uint
     return 1;
 }
 
-static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *pps, uint32_t addr, int skipped, int *qp)
+static int decode_mb(HostDec *d, BitReader *br, const SliceHdr *sh, const Pps *pps, uint32_t addr, int skipped, int *qp, int ref0_slot)
 {
-    if (skipped && !hd_no_fast_skip && decode_skip_fast(d, sh, pps, addr, *qp)) return 0;
+    if (skipped && !hd_no_fast_skip && decode_skip_fast(d, sh, pps, addr, *qp, ref0_slot)) return 0;
     const uint32_t coef_start = d->coef_blocks;
     const int rc = decode_mb_body(d, br, sh, pps, addr, skipped, qp);
     if (rc) d->coef_blocks = coef_start;
@@ -737,6 +737,7 @@ int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_
     int qp = pps->pic_init_qp + sh->slice_qp_delta;
     d->slice_id++;
     d->last_mb_addr = 0;
+    const int ref0_slot = sh->is_p ? hd_dpb_ref_slot(&d->dpb, 0) : -1;      /* P_Skip predicts from it (decode_skip_fast) */
     if (sh->redundant_pic_cnt) d->slice_ids_rewritten = 1;
 
     do {
@@ -768,7 +769,7 @@ int hd_decode_slice_data(HostDec *d, BitReader *br, const SliceHdr *sh, int nal_
         int skipped = 0;
         if (skip_run) { skip_run--; skipped = 1; }
         else prev_skipped = 0;
-        if (decode_mb(d, br, sh, pps, addr, skipped, &qp)) FAIL;
+        if (decode_mb(d, br, sh, pps, addr, skipped, &qp, ref0_slot)) FAIL;
         if (d->mb_decoded[addr] == 1) count++;
         more = br_more_rbsp_data(br) || skip_run;
         if (!sh->is_p) d->last_mb_addr = addr;
