@@ -2024,56 +2024,68 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
     const unsigned long long d3 = DTICK();
 
     /* ---- store: own macroblock (whole, or what its two macroblock edges can have changed), the last 3 (1) columns of the left
-     * and rows of the upper neighbour ---- */
+     * and rows of the upper neighbour.  Everything that may be stored is read from the tile FIRST, unconditionally, in one burst
+     * of LDS reads; the stores that follow are predicated but wait for nothing.  (Written the natural way — every condition
+     * reads what it stores — the compiler emits ten read -> wait -> store sequences one after the other behind their exec-mask
+     * branches: 4-5.6 k cycles per step, more than a filter pass, measured with tools/prof_tail.py.) ---- */
     if (act) {
         const uint32_t t = (uint32_t)mb * TILE;
         uint8_t *cur = fd.cur;
         H264K_GLOBAL uint8_t *curg = (H264K_GLOBAL uint8_t *)fd.cur;
+        uint4 yr[2];
+        uint2 cr[2];
+        uint32_t lyv[2], lcv[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            yr[h] = *reinterpret_cast<const uint4 *>(&lt[(4 + 2 * l + h) * LS + LX]);
+            cr[h] = *reinterpret_cast<const uint2 *>(&ct[(2 + 2 * c4 + h) * CS + CX]);
+            lyv[h] = *reinterpret_cast<const uint32_t *>(&lt[(4 + 2 * l + h) * LS + LX - 4]);
+            lcv[h] = *reinterpret_cast<const uint32_t *>(&ct[(2 + 2 * c4 + h) * CS + CX - 4]);
+        }
+        uint2 tyv = *reinterpret_cast<const uint2 *>(&lt[(l >> 1) * LS + LX + 8 * (l & 1)]);
+        uint32_t tcv = *reinterpret_cast<const uint32_t *>(&ct[1 * CS + CX + 4 * (c4 & 1)]);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            asm volatile("" : "+v"(yr[h].x), "+v"(yr[h].y), "+v"(yr[h].z), "+v"(yr[h].w), "+v"(cr[h].x), "+v"(cr[h].y), "+v"(lyv[h]), "+v"(lcv[h]));
+        asm volatile("" : "+v"(tyv.x), "+v"(tyv.y), "+v"(tcv));
 #pragma unroll
         for (int h = 0; h < 2; h++) {                              /* luma rows 2l, 2l+1 */
             const int row = 2 * l + h;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(&lt[(4 + row) * LS + LX]);
             const uint32_t o = t + 16u * row;
             if (inner || (f_top && row < 3)) {
-                const uint4 v4 = *reinterpret_cast<const uint4 *>(src);
-                if (BANDED && wt) put16(cur + o, v4, true); else st16g(curg + o, v4);
+                if (BANDED && wt) put16(cur + o, yr[h], true); else st16g(curg + o, yr[h]);
             } else if (f_left) {
-                if (BANDED && wt) put4(cur + o, src[0], true); else *(H264K_GLOBAL uint32_t *)(curg + o) = src[0];
+                if (BANDED && wt) put4(cur + o, yr[h].x, true); else *(H264K_GLOBAL uint32_t *)(curg + o) = yr[h].x;
             }
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {                              /* chroma rows 2 c4, 2 c4 + 1 of plane l >> 2 */
             const int row = 2 * c4 + h;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(&ct[(2 + row) * CS + CX]);
             const uint32_t o = t + T_CB + 64u * (l >> 2) + 8u * row;
             if (inner || (f_top && row == 0)) {
-                const uint2 v2 = *reinterpret_cast<const uint2 *>(src);
-                if (BANDED && wt) put8(cur + o, v2, true); else *(H264K_GLOBAL u32x2 *)(curg + o) = (u32x2){ v2.x, v2.y };
+                if (BANDED && wt) put8(cur + o, cr[h], true); else *(H264K_GLOBAL u32x2 *)(curg + o) = (u32x2){ cr[h].x, cr[h].y };
             } else if (f_left) {
-                if (BANDED && wt) put4(cur + o, src[0], true); else *(H264K_GLOBAL uint32_t *)(curg + o) = src[0];
+                if (BANDED && wt) put4(cur + o, cr[h].x, true); else *(H264K_GLOBAL uint32_t *)(curg + o) = cr[h].x;
             }
         }
         if (f_left) {
             const uint32_t tl = t - TILE;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const uint32_t vy = *reinterpret_cast<const uint32_t *>(&lt[(4 + 2 * l + h) * LS + LX - 4]), vc = *reinterpret_cast<const uint32_t *>(&ct[(2 + 2 * c4 + h) * CS + CX - 4]);
                 const uint32_t oy = tl + 16u * (2 * l + h) + 12u, oc = tl + T_CB + 64u * (l >> 2) + 8u * (2 * c4 + h) + 4u;
-                if (BANDED && wt) { put4(cur + oy, vy, true); put4(cur + oc, vc, true); }
-                else { *(H264K_GLOBAL uint32_t *)(curg + oy) = vy; *(H264K_GLOBAL uint32_t *)(curg + oc) = vc; }
+                if (BANDED && wt) { put4(cur + oy, lyv[h], true); put4(cur + oc, lcv[h], true); }
+                else { *(H264K_GLOBAL uint32_t *)(curg + oy) = lyv[h]; *(H264K_GLOBAL uint32_t *)(curg + oc) = lcv[h]; }
             }
         }
         if (f_top) {
             const uint32_t tu = t - (uint32_t)fd.wmb * TILE;
             if (l >= 2) {                                          /* luma strip rows 1..3 (row 0 = p3 never changes): dwords 2l, 2l+1 of the strip */
-                const uint2 v2 = *reinterpret_cast<const uint2 *>(&lt[(l >> 1) * LS + LX + 8 * (l & 1)]);
                 const uint32_t o = tu + 192u + 8u * l;
-                if (BANDED && wt) put8(cur + o, v2, true); else *(H264K_GLOBAL u32x2 *)(curg + o) = (u32x2){ v2.x, v2.y };
+                if (BANDED && wt) put8(cur + o, tyv, true); else *(H264K_GLOBAL u32x2 *)(curg + o) = (u32x2){ tyv.x, tyv.y };
             }
             if (c4 >= 2) {                                         /* chroma strip row 1 (row 0 = p1 never changes) */
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(&ct[1 * CS + CX + 4 * (c4 & 1)]);
                 const uint32_t o = tu + T_CB + 64u * (l >> 2) + 56u + 4u * (c4 & 1);
-                if (BANDED && wt) put4(cur + o, v, true); else *(H264K_GLOBAL uint32_t *)(curg + o) = v;
+                if (BANDED && wt) put4(cur + o, tcv, true); else *(H264K_GLOBAL uint32_t *)(curg + o) = tcv;
             }
         }
     }
