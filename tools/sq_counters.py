@@ -63,3 +63,31 @@ for k in order:
                                "lds_wave_instr_per_launch": v.get("SQ_INSTS_LDS", 0.0), "active_lanes_per_valu_instr": (v.get("SQ_THREAD_CYCLES_VALU", 0.0) / v["SQ_INSTS_VALU"] / 4.0) if v.get("SQ_INSTS_VALU") else None}
 json.dump(table, open(os.path.join(root, "profiles", f"{tag}_sq_counters.json"), "w"), indent=1)
 print("\n".join(out[:24]))
+
+# the committed bench line was printed before the counter passes of this session existed: fill its roofline.valu from them, with
+# the launch durations of that very line (the same arithmetic as bench.py, which reports it live once this table matches the sources)
+blp = os.path.join(root, "profiles", f"{tag}_bench_line.json")
+if os.path.exists(blp):
+    line = json.loads(open(blp).read())
+    rf = line.get("roofline", {})
+    v0 = rf.get("valu")
+    if (v0 is None or "per_kernel" not in v0) and rf.get("device_ms_per_step") and rf.get("launches_per_step"):
+        peak = 1024 * 2.4e9 / VALU_CYC
+        n_mbs_tick = float(rf.get("mbs_per_launch", 256 * 8160))
+        per = {}
+        for k, kv in table["kernels"].items():
+            ms, n = rf["device_ms_per_step"].get(k), rf["launches_per_step"].get(k)
+            if not ms or not n:
+                continue
+            n_i, t_s = kv["valu_wave_instr_per_launch"], ms * 1e-3 / n
+            per[k] = {"wave_instr_per_launch": n_i, "avg_launch_us": t_s * 1e6, "achieved": n_i / t_s, "frac": n_i / t_s / peak,
+                      "wave_instr_per_macroblock": n_i / n_mbs_tick}
+        tot_i = sum(p["wave_instr_per_launch"] for p in per.values())
+        ticks = max(rf["launches_per_step"].values())
+        total_s = rf["device_ms_per_step"]["total"] * 1e-3
+        rf["valu"] = {"peak_wave_instr_per_s": peak, "cycles_per_wave_instruction": VALU_CYC, "source": f"profiles/{tag}_sq_counters.json",
+                      "filled_in_by": "tools/sq_counters.py: counters collected in separate rocprofv3 --pmc passes right after this line on the same box, launch durations of this line",
+                      "per_kernel": per, "whole_path": {"wave_instr_per_tick": tot_i, "achieved": tot_i * ticks / total_s, "frac": tot_i * ticks / total_s / peak,
+                                                        "note": "every kernel runs once per tick; k_dbk runs next to the others, its time is not in the total"}}
+        open(blp, "w").write(json.dumps(line) + "\n")
+        print("filled roofline.valu of", os.path.relpath(blp, root), {k: round(p["frac"], 3) for k, p in per.items()}, "whole path", round(rf["valu"]["whole_path"]["frac"], 3))
