@@ -582,7 +582,7 @@ static void select_sps(HostDec *d, int pps_id)
     d->width_mbs = d->active_sps->width_mbs;
     d->height_mbs = d->active_sps->height_mbs;
     d->pic_size_mbs = d->width_mbs * d->height_mbs;
-    d->width_magic = d->pic_size_mbs < 65536u ? (uint32_t)(0x100000000ull / d->width_mbs) + 1u : 0u;
+    d->width_magic = d->pic_size_mbs < 65536u && d->width_mbs > 1u ? (uint32_t)(0x100000000ull / d->width_mbs) + 1u : 0u;     /* (width 1: 2^32 + 1 does not fit) */
     d->pending_activation = 1;
 }
 
