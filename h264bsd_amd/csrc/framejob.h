@@ -64,10 +64,12 @@
                                  the pixels of the job before — it replaced pixels that other macroblocks had already predicted
                                  from (concealment of, or a later slice over, a macroblock that a failed redundant slice un-decoded) */
 #define FJ_PRED_UNIFORM_MV 0x40u /* inter macroblocks: the 16 motion vectors are 16 copies of one vector and the four references are equal.
-                                  Before fj_finalize() it is a hint of the parser (P_Skip, P_L0_16x16: no need to compare them; a job
-                                  built elsewhere may leave it clear); fj_finalize() sets it wherever it holds, and in a FINISHED job
-                                  it says where the vectors are: set -> FjMbRec.mv is the macroblock's one vector, clear -> the 16
-                                  vectors are entry FjMbRec.mvx of the sparse section at FjHeader.mvx_off. */
+                                  Before fj_finalize() it is a statement of whoever built the record (the parser: P_Skip, P_L0_16x16):
+                                  the one vector is ALREADY in FjMbRec.mv and the macroblock's entry of the dense array at mv_off is not
+                                  written and will not be read; a job built elsewhere may leave it clear and fill the dense entry —
+                                  fj_finalize() then compares the sixteen vectors itself.  fj_finalize() sets the bit wherever it holds,
+                                  and in a FINISHED job it says where the vectors are: set -> FjMbRec.mv is the macroblock's one vector,
+                                  clear -> the 16 vectors are entry FjMbRec.mvx of the sparse section at FjHeader.mvx_off. */
 #define FJ_PRED_PARTS_SHIFT 4  /* inter macroblocks, pred bits 4-5: where the macroblock TYPE allows motion to differ inside it — the
                                  deblocking filter compares motion vectors / references only there (reference
                                  deblocking.c:1266-1345) */

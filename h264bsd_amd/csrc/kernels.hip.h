@@ -1518,8 +1518,11 @@ __device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, co
 }
 
 __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0,
-                                         const uint4 *i4tab, const uint32_t *rec_lds, const IntraLoads &L, bool wt, int16_t *res_defer = nullptr)
+                                         const uint4 *i4tab, const uint32_t *rec_lds, const IntraLoads &L, bool wt, int16_t *res_defer = nullptr,
+                                         unsigned long long *tp = nullptr)
 {
+#define ITICK() (tp ? __builtin_readcyclecounter() : 0ull)
+    const unsigned long long i0 = ITICK();
     const FjMbRec rec = rec_from_lds(rec_lds);
     const int16_t *coef = fd.coefs + 16 * (size_t)rec.coef_idx;
     /* the macroblock's tile (Y 16x16 | Cb 8x8 | Cr 8x8) */
@@ -1546,6 +1549,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
     if (nb_y_at >= 0) tile[nb_y_at] = (uint8_t)nb_y;
     if (nb_c_at >= 0) ctile0[nb_c_at] = (uint8_t)nb_c;
     wave_sync();
+    const unsigned long long i1 = ITICK();
 
     if (rec.kind == FJ_MB_I16x16) {
         const int mode = rec.pred & 3;
@@ -1612,6 +1616,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
         }
     }
 
+    const unsigned long long i2 = ITICK();
     /* chroma: lanes 0..31, lane = 4*k + row */
     if (lane < 32) {
         const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
@@ -1652,6 +1657,8 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
         put4(Y + T_CB + plane * 64 + y * 8 + x0, pack4(clip255(pr[0] + rc[0]), clip255(pr[1] + rc[1]), clip255(pr[2] + rc[2]), clip255(pr[3] + rc[3])), wt);
     }
     wave_sync();          /* the tiles are reused by this wave's next macroblock */
+    if (tp && lane == 0) { const unsigned long long i3 = ITICK(); tp[5] += i1 - i0; tp[6] += i2 - i1; tp[7] += i3 - i2; }
+#undef ITICK
 }
 #undef I4_T
 #undef I4_L
@@ -2343,9 +2350,9 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
             /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
             if (kind == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
             else if (kind == FJ_MB_I4x4 && k > 1) {
-                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, wt, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512));
+                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, wt, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512), tp);
                 if ((uint32_t)(lane >> 4) == j) joint_mb = (int)mb;
-            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, wt);
+            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, wt, nullptr, tp);
             if (j + 1 < k) cur_loads = next_loads;
         }
         if (__ballot(joint_mb >= 0) != 0ull) intra4_joint(fd, joint_mb, lane, my, i4tab, BANDED && joint_mb >= wt_lo);

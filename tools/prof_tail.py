@@ -21,7 +21,7 @@ for tick in (0, 9, 22, 28, 41, 60):
     tot = out[:, 4].astype(float).sum()
     it = float(intra[:, :3].sum()) or 1.0
     print(f"tick {tick}: k_frame_intra {t['k_frame_intra'][0]:.3f} ms; MBs by WG0: {int(intra[:,3].sum())}; idle {intra[:,0].sum()/it:.0%} work {intra[:,1].sum()/it:.0%} "
-          f"store-wait+release {intra[:,2].sum()/it:.0%}; cycles per MB: work {intra[:,1].sum()/max(1,intra[:,3].sum()):.0f} (of which the record round trip {intra[:,4].sum()/max(1,intra[:,3].sum()):.0f}) release {intra[:,2].sum()/max(1,intra[:,3].sum()):.0f}")
+          f"store-wait+release {intra[:,2].sum()/it:.0%}; cycles per MB: work {intra[:,1].sum()/max(1,intra[:,3].sum()):.0f} (of which the record round trip {intra[:,4].sum()/max(1,intra[:,3].sum()):.0f}) release {intra[:,2].sum()/max(1,intra[:,3].sum()):.0f}; inside intra_mb per MB: residual + staging {intra[:,5].sum()/max(1,intra[:,3].sum()):.0f}, luma prediction {intra[:,6].sum()/max(1,intra[:,3].sum()):.0f}, chroma + stores {intra[:,7].sum()/max(1,intra[:,3].sum()):.0f}")
     print(f"tick {tick}: k_frame_dbk {t['k_frame_dbk'][0]:.3f} ms; MBs filtered by WG0: {int(out[:,3].sum())}; "
           f"idle {out[:,0].sum()/tot:.0%}  filter {out[:,1].sum()/tot:.0%}  store-wait+release {out[:,2].sum()/tot:.0%}; "
           f"active waves {int((out[:,5] > 0).sum())}; wave cycles {tot/max(1,(out[:,5] > 0).sum()):.0f} avg; steps/wave {out[:,5].sum()/max(1,(out[:,5] > 0).sum()):.0f}, MBs per step {out[:,3].sum()/max(1,out[:,5].sum()):.2f}, "
