@@ -202,6 +202,8 @@ __device__ __forceinline__ void put16(void *p, uint4 v, bool wt)
  * in the middle of a macroblock (the reference is handed through the inlined helpers as an ordinary one; the address space is
  * inferred from this cast). */
 #define FD_REF(frames, i) (*(const FrameDesc *)((const H264K_CONST FrameDesc *)(frames) + (i)))
+/* row of a macroblock address without a division: FrameDesc.wmb_magic (a run-time division is a dozen or two vector instructions) */
+__device__ __forceinline__ uint32_t mb_row(const FrameDesc &fd, uint32_t mb) { return fd.wmb == 1 ? mb : __umulhi(mb, fd.wmb_magic); }
 /* plain loads / stores with the address space spelled out (global_load / global_store / s_load instead of flat); the HIP vector
  * classes cannot be copied out of a qualified address space, the native vector types can */
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -672,7 +674,8 @@ __global__ __launch_bounds__(64 * DBK_WG_WAVES) void k_dbk(const FrameDesc *__re
     uint32_t nmb = mb;
     const bool nlive = live && ndi < n_dbk;
     if (nlive) nmb = fd.dbki[ndi];
-    const uint32_t mbl = mb % (uint32_t)wmb ? mb - 1 : mb, mbt = mb >= (uint32_t)wmb ? mb - wmb : mb;    /* in-picture stand-ins */
+    const uint32_t mbx = mb - mb_row(fd, mb) * (uint32_t)wmb;
+    const uint32_t mbl = mbx ? mb - 1 : mb, mbt = mb >= (uint32_t)wmb ? mb - wmb : mb;    /* in-picture stand-ins */
     FjMbRec q, pl, pt;
     const int dir = m >> 3, e = (m >> 1) & 3, kh = m & 1;
     int qx[2], qy[2], px[2], py[2];
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(64 * DBK_WG_WAVES) void k_dbk(const FrameDesc *__re
     uint32_t bs2 = 0;                                              /* the lane's two strengths: low and high nibble of byte m */
     /* k_frame_dbk relies on it for its addresses: a left / upper macroblock edge is only ever active where that neighbour exists
      * (the host never says otherwise: GetMbFilteringFlags, deblocking.c:289-320 — enforced here for hand-built jobs) */
-    const bool f_left = (q.dbk & FJ_DBK_LEFT) && mb % (uint32_t)wmb, f_top = (q.dbk & FJ_DBK_TOP) && mb >= (uint32_t)wmb;
+    const bool f_left = (q.dbk & FJ_DBK_LEFT) && mbx, f_top = (q.dbk & FJ_DBK_TOP) && mb >= (uint32_t)wmb;
     if (filtered) {
         const bool edge_on = e ? true : (dir ? f_top : f_left);
         if (edge_on) {
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(256) void k_copy(const FrameDesc *__restrict__ fram
     } else {
     /* displaced: clamp-to-edge sample gather (h264bsdFillBlock, reconstruct.c:2244), lane = (row, 4-sample piece) */
     const int W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
-    const int mbx = e.mb % wmb, mby = e.mb / wmb;
+    const int mby = (int)mb_row(fd, e.mb), mbx = (int)e.mb - mby * wmb;
     for (int m = 0; m < cnt; m++) {
         const int x0 = (mbx + m) * 16 + e.dx, y0 = mby * 16 + e.dy;
         uint8_t *dt = fd.cur + (size_t)(e.mb + m) * TILE;
@@ -2215,7 +2218,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
     __syncthreads();
     /* neighbour b of (x,y): b = 0 L, 1 UL, 2 U, 3 UR, 4 R, 5 DR, 6 D, 7 DL  (b ^ 4 = opposite direction) */
     auto neighbour = [&](int mb, int b) -> int {
-        const int x = mb % wmb, y = mb / wmb;
+        const int y = (int)mb_row(fd, (uint32_t)mb), x = mb - y * wmb;
         const int dx = (b == 2 || b == 6) ? 0 : (b >= 3 && b <= 5) ? 1 : -1;
         const int dy = (b >= 1 && b <= 3) ? -1 : (b >= 5) ? 1 : 0;
         const int nx = x + dx, ny = y + dy;
