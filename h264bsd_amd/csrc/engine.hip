@@ -72,6 +72,9 @@ struct StreamCtx {
 #ifndef DBK_AT_INTRA_DEFAULT
 #define DBK_AT_INTRA_DEFAULT false
 #endif
+#ifndef DBK_AT_INTER_DEFAULT
+#define DBK_AT_INTER_DEFAULT false
+#endif
 struct SideLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join_copy = nullptr; };
 
 /* A lane = one HIP stream that runs ticks one after the other, with its own device arena for the frame jobs of a tick
@@ -466,7 +469,9 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     /* where k_dbk runs: "lists" = next to the copy and inter kernels from the start of the tick (rounds 1-3), "intra" = next to
      * k_frame_intra (whose P-picture ticks leave the device nearly idle), forked behind the inter kernels.  H264BSDMI_DBK_AT */
     static const bool dbk_late = [] { const char *v = getenv("H264BSDMI_DBK_AT"); return v ? !strcmp(v, "intra") : DBK_AT_INTRA_DEFAULT; }();
-    if (aside && !dbk_late) {
+    /* "inter": forked behind k_copy — the copy kernel (bound by HBM) runs alone, k_dbk next to the inter kernels only */
+    static const bool dbk_mid = [] { const char *v = getenv("H264BSDMI_DBK_AT"); return v ? !strcmp(v, "inter") : DBK_AT_INTER_DEFAULT; }();
+    if (aside && !dbk_late && !(dbk_mid && do_copy && !copy_aside)) {
         HIP_TRY(hipEventRecord(side->fork, st));                 /* after the previous tick's k_frame_dbk: the records are free */
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
         if (copy_aside) {
@@ -481,6 +486,11 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         if (launches) launches[0]++;
     }
     if (EV_NEEDED(1)) HIP_TRY(hipEventRecord(tt->ev[1], st));
+    if (aside && !dbk_late && dbk_mid && do_copy && !copy_aside) {
+        HIP_TRY(hipEventRecord(side->fork, st));
+        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        if (launch_kdbk_aside(side, 0, d_desc, s, tt, launches, stages)) return -1;
+    }
     if ((stages & 1u) && s.max_gen) {
 #if INTER_NMB > 1
         if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_uni, dim3((s.max_gen_uni + 4 * INTER_NMB - 1) / (4 * INTER_NMB), s.n_frames), dim3(256), 0, st, d_desc);
