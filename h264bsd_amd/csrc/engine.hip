@@ -64,6 +64,7 @@ struct StreamCtx {
     int group = 0, last_lane = -1;
     unsigned long long last_launch = 0;
     unsigned ready_round = 0;
+    size_t flush_quota = 0;                 /* jobs that were queued when the current flush began: it takes no others (flush_locked) */
 };
 
 /* k_dbk (boundary strengths) needs only the frame job, not pixels: it runs on a second HIP stream next to the
@@ -731,15 +732,20 @@ int flush_locked(Engine *e, bool wait = true)
     bool started = false;
     std::vector<std::vector<StreamCtx *>> part(e->n_light);
     std::vector<StreamCtx *> heavy;
+    /* A flush enqueues what was submitted BEFORE it began.  An application may call h264bsdmiFlushAsync() on one thread while
+     * its other threads are already parsing the next round (the call takes as long as enqueueing 256 jobs does): pictures that
+     * arrive meanwhile wait for the next flush instead of forming straggler ticks of a few streams each. */
+    for (StreamCtx *s : e->streams) { std::lock_guard<std::mutex> ql(s->qmu); s->flush_quota = s->pending.size(); }
     for (unsigned round = 0;; round++) {
         bool any_pending = false;
         for (auto &p : part) p.clear();
         heavy.clear();
         for (StreamCtx *s : e->streams) {
             std::lock_guard<std::mutex> ql(s->qmu);
-            if (s->pending.empty()) continue;
+            if (s->pending.empty() || !s->flush_quota) continue;
             any_pending = true;
             if (s->ready_round > round) continue;
+            s->flush_quota--;
             const FjHeader *h = reinterpret_cast<const FjHeader *>(s->pending.front().host);
             if (e->n_heavy && h->n_intra * 4u > h->n_mbs) heavy.push_back(s);
             else part[(unsigned)s->group % e->n_light].push_back(s);

@@ -11,13 +11,25 @@ threads = L.h264bsdmiSetParserThreads(int(sys.argv[1]) if len(sys.argv) > 1 else
 decs = [h.Decoder() for _ in range(streams)]
 drv = h.BatchDriver(decs, [data * (laps + 1)] * streams)
 t_step = t_flush = t_call = 0.0
+import threading
+overlap = len(sys.argv) > 4 and sys.argv[4] == "overlap"
+flusher = None
 orig = L.h264bsdmiDecodePictureBatch
 for pic in range(73 * (laps + 1)):
     if pic == 73:
-        L.h264bsdmiFlush(); t0 = time.perf_counter(); t_step = t_flush = 0.0
-    a = time.perf_counter(); drv.step(); b = time.perf_counter(); L.h264bsdmiFlushAsync(); c = time.perf_counter()
+        L.h264bsdmiFlush(); t0 = time.perf_counter(); c0 = time.process_time(); t_step = t_flush = 0.0
+    a = time.perf_counter(); drv.step(); b = time.perf_counter()
+    if overlap:
+        # the enqueueing of round k on a thread of its own, next to the parse of round k + 1 (ctypes releases the GIL)
+        if flusher is not None: flusher.join()
+        flusher = threading.Thread(target=L.h264bsdmiFlushAsync); flusher.start()
+    else:
+        L.h264bsdmiFlushAsync()
+    c = time.perf_counter()
     t_step += b - a; t_flush += c - b
+if flusher is not None: flusher.join()
 L.h264bsdmiFlush()
 dt = time.perf_counter() - t0
+cpu = time.process_time() - c0              # user + system time of every thread of the process
 n = 73 * laps
-print(f"threads {threads}: {streams * n / dt:.0f} fps; per round {dt / n * 1e3:.2f} ms = step {t_step / n * 1e3:.2f} + FlushAsync {t_flush / n * 1e3:.2f} + rest {(dt - t_step - t_flush) / n * 1e3:.2f}")
+print(f"threads {threads}: {streams * n / dt:.0f} fps; per round {dt / n * 1e3:.2f} ms = step {t_step / n * 1e3:.2f} + FlushAsync {t_flush / n * 1e3:.2f} + rest {(dt - t_step - t_flush) / n * 1e3:.2f}; CPU time {cpu / n * 1e3:.0f} ms per round = {cpu / dt:.1f} CPUs busy, {cpu / (streams * n) * 1e3:.3f} ms per picture")
