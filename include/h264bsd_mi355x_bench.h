@@ -14,8 +14,12 @@ extern "C" {
 
 /* Complete a frame job built outside the parser (tests, tools): given a buffer whose FjHeader geometry /
  * rec_off / mv_off / coef_off, records, motion vectors and n_coef_blocks coefficient blocks are filled in,
- * derive the schedules (intra levels, copy runs, general-inter list, deblocking index) and total_bytes exactly
- * as the parser does.  cur_slot / n_slots / is_idr stay as the caller set them.  0 = ok. */
+ * derive the schedules (intra levels, copy runs, general-inter list, deblocking index), the compact form of the
+ * motion vectors (one vector in the record of a macroblock that has one, a sparse section for the others: framejob.h)
+ * and total_bytes exactly as the parser does.  The dense array int16 mv[n_mbs][16][2] at mv_off is INPUT only: it
+ * must lie in front of coef_off or behind everything else the job can grow to (capacity: + 64 bytes per macroblock
+ * for the sparse section); nothing on the device reads it.  cur_slot / n_slots / is_idr stay as the caller set them.
+ * 0 = ok. */
 int h264bsdmiJobFinalize(u8 *job, u32 capacity, u32 n_coef_blocks);
 
 /* ---- HBM-resident replay (bench / parity tests): kernels only, no host parsing in the loop ----

@@ -1,5 +1,6 @@
 """The frame job carries motion vectors compact (framejob.h): one vector in the record of a macroblock that has one, a sparse
 64-byte entry for the others; the dense array is only the input of fj_finalize() and stays on the host.  CPU only."""
+import os
 import struct
 
 import numpy as np
@@ -53,7 +54,7 @@ def test_finished_job_reproduces_the_dense_vectors_it_was_built_from(lib, seed):
 
 
 def test_parser_jobs_keep_the_dense_array_off_the_wire():
-    data = open(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "test_640x360.h264"), "rb").read()
+    data = open(os.path.join(os.path.dirname(__file__), "golden", "test_640x360.h264"), "rb").read()
     jobs, _, _ = h264bsd_amd.capture_stream(data)
     assert jobs
     for j in jobs:
