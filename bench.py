@@ -251,11 +251,30 @@ def main():
     kernels = h264bsd_amd.Replay.KERNELS
     golden_sums = golden["frame_checksum64"]
 
+    # ONE replay set (jobs + DPBs resident in HBM: 22 GB for 256 x 1080p) serves every leg that replays these jobs — lock-step,
+    # staggered, + conversion, the three desynchronised schedules: a leg asks for its schedule (Replay.reschedule: new
+    # descriptors, zeroed frame buffers), nothing is allocated or uploaded twice.  Only the leg without copy elision replays
+    # OTHER jobs and builds its own set.
+    shared = {"rep": None}
+
+    def replay_for(these_jobs, **sched):
+        if these_jobs is jobs:
+            if shared["rep"] is None:
+                shared["rep"] = h264bsd_amd.Replay(jobs, n_streams=args.streams, **sched)
+            else:
+                shared["rep"].reschedule(**sched)
+            return shared["rep"]
+        return h264bsd_amd.Replay(these_jobs, n_streams=args.streams, **sched)
+
+    def release(rep):
+        if rep is not shared["rep"]:
+            rep.close()
+
     def run_variant(odd_offset, steps, jobs=jobs, main=True):
         """Verify, warm up and time one variant of the workload.  odd_offset = 0: lock-step (every stream on
         the same picture index: two all-IDR ticks per step, the worst case); otherwise odd streams start at the
         second IDR (SURVEY.md §8d config 4 "staggered").  Returns (elapsed s, kernel ms, launches, device ms, job bytes)."""
-        rep = h264bsd_amd.Replay(jobs, n_streams=args.streams, odd_offset=odd_offset)   # jobs + DPBs resident in HBM
+        rep = replay_for(jobs, odd_offset=odd_offset)
         extra = {}
 
         def verify(i):
@@ -323,7 +342,7 @@ def main():
             breakdown = {k: (k_ms[k] / steps, k_n[k] // steps) for k in kernels}
         verify(n_pics - 1)                                     # the final pictures, after the timed region
         job_bytes = rep.job_bytes
-        rep.close()
+        release(rep)
         local = elapsed
         if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -352,7 +371,7 @@ def main():
     argb = None
     if not args.no_argb:
         import hashlib
-        rep = h264bsd_amd.Replay(jobs, n_streams=args.streams)
+        rep = replay_for(jobs)
         w_px, h_px = info["width_mbs"] * 16, info["height_mbs"] * 16
         for i in range(n_pics):
             rep.run(i, 1)
@@ -376,7 +395,8 @@ def main():
         sums = rep.checksums(heads[-1]["cur_slot"])
         if not (sums == golden_sums[-1]).all():
             raise SystemExit(f"rank {rank}: ARGB variant: final pictures are not bit-exact")
-        rep.close()
+        rep.set_convert(-1)
+        release(rep)
         if dist is not None:
             tt = torch.tensor([a_elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -396,7 +416,7 @@ def main():
         slots = sorted(set(h["cur_slot"] for h in heads))
         desync = {"offsets": "stream s starts at picture floor(s * n_pics / n_streams)"}
         for key, lanes, delay, groups in (("common_ticks", 0, 0, 1), ("heavy_lanes", 4, 4, 1), ("heavy_lanes_9_groups", 3, 4, 9)):
-            rep = h264bsd_amd.Replay(jobs, n_streams=args.streams, offsets=offsets, heavy_lanes=lanes, heavy_delay=delay, groups=groups)
+            rep = replay_for(jobs, offsets=offsets, heavy_lanes=lanes, heavy_delay=delay, groups=groups)
 
             def verify_lap():
                 sums = {sl: rep.checksums(sl) for sl in slots}
@@ -414,13 +434,17 @@ def main():
             barrier()
             dt = time.perf_counter() - t0
             verify_lap()
-            rep.close()
+            release(rep)
             if dist is not None:
                 tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = float(tt.item())
             desync[key] = {"value": n_pics * args.streams * world * n_mbs * side_steps / dt, "unit": "macroblocks/s",
                            "ms_per_step": dt * 1e3 / side_steps, "steps": side_steps, "lanes": lanes, "rejoin_after_ticks": delay, "stream_groups": groups}
+
+    if shared["rep"] is not None:
+        shared["rep"].close()
+        shared["rep"] = None
 
     # on-box ceiling of a plain device-to-device copy (report the fraction of both peaks)
     copy_gbs = None

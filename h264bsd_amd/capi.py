@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdConvertToYCbCrA",
     "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync", "h264bsdmiDeviceErrors",
     "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads", "h264bsdmiSetInputReadOnly", "h264bsdmiSetCopyElision",
-    "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayCreateSched", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
+    "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayCreateSched", "h264bsdmiReplayReschedule", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiDebugSetTail", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
 ]
@@ -130,6 +130,7 @@ def lib():
     L.h264bsdmiReplayCreateDesync.restype = vp
     L.h264bsdmiReplayCreateSched.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32, P32, u32, u32, u32]
     L.h264bsdmiReplayCreateSched.restype = vp
+    L.h264bsdmiReplayReschedule.argtypes = [vp, P32, u32, u32, u32]
     L.h264bsdmiReplayDestroy.argtypes = [vp]
     L.h264bsdmiReplayDestroy.restype = None
     L.h264bsdmiReplayRun.argtypes = [vp, u32, u32]
@@ -441,6 +442,17 @@ class Replay:
             raise RuntimeError("h264bsdmiReplayCreate failed (no HIP device or out of memory)")
         self.frame_bytes = int(L.h264bsdmiReplayFrameBytes(self._h))
         self.job_bytes = int(L.h264bsdmiReplayJobBytes(self._h))
+
+    def reschedule(self, odd_offset=0, offsets=None, heavy_lanes=0, heavy_delay=4, groups=1):
+        """Another schedule for the same resident jobs (arguments as in __init__): no second allocation and upload.
+        Frame buffers start from zero again."""
+        if offsets is None:
+            offsets = [odd_offset if s & 1 else 0 for s in range(self.n_streams)]
+        self.odd_offset = odd_offset
+        self.offsets = [int(o) for o in offsets]
+        offs = (ctypes.c_uint32 * self.n_streams)(*self.offsets)
+        if self._L.h264bsdmiReplayReschedule(self._h, offs, heavy_lanes, heavy_delay, groups) != 0:
+            raise RuntimeError("h264bsdmiReplayReschedule failed")
 
     def close(self):
         if self._h:

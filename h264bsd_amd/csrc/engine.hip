@@ -1136,6 +1136,10 @@ struct h264bsdmi_replay {
     SideLane lane_side[MAX_LANES];        /* k_dbk next to the reconstruction kernels, per light lane */
     uint32_t n_lanes = 0, n_light = 0;
     std::vector<uint32_t> offsets;    /* first picture of every stream */
+    /* what a schedule is built from (replay_schedule: at creation and again for every h264bsdmiReplayReschedule) */
+    std::vector<FjHeader> heads;      /* the headers of the n_pics jobs (host copies) */
+    std::vector<size_t> blob_off;     /* where job p lies inside a stream's blobs */
+    size_t frames_per_stream = 0, dbk_half = 0, dbk_stride = 0;
     /* config 3 ("ARGB conversion on-GPU"): colour conversion of every produced picture inside the run, timed */
     int convert_fmt = -1;
     std::vector<hipEvent_t> cev;      /* 2 per tick */
@@ -1144,93 +1148,30 @@ struct h264bsdmi_replay {
 h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
                                              const u32 *offsets, u32 heavy_lanes, u32 heavy_delay, u32 groups);
 
-h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams)
+/* Descriptors and launch schedule of a replay set for the offsets in r->offsets: lock-step / staggered / common ticks
+ * (heavy_lanes == 0, groups <= 1: tick i = picture (i + offset) mod n_pics of every stream) or the static schedule of
+ * stream groups and heavy lanes (h264bsdmiReplayCreateDesync).  Called at creation and by h264bsdmiReplayReschedule,
+ * which has torn the previous schedule down. */
+static bool replay_schedule(h264bsdmi_replay *r, u32 heavy_lanes, u32 heavy_delay, u32 groups)
 {
-    return h264bsdmiReplayCreateDesync(blobs, bytes, n_pics, n_streams, nullptr, 0, 0);
-}
-
-/* odd_offset != 0: the "staggered" variant of SURVEY.md §8d config 4 — odd-numbered streams run picture
- * (i + odd_offset) mod n_pics in tick i (odd_offset must be the index of an IDR picture, so that both the
- * start and the wrap-around are clean decoder starts); every tick then mixes two different pictures */
-h264bsdmi_replay *h264bsdmiReplayCreateStaggered(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams, u32 odd_offset)
-{
-    if (odd_offset >= n_pics) return nullptr;
-    std::vector<u32> offs(n_streams, 0);
-    for (u32 s = 1; s < n_streams; s += 2) offs[s] = odd_offset;
-    return h264bsdmiReplayCreateDesync(blobs, bytes, n_pics, n_streams, offs.data(), 0, 0);
-}
-
-/* Streams that are NOT in step: stream s starts at picture offsets[s] (nullptr = all 0) and runs n_pics pictures,
- * wrapping around (picture 0 must be an IDR picture).  heavy_lanes == 0: tick i holds picture (i + offsets[s]) mod
- * n_pics of every stream — a tick then lasts as long as its slowest picture.  heavy_lanes > 0: a static schedule of
- * what a scheduler achieves that keeps light pictures from waiting for heavy ones:
- *   - the streams are split into `groups` groups (stream s -> group s % groups), every group runs its own ticks on its
- *     own HIP stream ("light lane"): a group's tick lasts as long as ITS slowest picture, and the workgroups of the
- *     other groups fill the compute units it leaves idle (tail kernels are one workgroup per picture);
- *   - pictures that are mostly intra-coded ("heavy", more than a quarter of their macroblocks) leave their group's
- *     tick and run on one of heavy_lanes extra HIP streams; their stream of pictures rejoins its group heavy_delay
- *     ticks later (an event makes the group's tick wait if the heavy picture is not finished by then). */
-h264bsdmi_replay *h264bsdmiReplayCreateDesync(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
-                                              const u32 *offsets, u32 heavy_lanes, u32 heavy_delay)
-{
-    return h264bsdmiReplayCreateSched(blobs, bytes, n_pics, n_streams, offsets, heavy_lanes, heavy_delay, 1);
-}
-
-h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
-                                             const u32 *offsets, u32 heavy_lanes, u32 heavy_delay, u32 groups)
-{
-    if (groups < 1) groups = 1;
-    if (groups > 16 || groups > n_streams) return nullptr;
-    if (heavy_lanes + groups > (u32)h264bsdmi_replay::MAX_LANES) return nullptr;
-    for (u32 s = 0; offsets && s < n_streams; s++) if (offsets[s] >= n_pics) return nullptr;
-    Engine *e = engine_get();
-    if (!e || !n_pics || !n_streams) {
-        if (!e) fprintf(stderr, "h264bsd-mi355x: h264bsdmiReplayCreate: no usable HIP device\n");
-        return nullptr;
-    }
-    std::lock_guard<std::mutex> lk(e->mu);
-    if (hipSetDevice(e->device) != hipSuccess) return nullptr;
-    h264bsdmi_replay *r = new h264bsdmi_replay();
-    r->e = e; r->n_pics = n_pics; r->n_streams = n_streams;
-    r->offsets.assign(n_streams, 0);
-    if (offsets) r->offsets.assign(offsets, offsets + n_streams);
-    const FjHeader *h0 = reinterpret_cast<const FjHeader *>(blobs[0]);
-    r->wmb = h0->width_mbs; r->hmb = h0->height_mbs; r->n_slots = h0->n_slots;
-    r->frame_bytes = fj_frame_bytes(r->wmb, r->hmb);
-    std::vector<size_t> offs(n_pics);
-    size_t total = 0;
-    r->job_bytes = 0;
-    for (u32 i = 0; i < n_pics; i++) { offs[i] = total; total += ((size_t)bytes[i] + 255u) & ~(size_t)255u; r->job_bytes += bytes[i]; }
-    r->blob_stride = total;
-    r->d_blobs = nullptr; r->d_frames = nullptr; r->d_desc = nullptr; r->d_conv = nullptr; r->d_sums = nullptr; r->d_dbk = nullptr;
-    const size_t frames_per_stream = (size_t)r->n_slots * r->frame_bytes;
-    const size_t dbk_half = (DBK_SCRATCH_BYTES(h0->n_mbs) + 255) & ~(size_t)255, dbk_stride = 2 * dbk_half;   /* two buffers per stream: "k_dbk ahead" */
-    bool ok = hipMalloc((void **)&r->d_blobs, total * n_streams) == hipSuccess &&
-              hipMalloc((void **)&r->d_frames, frames_per_stream * n_streams + 256) == hipSuccess &&
-              hipMalloc((void **)&r->d_desc, sizeof(FrameDesc) * (size_t)n_pics * n_streams) == hipSuccess &&
-              hipMalloc((void **)&r->d_sums, sizeof(unsigned long long) * n_streams) == hipSuccess &&
-              hipMalloc((void **)&r->d_dbk, (size_t)n_streams * dbk_stride) == hipSuccess;
-    if (ok) ok = hipMemsetAsync(r->d_dbk, 0, (size_t)n_streams * dbk_stride, e->stream) == hipSuccess;
-    if (ok) ok = hipMemsetAsync(r->d_frames, 0, frames_per_stream * n_streams + 256, e->stream) == hipSuccess;
-    /* stream 0 from the host, the other copies device-to-device: every stream owns private jobs */
-    for (u32 i = 0; ok && i < n_pics; i++) {
-        ok = hipMemcpyAsync(r->d_blobs + offs[i], blobs[i], bytes[i], hipMemcpyHostToDevice, e->stream) == hipSuccess;
-        const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[i]);
-        if (h->width_mbs != r->wmb || h->height_mbs != r->hmb || h->n_slots != r->n_slots) ok = false;
-        TickShape s;
+    Engine *e = r->e;
+    const u32 n_pics = r->n_pics, n_streams = r->n_streams;
+    const size_t total = r->blob_stride, frames_per_stream = r->frames_per_stream, dbk_half = r->dbk_half, dbk_stride = r->dbk_stride;
+    const std::vector<size_t> &offs = r->blob_off;
+    auto blob_of = [&](u32 p) { return reinterpret_cast<const uint8_t *>(&r->heads[p]); };     /* make_desc reads the header only */
+    bool ok = true;
+    r->shapes.assign(n_pics, TickShape());
+    for (u32 i = 0; i < n_pics; i++) {
+        TickShape s0;
         FrameDesc tmp;
-        make_desc(tmp, blobs[i], nullptr, nullptr, 0, nullptr, &s, nullptr);
-        s.n_frames = n_streams;
-        r->shapes.push_back(s);
-        r->cur_slot.push_back(h->cur_slot);
+        make_desc(tmp, blob_of(i), nullptr, nullptr, 0, nullptr, &s0, nullptr);
+        s0.n_frames = n_streams;
+        r->shapes[i] = s0;
     }
-    if (ok) ok = hipStreamSynchronize(e->stream) == hipSuccess;
-    for (u32 s = 1; ok && s < n_streams; s++)
-        ok = hipMemcpyAsync(r->d_blobs + (size_t)s * total, r->d_blobs, total, hipMemcpyDeviceToDevice, e->stream) == hipSuccess;
     if (ok) {
         std::vector<FrameDesc> descs((size_t)n_pics * n_streams);
         auto desc_of = [&](FrameDesc &d, u32 s, u32 p, TickShape *shape, u32 tick = 0) {
-            make_desc(d, blobs[p], r->d_blobs + (size_t)s * total + offs[p], r->d_frames + (size_t)s * frames_per_stream,
+            make_desc(d, blob_of(p), r->d_blobs + (size_t)s * total + offs[p], r->d_frames + (size_t)s * frames_per_stream,
                       r->frame_bytes, r->d_dbk + (size_t)s * dbk_stride + (tick & 1u) * dbk_half, shape, e->d_err);
         };
         if (!heavy_lanes && groups <= 1) {
@@ -1245,7 +1186,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
             std::vector<int> last_ev(n_streams, -1);     /* event of the heavy launch a stream's previous picture ran in */
             size_t n_desc = 0;
             u32 left = n_streams, heavy_count = 0;
-            auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[p]); return heavy_lanes && h->n_intra * 4u > h->n_mbs; };      /* (no heavy lanes: heavy pictures stay in their group's tick) */
+            auto is_heavy = [&](u32 p) { const FjHeader *h = reinterpret_cast<const FjHeader *>(blob_of(p)); return heavy_lanes && h->n_intra * 4u > h->n_mbs; };      /* (no heavy lanes: heavy pictures stay in their group's tick) */
             /* Cost-affine groups: a group's tick lasts as long as its slowest picture, so streams whose next pictures cost
              * about the same belong together.  Every REGROUP rounds the streams are sorted by the estimated per-picture
              * kernel time of their next REGROUP pictures (from the job headers: intra and filtered macroblock counts) and
@@ -1261,7 +1202,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
             auto upcoming_cost = [&](u32 s) {
                 uint64_t c = 0;
                 for (u32 i = 0; i < REGROUP && done[s] + i < n_pics; i++) {
-                    const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[(r->offsets[s] + done[s] + i) % n_pics]);
+                    const FjHeader *h = &r->heads[(r->offsets[s] + done[s] + i) % n_pics];
                     c += 11u * h->n_intra + 4u * h->n_dbk;          /* ~0.55 us per intra macroblock, ~0.2 us per filtered one */
                 }
                 return c;
@@ -1349,6 +1290,91 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
         if (ok) ok = hipMemcpyAsync(r->d_desc, descs.data(), descs.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, e->stream) == hipSuccess &&
                      hipStreamSynchronize(e->stream) == hipSuccess;
     }
+    return ok;
+}
+
+h264bsdmi_replay *h264bsdmiReplayCreate(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams)
+{
+    return h264bsdmiReplayCreateDesync(blobs, bytes, n_pics, n_streams, nullptr, 0, 0);
+}
+
+/* odd_offset != 0: the "staggered" variant of SURVEY.md §8d config 4 — odd-numbered streams run picture
+ * (i + odd_offset) mod n_pics in tick i (odd_offset must be the index of an IDR picture, so that both the
+ * start and the wrap-around are clean decoder starts); every tick then mixes two different pictures */
+h264bsdmi_replay *h264bsdmiReplayCreateStaggered(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams, u32 odd_offset)
+{
+    if (odd_offset >= n_pics) return nullptr;
+    std::vector<u32> offs(n_streams, 0);
+    for (u32 s = 1; s < n_streams; s += 2) offs[s] = odd_offset;
+    return h264bsdmiReplayCreateDesync(blobs, bytes, n_pics, n_streams, offs.data(), 0, 0);
+}
+
+/* Streams that are NOT in step: stream s starts at picture offsets[s] (nullptr = all 0) and runs n_pics pictures,
+ * wrapping around (picture 0 must be an IDR picture).  heavy_lanes == 0: tick i holds picture (i + offsets[s]) mod
+ * n_pics of every stream — a tick then lasts as long as its slowest picture.  heavy_lanes > 0: a static schedule of
+ * what a scheduler achieves that keeps light pictures from waiting for heavy ones:
+ *   - the streams are split into `groups` groups (stream s -> group s % groups), every group runs its own ticks on its
+ *     own HIP stream ("light lane"): a group's tick lasts as long as ITS slowest picture, and the workgroups of the
+ *     other groups fill the compute units it leaves idle (tail kernels are one workgroup per picture);
+ *   - pictures that are mostly intra-coded ("heavy", more than a quarter of their macroblocks) leave their group's
+ *     tick and run on one of heavy_lanes extra HIP streams; their stream of pictures rejoins its group heavy_delay
+ *     ticks later (an event makes the group's tick wait if the heavy picture is not finished by then). */
+h264bsdmi_replay *h264bsdmiReplayCreateDesync(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
+                                              const u32 *offsets, u32 heavy_lanes, u32 heavy_delay)
+{
+    return h264bsdmiReplayCreateSched(blobs, bytes, n_pics, n_streams, offsets, heavy_lanes, heavy_delay, 1);
+}
+
+h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
+                                             const u32 *offsets, u32 heavy_lanes, u32 heavy_delay, u32 groups)
+{
+    if (groups < 1) groups = 1;
+    if (groups > 16 || groups > n_streams) return nullptr;
+    if (heavy_lanes + groups > (u32)h264bsdmi_replay::MAX_LANES) return nullptr;
+    for (u32 s = 0; offsets && s < n_streams; s++) if (offsets[s] >= n_pics) return nullptr;
+    Engine *e = engine_get();
+    if (!e || !n_pics || !n_streams) {
+        if (!e) fprintf(stderr, "h264bsd-mi355x: h264bsdmiReplayCreate: no usable HIP device\n");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (hipSetDevice(e->device) != hipSuccess) return nullptr;
+    h264bsdmi_replay *r = new h264bsdmi_replay();
+    r->e = e; r->n_pics = n_pics; r->n_streams = n_streams;
+    r->offsets.assign(n_streams, 0);
+    if (offsets) r->offsets.assign(offsets, offsets + n_streams);
+    const FjHeader *h0 = reinterpret_cast<const FjHeader *>(blobs[0]);
+    r->wmb = h0->width_mbs; r->hmb = h0->height_mbs; r->n_slots = h0->n_slots;
+    r->frame_bytes = fj_frame_bytes(r->wmb, r->hmb);
+    std::vector<size_t> offs(n_pics);
+    size_t total = 0;
+    r->job_bytes = 0;
+    for (u32 i = 0; i < n_pics; i++) { offs[i] = total; total += ((size_t)bytes[i] + 255u) & ~(size_t)255u; r->job_bytes += bytes[i]; }
+    r->blob_stride = total;
+    r->blob_off = offs;
+    r->d_blobs = nullptr; r->d_frames = nullptr; r->d_desc = nullptr; r->d_conv = nullptr; r->d_sums = nullptr; r->d_dbk = nullptr;
+    const size_t frames_per_stream = (size_t)r->n_slots * r->frame_bytes;
+    const size_t dbk_half = (DBK_SCRATCH_BYTES(h0->n_mbs) + 255) & ~(size_t)255, dbk_stride = 2 * dbk_half;   /* two buffers per stream: "k_dbk ahead" */
+    r->frames_per_stream = frames_per_stream; r->dbk_half = dbk_half; r->dbk_stride = dbk_stride;
+    bool ok = hipMalloc((void **)&r->d_blobs, total * n_streams) == hipSuccess &&
+              hipMalloc((void **)&r->d_frames, frames_per_stream * n_streams + 256) == hipSuccess &&
+              hipMalloc((void **)&r->d_desc, sizeof(FrameDesc) * (size_t)n_pics * n_streams) == hipSuccess &&
+              hipMalloc((void **)&r->d_sums, sizeof(unsigned long long) * n_streams) == hipSuccess &&
+              hipMalloc((void **)&r->d_dbk, (size_t)n_streams * dbk_stride) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(r->d_dbk, 0, (size_t)n_streams * dbk_stride, e->stream) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(r->d_frames, 0, frames_per_stream * n_streams + 256, e->stream) == hipSuccess;
+    /* stream 0 from the host, the other copies device-to-device: every stream owns private jobs */
+    for (u32 i = 0; ok && i < n_pics; i++) {
+        ok = hipMemcpyAsync(r->d_blobs + offs[i], blobs[i], bytes[i], hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        const FjHeader *h = reinterpret_cast<const FjHeader *>(blobs[i]);
+        if (h->width_mbs != r->wmb || h->height_mbs != r->hmb || h->n_slots != r->n_slots) ok = false;
+        r->heads.push_back(*h);
+        r->cur_slot.push_back(h->cur_slot);
+    }
+    if (ok) ok = hipStreamSynchronize(e->stream) == hipSuccess;
+    for (u32 s = 1; ok && s < n_streams; s++)
+        ok = hipMemcpyAsync(r->d_blobs + (size_t)s * total, r->d_blobs, total, hipMemcpyDeviceToDevice, e->stream) == hipSuccess;
+    if (ok) ok = replay_schedule(r, heavy_lanes, heavy_delay, groups);
     r->timers.resize(n_pics);
     for (auto &t : r->timers) {
         for (auto &ev : t.ev) if (ok) ok = hipEventCreate(&ev) == hipSuccess;
@@ -1393,6 +1419,45 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     for (auto &st : r->lanes) if (st) { tickets_release(st); hipStreamDestroy(st); }
     for (auto &sl : r->lane_side) { if (sl.stream) hipStreamDestroy(sl.stream); if (sl.fork) hipEventDestroy(sl.fork); if (sl.join) hipEventDestroy(sl.join); }
     delete r;
+}
+
+/* The same resident jobs and frame buffers under another schedule (other first pictures, heavy lanes, stream groups): what
+ * a second h264bsdmiReplayCreate* would build, without allocating and uploading 20 GB again.  Frame buffers and deblocking
+ * scratch start from zero like those of a new set.  0 = ok; after a failure the set can only be destroyed. */
+int h264bsdmiReplayReschedule(h264bsdmi_replay *r, const u32 *offsets, u32 heavy_lanes, u32 heavy_delay, u32 groups)
+{
+    if (!r) return -1;
+    if (groups < 1) groups = 1;
+    if (groups > 16 || groups > r->n_streams || heavy_lanes + groups > (u32)h264bsdmi_replay::MAX_LANES) return -1;
+    for (u32 s = 0; offsets && s < r->n_streams; s++) if (offsets[s] >= r->n_pics) return -1;
+    Engine *e = r->e;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    /* everything the old schedule launched has to be over before its streams and events go */
+    for (auto &st : r->lanes) if (st) HIP_TRY(hipStreamSynchronize(st));
+    for (int g = 0; g < 8; g++) if (r->gstream[g]) HIP_TRY(hipStreamSynchronize(r->gstream[g]));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (poll_errors(e)) return -1;
+    for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
+    r->sched_ev.clear(); r->sched.clear();
+    for (auto &st : r->lanes) if (st) { tickets_release(st); hipStreamDestroy(st); st = nullptr; }
+    for (auto &sl : r->lane_side) {
+        if (sl.stream) hipStreamDestroy(sl.stream);
+        if (sl.fork) hipEventDestroy(sl.fork);
+        if (sl.join) hipEventDestroy(sl.join);
+        if (sl.join_copy) hipEventDestroy(sl.join_copy);
+        sl = SideLane();
+    }
+    r->n_lanes = r->n_light = 0;
+    r->n_groups = 1;                                  /* (h264bsdmiReplaySetGroups: a property of the schedule it was set for) */
+    r->convert_fmt = -1; r->timed_mask = 31u; r->stages = 7u;
+    r->offsets.assign(r->n_streams, 0);
+    if (offsets) r->offsets.assign(offsets, offsets + r->n_streams);
+    HIP_TRY(hipMemsetAsync(r->d_dbk, 0, (size_t)r->n_streams * r->dbk_stride, e->stream));
+    HIP_TRY(hipMemsetAsync(r->d_frames, 0, r->frames_per_stream * r->n_streams + 256, e->stream));
+    if (!replay_schedule(r, heavy_lanes, heavy_delay, groups)) return -1;
+    r->timed_first = r->timed_count = 0;
+    return 0;
 }
 
 int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)

@@ -47,6 +47,10 @@ h264bsdmi_replay *h264bsdmiReplayCreateDesync(const u8 *const *blobs, const u32 
  * workgroups fill the compute units it leaves idle.  groups == 1 is h264bsdmiReplayCreateDesync. */
 h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
                                              const u32 *offsets, u32 heavy_lanes, u32 heavy_delay, u32 groups);
+/* Give an existing set another schedule (other first pictures, heavy lanes, stream groups; arguments as above) without
+ * allocating and uploading its jobs again: the measurement legs of bench.py share one set.  Frame buffers and deblocking
+ * scratch are zeroed like those of a new set; whatever the old schedule had enqueued is waited for.  0 = ok. */
+int  h264bsdmiReplayReschedule(h264bsdmi_replay *r, const u32 *offsets, u32 heavy_lanes, u32 heavy_delay, u32 groups);
 void h264bsdmiReplayDestroy(h264bsdmi_replay *r);
 /* Enqueue ticks [first, first+count) on the engine stream; asynchronous.  0 = ok. */
 int  h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count);

@@ -132,6 +132,55 @@ def test_desynchronised_streams(lanes, delay, groups, S, built, captured, golden
         rep.close()
 
 
+def test_one_replay_set_under_one_schedule_after_the_other(built, captured, golden):
+    """h264bsdmiReplayReschedule: the resident jobs of ONE set replayed lock-step, staggered, desynchronised with heavy lanes
+    and stream groups, with 4 lock-step groups, and lock-step again — every schedule bit-exact, like a set created for it
+    (bench.py shares one set between its legs this way)"""
+    name = "test_640x360"
+    jobs, _, _ = captured(name)
+    g = golden[name]["frame_checksum64"]
+    heads = [pyoracle.blob_header(j) for j in jobs]
+    n, S = len(jobs), 12
+    slots = set(h["cur_slot"] for h in heads)
+    rep = built.Replay(jobs, n_streams=S)
+
+    def lock_step_pass():
+        for i in range(n):
+            rep.run(i, 1)
+            assert [int(x) for x in rep.checksums(heads[i]["cur_slot"])] == [g[i]] * S, i
+
+    def laps(offsets, count):
+        for lap in range(count):
+            rep.run(); rep.sync()
+            sums = {slot: rep.checksums(slot) for slot in slots}
+            for s in range(S):
+                last = (offsets[s] - 1) % n
+                assert int(sums[heads[last]["cur_slot"]][s]) == g[last], (lap, s, last)
+
+    try:
+        lock_step_pass()
+        off = [i for i, h in enumerate(heads) if h["is_idr"] and i > 0][0]
+        rep.reschedule(odd_offset=off)
+        for i in range(n):
+            rep.run(i, 1)
+            p = (i + off) % n
+            assert [int(x) for x in rep.checksums(heads[i]["cur_slot"])[0::2]] == [g[i]] * (S // 2), i
+            assert [int(x) for x in rep.checksums(heads[p]["cur_slot"])[1::2]] == [g[p]] * (S // 2), (i, p)
+        offsets = [(s * n) // S for s in range(S)]
+        rep.reschedule(offsets=offsets, heavy_lanes=2, heavy_delay=3, groups=3)
+        laps(offsets, 2)
+        rep.reschedule(offsets=offsets)                  # common ticks
+        laps(offsets, 2)
+        rep.reschedule()
+        rep.set_groups(4)
+        rep.run(); rep.sync()
+        assert [int(x) for x in rep.checksums(heads[-1]["cur_slot"])] == [g[-1]] * S
+        rep.reschedule()
+        lock_step_pass()
+    finally:
+        rep.close()
+
+
 @pytest.mark.parametrize("name", ["test_640x360", "test_1920x1080_fullRange"])
 def test_on_device_colour_conversion(name, built, captured, golden):
     jobs, _, info = captured(name)
