@@ -1485,44 +1485,58 @@ __device__ __forceinline__ FjMbRec rec_from_lds(const uint32_t *rec_lds)
  * reconstructed), so that the round trip hides behind that work. */
 /* cross: the macroblock lies in the first row of a row band (k_frame_intra): the tiles above were written by another
  * workgroup and are read past the L1 (ld_agent_u8). */
-__device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, const uint32_t *rec_lds, int lane, IntraLoads &L, bool cross = false)
+/* Which neighbour sample a lane fetches for a macroblock is the same for every macroblock of a picture: byte offsets from
+ * the macroblock's tile (the row above lies wmb tiles back) and the availability bit that gates the load, worked out once
+ * per wavefront.  y: lanes 0..20 = corner, 16 above, 4 above-right; lanes 32..47 = the column to the left.  c: lanes 0..17 =
+ * corner + 8 above of both planes; lanes 32..47 = the columns to the left.  (intra_issue used to derive them per macroblock
+ * with a dozen selects per lane class: issuing the loads was 1.4 of the 12.7 k cycles an intra macroblock takes.) */
+struct IntraLaneOffs { int y_off, c_off; uint32_t y_bit, c_bit; int y_at, c_at; };    /* y_at / c_at: where the fetched sample goes in the LDS tiles (-1: nowhere) */
+__device__ __forceinline__ IntraLaneOffs intra_lane_offs(int wmb, int lane)
 {
-    const FjMbRec rec = rec_from_lds(rec_lds);
-    L.nb_y = L.nb_c = 128;
-    L.rows.y = L.rows.c = L.rows.cdc = make_int2(0, 0);
-    L.rows.ldc = 0;
-    if (rec.kind == FJ_MB_IPCM || rec.kind == FJ_MB_CONCEAL_I) return;
-    const uint8_t *Y = fd.cur + (size_t)mb * TILE;       /* neighbours: one tile to the left, wmb tiles up */
-    const ptrdiff_t up = -(ptrdiff_t)fd.wmb * TILE;
-    const bool av_a = rec.avail & FJ_AVAIL_A, av_b = rec.avail & FJ_AVAIL_B, av_c = rec.avail & FJ_AVAIL_C, av_d = rec.avail & FJ_AVAIL_D;
+    IntraLaneOffs o;
+    const int up = -wmb * TILE;
+    o.y_off = 0; o.c_off = 0; o.y_bit = 0u; o.c_bit = 0u;
+    o.y_at = lane < 21 ? 3 + lane : (lane >= 32 && lane < 48) ? (lane - 32 + 1) * TS + 3 : -1;
+    o.c_at = lane < 18 ? (lane / 9) * 144 + lane % 9 : (lane >= 32 && lane < 48) ? ((lane - 32) >> 3) * 144 + (((lane - 32) & 7) + 1) * 16 : -1;
     if (lane < 21) {
-        const int c = lane;                               /* corner, 16 above, 4 above-right: last row of the tiles above */
-        const bool ok = c == 0 ? av_d : c <= 16 ? av_b : av_c;
-        if (ok) {
-            const uint8_t *q = c == 0 ? Y + up - TILE + 255 : c <= 16 ? Y + up + 240 + (c - 1) : Y + up + TILE + 240 + (c - 17);
-            L.nb_y = cross ? (int)ld_agent_u8(q) : (int)*q;
-        }
+        const int c = lane;
+        o.y_bit = c == 0 ? FJ_AVAIL_D : c <= 16 ? FJ_AVAIL_B : FJ_AVAIL_C;
+        o.y_off = c == 0 ? up - TILE + 255 : c <= 16 ? up + 240 + (c - 1) : up + TILE + 240 + (c - 17);
     } else if (lane >= 32 && lane < 48) {
-        if (av_a) L.nb_y = Y[-TILE + (lane - 32) * 16 + 15];   /* last column of the tile to the left */
+        o.y_bit = FJ_AVAIL_A;
+        o.y_off = -TILE + (lane - 32) * 16 + 15;
     }
     if (lane < 18) {
         const int plane = lane / 9, c = lane % 9;
-        const uint8_t *P = Y + T_CB + plane * 64;
-        const bool ok = c == 0 ? av_d : av_b;
-        if (ok) {
-            const uint8_t *q = c == 0 ? P + up - TILE + 63 : P + up + 56 + (c - 1);
-            L.nb_c = cross ? (int)ld_agent_u8(q) : (int)*q;
-        }
+        o.c_bit = c == 0 ? FJ_AVAIL_D : FJ_AVAIL_B;
+        o.c_off = T_CB + plane * 64 + (c == 0 ? up - TILE + 63 : up + 56 + (c - 1));
     } else if (lane >= 32 && lane < 48) {
         const int plane = (lane - 32) >> 3, r = (lane - 32) & 7;
-        if (av_a) L.nb_c = (Y + T_CB + plane * 64)[-TILE + r * 8 + 7];
+        o.c_bit = FJ_AVAIL_A;
+        o.c_off = T_CB + plane * 64 - TILE + r * 8 + 7;
     }
-    L.rows = mb_residual_fetch(rec.coded, fd.coefs + 16 * (size_t)rec.coef_idx, lane);
+    return o;
+}
+
+__device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, const uint32_t *rec_lds, int lane, IntraLoads &L, const IntraLaneOffs &lo, bool cross = false)
+{
+    /* only the head of the record (kind, availability) and its coefficient fields are needed here */
+    const uint32_t head = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_lds[0]);
+    const uint32_t coded = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_lds[2]), coef_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_lds[3]);
+    const uint32_t kind = head & 255u, avail = head >> 24;
+    L.nb_y = L.nb_c = 128;
+    L.rows.y = L.rows.c = L.rows.cdc = make_int2(0, 0);
+    L.rows.ldc = 0;
+    if (kind == FJ_MB_IPCM || kind == FJ_MB_CONCEAL_I) return;
+    const uint8_t *Y = fd.cur + (size_t)mb * TILE;
+    if (avail & lo.y_bit) L.nb_y = cross && lane < 21 ? (int)ld_agent_u8(Y + lo.y_off) : (int)Y[lo.y_off];
+    if (avail & lo.c_bit) L.nb_c = cross && lane < 18 ? (int)ld_agent_u8(Y + lo.c_off) : (int)Y[lo.c_off];
+    L.rows = mb_residual_fetch(coded, fd.coefs + 16 * (size_t)coef_idx, lane);
 }
 
 __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0,
-                                         const uint4 *i4tab, const uint32_t *rec_lds, const IntraLoads &L, bool wt, int16_t *res_defer = nullptr,
-                                         unsigned long long *tp = nullptr)
+                                         const uint4 *i4tab, const uint32_t *rec_lds, const IntraLoads &L, const IntraLaneOffs &lo, bool wt,
+                                         int16_t *res_defer = nullptr, unsigned long long *tp = nullptr)
 {
 #define ITICK() (tp ? __builtin_readcyclecounter() : 0ull)
     const unsigned long long i0 = ITICK();
@@ -1542,8 +1556,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
 
     const bool av_a = rec.avail & FJ_AVAIL_A, av_b = rec.avail & FJ_AVAIL_B, av_c = rec.avail & FJ_AVAIL_C;
     /* where the prefetched neighbour samples (intra_issue) go in the tiles */
-    const int nb_y_at = lane < 21 ? 3 + lane : (lane >= 32 && lane < 48) ? (lane - 32 + 1) * TS + 3 : -1;
-    const int nb_c_at = lane < 18 ? (lane / 9) * 144 + lane % 9 : (lane >= 32 && lane < 48) ? ((lane - 32) >> 3) * 144 + (((lane - 32) & 7) + 1) * 16 : -1;
+    const int nb_y_at = lo.y_at, nb_c_at = lo.c_at;
     const int nb_y = L.nb_y, nb_c = L.nb_c;
 
     int ry[4], rc[4];
@@ -1565,9 +1578,20 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
         } else if (mode == 1) {
             pr[0] = pr[1] = pr[2] = pr[3] = left[y * TS];
         } else if (mode == 2) {
-            int st = 0, sl = 0;
-#pragma unroll
-            for (int i = 0; i < 16; i++) { st += top[i]; sl += left[i * TS]; }
+            /* the sixteen samples above as four dwords summed by byte dot products; of the sixteen to the left every lane of a
+             * 16-lane row reads ONE and the row adds them up (four rotating DPP adds): 14 instructions where 32 byte reads and
+             * 32 adds per lane used to produce the same number in all 64 lanes */
+            const uint32_t *tw = reinterpret_cast<const uint32_t *>(top);
+            uint32_t stu = __builtin_amdgcn_udot4(tw[0], 0x01010101u, 0u, false);
+            stu = __builtin_amdgcn_udot4(tw[1], 0x01010101u, stu, false);
+            stu = __builtin_amdgcn_udot4(tw[2], 0x01010101u, stu, false);
+            stu = __builtin_amdgcn_udot4(tw[3], 0x01010101u, stu, false);
+            int sl = (int)left[(lane & 15) * TS];
+            sl += __builtin_amdgcn_update_dpp(0, sl, 0x128, 0xF, 0xF, false);      /* row_ror:8 */
+            sl += __builtin_amdgcn_update_dpp(0, sl, 0x124, 0xF, 0xF, false);      /* row_ror:4 */
+            sl += __builtin_amdgcn_update_dpp(0, sl, 0x122, 0xF, 0xF, false);      /* row_ror:2 */
+            sl += __builtin_amdgcn_update_dpp(0, sl, 0x121, 0xF, 0xF, false);      /* row_ror:1 */
+            const int st = (int)stu;
             const int dc = (av_a && av_b) ? (st + sl + 16) >> 5 : av_a ? (sl + 8) >> 4 : av_b ? (st + 8) >> 4 : 128;
             pr[0] = pr[1] = pr[2] = pr[3] = dc;
         } else {
@@ -2264,6 +2288,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
     unsigned long long *const tp = nullptr;        /* (the cycle accounting costs registers in a loop that has none to spare: -DH264K_TAIL_PROFILE builds it, tools/prof_tail.py) */
     (void)prof;
 #endif
+    const IntraLaneOffs lane_offs = intra_lane_offs(wmb, lane);
     unsigned long long t_idle = 0, t_work = 0, t_rel = 0, t_rec = 0, n_done = 0, t_mark = tp ? __builtin_readcyclecounter() : 0ull;
     /* Pull model: a free wavefront takes up to FOUR ready macroblocks at once.  Each is prepared by the whole wavefront
      * in turn (neighbours, residual, chroma; Intra16x16 / I_PCM / concealed macroblocks completely); the luma of the
@@ -2338,7 +2363,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
         IntraLoads cur_loads, next_loads;
         {
             const int mb0 = __builtin_amdgcn_readfirstlane(__shfl(v, 0));
-            intra_issue(fd, (uint32_t)mb0, rec_lds, lane, cur_loads, BANDED && mb0 >= cross_lo && mb0 < cross_hi);
+            intra_issue(fd, (uint32_t)mb0, rec_lds, lane, cur_loads, lane_offs, BANDED && mb0 >= cross_lo && mb0 < cross_hi);
         }
         for (uint32_t j = 0; j < k; j++) {
             const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(v, (int)j));
@@ -2348,14 +2373,14 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
             uint8_t *slot = my + j * INTRA_SLOT;
             if (j + 1 < k) {
                 const int mbn = __builtin_amdgcn_readfirstlane(__shfl(v, (int)j + 1));
-                intra_issue(fd, (uint32_t)mbn, rec_lds + 8 * (j + 1), lane, next_loads, BANDED && mbn >= cross_lo && mbn < cross_hi);
+                intra_issue(fd, (uint32_t)mbn, rec_lds + 8 * (j + 1), lane, next_loads, lane_offs, BANDED && mbn >= cross_lo && mbn < cross_hi);
             }
             /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
             if (kind == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
             else if (kind == FJ_MB_I4x4 && k > 1) {
-                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, wt, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512), tp);
+                intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, lane_offs, wt, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512), tp);
                 if ((uint32_t)(lane >> 4) == j) joint_mb = (int)mb;
-            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, wt, nullptr, tp);
+            } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, lane_offs, wt, nullptr, tp);
             if (j + 1 < k) cur_loads = next_loads;
         }
         if (__ballot(joint_mb >= 0) != 0ull) intra4_joint(fd, joint_mb, lane, my, i4tab, BANDED && joint_mb >= wt_lo);
