@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads", "h264bsdmiSetInputReadOnly", "h264bsdmiSetCopyElision",
     "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayCreateSched", "h264bsdmiReplayReschedule", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
-    "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiDebugSetTail", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
+    "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiDebugSetTail", "h264bsdmiDebugDeviceErrorEvents", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
 ]
 
 class DevicePicture(ctypes.Structure):
@@ -174,6 +174,13 @@ def device_errors():
     L = lib()
     L.h264bsdmiDeviceErrors.restype = ctypes.c_uint
     return int(L.h264bsdmiDeviceErrors())
+
+
+def device_error_events():
+    """how often a tripwire of the kernels has fired since the library was loaded (monotonic; bench library)"""
+    L = lib()
+    L.h264bsdmiDebugDeviceErrorEvents.restype = ctypes.c_uint
+    return int(L.h264bsdmiDebugDeviceErrorEvents())
 
 
 class Decoder:

@@ -29,6 +29,24 @@ typedef struct ApiDec {
     void *cb_user;
 } ApiDec;
 
+/* Every H264BSDMI_* variable this library reads (tests/test_abi.py compares the list with the sources and INTEGRATION.md).  A
+ * variable of that family that is NOT in the list — a typing error, or a switch of an earlier release — is named on stderr when
+ * the library is loaded instead of being silently ignored. */
+extern char **environ;
+__attribute__((constructor)) static void report_unknown_switches(void)
+{
+    static const char *const known[] = { "H264BSDMI_LANES", "H264BSDMI_TAIL", "H264BSDMI_BAND_BUDGET", "H264BSDMI_HEAVY_BUDGET", "H264BSDMI_TRACE_LANES",
+                                         "H264BSDMI_COPY_ELISION", "H264BSDMI_THREADS", "H264BSDMI_HOST_SHARE", "H264BSDMI_PIN", NULL };
+    for (char **e = environ; e && *e; e++) {
+        if (strncmp(*e, "H264BSDMI_", 10) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
+        int ok = 0;
+        for (int k = 0; known[k] && !ok; k++) ok = strlen(known[k]) == len && strncmp(known[k], *e, len) == 0;
+        if (!ok) fprintf(stderr, "h264bsd-mi355x: unknown environment switch %.*s ignored (INTEGRATION.md lists the ones this library reads)\n", (int)len, *e);
+    }
+}
+
 static ApiDec *dec_of(storage_t *s) { return s ? (ApiDec *)s->opaque : NULL; }
 
 /* ---- capture sink ---- */
@@ -64,6 +82,7 @@ static u32 init_common(storage_t *s, u32 no_reorder, h264bsdmi_job_cb cb, void *
          * (hostdec.h, copy elision).  H264BSDMI_COPY_ELISION=0 switches it off for the process. */
         const char *e = getenv("H264BSDMI_COPY_ELISION");
         a->hd->copy_elision = !(e && *e == '0');
+        a->hd->sink_errors_at_start = a->hd->sink.errors ? a->hd->sink.errors(a->hd->sink.user) : 0;
     }
     s->opaque = a;
     return HANTRO_OK;
@@ -417,10 +436,22 @@ static long usable_cpus(void)
     return n < 1 ? 1 : n;
 }
 
+/* Processes that share this host's CPUs, one per GPU (the usual multi-GPU launch): every one of them sizes its
+ * parser pool for ITS share of the CPUs the container may use — eight ranks that each start usable_cpus() threads only take
+ * turns.  H264BSDMI_HOST_SHARE says how many; without it the launcher's LOCAL_WORLD_SIZE (torch.distributed.run, mpirun
+ * wrappers) is taken. */
+static long host_share(void)
+{
+    const char *e = getenv("H264BSDMI_HOST_SHARE");
+    if (!e || !*e) e = getenv("LOCAL_WORLD_SIZE");
+    const long n = e ? atol(e) : 1;
+    return n < 1 ? 1 : n > 64 ? 64 : n;
+}
+
 static int pool_default_threads(void)
 {
     const char *e = getenv("H264BSDMI_THREADS");
-    long n = e ? atol(e) : usable_cpus();
+    long n = e ? atol(e) : (usable_cpus() + host_share() - 1) / host_share();
     if (n < 1) n = 1;
     if (n > 64) n = 64;
     return (int)n;

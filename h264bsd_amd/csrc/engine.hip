@@ -68,15 +68,11 @@ struct StreamCtx {
 };
 
 /* k_dbk (boundary strengths) needs only the frame job, not pixels: it runs on a second HIP stream next to the
- * reconstruction kernels of the same tick and joins before k_frame_dbk (measured: 245.2 -> 237.5 ms per step).
- * Putting k_copy there as well was tried and lost (it competes with k_recon_inter for the memory system). */
-#ifndef DBK_AT_INTRA_DEFAULT
-#define DBK_AT_INTRA_DEFAULT false
-#endif
-#ifndef DBK_AT_INTER_DEFAULT
-#define DBK_AT_INTER_DEFAULT false
-#endif
-struct SideLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join_copy = nullptr; };
+ * reconstruction kernels of the same tick and joins before k_frame_dbk (measured: 245.2 -> 237.5 ms per step).  Every other
+ * placement that was measured — k_copy on the side stream as well, k_dbk forked behind k_copy or behind the inter kernels,
+ * k_dbk of the NEXT tick next to this tick's per-picture kernels — kept the sum or lost (docs/EXPERIMENTS.md); those
+ * variants are not in the product. */
+struct SideLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 
 /* A lane = one HIP stream that runs ticks one after the other, with its own device arena for the frame jobs of a tick
  * and its own descriptor staging.  Light lanes: one per stream group (decoder instances are dealt round-robin to the
@@ -113,9 +109,10 @@ constexpr unsigned CONVERT_WGS = CONVERT_WGS_N;      /* workgroups per picture o
 /* Under lane scheduling a k_frame_dbk workgroup shares its compute unit with the other lanes' kernels: 8 wavefronts
  * hold less of the register file than the 12 that are best when a tick has the GPU to itself (desynchronised replay
  * with 9 groups: 763 vs 734 M MB/s; lock-step, single lane: 12 wavefronts 54.9 ms per step, 8: 56.8). */
-constexpr uint32_t LANE_DBK_WAVES_DEFAULT = 8;
-static uint32_t lane_dbk_waves() { const char *e = getenv("H264BSDMI_LANE_DBK_WAVES"); const uint32_t v = e ? (uint32_t)atoi(e) : 0u; return v ? v : LANE_DBK_WAVES_DEFAULT; }
-#define LANE_DBK_WAVES lane_dbk_waves()
+#ifndef LANE_DBK_WAVES_N
+#define LANE_DBK_WAVES_N 8
+#endif
+constexpr uint32_t LANE_DBK_WAVES = LANE_DBK_WAVES_N;
 
 struct Engine {
     std::mutex mu;
@@ -132,7 +129,9 @@ struct Engine {
     /* device error word (DEVERR_* bits, kernels.hip.h): the kernels OR into d_err, poll_errors() folds it into `errors`
      * whenever the host has waited for the device anyway */
     uint32_t *d_err = nullptr, *h_err = nullptr;
-    uint32_t errors = 0;
+    uint32_t errors = 0;                       /* sticky bits (written with __atomic_fetch_or under mu, read without the lock) */
+    uint32_t error_events = 0;                 /* how often a tripwire fired, ever: monotonic, so that a NEW occurrence of a bit that is
+                                                  already set is visible (per-decoder copy-elision guard, the tests' delta) */
     unsigned long long *tail_prof = nullptr;   /* debug: per-wave cycle accounting of the per-picture kernels (block 0) */
 };
 
@@ -259,18 +258,16 @@ Engine *engine_get(int device = -1)
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return nullptr; }
     if (hipEventCreateWithFlags(&e->inflight_done, hipEventDisableTiming) != hipSuccess ||
         [&] {   /* the side stream (k_dbk next to the copy and inter kernels) gets the highest priority the device has: its few workgroups
-                  * must not queue behind the hundred thousand of k_recon_inter (H264BSDMI_SIDE_PRIO=0: default priority) */
+                  * must not queue behind the hundred thousand of k_recon_inter */
             int lo = 0, hi = 0;
-            const bool prio = !(getenv("H264BSDMI_SIDE_PRIO") && atoi(getenv("H264BSDMI_SIDE_PRIO")) == 0);
-            if (!prio || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(&e->side.stream, hipStreamNonBlocking);
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(&e->side.stream, hipStreamNonBlocking);
             return hipStreamCreateWithPriority(&e->side.stream, hipStreamNonBlocking, hi);
         }() != hipSuccess ||
         hipEventCreateWithFlags(&e->side.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->side.join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->side.join_copy, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&e->d_err, 256) != hipSuccess || hipMemset(e->d_err, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||   /* (hipMemset returns before the fill has run) */
         hipHostMalloc((void **)&e->h_err, 64, hipHostMallocDefault) != hipSuccess) { delete e; return nullptr; }
-    *e->h_err = 0;
+    e->h_err[0] = e->h_err[1] = 0;
     g_engines[device] = e;
     return e;
 }
@@ -432,8 +429,8 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
 struct TickTimers { hipEvent_t ev[6]; hipEvent_t sev[3] = { nullptr, nullptr, nullptr }; bool on = false; unsigned mask = 31u; };   /* mask bit k: kernel k of KERNELS is timed */   /* boundaries of the 5 kernels of a tick; sev = k_copy, k_dbk on the side stream */
 
 /* k_dbk of one tick on the side stream (which must already wait for whatever frees the tick's deblocking scratch);
- * records the join event of the scratch buffer `parity` behind it */
-static int launch_kdbk_aside(const SideLane *side, int parity, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5], unsigned stages)
+ * records the join event behind it */
+static int launch_kdbk_aside(const SideLane *side, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5], unsigned stages)
 {
     const bool do_dbk = (stages & 4u) && s.any_deblock && s.max_dbk;
     const bool timed = tt && tt->on && (tt->mask & 4u);
@@ -443,19 +440,12 @@ static int launch_kdbk_aside(const SideLane *side, int parity, const FrameDesc *
         if (launches) launches[2]++;
     }
     if (timed && tt->sev[2]) HIP_TRY(hipEventRecord(tt->sev[2], side->stream));
-    HIP_TRY(hipEventRecord(parity ? side->join_copy : side->join, side->stream));
+    HIP_TRY(hipEventRecord(side->join, side->stream));
     return 0;
 }
 
-/* "k_dbk ahead" (replay sets): the boundary strengths of tick i+1 need nothing but its frame job, so they are computed
- * while tick i is in its two per-picture kernels — whose wavefronts wait for their dependency chains half of the time —
- * instead of next to the copy and inter kernels of their own tick, which are bound by instruction issue and lose a
- * quarter of it to k_dbk.  The deblocking scratch is double-buffered for this (parity = tick & 1). */
-struct AheadDbk { const FrameDesc *next_desc; const TickShape *next_shape; TickTimers *next_tt; int parity; };
-
 int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, TickTimers *tt, uint32_t launches[5],
-                unsigned stages = 7u, const SideLane *side = nullptr, unsigned long long *prof = nullptr, const AheadDbk *ahead = nullptr,
-                hipEvent_t after_lists = nullptr)       /* recorded behind the list-driven kernels (copy, inter, strengths): the stream groups' ring */
+                unsigned stages = 7u, const SideLane *side = nullptr, unsigned long long *prof = nullptr)
 {
     const bool timed = tt && tt->on;
     const unsigned tmask = timed ? tt->mask : 0u;
@@ -463,64 +453,29 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     if (EV_NEEDED(0)) HIP_TRY(hipEventRecord(tt->ev[0], st));
     const bool do_dbk = (stages & 4u) && s.any_deblock && s.max_dbk;
     const bool do_copy = (stages & 1u) && s.max_copy;
-    const bool use_ahead = ahead && side && side->stream;        /* this tick's k_dbk was launched by the tick before it (or the caller) */
-    const bool aside = !use_ahead && side && side->stream && do_dbk;
-    static const bool copy_aside_env = getenv("H264BSDMI_COPY_ASIDE") && atoi(getenv("H264BSDMI_COPY_ASIDE")) != 0;
-    const bool copy_aside = copy_aside_env && aside && do_copy;       /* experiment: k_copy (bound by HBM) next to k_recon_inter (bound by issue and latency) */
-    /* where k_dbk runs: "lists" = next to the copy and inter kernels from the start of the tick (rounds 1-3), "intra" = next to
-     * k_frame_intra (whose P-picture ticks leave the device nearly idle), forked behind the inter kernels.  H264BSDMI_DBK_AT */
-    static const bool dbk_late = [] { const char *v = getenv("H264BSDMI_DBK_AT"); return v ? !strcmp(v, "intra") : DBK_AT_INTRA_DEFAULT; }();
-    /* "inter": forked behind k_copy — the copy kernel (bound by HBM) runs alone, k_dbk next to the inter kernels only */
-    static const bool dbk_mid = [] { const char *v = getenv("H264BSDMI_DBK_AT"); return v ? !strcmp(v, "inter") : DBK_AT_INTER_DEFAULT; }();
-    if (aside && !dbk_late && !(dbk_mid && do_copy && !copy_aside)) {
+    const bool aside = side && side->stream && do_dbk;
+    if (aside) {
         HIP_TRY(hipEventRecord(side->fork, st));                 /* after the previous tick's k_frame_dbk: the records are free */
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-        if (copy_aside) {
-            hipLaunchKernelGGL(h264k::k_copy, dim3(std::min<uint32_t>((s.max_copy + 3) / 4, COPY_WGS), s.n_frames), dim3(256), 0, side->stream, d_desc);
-            if (launches) launches[0]++;
-            HIP_TRY(hipEventRecord(side->join_copy, side->stream));
-        }
-        if (launch_kdbk_aside(side, 0, d_desc, s, tt, launches, stages)) return -1;
+        if (launch_kdbk_aside(side, d_desc, s, tt, launches, stages)) return -1;
     }
-    if (do_copy && !copy_aside) {
+    if (do_copy) {
         hipLaunchKernelGGL(h264k::k_copy, dim3(std::min<uint32_t>((s.max_copy + 3) / 4, COPY_WGS), s.n_frames), dim3(256), 0, st, d_desc);   /* COPY_WGS workgroups per picture walk its run list */
         if (launches) launches[0]++;
     }
     if (EV_NEEDED(1)) HIP_TRY(hipEventRecord(tt->ev[1], st));
-    if (aside && !dbk_late && dbk_mid && do_copy && !copy_aside) {
-        HIP_TRY(hipEventRecord(side->fork, st));
-        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-        if (launch_kdbk_aside(side, 0, d_desc, s, tt, launches, stages)) return -1;
-    }
     if ((stages & 1u) && s.max_gen) {
-#if INTER_NMB > 1
-        if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_uni, dim3((s.max_gen_uni + 4 * INTER_NMB - 1) / (4 * INTER_NMB), s.n_frames), dim3(256), 0, st, d_desc);
-#else
         if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_inter<0>, dim3((s.max_gen_uni + INTER_WG_WAVES - 1) / INTER_WG_WAVES, s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
-#endif
         if (s.max_gen_quad) hipLaunchKernelGGL(h264k::k_recon_inter<1>, dim3((s.max_gen_quad + INTER_WG_WAVES - 1) / INTER_WG_WAVES, s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
         if (s.max_gen_rest) hipLaunchKernelGGL(h264k::k_recon_inter<2>, dim3((s.max_gen_rest + INTER_WG_WAVES - 1) / INTER_WG_WAVES, s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
         if (launches) launches[1]++;
     }
-    if (aside && dbk_late) {
-        HIP_TRY(hipEventRecord(side->fork, st));
-        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-        if (launch_kdbk_aside(side, 0, d_desc, s, tt, launches, stages)) return -1;
-    }
     if (EV_NEEDED(2)) HIP_TRY(hipEventRecord(tt->ev[2], st));
-    if (use_ahead && ahead->next_desc) {
-        /* the next tick's strengths go into the other scratch buffer, which the PREVIOUS tick's k_frame_dbk has left by now */
-        HIP_TRY(hipEventRecord(side->fork, st));
-        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-        if (launch_kdbk_aside(side, ahead->parity ^ 1, ahead->next_desc, *ahead->next_shape, ahead->next_tt, launches, stages)) return -1;
-    }
-    if (do_dbk && !aside && !use_ahead) {
+    if (do_dbk && !aside) {
         hipLaunchKernelGGL(h264k::k_dbk, dim3(std::min<uint32_t>((s.max_dbk + 4 * DBK_WG_WAVES - 1) / (4 * DBK_WG_WAVES), DBK_WGS * 4 / DBK_WG_WAVES), s.n_frames), dim3(64 * DBK_WG_WAVES), 0, st, d_desc);
         if (launches) launches[2]++;
     }
-    if (copy_aside) HIP_TRY(hipStreamWaitEvent(st, side->join_copy, 0));      /* intra prediction reads copied neighbours */
     if (EV_NEEDED(3)) HIP_TRY(hipEventRecord(tt->ev[3], st));
-    if (after_lists) HIP_TRY(hipEventRecord(after_lists, st));
     /* The two per-picture kernels keep per-macroblock scheduling state in LDS next to their wavefronts' tiles: for
      * pictures that leave less than 16 wavefronts' worth of tile space in the 160 KB of a CU, fewer wavefronts run. */
     constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
@@ -583,7 +538,6 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     }
     if (EV_NEEDED(4)) HIP_TRY(hipEventRecord(tt->ev[4], st));
     if (aside) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
-    if (use_ahead) HIP_TRY(hipStreamWaitEvent(st, ahead->parity ? side->join_copy : side->join, 0));
     if (s.any_deblock && (stages & 4u)) {
         BandPlan bp;
         if (plan(0, std::max<uint32_t>(1u, std::min<uint32_t>(s.dbk_waves ? s.dbk_waves : tc.dbk_waves, h264k::DBK_WAVES)), h264k::dbk_lds_bytes, true, bp)) {
@@ -618,14 +572,15 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
 /* Fold the device error word into the engine's sticky error bits.  Called where the host waits for the stream anyway. */
 int poll_errors(Engine *e)
 {
-    HIP_TRY(hipMemcpyAsync(e->h_err, e->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_err, e->d_err, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    const uint32_t fresh = *e->h_err & ~e->errors;
+    const uint32_t fresh = e->h_err[0] & ~e->errors;
+    __atomic_store_n(&e->error_events, e->h_err[1], __ATOMIC_RELAXED);
     if (fresh) {
         fprintf(stderr, "h264bsd-mi355x: DEVICE ERROR 0x%x:%s%s%s — pixels of the affected pictures are not trustworthy\n", fresh,
                 (fresh & DEVERR_RESIDUAL_RANGE) ? " residual outside [-512,511] reached the kernels (host check missed it)" : "",
                 (fresh & DEVERR_INTRA_SCHED) ? " k_frame_intra scheduler gave up" : "", (fresh & DEVERR_DBK_SCHED) ? " k_frame_dbk scheduler gave up" : "");
-        e->errors |= fresh;
+        __atomic_fetch_or(&e->errors, fresh, __ATOMIC_RELAXED);
         tickets_rezero(e->device);
     }
     return 0;
@@ -681,9 +636,7 @@ static int lane_launch(Engine *e, unsigned lane_idx, const std::vector<StreamCtx
     if (l.ticks >= 2) HIP_TRY(hipEventSynchronize(l.desc_ev[l.flip]));
     FrameDesc *descs = l.h_desc + (size_t)l.flip * l.desc_cap;
     h264k::H2dItem *items = l.h_items + (size_t)l.flip * l.desc_cap;
-    /* how the jobs reach the device: one k_h2d launch that reads the pinned staging buffers (default), or one hipMemcpyAsync
-     * per job (H264BSDMI_H2D=memcpy) */
-    static const bool h2d_kernel = [] { const char *v = getenv("H264BSDMI_H2D"); return !(v && !strcmp(v, "memcpy")); }();
+    /* how the jobs reach the device: one k_h2d launch that reads the pinned staging buffers (256 hipMemcpyAsync calls per tick before) */
     TickShape shape;
     size_t off = 0;
     std::vector<std::pair<int, unsigned long long>> waited;
@@ -698,15 +651,14 @@ static int lane_launch(Engine *e, unsigned lane_idx, const std::vector<StreamCtx
                 waited.push_back(key);
             }
         }
-        if (h2d_kernel) items[i] = h264k::H2dItem{ j.dev, l.d_arena + off, j.bytes, 0u };
-        else HIP_TRY(hipMemcpyAsync(l.d_arena + off, j.host, j.bytes, hipMemcpyHostToDevice, l.st));
+        items[i] = h264k::H2dItem{ j.dev, l.d_arena + off, j.bytes, 0u };
         make_desc(descs[i], j.host, l.d_arena + off, s->d_frames, s->frame_bytes, s->d_dbk, &shape, e->d_err);
         off += (j.bytes + 255u) & ~255u;
         e->inflight.emplace_back(s, j);
         e->inflight_recorded = false;
         s->last_lane = (int)lane_idx; s->last_launch = l.launches;
     }
-    if (h2d_kernel) hipLaunchKernelGGL(h264k::k_h2d, dim3(h264k::H2D_CHUNKS, (uint32_t)part.size()), dim3(256), 0, l.st, l.dv_items + (size_t)l.flip * l.desc_cap);
+    hipLaunchKernelGGL(h264k::k_h2d, dim3(h264k::H2D_CHUNKS, (uint32_t)part.size()), dim3(256), 0, l.st, l.dv_items + (size_t)l.flip * l.desc_cap);
     HIP_TRY(hipMemcpyAsync(l.d_desc, descs, part.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, l.st));
     HIP_TRY(hipEventRecord(l.desc_ev[l.flip], l.st));
     l.flip ^= 1;
@@ -880,11 +832,12 @@ int sink_submit(void *user, const uint8_t *blob, uint32_t bytes)
     return 0;
 }
 
-/* the engine's sticky error bits as last folded in (poll_errors runs wherever the host waits for the device): no wait here */
+/* how often a tripwire of the kernels has fired on this device, as last folded in (poll_errors runs wherever the host waits for the
+ * device): no wait here.  Monotonic: a decoder compares it with the value it saw when it was created */
 uint32_t sink_errors(void *user)
 {
     SinkUser *u = static_cast<SinkUser *>(user);
-    return __atomic_load_n(&u->e->errors, __ATOMIC_RELAXED);
+    return __atomic_load_n(&u->e->error_events, __ATOMIC_RELAXED);
 }
 
 uint8_t *sink_fetch(void *user, uint32_t slot)
@@ -1080,6 +1033,22 @@ unsigned h264bsdmiDeviceErrors(void)
     return all;
 }
 
+/* test harness (bench library): tripwire events of all devices so far, after waiting for the devices — monotonic, unlike the
+ * sticky bits of h264bsdmiDeviceErrors(): a test asserts that its own pictures added none */
+unsigned h264bsdmiDebugDeviceErrorEvents(void)
+{
+    unsigned all = 0;
+    for (int d = 0; d < MAX_DEVICES; d++) {
+        Engine *e;
+        { std::lock_guard<std::mutex> lk(g_engine_mu); e = g_engines[d]; }
+        if (!e) continue;
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (hipSetDevice(e->device) != hipSuccess || poll_errors(e)) return 0xFFFFFFFFu;
+        all += e->error_events;
+    }
+    return all;
+}
+
 static int flush_all(bool wait)
 {
     int rc = 0, any = 0;
@@ -1122,10 +1091,7 @@ struct h264bsdmi_replay {
     uint32_t n_groups;
     hipStream_t gstream[8];
     hipEvent_t gdone[8];
-    hipEvent_t gring[8];            /* ring of the stream groups: group g has finished the list-driven kernels of its current tick */
-    bool group_ring = false;
     bool overlap_dbk = true;
-    bool dbk_ahead = false;           /* lock-step / staggered sets: k_dbk of tick i+1 next to the per-picture kernels of tick i (AheadDbk) */
     unsigned timed_mask = 31u;
     /* desynchronised sets with heavy lanes (h264bsdmiReplayCreateDesync, lanes > 0): a static launch schedule */
     struct Launch { size_t first; TickShape shape; int lane; std::vector<int> waits; int record_ev; bool light; };
@@ -1156,7 +1122,7 @@ static bool replay_schedule(h264bsdmi_replay *r, u32 heavy_lanes, u32 heavy_dela
 {
     Engine *e = r->e;
     const u32 n_pics = r->n_pics, n_streams = r->n_streams;
-    const size_t total = r->blob_stride, frames_per_stream = r->frames_per_stream, dbk_half = r->dbk_half, dbk_stride = r->dbk_stride;
+    const size_t total = r->blob_stride, frames_per_stream = r->frames_per_stream, dbk_stride = r->dbk_stride;
     const std::vector<size_t> &offs = r->blob_off;
     auto blob_of = [&](u32 p) { return reinterpret_cast<const uint8_t *>(&r->heads[p]); };     /* make_desc reads the header only */
     bool ok = true;
@@ -1172,7 +1138,7 @@ static bool replay_schedule(h264bsdmi_replay *r, u32 heavy_lanes, u32 heavy_dela
         std::vector<FrameDesc> descs((size_t)n_pics * n_streams);
         auto desc_of = [&](FrameDesc &d, u32 s, u32 p, TickShape *shape, u32 tick = 0) {
             make_desc(d, blob_of(p), r->d_blobs + (size_t)s * total + offs[p], r->d_frames + (size_t)s * frames_per_stream,
-                      r->frame_bytes, r->d_dbk + (size_t)s * dbk_stride + (tick & 1u) * dbk_half, shape, e->d_err);
+                      r->frame_bytes, r->d_dbk + (size_t)s * dbk_stride, shape, e->d_err);
         };
         if (!heavy_lanes && groups <= 1) {
             for (u32 i = 0; i < n_pics; i++) {
@@ -1354,7 +1320,7 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
     r->blob_off = offs;
     r->d_blobs = nullptr; r->d_frames = nullptr; r->d_desc = nullptr; r->d_conv = nullptr; r->d_sums = nullptr; r->d_dbk = nullptr;
     const size_t frames_per_stream = (size_t)r->n_slots * r->frame_bytes;
-    const size_t dbk_half = (DBK_SCRATCH_BYTES(h0->n_mbs) + 255) & ~(size_t)255, dbk_stride = 2 * dbk_half;   /* two buffers per stream: "k_dbk ahead" */
+    const size_t dbk_half = (DBK_SCRATCH_BYTES(h0->n_mbs) + 255) & ~(size_t)255, dbk_stride = dbk_half;
     r->frames_per_stream = frames_per_stream; r->dbk_half = dbk_half; r->dbk_stride = dbk_stride;
     bool ok = hipMalloc((void **)&r->d_blobs, total * n_streams) == hipSuccess &&
               hipMalloc((void **)&r->d_frames, frames_per_stream * n_streams + 256) == hipSuccess &&
@@ -1384,11 +1350,8 @@ h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *
                  hipEventCreateWithFlags(&r->gdone_any, hipEventDisableTiming) == hipSuccess;
     r->timed_first = r->timed_count = 0;
     r->stages = 7u;
-    r->dbk_ahead = getenv("H264BSDMI_AHEAD") != nullptr;       /* measured: 128.2 vs 126.4 ms per step — it moves k_dbk's instructions from one
-                                                                    instruction-bound phase into another (kept as an experiment) */
     r->n_groups = 1;
-    for (int g = 0; g < 8; g++) { r->gstream[g] = nullptr; r->gdone[g] = nullptr; r->gring[g] = nullptr; }
-    r->group_ring = getenv("H264BSDMI_GROUP_RING") && atoi(getenv("H264BSDMI_GROUP_RING")) != 0;     /* measured: the ring loses (1388 / 1416 vs 1435 / 1484 M MB/s with 2 / 4 groups): off unless asked for */
+    for (int g = 0; g < 8; g++) { r->gstream[g] = nullptr; r->gdone[g] = nullptr; }
     if (!ok) {
         fprintf(stderr, "h264bsd-mi355x: h264bsdmiReplayCreate failed (%s)\n", hipGetErrorString(hipGetLastError()));
         if (r->d_blobs) hipFree(r->d_blobs);
@@ -1413,7 +1376,7 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     if (r->d_planar) hipFree(r->d_planar);
     for (auto &t : r->timers) for (auto &ev : t.ev) hipEventDestroy(ev);
     hipEventDestroy(r->ev_begin); hipEventDestroy(r->ev_end); if (r->gdone_any) hipEventDestroy(r->gdone_any);
-    for (int g = 0; g < 8; g++) { if (r->gstream[g]) { tickets_release(r->gstream[g]); hipStreamDestroy(r->gstream[g]); } if (r->gdone[g]) hipEventDestroy(r->gdone[g]); if (r->gring[g]) hipEventDestroy(r->gring[g]); }
+    for (int g = 0; g < 8; g++) { if (r->gstream[g]) { tickets_release(r->gstream[g]); hipStreamDestroy(r->gstream[g]); } if (r->gdone[g]) hipEventDestroy(r->gdone[g]); }
     for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
     for (auto &ev : r->cev) hipEventDestroy(ev);
     for (auto &st : r->lanes) if (st) { tickets_release(st); hipStreamDestroy(st); }
@@ -1445,7 +1408,6 @@ int h264bsdmiReplayReschedule(h264bsdmi_replay *r, const u32 *offsets, u32 heavy
         if (sl.stream) hipStreamDestroy(sl.stream);
         if (sl.fork) hipEventDestroy(sl.fork);
         if (sl.join) hipEventDestroy(sl.join);
-        if (sl.join_copy) hipEventDestroy(sl.join_copy);
         sl = SideLane();
     }
     r->n_lanes = r->n_light = 0;
@@ -1491,17 +1453,9 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
             HIP_TRY(hipStreamWaitEvent(r->e->stream, r->gdone_any, 0));
         }
     } else if (r->n_groups <= 1) {
-        const bool ahead_on = r->overlap_dbk && !(r->stages & 8u) && r->dbk_ahead && count > 0;
         for (u32 i = first; i < first + count; i++) { r->timers[i].on = true; r->timers[i].mask = r->timed_mask; }
-        if (ahead_on) {                                       /* the first tick's strengths: nothing to hide behind yet */
-            HIP_TRY(hipEventRecord(r->e->side.fork, r->e->stream));
-            HIP_TRY(hipStreamWaitEvent(r->e->side.stream, r->e->side.fork, 0));
-            if (launch_kdbk_aside(&r->e->side, (int)(first & 1u), r->d_desc + (size_t)first * r->n_streams, r->shapes[first], &r->timers[first], r->launches, r->stages)) return -1;
-        }
         for (u32 i = first; i < first + count; i++) {
-            AheadDbk ah = { nullptr, nullptr, nullptr, (int)(i & 1u) };
-            if (i + 1 < first + count) { ah.next_desc = r->d_desc + (size_t)(i + 1) * r->n_streams; ah.next_shape = &r->shapes[i + 1]; ah.next_tt = &r->timers[i + 1]; }
-            if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr, r->e->tail_prof, ahead_on ? &ah : nullptr)) return -1;
+            if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr, r->e->tail_prof)) return -1;
             if (r->convert_fmt >= 0) {
                 /* the picture every stream has just produced, converted where it lies (tiles -> packed 32-bit pixels) */
                 const uint32_t w = r->wmb * 16, h = r->hmb * 16;
@@ -1527,14 +1481,10 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
                 sh.load = r->n_streams;
                 TickTimers &tt = r->timers[(size_t)g * r->n_pics + i];
                 tt.on = true; tt.mask = r->timed_mask;
-                /* The groups take turns at the list-driven kernels (copy, inter, strengths: bound by instruction issue, they gain
-                 * nothing from running side by side) and overlap in the per-picture kernels (bound by the latency of their dependency
-                 * chains, with half of the vector pipe to spare): group g starts its lists when group g-1 has finished the lists of
-                 * the same tick (group 0: the last group's lists of the tick before).  Left to themselves the groups stay in phase —
-                 * all of them in their list kernels, then all of them in their chains — and the split buys nothing. */
-                if (r->group_ring && (g > 0 || i > first)) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->gring[g > 0 ? g - 1 : G - 1], 0));
-                else if (!r->group_ring && i == first && g > 0) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->timers[(size_t)(g - 1) * r->n_pics + i].ev[3], 0));
-                if (launch_tick(r->gstream[g], r->d_desc + (size_t)i * r->n_streams + s0, sh, &tt, r->launches, r->stages, nullptr, nullptr, nullptr, r->group_ring ? r->gring[g] : nullptr)) return -1;
+                /* (making the groups take turns at the list-driven kernels — a ring of events — works as designed in the kernel
+                 * trace and loses: docs/EXPERIMENTS.md) */
+                if (i == first && g > 0) HIP_TRY(hipStreamWaitEvent(r->gstream[g], r->timers[(size_t)(g - 1) * r->n_pics + i].ev[3], 0));
+                if (launch_tick(r->gstream[g], r->d_desc + (size_t)i * r->n_streams + s0, sh, &tt, r->launches, r->stages)) return -1;
             }
         }
         for (u32 g = 0; g < G; g++) {
@@ -1559,7 +1509,6 @@ int h264bsdmiReplaySetGroups(h264bsdmi_replay *r, u32 n_groups)
     for (u32 g = 0; g < n_groups; g++) {
         if (!r->gstream[g]) HIP_TRY(hipStreamCreateWithFlags(&r->gstream[g], hipStreamNonBlocking));
         if (!r->gdone[g]) HIP_TRY(hipEventCreateWithFlags(&r->gdone[g], hipEventDisableTiming));
-        if (!r->gring[g]) HIP_TRY(hipEventCreateWithFlags(&r->gring[g], hipEventDisableTiming));
     }
     r->n_groups = n_groups;
     return 0;

@@ -133,6 +133,10 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
     const uint32_t n = h->n_mbs, w = h->width_mbs;
     FjMbRec *recs = (FjMbRec *)(job + h->rec_off);
     const int16_t (*mvs)[16][2] = (const int16_t (*)[16][2])(job + h->mv_off);
+    /* the dense vectors (n x 64 bytes, read from here on) must lie inside the buffer, and whole: in front of the coefficients
+     * (hand-built jobs) or behind them; that they also clear the finished job is checked once its size is known */
+    if ((size_t)h->mv_off + (size_t)n * 64u > cap) return -1;
+    if (h->mv_off < h->coef_off && (size_t)h->mv_off + (size_t)n * 64u > h->coef_off) return -1;
     {
         const size_t need_bytes = (size_t)n * (1 + 8 + 16 + 2 + 2 + 2) + ((size_t)n + 2) * 4 + 64;
         if (tl_scratch_cap < need_bytes) {
@@ -390,7 +394,7 @@ deblock_index:
     h->total_bytes = fj_align32(h->mvx_off + n_mvx * 64u);
     if (h->total_bytes > cap) return -1;
     /* the dense vectors are read below: they lie in front of the coefficients (hand-built jobs) or behind everything (the parser) */
-    if (h->mv_off >= h->coef_off && h->mv_off < h->total_bytes) return -1;
+    if (h->mv_off >= h->coef_off && h->mv_off < h->total_bytes) return -1;       /* (behind the coefficients = behind the whole job) */
     for (uint32_t i = 0; i < n_mvx; i++) memcpy(job + h->mvx_off + (size_t)i * 64u, mvs[mvx_list[i]], 64);
     memcpy(job + h->copy_off, copy_tmp, (size_t)n_copy * 8u);
     {   /* general-inter list: the entries with one motion vector per macroblock first (k_recon_inter<0>), then those with
@@ -530,7 +534,12 @@ int hd_job_finish(HostDec *d, int is_idr, int single_job)
         /* submit() succeeding only means "queued": if the device has since reported an error (a tripwire of the kernels, a
          * scheduler that gave up), some picture was not produced as its job said — nothing the buffers hold is relied on any
          * more, for the rest of this decoder's life */
-        if (d->copy_elision && d->sink.errors && d->sink.errors(d->sink.user)) { d->copy_elision = 0; tiles_forget(d); }
+        if (d->copy_elision && d->sink.errors && d->sink.errors(d->sink.user) != d->sink_errors_at_start) {
+            /* (errors that the device reported before this decoder existed — another decoder's, a test's hand-built job — say
+             * nothing about ITS frame buffers: only events since then count) */
+            fprintf(stderr, "h264bsd-mi355x: the device reported an error since this decoder was created: copy elision is off for the rest of its life\n");
+            d->copy_elision = 0; tiles_forget(d);
+        }
         if (d->tile_serial > 0xFFFF0000u) { d->tile_serial = 0; tiles_forget(d); }    /* (numbers are compared for equality: no wrap-around) */
         /* An IDR picture starts a sequence that must be decodable on its own — replay sets start there — so nothing that
          * the other slots held before it is relied on afterwards */

@@ -233,9 +233,10 @@ typedef struct JobSink {
     /* slot (cropped to x0,y0,w,h; fmt 0..2 converted, 3 = I420) as a DEVICE pointer; *stream = the HIP stream used */
     void *(*fetch_device)(void *user, uint32_t slot, int fmt, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void **stream);
     void (*close)(void *user);
-    /* optional: the sink's sticky error bits as far as it knows them without waiting (the engine's device error word, folded in
-     * wherever the host waits for the device anyway).  Non-zero = pictures may not have been produced as submitted: the
-     * parser stops relying on what the frame buffers hold (copy elision, hd_job_finish) */
+    /* optional: how often the sink's device has reported an error so far, as far as it knows without waiting (the engine's
+     * tripwire counter, folded in wherever the host waits for the device anyway; monotonic).  More than when the decoder was
+     * created = pictures may not have been produced as submitted: the parser stops relying on what the frame buffers hold
+     * (copy elision, hd_job_finish) */
     uint32_t (*errors)(void *user);
 } JobSink;
 
@@ -327,6 +328,7 @@ typedef struct HostDec {
      * of the job's copy list.  tile_ver = [n_slots][pic_size_mbs]; tile_pending = the numbers of the job being submitted,
      * committed when the sink has taken it. */
     uint8_t  copy_elision;          /* on for decoders bound to a device, off in capture mode unless asked for (h264bsdmiSetCopyElision) */
+    uint32_t sink_errors_at_start;  /* sink.errors() when this decoder was bound to its sink: only LATER device errors switch its elision off */
     uint8_t  tile_uncommitted;      /* a job was finalised but its submission was never confirmed: nothing is known any more */
     uint32_t *tile_ver, *tile_pending;
     uint32_t tile_slots, tile_mbs, tile_serial, tile_pending_slot;

@@ -61,7 +61,7 @@ struct FrameDesc {
     uint32_t        any_deblock;
     uint16_t        dbk_bands, intra_bands;   /* row bands (= workgroups) the per-picture kernels may split this picture into (>= 1; the launch caps it) */
     uint16_t        heavy;                    /* 1: mostly intra coded — several times the work of the other pictures of its tick */
-    uint32_t       *err;          /* device error word of the engine (DEVERR_* bits, atomicOr): must stay 0 */
+    uint32_t       *err;          /* device error word of the engine (DEVERR_* bits, atomicOr: must stay 0), err[1] = number of times a tripwire fired */
     uint8_t        *slot[FJ_MAX_SLOTS];
 };
 
@@ -157,6 +157,13 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 #ifndef H264K_RELEASE_WAITS
 #define H264K_RELEASE_WAITS 0                                /* 1: the conservative form (wait for every store) for A/B runs */
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__gfx950__) && !defined(__gfx942__)
+#error "kernels.hip.h relies on gfx942 / gfx950 memory ordering inside a workgroup (release_stores): build with --offload-arch=gfx950"
+#endif
+#endif
+/* (-mtgsplit, under which a workgroup may span compute units, defines no macro: the Makefile and tools/experiments/build_variant.sh
+ * refuse the flag, and tests/test_abi.py checks the kernel descriptors of the built library for the threadgroup-split bit) */
 __device__ __forceinline__ void release_stores(bool leaves_the_workgroup)
 {
     if (H264K_RELEASE_WAITS || __ballot(leaves_the_workgroup) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -359,10 +366,17 @@ __device__ __forceinline__ bool mb_residual(uint32_t coded, int qp_y, int qp_c, 
     const ResidRows rows = mb_residual_fetch(coded, coef, lane);
     return mb_residual_compute(coded, qp_y, qp_c, is_i16, coef, lane, rows, ry, rc);
 }
+/* a tripwire fired: its bit in the sticky error word, and one more EVENT in the counter next to it (the word cannot say that a bit
+ * which is already set fired again: the counter can — tests and the per-decoder copy-elision guard look at its delta) */
+__device__ __forceinline__ void report_device_error(const FrameDesc &fd, uint32_t bit)
+{
+    atomicOr(fd.err, bit);
+    atomicAdd(fd.err + 1, 1u);
+}
 __device__ __forceinline__ void report_residual_range(const FrameDesc &fd, bool bad, int lane)
 {
     const unsigned long long m = __ballot(bad);
-    if (m != 0ull && lane == (int)__ffsll((long long)m) - 1) atomicOr(fd.err, DEVERR_RESIDUAL_RANGE);
+    if (m != 0ull && lane == (int)__ffsll((long long)m) - 1) report_device_error(fd, DEVERR_RESIDUAL_RANGE);
 }
 
 /* DPB slot k of the picture's stream.  The slots of a stream are contiguous (engine.hip make_desc), so the address is
@@ -910,15 +924,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
     const FrameDesc &fd = FD_REF(frames, blockIdx.y);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform: the list entry, the record and
                                                                                  everything derived live in scalar registers */
-#ifdef INTER_XCD
-    /* Workgroups are dealt to the eight XCDs round robin in dispatch order (x fastest), and every XCD has its own L2: with the
-     * plain mapping the four macroblocks of workgroup b and those of b + 1 — neighbours in the picture, whose reference windows
-     * overlap — never share an L2.  Here the workgroups x = c (mod 8) of a picture — one XCD's — take the c-th contiguous eighth of its list. */
-    const uint32_t cls8 = blockIdx.x & 7u, per8 = gridDim.x >> 3, rem8 = gridDim.x & 7u;      /* the workgroups x = cls8 (mod 8) of a picture land on one XCD */
-    const uint32_t bx_ = cls8 * per8 + (cls8 < rem8 ? cls8 : rem8) + (blockIdx.x >> 3);
-#else
     const uint32_t bx_ = blockIdx.x;
-#endif
     const uint32_t gi = (PATH == 0 ? 0u : PATH == 1 ? fd.n_gen_uni : fd.n_gen_uni + fd.n_gen_quad) + bx_ * INTER_WG_WAVES + wave;
     if (gi >= (PATH == 0 ? fd.n_gen_uni : PATH == 1 ? fd.n_gen_uni + fd.n_gen_quad : fd.n_gen)) return;
     /* list entry and record as whole dwords from a wave-uniform address in read-only memory: scalar loads (there is no scalar
@@ -1169,137 +1175,6 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
         *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + T_CB + plane * 64 + (cby * 4 + row) * 8 + cbx * 4) = chroma_dw;
     }
 }
-
-/* ---- the one-motion-vector entries of the general-inter list, INTER_NMB macroblocks per wavefront ----
- * k_recon_inter<0> gives a wavefront one macroblock, and a wavefront's life is then three dependent memory round trips (launch
- * descriptor -> list entry -> reference window and coefficient rows) followed by ~290 vector instructions: at the machine's
- * eight wavefronts per SIMD the kernel waits for memory 56 % of the time, and neither fewer instructions (-10 %: no change) nor
- * fewer bytes (XCD-aware order: no change) nor a quieter memory system (k_copy elsewhere: no change) moves it.  Here a wavefront
- * takes INTER_NMB consecutive entries, requests EVERYTHING of all of them — entries, records, windows, coefficient rows —
- * before it looks at any of it, and reconstructs them one after the other: the same occupancy carries INTER_NMB times the
- * bytes in flight.  Lane constants (which window piece a lane stages, where it lands in LDS) are shared. */
-#ifndef INTER_NMB
-#define INTER_NMB 1      /* measured: 2 per wavefront 39.8 instead of 38.8 ms per step (70 VGPRs, 7 waves per SIMD), 3: 47.3 (84, 5) — bit-exact, not
-                            adopted: the experiment stays behind -DINTER_NMB=2 */
-#endif
-#if INTER_NMB > 1
-struct UniMb {
-    FjGen ge; uint32_t qps;              /* scalar: the list entry, qp_y | qp_c << 8 */
-    uint4 vl; uint2 vc; ResidRows rr;    /* the lane's window pieces and coefficient rows, in flight */
-    bool l_on, c_on;
-};
-__global__ __launch_bounds__(256, INTER_OCC) void k_recon_uni(const FrameDesc *__restrict__ frames)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * INTER_NMB * INTER_WAVE_LDS];
-    const FrameDesc &fd = FD_REF(frames, blockIdx.y);
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_uni = fd.n_gen_uni;
-    const uint32_t gi0 = (blockIdx.x * 4 + wave) * INTER_NMB;
-    if (gi0 >= n_uni) return;
-    const int lane = threadIdx.x & 63;
-    const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
-    H264K_GLOBAL uint8_t *cur = (H264K_GLOBAL uint8_t *)fd.cur;
-    const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
-    /* which piece of a window this lane stages: luma lane = 3 * row + tile (63 lanes), chroma lane = 18 * plane + 2 * row + tile (36 lanes) */
-    const int lr = (lane * 43) >> 7, lk = lane - 3 * lr;
-    const int cp = lane >= 18, rem = cp ? lane - 18 : lane, cr = rem >> 1, ck = rem & 1;
-    UniMb m[INTER_NMB];
-#pragma unroll
-    for (int it = 0; it < INTER_NMB; it++) {
-        const uint32_t gi = gi0 + it < n_uni ? gi0 + it : gi0;              /* (a wavefront at the end of the list does its first entry again and drops it) */
-        {
-            const uint4 w = ld16c((const H264K_CONST FjGen *)fd.gen + gi);
-            __builtin_memcpy(&m[it].ge, &w, 16);
-        }
-        const FjGen &ge = m[it].ge;
-        const uint32_t mb = ge.mb;
-        {
-            const uint32_t w0 = *(const H264K_CONST uint32_t *)((const H264K_CONST FjMbRec *)fd.recs + mb);      /* kind, qp_y, qp_c, avail */
-            m[it].qps = (w0 >> 8) & 0xFFFFu;
-        }
-        const int mby = wmb == 1 ? (int)mb : (int)__umulhi(mb, fd.wmb_magic), mbx = (int)mb - mby * wmb;
-        const int mvx = ge.mvx, mvy = ge.mvy;
-        const H264K_GLOBAL uint8_t *ref = (const H264K_GLOBAL uint8_t *)slot_ptr(fd, ge.slot);
-        const int xi = mbx * 16 + (mvx >> 2) - 2, yi = mby * 16 + (mvy >> 2) - 2, xs = (xi >> 4) << 4;
-        const int cxi = mbx * 8 + (mvx >> 3), cyi = mby * 8 + (mvy >> 3), cxs = (cxi >> 3) << 3;
-        const bool lfast = xi >= 0 && xi + 21 <= W && yi >= 0 && yi + 21 <= H;
-        const bool cfast = cxi >= 0 && cxi + 9 <= CW && cyi >= 0 && cyi + 9 <= CH;
-        const int lx = xs + 16 * lk, cx = cxs + 8 * ck;
-        m[it].l_on = lfast && lane < 63 && lx < W && (lk < 2 || xi - xs >= 12);      /* (the third tile only when the window reaches it) */
-        m[it].c_on = cfast && lane < 36 && cx < CW;
-        m[it].vl = ld16g(ref + (m[it].l_on ? luma_at(wmb, lx, yi + lr) : (size_t)0));
-        m[it].vc = ld8g(ref + (m[it].c_on ? chroma_at(wmb, cp, cx, cyi + cr) : (size_t)0));
-        m[it].rr = mb_residual_fetch(ge.coded, (const int16_t *)((const H264K_CONST int16_t *)fd.coefs + 16 * (size_t)ge.coef_idx), lane);
-    }
-#pragma unroll
-    for (int it = 0; it < INTER_NMB; it++) {
-        if (it && gi0 + it >= n_uni) break;                                  /* wave-uniform */
-        const FjGen &ge = m[it].ge;
-        const uint32_t mb = ge.mb;
-        uint8_t *lw = lds + (wave * INTER_NMB + it) * INTER_WAVE_LDS, *lc = lw + 21 * IW_STRIDE;
-        const int mby = wmb == 1 ? (int)mb : (int)__umulhi(mb, fd.wmb_magic), mbx = (int)mb - mby * wmb;
-        const int mvx = ge.mvx, mvy = ge.mvy;
-        const int xi = mbx * 16 + (mvx >> 2) - 2, yi = mby * 16 + (mvy >> 2) - 2, xs = (xi >> 4) << 4;
-        const int cxi = mbx * 8 + (mvx >> 3), cyi = mby * 8 + (mvy >> 3), cxs = (cxi >> 3) << 3;
-        const bool lfast = xi >= 0 && xi + 21 <= W && yi >= 0 && yi + 21 <= H;
-        const bool cfast = cxi >= 0 && cxi + 9 <= CW && cyi >= 0 && cyi + 9 <= CH;
-        if (m[it].l_on) {
-            uint32_t *d32 = reinterpret_cast<uint32_t *>(lw + lr * IW_STRIDE + 16 * lk);
-            d32[0] = m[it].vl.x; d32[1] = m[it].vl.y; d32[2] = m[it].vl.z; d32[3] = m[it].vl.w;
-        }
-        if (m[it].c_on) {
-            uint32_t *d32 = reinterpret_cast<uint32_t *>(lc + cp * 9 * IC_STRIDE + cr * IC_STRIDE + 8 * ck);
-            d32[0] = m[it].vc.x; d32[1] = m[it].vc.y;
-        }
-        if (!lfast || !cfast) {                                              /* windows that leave the picture (h264bsdFillBlock, reconstruct.c:2244) */
-            const uint8_t *ref = slot_ptr(fd, ge.slot);
-            if (!lfast)
-                for (int d = lane; d < 21 * 48; d += 64) {
-                    const int r = d / 48, c = d % 48;
-                    lw[r * IW_STRIDE + c] = ref[luma_at(wmb, clip3(0, W - 1, xs + c), clip3(0, H - 1, yi + r))];
-                }
-            if (!cfast)
-                for (int d = lane; d < 2 * 9 * 16; d += 64) {
-                    const int pp = d / 144, r = (d % 144) / 16, c = d % 16;
-                    lc[pp * 9 * IC_STRIDE + r * IC_STRIDE + c] = ref[chroma_at(wmb, pp, clip3(0, CW - 1, cxs + c), clip3(0, CH - 1, cyi + r))];
-                }
-        }
-        wave_sync();
-        s2 pl01, pl23;
-        int pc[4] = { 0, 0, 0, 0 };
-        {
-            const int o = (xi - xs) + 4 * bx, sh = 8 * (o & 3);
-            luma_pred_lds(lw + (4 * by + row) * IW_STRIDE + (o & ~3), IW_STRIDE, sh, mvx & 3, mvy & 3, pl01, pl23);
-        }
-        if (lane < 32) {
-            const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
-            const int cy = cby * 4 + row, cx0 = cbx * 4;
-            const uint8_t *s0 = lc + plane * 9 * IC_STRIDE + cy * IC_STRIDE + (cxi - cxs) + cx0, *s1 = s0 + IC_STRIDE;
-            int a[5], b[5];
-#pragma unroll
-            for (int i = 0; i < 5; i++) { a[i] = s0[i]; b[i] = s1[i]; }
-            chroma_from_rows(a, b, mvx & 7, mvy & 7, pc);
-            chroma_from_rows(a + 2, b + 2, mvx & 7, mvy & 7, pc + 2);
-        }
-        H264K_GLOBAL uint8_t *T = cur + (size_t)mb * TILE;
-        uint32_t luma_dw, chroma_dw;
-        if ((ge.coded & 0x03FFFFFFu) == 0u) {                    /* wave-uniform: nothing to add */
-            luma_dw = perm(as_u32(pl23), as_u32(pl01), 0x06040200u);
-            chroma_dw = pack4(pc[0], pc[1], pc[2], pc[3]);
-        } else {
-            int ry[4], rc[4];
-            report_residual_range(fd, mb_residual_compute<false>(ge.coded, (int)(m[it].qps & 255u), (int)(m[it].qps >> 8), false, nullptr, lane, m[it].rr, ry, rc), lane);
-            luma_dw = pack4(clip255(pl01.x + ry[0]), clip255(pl01.y + ry[1]), clip255(pl23.x + ry[2]), clip255(pl23.y + ry[3]));
-            chroma_dw = pack4(clip255(pc[0] + rc[0]), clip255(pc[1] + rc[1]), clip255(pc[2] + rc[2]), clip255(pc[3] + rc[3]));
-        }
-        *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + (by * 4 + row) * 16 + bx * 4) = luma_dw;
-        if (lane < 32) {
-            const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
-            *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + T_CB + plane * 64 + (cby * 4 + row) * 8 + cbx * 4) = chroma_dw;
-        }
-    }
-}
-#endif
 
 /* ------------------------------------------------------------------ intra macroblocks */
 constexpr int TS = 32;   /* intra luma tile: row 0 = row above, rows 1..16 = MB; byte 3 = left column / corner,
@@ -2309,7 +2184,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
         }
         cbase = __shfl(cbase, 0); k = __shfl(k, 0);
         if (k == 0xFFFFFFFFu) break;
-        if (++spins > (1u << 24)) { if (lane == 0) atomicOr(fd.err, DEVERR_INTRA_SCHED); break; }
+        if (++spins > (1u << 24)) { if (lane == 0) report_device_error(fd, DEVERR_INTRA_SCHED); break; }
         if (k == 0) {
             /* nothing ready: have macroblocks of the band above, which the first row waits for, finished? (k_frame_dbk) */
             bool polled = false;
@@ -2587,7 +2462,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
         }
         cbase = __shfl(cbase, 0); k = __shfl(k, 0); cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(cls, 0));
         if (k == 0xFFFFFFFFu) break;
-        if (++spins > (1u << 24)) { if (lane == 0) atomicOr(fd.err, DEVERR_DBK_SCHED); break; }
+        if (++spins > (1u << 24)) { if (lane == 0) report_device_error(fd, DEVERR_DBK_SCHED); break; }
         if (k == 0) {
             /* nothing ready.  If the first row still waits for macroblocks of the band above, look whether they are done:
              * one wavefront of the band at a time, lane -> column */

@@ -98,6 +98,10 @@ int  h264bsdmiDebugTailProfile(int enable, unsigned long long *out);
  * 0xFFFFFFFF leaves a setting alone.  Also settable through H264BSDMI_TAIL="a,b,c,d,e,f" / H264BSDMI_BAND_BUDGET. */
 int  h264bsdmiDebugSetTail(u32 dbk_rows_light, u32 dbk_rows_heavy, u32 dbk_waves, u32 intra_rows_light, u32 intra_rows_heavy, u32 intra_waves,
                            u32 band_budget);
+/* How often a tripwire of the kernels (DEVERR_*, h264bsdmiDeviceErrors) has fired on all devices since the library was loaded,
+ * after waiting for the devices.  Monotonic — the bits of h264bsdmiDeviceErrors() are sticky and cannot show that a bit which a
+ * hand-built test job set earlier fired again: tests assert that their own pictures add no event.  0xFFFFFFFF = HIP error. */
+unsigned h264bsdmiDebugDeviceErrorEvents(void);
 /* Bytes of packed syntax (frame jobs) per stream and of one frame, for the byte accounting. */
 unsigned long long h264bsdmiReplayJobBytes(h264bsdmi_replay *r);
 u32  h264bsdmiReplayFrameBytes(h264bsdmi_replay *r);

@@ -237,7 +237,7 @@ def test_72_different_streams_through_the_batch_api(built, golden):
         streams.append(data); want.append([tuple(p) for p in gold[n]["pics"]]); kind.append("synth")
     for n in ["test_640x360", "test_1920x1080", "test_1920x1080_fullRange"] * 4:
         streams.append(stream_bytes(n)); want.append(golden[n]["frame_sha256"]); kind.append("bundled")
-    errs_before = built.device_errors()          # sticky for the life of the process (other tests feed hand-built jobs on purpose)
+    errs_before = built.device_error_events()    # (a counter, not the sticky bits: a bit that a hand-built test job set earlier firing AGAIN would show)
     N = len(streams)
     assert N == 72
     L = built.lib()
@@ -277,7 +277,7 @@ def test_72_different_streams_through_the_batch_api(built, golden):
         decs[k].flush_buffer()
         pull(k)
         assert got[k] == want[k], f"instance {k} ({kind[k]}) differs from the reference"
-    assert built.device_errors() == errs_before
+    assert built.device_error_events() == errs_before
     for d in decs:
         d.close()
 

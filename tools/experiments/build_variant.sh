@@ -3,6 +3,7 @@
 # (H264BSD_VARIANT=<name> makes the Python mirror, and with it bench.py, load that one)
 set -e
 name=$1; shift
+case " $* " in *tgsplit*) echo "refusing -mtgsplit: release_stores() relies on a workgroup living on one compute unit" >&2; exit 1;; esac
 cd "$(dirname "$0")/../../h264bsd_amd/csrc"
 mkdir -p build_$name ../lib_$name
 /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-value "$@" -c engine.hip -o build_$name/engine.o
