@@ -275,7 +275,31 @@ void h264bsdFlushBuffer(storage_t *s)
 }
 
 /* test/tooling hook: complete a hand-built frame job (see fj_finalize, hd_core.c) */
-int h264bsdmiJobFinalize(u8 *job, u32 capacity, u32 n_coef_blocks) { return fj_finalize(job, capacity, n_coef_blocks); }
+int h264bsdmiJobFinalize(u8 *job, u32 capacity, u32 n_coef_blocks)
+{
+    /* a hand-built job carries no FJ_CODED_WIDE flags (the parser sets them while it sums up the levels): derive them from
+     * the coefficient blocks, with the parser's own bound */
+    FjHeader *h = (FjHeader *)job;
+    if (capacity >= sizeof(FjHeader) && (size_t)h->rec_off + (size_t)h->n_mbs * sizeof(FjMbRec) <= capacity) {
+        FjMbRec *recs = (FjMbRec *)(job + h->rec_off);
+        for (u32 a = 0; a < h->n_mbs; a++) {
+            FjMbRec *r = &recs[a];
+            r->coded &= ~FJ_CODED_WIDE;
+            if (r->kind != FJ_MB_INTER || !(r->coded & 0x02FFFFFFu)) continue;
+            const u32 n_l = (u32)__builtin_popcount(r->coded & 0xFFFFu), n_c = (u32)__builtin_popcount((r->coded >> 16) & 0xFFu);
+            const u32 has_cdc = (r->coded & FJ_CODED_CHROMA_DC) ? 1u : 0u;
+            if ((size_t)h->coef_off + ((size_t)r->coef_idx + n_l + has_cdc + n_c) * 32u > capacity) continue;      /* (fj_finalize rejects the job) */
+            const int16_t *p = (const int16_t *)(job + h->coef_off) + 16u * (size_t)r->coef_idx;
+            u32 sl = 0, sd = 0, sc = 0;
+            for (u32 i = 0; i < 16u * n_l; i++) sl += (u32)abs(p[i]);
+            p += 16u * n_l;
+            if (has_cdc) { for (int i = 0; i < 8; i++) sd += (u32)abs(p[i]); p += 16; }
+            for (u32 i = 0; i < 16u * n_c; i++) sc += (u32)abs(p[i]);
+            if (!hd_residual_bound_ok(sl, sd, sc, r->qp_y, r->qp_c)) r->coded |= FJ_CODED_WIDE;
+        }
+    }
+    return fj_finalize(job, capacity, n_coef_blocks);
+}
 
 void h264bsdConvertToRGBA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(0, width, height, data, pOutput); }
 void h264bsdConvertToBGRA(u32 width, u32 height, u8 *data, u32 *pOutput) { eng_convert_host(1, width, height, data, pOutput); }

@@ -465,9 +465,9 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     }
     if (EV_NEEDED(1)) HIP_TRY(hipEventRecord(tt->ev[1], st));
     if ((stages & 1u) && s.max_gen) {
-        if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_inter<0>, dim3((s.max_gen_uni + INTER_WG_WAVES - 1) / INTER_WG_WAVES, s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
-        if (s.max_gen_quad) hipLaunchKernelGGL(h264k::k_recon_inter<1>, dim3((s.max_gen_quad + INTER_WG_WAVES - 1) / INTER_WG_WAVES, s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
-        if (s.max_gen_rest) hipLaunchKernelGGL(h264k::k_recon_inter<2>, dim3((s.max_gen_rest + INTER_WG_WAVES - 1) / INTER_WG_WAVES, s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
+        if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_inter<0>, dim3((s.max_gen_uni + INTER_WG_WAVES * h264k::inter_per_wave<0>() - 1) / (INTER_WG_WAVES * h264k::inter_per_wave<0>()), s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
+        if (s.max_gen_quad) hipLaunchKernelGGL(h264k::k_recon_inter<1>, dim3((s.max_gen_quad + INTER_WG_WAVES * h264k::inter_per_wave<1>() - 1) / (INTER_WG_WAVES * h264k::inter_per_wave<1>()), s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
+        if (s.max_gen_rest) hipLaunchKernelGGL(h264k::k_recon_inter<2>, dim3((s.max_gen_rest + INTER_WG_WAVES * h264k::inter_per_wave<2>() - 1) / (INTER_WG_WAVES * h264k::inter_per_wave<2>()), s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
         if (launches) launches[1]++;
     }
     if (EV_NEEDED(2)) HIP_TRY(hipEventRecord(tt->ev[2], st));
@@ -1048,6 +1048,21 @@ unsigned h264bsdmiDebugDeviceErrorEvents(void)
     }
     return all;
 }
+
+#ifdef H264K_INTER_PROFILE
+/* profiling build only: the 24 64-bit counters behind the device error word (k_recon_inter's cycle accounting), read and zeroed */
+int h264bsdmiDebugReadCounters(unsigned long long *out)
+{
+    Engine *e = engine_get();
+    if (!e) return -1;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, reinterpret_cast<uint8_t *>(e->d_err) + 64, 192, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(reinterpret_cast<uint8_t *>(e->d_err) + 64, 0, 192));
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+#endif
 
 static int flush_all(bool wait)
 {

@@ -101,6 +101,13 @@
                                          produces it (a chroma AC block whose last coefficient lands in the luma DC
                                          array of an Intra16x16 macroblock that coded no DC, hd_mb.c parse_residual) */
 
+#define FJ_CODED_WIDE (1u << 27)     /* the cheap magnitude bound of hd_resid.c (sum of the level magnitudes x the largest scale <= 32735)
+                                         does NOT hold for this macroblock: some intermediate of its inverse transforms may leave 16
+                                         bits.  Clear (almost always): every intermediate fits 16 bits and the residual lies in
+                                         [-512, 511], so the inter kernels run luma and chroma as ONE packed 16-bit transform
+                                         (kernels.hip.h mb_residual_pk).  Set by the parser; h264bsdmiJobFinalize() sets it for
+                                         hand-built jobs.  Inter macroblocks only (the intra kernel always computes in 32 bits) */
+
 typedef struct FjHeader {
     uint32_t magic;
     uint32_t total_bytes;     /* whole blob                                                   */

@@ -560,10 +560,13 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
         int qi = (int)m->qp + pps->chroma_qp_index_offset;
         qi = qi < 0 ? 0 : qi > 51 ? 51 : qi;
         /* (almost every macroblock is cleared by the bound on the level magnitudes the parse has summed up) */
-        if (!((rec.coded & FJ_CODED_LUMA_DC) == 0 && hd_residual_bound_ok(level_sums[0], level_sums[1], level_sums[2], m->qp, qpc_table[qi])) &&
-            hd_residual_out_of_range(coefs + 16u * coef_start, rec.coded, m->qp, qpc_table[qi], rec.kind == FJ_MB_I16x16)) {
-            P2ERR(&c);
-            c.ok_blocks = 0; c.ok_quads = 0;   /* the residual is processed before the prediction: no motion vector was written */
+        if (!((rec.coded & FJ_CODED_LUMA_DC) == 0 && hd_residual_bound_ok(level_sums[0], level_sums[1], level_sums[2], m->qp, qpc_table[qi]))) {
+            /* the bound does not clear it: the kernels must not run this macroblock's transforms in 16 bits (framejob.h) */
+            if (rec.kind == FJ_MB_INTER) rec.coded |= FJ_CODED_WIDE;
+            if (hd_residual_out_of_range(coefs + 16u * coef_start, rec.coded, m->qp, qpc_table[qi], rec.kind == FJ_MB_I16x16)) {
+                P2ERR(&c);
+                c.ok_blocks = 0; c.ok_quads = 0;   /* the residual is processed before the prediction: no motion vector was written */
+            }
         }
     }
     if (c.p2err) restore_unwritten(&c);

@@ -139,6 +139,21 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
     return v;
 }
 
+/* ---- packed 16-bit helpers (two samples per register, v_pk_*_i16) ---- */
+typedef short s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2 pk(int x) { return (s2){ (short)x, (short)x }; }
+__device__ __forceinline__ s2 pk_lt(s2 a, s2 b) { return (a - b) >> pk(15); }                  /* a < b ? -1 : 0 */
+__device__ __forceinline__ s2 pk_abs(s2 a) { return __builtin_elementwise_max(a, -a); }
+__device__ __forceinline__ s2 pk_clip(s2 lo, s2 hi, s2 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi); }
+__device__ __forceinline__ s2 pk_sel(s2 m, s2 a, s2 b) { return (a & m) | (b & ~m); }
+
+__device__ __forceinline__ s2 as_s2(uint32_t x) { s2 r; __builtin_memcpy(&r, &x, 4); return r; }
+__device__ __forceinline__ uint32_t as_u32(s2 x) { uint32_t r; __builtin_memcpy(&r, &x, 4); return r; }
+/* v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8 bytes {lo = 0..3, hi = 4..7}; selector 12 = 0x00 */
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+
+
 /* ---- hand-over between workgroups (row bands of one picture, k_frame_dbk / k_frame_intra) ----
  * Workgroups of one launch may sit on different XCDs, whose L2s are not coherent with each other, and a CU's vector L1 is
  * never refreshed by another CU's stores (MI355X_MICROARCH.md, "inter-workgroup visibility").  The samples a band hands to
@@ -361,6 +376,80 @@ __device__ __forceinline__ bool mb_residual_compute(uint32_t coded, int qp_y, in
     return over > 1023u;
 }
 
+/* ---- the same residual in PACKED 16-bit arithmetic, luma and chroma in ONE pass (inter macroblocks whose FJ_CODED_WIDE is clear) ----
+ * The host's magnitude bound (hd_resid.c: sum of the level magnitudes x the largest scale <= 32735 per plane) proves that every
+ * dequantised level, every intermediate of the two butterflies and every "+ 32" sum fits a signed 16-bit half and that the
+ * residual lies in [-512, 511]: nothing wraps, no tripwire is needed.  Every register holds the luma value in its low half and —
+ * in lanes 0..31, lane = 4 * (chroma block k) + row like the luma lanes' 4 * block + row — the chroma value in its high half, so
+ * the chroma transform costs nothing on top of the luma one: dequantisation by one v_pk_mul_lo_u16 with (scale << qp/6) per half,
+ * two butterflies of 10 + 16 packed instructions, two quad transposes of 12 (select fused with the DPP move).  The 32-bit form
+ * above spends 135 instructions per coded macroblock on two transforms, this one ~80. */
+__device__ __forceinline__ void quad_transpose4(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3, int lane)
+{
+    /* lane q of a quad holds row q in v0..v3 -> holds column q.  Exchange with lane ^ 1, then with lane ^ 2.  Selects are BITWISE
+     * with a lane mask in a vector register (v_bitop3_b32: 2.3 cycles per wave64 instruction when two wavefronts share a SIMD),
+     * not v_cndmask: its VOP2 form — the only one that can carry a DPP move — takes ~19 cycles when two of them follow each
+     * other (tools/probes/op_cost_probe.hip), its VOP3 form 4.3.  Per exchanged pair: one select of what is given away, one
+     * v_mov_b32_dpp, two selects of what is kept: 12 + 4 instructions per transpose. */
+    uint32_t m1 = (uint32_t)-(lane & 1), m2 = (uint32_t)-((lane >> 1) & 1);
+    asm("" : "+v"(m1), "+v"(m2));                        /* (masks of unknown origin: left to itself the compiler turns the bitwise selects back into v_cmp + v_cndmask) */
+    auto sel = [](uint32_t m, uint32_t a, uint32_t b) { return (uint32_t)__builtin_amdgcn_bitop3_b32(a, b, m, 0xE4); };      /* (a & m) | (b & ~m) */
+    auto x1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); };   /* quad_perm [1,0,3,2] */
+    auto x2 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); };   /* quad_perm [2,3,0,1] */
+    {
+        const uint32_t r01 = x1(sel(m1, v0, v1)), r23 = x1(sel(m1, v2, v3));      /* odd lanes give v0 / v2 and get the neighbour's v1 / v3 */
+        v1 = sel(m1, v1, r01); v0 = sel(m1, r01, v0);
+        v3 = sel(m1, v3, r23); v2 = sel(m1, r23, v2);
+    }
+    {
+        const uint32_t r02 = x2(sel(m2, v0, v2)), r13 = x2(sel(m2, v1, v3));
+        v2 = sel(m2, v2, r02); v0 = sel(m2, r02, v0);
+        v3 = sel(m2, v3, r13); v1 = sel(m2, r13, v1);
+    }
+}
+/* out: the lane's four residual samples as packed pairs — luma (y01, y23), chroma (c01, c23; lanes 0..31).  Must be called by
+ * all 64 lanes. */
+__device__ __forceinline__ void mb_residual_pk(uint32_t coded, int qp_y, int qp_c, int lane, const ResidRows &rows, s2 &y01, s2 &y23, s2 &c01, s2 &c23)
+{
+    const int q = lane & 3;
+    const bool odd = q & 1;
+    /* (scale << qp / 6) per coefficient class, luma | chroma << 16: wave-uniform, scalar registers */
+    const int my = qp_y % 6, sy = qp_y / 6, mc = qp_c % 6, sc = qp_c / 6;
+    const uint32_t L0 = (uint32_t)(level_scale(my, 0) << sy) | ((uint32_t)(level_scale(mc, 0) << sc) << 16);
+    const uint32_t L1 = (uint32_t)(level_scale(my, 1) << sy) | ((uint32_t)(level_scale(mc, 1) << sc) << 16);
+    const uint32_t L2 = (uint32_t)(level_scale(my, 2) << sy) | ((uint32_t)(level_scale(mc, 2) << sc) << 16);
+    const s2 A = as_s2(odd ? L1 : L0), B = as_s2(odd ? L2 : L1);         /* columns 0, 2 / columns 1, 3 of row q */
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    auto mul = [](uint32_t a, s2 b) { us2 x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4); x = x * y; s2 r; __builtin_memcpy(&r, &x, 4); return r; };
+    const uint32_t yx = (uint32_t)rows.y.x, yy = (uint32_t)rows.y.y, cx = (uint32_t)rows.c.x, cy = (uint32_t)rows.c.y;
+    s2 d0 = mul(perm(cx, yx, 0x05040100u), A), d1 = mul(perm(cx, yx, 0x07060302u), B);
+    s2 d2 = mul(perm(cy, yy, 0x05040100u), A), d3 = mul(perm(cy, yy, 0x07060302u), B);
+    if (coded & 0x02FF0000u) {                                   /* wave-uniform: chroma has coefficients */
+        /* the chroma block's DC replaces element (0, 0) after scaling (8.5.11), as in mb_residual_compute */
+        int dc = 0;
+        if (coded & FJ_CODED_CHROMA_DC) {
+            const int i = (lane >> 2) & 3;
+            int cc[4];
+            unpack_row4(rows.cdc, cc);
+            const int f = cc[0] + ((i & 1) ? -cc[1] : cc[1]) + ((i & 2) ? -cc[2] : cc[2]) + ((i == 1 || i == 2) ? -cc[3] : cc[3]);
+            const int ls = level_scale(mc, 0);
+            dc = sc >= 1 ? (f * ls) << (sc - 1) : (f * ls) >> 1;
+        }
+        if (q == 0) d0 = as_s2(perm((uint32_t)dc, as_u32(d0), 0x05040100u));
+    }
+    {
+        const s2 e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> pk(1)) - d3, e3 = d1 + (d3 >> pk(1));
+        uint32_t f0 = as_u32(e0 + e3), f1 = as_u32(e1 + e2), f2 = as_u32(e1 - e2), f3 = as_u32(e0 - e3);
+        quad_transpose4(f0, f1, f2, f3, lane);                   /* lane q: column q, f_k = row k */
+        const s2 g0 = as_s2(f0) + as_s2(f2) + pk(32), g1 = as_s2(f0) - as_s2(f2) + pk(32);
+        const s2 g2 = (as_s2(f1) >> pk(1)) - as_s2(f3), g3 = as_s2(f1) + (as_s2(f3) >> pk(1));
+        uint32_t r0 = as_u32((g0 + g3) >> pk(6)), r1 = as_u32((g1 + g2) >> pk(6)), r2 = as_u32((g1 - g2) >> pk(6)), r3 = as_u32((g0 - g3) >> pk(6));
+        quad_transpose4(r0, r1, r2, r3, lane);                   /* back to row q: r_k = sample k, luma | chroma << 16 */
+        y01 = as_s2(perm(r1, r0, 0x05040100u)); y23 = as_s2(perm(r3, r2, 0x05040100u));
+        c01 = as_s2(perm(r1, r0, 0x07060302u)); c23 = as_s2(perm(r3, r2, 0x07060302u));
+    }
+}
+
 __device__ __forceinline__ bool mb_residual(uint32_t coded, int qp_y, int qp_c, bool is_i16, const int16_t *coef, int lane, int ry[4], int rc[4])
 {
     const ResidRows rows = mb_residual_fetch(coded, coef, lane);
@@ -415,20 +504,6 @@ __device__ __forceinline__ uint32_t luma4_at(const uint8_t *__restrict__ f, int 
 }
 
 /* ------------------------------------------------------------------ inter prediction */
-/* ---- packed 16-bit helpers (two samples per register, v_pk_*_i16) ---- */
-typedef short s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s2 pk(int x) { return (s2){ (short)x, (short)x }; }
-__device__ __forceinline__ s2 pk_lt(s2 a, s2 b) { return (a - b) >> pk(15); }                  /* a < b ? -1 : 0 */
-__device__ __forceinline__ s2 pk_abs(s2 a) { return __builtin_elementwise_max(a, -a); }
-__device__ __forceinline__ s2 pk_clip(s2 lo, s2 hi, s2 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi); }
-__device__ __forceinline__ s2 pk_sel(s2 m, s2 a, s2 b) { return (a & m) | (b & ~m); }
-
-__device__ __forceinline__ s2 as_s2(uint32_t x) { s2 r; __builtin_memcpy(&r, &x, 4); return r; }
-__device__ __forceinline__ uint32_t as_u32(s2 x) { uint32_t r; __builtin_memcpy(&r, &x, 4); return r; }
-/* v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8 bytes {lo = 0..3, hi = 4..7}; selector 12 = 0x00 */
-__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-
-
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * (b + e) + 20 * (c + d) + f; }
 
 /* Register window of one lane: rows y-2..y+3, columns x-2..x+9 of the reference plane (9 columns used),
@@ -917,16 +992,40 @@ constexpr int INTER_WAVE_LDS = 2688;                 /* max(21 * IW_STRIDE + 2 *
                                 workgroup take 34.0 / 35.8 / 38.8 / 42.9 / 48.9 ms per step (the average occupancy, not the instruction
                                 count, was what held the kernel back: -10 % instructions had changed nothing) */
 #endif
+#ifndef INTER_PER_WAVE
+#define INTER_PER_WAVE 2     /* list entries per wavefront, the one-vector path: 1 / 2 / 3 / 4 / 6 / 8 -> 34.4 / 32.7 / 33.1 / 33.1 / 33.6 / 34.2 ms per step (both paths' time) */
+#endif
+#ifndef INTER_PER_WAVE_QUAD
+#define INTER_PER_WAVE_QUAD 2   /* ... the quadrant path (69 VGPRs: 7 wavefronts per SIMD instead of 8, and still 0.3 ms better); the finer partitions: always 1 */
+#endif
+template <int PATH> constexpr uint32_t inter_per_wave() { return PATH == 0 ? INTER_PER_WAVE : PATH == 1 ? INTER_PER_WAVE_QUAD : 1; }
+#ifdef H264K_INTER_PROFILE
+#define IPROF(k) do { if (PATH == 0) ipt[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define IPROF(k) do { } while (0)
+#endif
 template <int PATH>
 __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
+#ifdef H264K_INTER_PROFILE
+    unsigned long long ipt[6] = { 0, 0, 0, 0, 0, 0 };      /* cycle accounting of a wavefront's life (tools/inter_prof.py): start | entry here | windows staged | predicted | before the store | end */
+#endif
+    IPROF(0);
     __shared__ __attribute__((aligned(16))) uint8_t lds[INTER_WG_WAVES * INTER_WAVE_LDS];
     const FrameDesc &fd = FD_REF(frames, blockIdx.y);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform: the list entry, the record and
                                                                                  everything derived live in scalar registers */
-    const uint32_t bx_ = blockIdx.x;
-    const uint32_t gi = (PATH == 0 ? 0u : PATH == 1 ? fd.n_gen_uni : fd.n_gen_uni + fd.n_gen_quad) + bx_ * INTER_WG_WAVES + wave;
-    if (gi >= (PATH == 0 ? fd.n_gen_uni : PATH == 1 ? fd.n_gen_uni + fd.n_gen_quad : fd.n_gen)) return;
+    /* A wavefront reconstructs INTER_PER_WAVE consecutive list entries, one after the other (nothing of entry i + 1 is requested
+     * before entry i is stored: no register is carried from one to the next).  What that amortises is the START of a wavefront:
+     * with one macroblock per single-wavefront workgroup the kernel spends a third of its time launching workgroups that do
+     * nothing yet (measured with the body cut out behind the first scalar loads: 8 of 22 ms per step), and neighbours in the list
+     * are neighbours in the picture — their reference windows overlap, and the second one finds the first one's lines in the L1. */
+    const uint32_t g_first = (PATH == 0 ? 0u : PATH == 1 ? fd.n_gen_uni : fd.n_gen_uni + fd.n_gen_quad);
+    const uint32_t g_end = (PATH == 0 ? fd.n_gen_uni : PATH == 1 ? fd.n_gen_uni + fd.n_gen_quad : fd.n_gen);
+#pragma unroll 1
+  for (uint32_t it = 0; it < inter_per_wave<PATH>(); it++) {
+    const uint32_t gi = g_first + (blockIdx.x * INTER_WG_WAVES + wave) * inter_per_wave<PATH>() + it;
+    if (gi >= g_end) return;
     /* list entry and record as whole dwords from a wave-uniform address in read-only memory: scalar loads (there is no scalar
      * byte load: a struct copy would fetch the byte-sized members with vector loads and wait for them) */
     FjGen ge;
@@ -935,13 +1034,19 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
         __builtin_memcpy(&ge, &w, 16);
     }
     const uint32_t mb = ge.mb;
+#ifdef H264K_INTER_PROFILE
+    if (PATH == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
+    IPROF(1);
     FjMbRec rec;                                     /* only the QPs (and, partitioned, the references) are needed from it */
     {
         const uint4 w = ld16c((const H264K_CONST FjMbRec *)fd.recs + mb), w2 = ld16c((const H264K_CONST uint8_t *)((const H264K_CONST FjMbRec *)fd.recs + mb) + 16);
         __builtin_memcpy(&rec, &w, 16);
         __builtin_memcpy(reinterpret_cast<uint8_t *>(&rec) + 16, &w2, 16);
     }
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+    if (inter_per_wave<PATH>() > 1) asm volatile("" : "+v"(lane));                   /* (everything a lane derives from its number is worked out again for every entry: hoisted out of
+                                                        the loop it would live in registers the kernel does not have at 8 wavefronts per SIMD) */
     uint8_t *lw = lds + wave * INTER_WAVE_LDS, *lc = lw + 21 * IW_STRIDE;
     const int wmb = fd.wmb, W = wmb * 16, H = fd.hmb * 16, CW = W >> 1, CH = H >> 1;
     const int mby = wmb == 1 ? (int)mb : (int)__umulhi(mb, fd.wmb_magic), mbx = (int)mb - mby * wmb;     /* scalar: FrameDesc.wmb_magic */
@@ -986,11 +1091,31 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
         /* (the window's 21 columns reach into the third tile only when they start in the last four columns of the first:
          * in three cases out of four that tile is not requested at all — nothing reads the bytes it would have filled) */
         const bool l_on = lfast && lane < 63 && lx < W && (lk < 2 || xi - xs >= 12);
+#if defined(INTER_WHATIF) && (INTER_WHATIF & 4)
+        if (ge.coded != 0xFFFFFFFFu) continue;
+#endif
+#if defined(INTER_WHATIF) && (INTER_WHATIF & 1)
+        const uint4 vl = make_uint4(lane, mb, ge.coded, lx);
+#else
         const uint4 vl = ld16g(ref + (l_on ? luma_at(wmb, lx, yi + lr) : (size_t)0));
+#endif
         const int cp = lane >= 18, rem = cp ? lane - 18 : lane, cr = rem >> 1, ck = rem & 1, cx = cxs + 8 * ck;
         const bool c_on = cfast && lane < 36 && cx < CW;
+#if defined(INTER_WHATIF) && (INTER_WHATIF & 1)
+        const uint2 vc = make_uint2(lane, cx);
+        rrows.y = rrows.c = rrows.cdc = make_int2(lane, mb); rrows.ldc = 0;
+#else
         const uint2 vc = ld8g(ref + (c_on ? chroma_at(wmb, cp, cx, cyi + cr) : (size_t)0));
         rrows = mb_residual_fetch(ge.coded, coef, lane);
+#endif
+#if defined(INTER_WHATIF) && (INTER_WHATIF & 2)
+        {
+            H264K_GLOBAL uint8_t *T2 = cur + (size_t)mb * TILE;
+            *reinterpret_cast<H264K_GLOBAL uint32_t *>(T2 + (by * 4 + row) * 16 + bx * 4) = vl.x ^ vl.y ^ vl.z ^ vl.w ^ (uint32_t)rrows.y.x ^ (uint32_t)rrows.c.x ^ (uint32_t)rrows.cdc.x;
+            if (lane < 32) *reinterpret_cast<H264K_GLOBAL uint32_t *>(T2 + T_CB + 4 * lane) = vc.x ^ vc.y;
+            continue;
+        }
+#endif
         if (l_on) {
             uint32_t *d32 = reinterpret_cast<uint32_t *>(lw + lr * IW_STRIDE + 16 * lk);
             d32[0] = vl.x; d32[1] = vl.y; d32[2] = vl.z; d32[3] = vl.w;
@@ -1012,6 +1137,10 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
             }
         }
         wave_sync();
+#ifdef H264K_INTER_PROFILE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        IPROF(2);
         /* ---- luma: window rows (4*by+row)..+5, bytes o..o+11 with o = (xi-xs) + 4*bx ---- */
         {
             const int o = (xi - xs) + 4 * bx, sh = 8 * (o & 3);
@@ -1154,6 +1283,10 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
     /* (an unconditional use of the coefficient rows here — they arrived long ago — keeps the compiler from sinking their loads
      * into the residual code, where every coded macroblock would wait for a second memory round trip) */
     asm volatile("" :: "v"(rrows.y.x), "v"(rrows.y.y), "v"(rrows.c.x), "v"(rrows.c.y), "v"(rrows.cdc.x), "v"(rrows.cdc.y));
+#ifdef H264K_INTER_PROFILE
+    asm volatile("" :: "v"(pl01), "v"(pl23), "v"(pc[0]), "v"(pc[1]), "v"(pc[2]), "v"(pc[3]));
+#endif
+    IPROF(3);
     /* ---- residual add, clip, store.  Lane (block, row) holds 4 samples of row 4*by+row at column 4*bx: the 64 dwords of the
      * wavefront ARE the 256 luma bytes of the tile (each group of 16 lanes one 64-byte piece), the 32 chroma dwords its third
      * line — two coalesced stores, no detour through LDS.  A macroblock without coefficients (55 % of this list in the bundled
@@ -1163,18 +1296,42 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
     if ((ge.coded & 0x03FFFFFFu) == 0u) {                        /* wave-uniform */
         luma_dw = perm(as_u32(pl23), as_u32(pl01), 0x06040200u);
         chroma_dw = pack4(pc[0], pc[1], pc[2], pc[3]);
+    } else if (!(ge.coded & FJ_CODED_WIDE)) {                    /* wave-uniform: the host proved that 16 bits hold every intermediate */
+        s2 y01, y23, c01, c23;
+        mb_residual_pk(ge.coded, rec.qp_y, rec.qp_c, lane, rrows, y01, y23, c01, c23);
+        const s2 lo = pk(0), hi = pk(255);
+        const s2 l01 = pk_clip(lo, hi, pl01 + y01), l23 = pk_clip(lo, hi, pl23 + y23);
+        const s2 k01 = pk_clip(lo, hi, as_s2((uint32_t)pc[0] | ((uint32_t)pc[1] << 16)) + c01), k23 = pk_clip(lo, hi, as_s2((uint32_t)pc[2] | ((uint32_t)pc[3] << 16)) + c23);
+        luma_dw = perm(as_u32(l23), as_u32(l01), 0x06040200u);
+        chroma_dw = perm(as_u32(k23), as_u32(k01), 0x06040200u);
     } else {
         int ry[4], rc[4];
         report_residual_range(fd, mb_residual_compute<false>(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc), lane);
         luma_dw = pack4(clip255(pl01.x + ry[0]), clip255(pl01.y + ry[1]), clip255(pl23.x + ry[2]), clip255(pl23.y + ry[3]));
         chroma_dw = pack4(clip255(pc[0] + rc[0]), clip255(pc[1] + rc[1]), clip255(pc[2] + rc[2]), clip255(pc[3] + rc[3]));
     }
+#ifdef H264K_INTER_PROFILE
+    asm volatile("" :: "v"(luma_dw), "v"(chroma_dw));
+#endif
+    IPROF(4);
     *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + (by * 4 + row) * 16 + bx * 4) = luma_dw;
     if (lane < 32) {
         const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
         *reinterpret_cast<H264K_GLOBAL uint32_t *>(T + T_CB + plane * 64 + (cby * 4 + row) * 8 + cbx * 4) = chroma_dw;
     }
+    IPROF(5);
+#ifdef H264K_INTER_PROFILE
+    if (PATH == 0 && lane == 0 && (blockIdx.x & 63u) == 0u) {
+        unsigned long long *pc64 = reinterpret_cast<unsigned long long *>(fd.err) + 8;
+        for (int k = 0; k < 5; k++) atomicAdd(pc64 + k, ipt[k + 1] - ipt[k]);
+        atomicAdd(pc64 + 5, 1ull);
+        atomicAdd(pc64 + 6, (ge.coded & 0x03FFFFFFu) ? 1ull : 0ull);
+    }
+#endif
+    wave_sync();          /* the staged windows are overwritten by the next entry's */
+  }
 }
+
 
 /* ------------------------------------------------------------------ intra macroblocks */
 constexpr int TS = 32;   /* intra luma tile: row 0 = row above, rows 1..16 = MB; byte 3 = left column / corner,
@@ -1750,12 +1907,16 @@ __device__ __forceinline__ void dbk_load(const FrameDesc &fd, int mb, int l, Dbk
     const uint32_t umb = (uint32_t)mb, wmb = fd.wmb;
     const uint32_t t = umb * TILE, tl = (umb ? umb - 1u : 0u) * TILE, tu = (umb >= wmb ? umb - wmb : umb) * TILE;     /* stand-ins where there is no neighbour: never used (k_dbk: LEFT / TOP only where it exists) */
     const uint32_t ro = umb * DBK_REC_BYTES;
-    p.y0 = ld16g(cur + t + 32u * l);
-    p.y1 = ld16g(cur + t + 32u * l + 16u);
-    p.c = ld16g(cur + t + T_CB + 16u * l);
     p.r0 = ld16g(recs + ro);
     p.r1 = ld16g(recs + ro + 16u);
     p.r2 = ld16g(recs + ro + 32u);
+#if defined(DBK_WHATIF) && (DBK_WHATIF & 4)      /* timing experiment: no sample loads (only the record travels) */
+    p.y0 = p.y1 = p.c = make_uint4(umb, t, tl, tu); p.ly0 = p.ly1 = p.lc0 = p.lc1 = umb; p.ty = make_uint2(t, tl); p.tc = tu;
+    return;
+#endif
+    p.y0 = ld16g(cur + t + 32u * l);
+    p.y1 = ld16g(cur + t + 32u * l + 16u);
+    p.c = ld16g(cur + t + T_CB + 16u * l);
     p.ly0 = *(const H264K_GLOBAL uint32_t *)(cur + tl + 32u * l + 12u);
     p.ly1 = *(const H264K_GLOBAL uint32_t *)(cur + tl + 32u * l + 28u);
     p.lc0 = *(const H264K_GLOBAL uint32_t *)(cur + tl + T_CB + 16u * l + 4u);
@@ -1786,6 +1947,11 @@ __device__ __forceinline__ int tc0_of(uint32_t t4, int bs) { return (int)((t4 >>
  * wt: the macroblock lies in the last row of a row band, the band below reads what it writes: everything goes write-through. */
 /* SLOTS = 4: every edge.  SLOTS = 1: none of the wavefront's macroblocks has an active inner edge (DBKF_INNER clear: the step was
  * claimed from the second ready list, k_frame_dbk) — only the left and the upper macroblock edge exist: a third of the work. */
+#if defined(DBK_WHATIF) && (DBK_WHATIF & 2)
+#define DBK_BS(x) 0
+#else
+#define DBK_BS(x) (x)
+#endif
 template <bool BANDED, int SLOTS>
 __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, const DbkLoads &p, uint8_t *w, bool wt, bool inner, unsigned long long *tp = nullptr)
 {
@@ -1837,7 +2003,7 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
             const uint32_t t4_l = perm(t3a, w_ll, 0x0403020Cu), t4_i = perm(t3a, w_li, 0x0603020Cu);    /* { 0, tc0(1), tc0(2), tc0(3) } */
 #pragma unroll
             for (int e = 0; e < SLOTS; e++) {
-                const int bs = act ? bs_of(w0s, w1s, e) : 0;
+                const int bs = DBK_BS(act ? bs_of(w0s, w1s, e) : 0);
                 if (__ballot(bs != 0)) filter_luma_pk(px + 4 * e, bs, e ? A_i : A_l, e ? B_i : B_l, tc0_of(e ? t4_i : t4_l, bs), one);
             }
         }
@@ -1868,7 +2034,7 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
         }
         if (any_v) {
             const uint32_t w0s = p.r0.x >> (4 * c4), w1s = p.r0.y >> (4 * c4);     /* chroma rows 2 c4, 2 c4 + 1 = luma rows 4 c4 .. 4 c4 + 3: segment c4 */
-            const int bs0 = act ? (int)(w0s & 15u) : 0, bs1 = act ? (int)(w1s & 15u) : 0;
+            const int bs0 = DBK_BS(act ? (int)(w0s & 15u) : 0), bs1 = DBK_BS(act ? (int)(w1s & 15u) : 0);
             if (__ballot(bs0 != 0))
                 filter_chroma_pk(px + 2, bs0, pk_splat_byte(w_cl, 0), pk_splat_byte(w_cl, 1), tc0_of(perm(t3a, w_cl, 0x0703020Cu), bs0));
             if constexpr (SLOTS == 4) if (__ballot(bs1 != 0))
@@ -1902,7 +2068,7 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
         const uint32_t t4_t = perm(t3a, w_lt, 0x0503020Cu), t4_i = perm(t3a, w_li, 0x0603020Cu);
 #pragma unroll
         for (int e = 0; e < SLOTS; e++) {
-            const int bs = act ? bs_of(w0s, w1s, e) : 0;
+            const int bs = DBK_BS(act ? bs_of(w0s, w1s, e) : 0);
             if (__ballot(bs != 0)) {
                 filter_luma_pk(px + 4 * e, bs, e ? A_i : A_t, e ? B_i : B_t, tc0_of(e ? t4_i : t4_t, bs), one);
                 if (act) {
@@ -1919,7 +2085,7 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
 #pragma unroll
         for (int r = 0; r < (SLOTS == 4 ? 10 : 4); r++) px[r] = as_s2(perm(0u, *reinterpret_cast<const uint16_t *>(colp + r * CS), 0x0C010C00u));
         const uint32_t w0s = p.r0.z >> (4 * c4), w1s = p.r0.w >> (4 * c4);
-        const int bs0 = act ? (int)(w0s & 15u) : 0, bs1 = act ? (int)(w1s & 15u) : 0;
+        const int bs0 = DBK_BS(act ? (int)(w0s & 15u) : 0), bs1 = DBK_BS(act ? (int)(w1s & 15u) : 0);
         if (__ballot(bs0 != 0)) {
             filter_chroma_pk(px + 0, bs0, pk_splat_byte(w_ctp, 0), pk_splat_byte(w_ctp, 1), tc0_of(perm(t3b, w_ctp, 0x0403020Cu), bs0));
             if (act) { *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + 1 * CS) = (uint16_t)perm(0u, as_u32(px[1]), 0x0C0C0200u); *reinterpret_cast<uint16_t *>(const_cast<uint8_t *>(colp) + 2 * CS) = (uint16_t)perm(0u, as_u32(px[2]), 0x0C0C0200u); }
@@ -1937,7 +2103,11 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
      * of LDS reads; the stores that follow are predicated but wait for nothing.  (Written the natural way — every condition
      * reads what it stores — the compiler emits ten read -> wait -> store sequences one after the other behind their exec-mask
      * branches: 4-5.6 k cycles per step, more than a filter pass, measured with tools/prof_tail.py.) ---- */
+#ifdef DBK_WHATIF
+    if (act && !(DBK_WHATIF & 1)) {          /* (timing experiment: bit 0 = no store phase, bit 1 = no filter arithmetic; results are wrong) */
+#else
     if (act) {
+#endif
         const uint32_t t = (uint32_t)mb * TILE;
         uint8_t *cur = fd.cur;
         H264K_GLOBAL uint8_t *curg = (H264K_GLOBAL uint8_t *)fd.cur;
@@ -1957,6 +2127,7 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
         for (int h = 0; h < 2; h++)
             asm volatile("" : "+v"(yr[h].x), "+v"(yr[h].y), "+v"(yr[h].z), "+v"(yr[h].w), "+v"(cr[h].x), "+v"(cr[h].y), "+v"(lyv[h]), "+v"(lcv[h]));
         asm volatile("" : "+v"(tyv.x), "+v"(tyv.y), "+v"(tcv));
+        if (tp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tp[12] += DTICK() - d3; }
 #pragma unroll
         for (int h = 0; h < 2; h++) {                              /* luma rows 2l, 2l+1 */
             const int row = 2 * l + h;
@@ -1977,6 +2148,7 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
                 if (BANDED && wt) put4(cur + o, cr[h].x, true); else *(H264K_GLOBAL uint32_t *)(curg + o) = cr[h].x;
             }
         }
+        if (tp) tp[13] += DTICK() - d3;
         if (f_left) {
             const uint32_t tl = t - TILE;
 #pragma unroll
@@ -1998,6 +2170,7 @@ __device__ __forceinline__ void deblock_mb(const FrameDesc &fd, int mb, int l, c
             }
         }
     }
+    if (tp) tp[14] += DTICK() - d3;
     wave_sync();          /* tiles are reused by this worker's next macroblock */
     if (tp) { const unsigned long long d4 = DTICK(); tp[8] += d1 - d0; tp[9] += d2 - d1; tp[10] += d3 - d2; tp[11] += d4 - d3; }
 #undef DTICK

@@ -26,4 +26,5 @@ for tick in (0, 9, 22, 28, 41, 60):
           f"idle {out[:,0].sum()/tot:.0%}  filter {out[:,1].sum()/tot:.0%}  store-wait+release {out[:,2].sum()/tot:.0%}; "
           f"active waves {int((out[:,5] > 0).sum())}; wave cycles {tot/max(1,(out[:,5] > 0).sum()):.0f} avg; steps/wave {out[:,5].sum()/max(1,(out[:,5] > 0).sum()):.0f}, MBs per step {out[:,3].sum()/max(1,out[:,5].sum()):.2f}, "
           f"cycles per step {out[:,1].sum()/max(1,out[:,5].sum()):.0f} = load {out[:,8].sum()/max(1,out[:,5].sum()):.0f} + V {out[:,9].sum()/max(1,out[:,5].sum()):.0f} "
-          f"+ H {out[:,10].sum()/max(1,out[:,5].sum()):.0f} + store {out[:,11].sum()/max(1,out[:,5].sum()):.0f}")
+          f"+ H {out[:,10].sum()/max(1,out[:,5].sum()):.0f} + store {out[:,11].sum()/max(1,out[:,5].sum()):.0f} (LDS reads done at {out[:,12].sum()/max(1,out[:,5].sum()):.0f}, own tile stored at {out[:,13].sum()/max(1,out[:,5].sum()):.0f}, neighbours at {out[:,14].sum()/max(1,out[:,5].sum()):.0f}); "
+          f"per step outside deblock_mb: claim + load issue {(out[:,1].sum()-out[:,8:12].sum())/max(1,out[:,5].sum()):.0f}, release {out[:,2].sum()/max(1,out[:,5].sum()):.0f}")
