@@ -395,6 +395,11 @@ def main():
         sums = rep.checksums(heads[-1]["cur_slot"])
         if not (sums == golden_sums[-1]).all():
             raise SystemExit(f"rank {rank}: ARGB variant: final pictures are not bit-exact")
+        # ... and what the timed region converted last (on its own HIP stream, beside the next tick's per-picture kernels) is the reference's conversion
+        if str(n_pics - 1) in golden["convert_sha256"]:
+            got = rep.fetch_converted(0, w_px * h_px)
+            if hashlib.sha256(got.tobytes()).hexdigest() != golden["convert_sha256"][str(n_pics - 1)][h264bsd_amd.FMT_BGRA]:
+                raise SystemExit(f"rank {rank}: ARGB variant: the conversion inside the timed region differs from the reference")
         rep.set_convert(-1)
         release(rep)
         if dist is not None:

@@ -57,7 +57,37 @@ def _coef_block(rng, ac_only=False, density=0.3, amp=12):
     return c
 
 
-def build_job(lib, rng, wmb, hmb, cur_slot, n_slots, ref_slots, *, p_inter=0.6, p_pcm=0.03, mv_range=None, any_deblock=True, patch=None):
+LS2 = [16, 18, 20, 23, 25, 29]      # the largest level scale of qp % 6 (8.5.9), LS0 the scale of the chroma DC
+LS0 = [10, 11, 13, 14, 16, 18]
+
+
+def _to_bound(rng, coefs, first, n_luma, has_cdc, n_cac, qp_y, qp_c):
+    """Rescale the levels of an inter macroblock so that the parser's magnitude bound (hd_resid.c: sum of the level magnitudes x
+    the largest scale, <= 32735 per plane) lands within +-15 % of its limit: the macroblocks on either side of FJ_CODED_WIDE, and
+    intermediates that use most of 16 bits on the packed side of it."""
+    def rescale(lo, hi, scale, extra=0.0):
+        blk = coefs[lo:hi].astype(np.int64)
+        tot = np.abs(blk).sum()
+        if tot == 0:
+            return
+        target = rng.uniform(0.85, 1.15) * 32735.0 - extra
+        f = max(0.0, target) / (tot * scale)
+        new = np.clip(np.rint(blk * f), -2047, 2047).astype(np.int16)
+        if np.abs(new).sum() == 0:
+            new[np.argmax(np.abs(blk))] = 1
+        coefs[lo:hi] = new
+    o = 16 * first
+    rescale(o, o + 16 * n_luma, LS2[qp_y % 6] << (qp_y // 6))
+    o += 16 * n_luma
+    dc_max = 0.0
+    if has_cdc:
+        q6 = qp_c // 6
+        dc_max = float(np.abs(coefs[o:o + 8].astype(np.int64)).sum() * LS0[qp_c % 6] * (1 << (q6 - 1 if q6 >= 1 else 0)))
+        o += 16
+    rescale(o, o + 16 * n_cac, LS2[qp_c % 6] << (qp_c // 6), dc_max)
+
+
+def build_job(lib, rng, wmb, hmb, cur_slot, n_slots, ref_slots, *, p_inter=0.6, p_pcm=0.03, mv_range=None, any_deblock=True, patch=None, near_bound=False):
     """One random picture.  ref_slots: slots holding valid pictures (empty -> intra only).
     patch(recs, mvs): called on the records [n][32] and the dense vectors [n][16][2] before the job is finished — a finished
     job carries its vectors in the records and the sparse section (framejob.h), the dense array here is only h264bsdmiJobFinalize's input."""
@@ -111,6 +141,9 @@ def build_job(lib, rng, wmb, hmb, cur_slot, n_slots, ref_slots, *, p_inter=0.6, 
                     for k in range(8):
                         if rng.random() < 0.3:
                             coefs[16 * nblk:16 * nblk + 16] = _coef_block(rng, ac_only=True); nblk += 1; coded |= 1 << (16 + k)
+                if near_bound and coded:
+                    first = struct.unpack_from("<I", r, 12)[0]
+                    _to_bound(rng, coefs, first, bin(coded & 0xFFFF).count("1"), (coded >> 25) & 1, bin((coded >> 16) & 0xFF).count("1"), int(r[1]), int(r[2]))
         elif u < p_inter + p_pcm or (not ref_slots and u < p_pcm):
             r[0] = 3                                                   # I_PCM: 384 raw samples = 12 blocks
             r[1] = 0

@@ -53,6 +53,30 @@ def test_random_pictures_reconstruction_only(built, seed):
     _run(built, jobs, n_streams=1, stages=3)
 
 
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_residuals_at_the_16_bit_bound(built, seed):
+    """inter macroblocks whose level magnitudes put the parser's bound (hd_resid.c) within +-15 % of its limit: on one side
+    k_recon_inter runs luma and chroma as one packed 16-bit transform (intermediates use most of the 16 bits), on the other
+    (FJ_CODED_WIDE, set by h264bsdmiJobFinalize for hand-built jobs) in 32 bits; both must equal the oracle's 32-bit arithmetic"""
+    import struct
+    rng = np.random.default_rng(seed)
+    lib = built.lib()
+    jobs = [build_job(lib, rng, 9, 6, 0, 3, [])]
+    jobs.append(build_job(lib, rng, 9, 6, 1, 3, [0], p_inter=0.95, mv_range=80, near_bound=True))
+    jobs.append(build_job(lib, rng, 9, 6, 2, 3, [0, 1], p_inter=0.95, mv_range=80, near_bound=True))
+    wide = narrow = 0
+    for j in jobs[1:]:
+        h = pyoracle.blob_header(j)
+        for a in range(h["n_mbs"]):
+            kind = j[h["rec_off"] + 32 * a]
+            coded = struct.unpack_from("<I", j, h["rec_off"] + 32 * a + 8)[0]
+            if kind == 0 and coded & 0x02FFFFFF:
+                wide += (coded >> 27) & 1
+                narrow += 1 - ((coded >> 27) & 1)
+    assert wide >= 10 and narrow >= 10, (wide, narrow)
+    _run(built, jobs, stages=3)
+
+
 def test_no_deblocking_at_all(built):
     rng = np.random.default_rng(21)
     lib = built.lib()
