@@ -10,11 +10,12 @@ timed region starts; outputs stay in HBM and are verified on the device against 
 checksums (every picture of every stream, in an untimed verification pass, and the final picture after
 the timed region).  A run that is not bit-exact aborts.
 
-`value` is the LOCK-STEP variant (every stream on the same picture index, so the two IDR pictures of the
-stream give two all-intra ticks per step: the worst case).  The same work with odd-numbered streams
-started at the second IDR ("staggered") is measured in the same run and reported
-under `staggered`; streams that are not in step at all (every stream at its own picture index, with and
-without heavy lanes) under `desynchronised`.
+`value` is the LOCK-STEP variant (every stream on the same picture index: every tick holds 256 pictures of the same
+kind and cost, which is the FRIENDLIEST schedule for batched launches — the two IDR pictures of the stream give two
+all-intra ticks per step, but no tick ever waits for a stray heavy picture).  The same work with odd-numbered streams
+started at the second IDR ("staggered") is measured in the same run and reported under
+`staggered`; streams that are not in step at all (every stream at its own picture index: what 256 independent cameras
+deliver; with and without heavy lanes) under `desynchronised` — 0.32-0.65 of the lock-step figure.
 
 One process per GPU: `python bench.py` (N=1) or
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.  Streams are independent,
@@ -137,10 +138,13 @@ def cpu_baseline(data, seconds=10.0):
     return out
 
 
-def end_to_end(data, streams, threads, laps=2):
+def end_to_end(data, streams, threads, laps=2, pull=False, barrier=None):
     """the drop-in C API end to end — host parse on the library's parser threads
-    (h264bsdmiDecodePictureBatch), frame jobs built in pinned memory, one H2D copy per picture, kernels; pictures stay in
-    HBM (no D2H).  Round k+1 is parsed while round k reconstructs (h264bsdmiFlushAsync)."""
+    (h264bsdmiDecodePictureBatch), frame jobs built in pinned memory, one k_h2d launch per tick, kernels.  Round k+1 is parsed
+    while round k reconstructs (h264bsdmiFlushAsync).  pull = False: pictures stay in HBM (what a GPU consumer gets through
+    h264bsdmiNextOutputPictureDevice); pull = True: every picture is ALSO pulled to host memory through
+    h264bsdNextOutputPicture (h264bsdmiNextOutputPictureBatch: layout kernel + 3.1 MB over PCIe per picture, on the same
+    threads) before the next round is parsed, as the reference's call protocol demands (posix/test_h264bsd.c:146-177)."""
     import h264bsd_amd as h
     L = h.lib()
     decs = [h.Decoder() for _ in range(streams)]
@@ -150,22 +154,28 @@ def end_to_end(data, streams, threads, laps=2):
     for pic in range(73 * (laps + 1)):
         if pic == 73:                                         # first lap: untimed (pinned staging buffers are allocated)
             assert L.h264bsdmiFlush() == 0
+            if barrier is not None:
+                barrier()
             t0 = time.perf_counter()
         assert len(drv.step()) == streams
         assert L.h264bsdmiFlushAsync() == 0
+        if pull:
+            ptrs, _ = h.pull_batch(decs)
+            assert all(ptrs)
         timed += pic >= 73
     assert L.h264bsdmiFlush() == 0
     dt = time.perf_counter() - t0
-    jobs, _, _ = h.capture_stream(data, copy_elision=os.environ.get("H264BSDMI_COPY_ELISION", "1")[:1] != "0")
+    jobs, _, info = h.capture_stream(data, copy_elision=os.environ.get("H264BSDMI_COPY_ELISION", "1")[:1] != "0")
     h2d = sum(len(j) for j in jobs) * streams * laps
     for d in decs:
         d.close()
     pics = streams * timed
     return dict(value=pics * 8160 / dt, unit="macroblocks/s", fps=pics / dt, streams=streams, parser_threads=int(threads),
-                host_cores=os.cpu_count(), cpu_quota=cpu_quota(), h2d_bytes_per_picture=h2d / pics, d2h_bytes_per_picture=0,
+                host_cores=os.cpu_count(), cpu_quota=cpu_quota(), h2d_bytes_per_picture=h2d / pics,
+                d2h_bytes_per_picture=info["width_mbs"] * info["height_mbs"] * 384 if pull else 0, seconds=dt,
                 device_errors=h.device_errors(),
                 sample=f"{streams} decoder instances x {timed} pictures through h264bsdDecode-equivalent batch calls, PCIe inclusive, "
-                       f"{dt:.1f} s; pictures left in HBM")
+                       f"{dt:.1f} s; " + ("every picture pulled to host memory (h264bsdNextOutputPicture semantics)" if pull else "pictures left in HBM"))
 
 
 def main():
@@ -212,6 +222,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but {world} rank(s) were started (WORLD_SIZE): refusing to report a line for another GPU count")
     side_steps = args.side_steps or min(args.steps, 20)
+    # ranks on this host share its CPUs: the library's parser pool takes its share
+    os.environ.setdefault("H264BSDMI_HOST_SHARE", os.environ.get("LOCAL_WORLD_SIZE", str(world)))
 
     import torch
     import h264bsd_amd
@@ -272,7 +284,7 @@ def main():
 
     def run_variant(odd_offset, steps, jobs=jobs, main=True):
         """Verify, warm up and time one variant of the workload.  odd_offset = 0: lock-step (every stream on
-        the same picture index: two all-IDR ticks per step, the worst case); otherwise odd streams start at the
+        the same picture index: two all-IDR ticks per step, every tick homogeneous); otherwise odd streams start at the
         second IDR (SURVEY.md §8d config 4 "staggered").  Returns (elapsed s, kernel ms, launches, device ms, job bytes)."""
         rep = replay_for(jobs, odd_offset=odd_offset)
         extra = {}
@@ -474,6 +486,28 @@ def main():
         dist.all_gather(allv, mine)
         per_gpu = [n_pics * args.streams * n_mbs * args.steps / float(v.item()) for v in allv]
 
+    # ---- end to end through the drop-in C API, on EVERY rank at once ("end-to-end MB/s through the C API at 1/2/4/8
+    # GPUs"): each rank's library sizes its parser pool for its share of the CPUs the container may use (H264BSDMI_HOST_SHARE =
+    # ranks on this host) and pins it to its GPU's NUMA node; the node figure is all ranks' pictures over the slowest rank's time.
+    e2e = {}
+    if not args.no_end_to_end:
+        for key, pull, laps in (("end_to_end", False, 2), ("end_to_end_host_output", True, 1)):
+            barrier()
+            leg = end_to_end(data, min(args.streams, 256), 0, laps=laps, pull=pull, barrier=barrier if dist is not None else None)      # 0 threads: the library's default
+            if dist is not None:
+                mine = torch.tensor([leg["fps"], leg["seconds"], float(leg["parser_threads"])], dtype=torch.float64, device=red_dev)
+                allv = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allv, mine)
+                secs = max(float(v[1].item()) for v in allv)
+                pics = sum(float(v[0].item()) * float(v[1].item()) for v in allv)
+                leg["per_gpu"] = {"fps": [float(v[0].item()) for v in allv], "parser_threads": [int(v[2].item()) for v in allv],
+                                  "note": "each rank's own clock; the ranks share the host's CPUs (and its CPU quota, if any)"}
+                leg["fps"] = pics / secs
+                leg["value"] = pics * 8160 / secs
+                leg["n_gpus"] = world
+                leg["streams"] = leg["streams"] * world
+            e2e[key] = leg
+
     if rank == 0:
         pics_per_step = n_pics * args.streams * world
         mbs = pics_per_step * n_mbs * args.steps
@@ -624,8 +658,8 @@ def main():
                     d["whole_path_frac_moved"] = d["whole_path_frac"] * moved_per_mb / alg_per_mb      # (the copies that elision leaves out do not move)
                     d["vs_lock_step"] = d["value"] / (mbs / elapsed)
             out["desynchronised"] = desync
-        if world == 1 and not args.no_end_to_end:
-            out["end_to_end"] = end_to_end(data, min(args.streams, 256), 0)      # 0: the library's default (usable CPUs, at most 64)
+        for key, leg in e2e.items():
+            out[key] = leg
         out["device_errors"] = h264bsd_amd.device_errors()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data)

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdProfile", "h264bsdAlloc", "h264bsdFree", "h264bsdConvertToRGBA", "h264bsdConvertToBGRA",
     "h264bsdConvertToYCbCrA",
     "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync", "h264bsdmiDeviceErrors",
-    "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiSetParserThreads", "h264bsdmiSetInputReadOnly", "h264bsdmiSetCopyElision",
+    "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiNextOutputPictureBatch", "h264bsdmiSetParserThreads", "h264bsdmiSetInputReadOnly", "h264bsdmiSetCopyElision",
     "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayCreateSched", "h264bsdmiReplayReschedule", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiDebugSetTail", "h264bsdmiDebugDeviceErrorEvents", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
@@ -359,6 +359,25 @@ class BatchDriver:
                 self.pictures[k] += 1
                 ready.append(k)
         return ready
+
+
+def pull_batch(decoders, frame_bytes=None):
+    """h264bsdmiNextOutputPictureBatch: the next output picture of every decoder, pulled on the library's threads.
+    Returns (pointers, pic ids); with frame_bytes also numpy views of the pinned host pictures (valid until the next decode call)."""
+    import numpy as np
+    L = lib()
+    n = len(decoders)
+    VP = ctypes.c_void_p * n
+    U32 = ctypes.c_uint32 * n
+    dec = VP(*[d._st for d in decoders])
+    out, ids, idr, nerr = VP(), U32(), U32(), U32()
+    if L.h264bsdmiNextOutputPictureBatch(n, dec, out, ids, idr, nerr) != 0:
+        raise RuntimeError("h264bsdmiNextOutputPictureBatch failed")
+    ptrs = [out[i] for i in range(n)]
+    if frame_bytes is None:
+        return ptrs, list(ids)
+    views = [None if not p else np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), (frame_bytes,)) for p in ptrs]
+    return views, list(ids)
 
 
 def job_header(blob):

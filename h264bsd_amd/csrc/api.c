@@ -336,6 +336,7 @@ typedef struct Batch {
     u8 *const *buf;
     const u32 *len, *pic_id;
     u32 *status, *consumed, *n_errors;
+    u8 **out;                               /* non-NULL: a PULL batch — item i = h264bsdNextOutputPicture(dec[i]) -> out[i], pic_id[i], n_errors[i] */
     atomic_uchar *taken;                    /* one flag per item */
     int active;                             /* pool threads currently inside this batch (guarded by g_pool.mu) */
     signed char *item_dev;                  /* device of every item's decoder instance (-1: capture mode) */
@@ -355,6 +356,14 @@ static struct {
 
 static void batch_run_item(Batch *b, u32 i)
 {
+    if (b->out) {
+        u32 id = 0, idr = 0, nerr = 0;
+        b->out[i] = h264bsdNextOutputPicture(b->dec[i], &id, &idr, &nerr);
+        if (b->status) b->status[i] = idr;
+        if (b->consumed) b->consumed[i] = id;
+        if (b->n_errors) b->n_errors[i] = nerr;
+        return;
+    }
     b->status[i] = h264bsdmiDecodePicture(b->dec[i], b->buf[i], b->len[i], b->pic_id ? b->pic_id[i] : 0,
                                           &b->consumed[i], b->n_errors ? &b->n_errors[i] : NULL);
 }
@@ -500,38 +509,56 @@ int h264bsdmiSetParserThreads(int n)
     return r;
 }
 
-int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *dec, u8 *const *buf, const u32 *len, const u32 *picId,
-                                u32 *status, u32 *consumed, u32 *nErrors)
+static int run_batch(Batch *b)
 {
-    if (!dec || !buf || !len || !status || !consumed) return -1;
-    if (!n) return 0;
+    const u32 n = b->n;
     pthread_mutex_lock(&g_pool.api_mu);
     if (!g_pool.n_threads) h264bsdmiSetParserThreads(0);
     atomic_uchar *taken = (atomic_uchar *)calloc(n, sizeof(atomic_uchar));
     signed char *item_dev = (signed char *)malloc(n);
     if (!taken || !item_dev) { free(taken); free(item_dev); pthread_mutex_unlock(&g_pool.api_mu); return -1; }
-    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, taken, 0, item_dev, { 0 }, 0 };
+    b->taken = taken; b->item_dev = item_dev; b->active = 0; b->n_devs = 0;
     for (u32 i = 0; i < n; i++) {
-        const ApiDec *a = dec_of(dec[i]);
+        const ApiDec *a = dec_of(b->dec[i]);
         const int dv = a && a->hd ? eng_sink_device(&a->hd->sink) : -1;
         item_dev[i] = (signed char)dv;
         int known = dv < 0;
-        for (int k = 0; k < b.n_devs && !known; k++) known = b.devs[k] == dv;
-        if (!known && b.n_devs < 16) b.devs[b.n_devs++] = dv;
+        for (int k = 0; k < b->n_devs && !known; k++) known = b->devs[k] == dv;
+        if (!known && b->n_devs < 16) b->devs[b->n_devs++] = dv;
     }
     pthread_mutex_lock(&g_pool.mu);
-    g_pool.batch = &b;
+    g_pool.batch = b;
     g_pool.generation++;
     pthread_cond_broadcast(&g_pool.wake);
     const u32 nw = (u32)g_pool.n_threads;
     pthread_mutex_unlock(&g_pool.mu);
-    batch_work(&b, 0, nw);
+    batch_work(b, 0, nw);
     pthread_mutex_lock(&g_pool.mu);
     g_pool.batch = NULL;                    /* late wakers find nothing; those inside are counted in b.active */
-    while (b.active) pthread_cond_wait(&g_pool.idle, &g_pool.mu);
+    while (b->active) pthread_cond_wait(&g_pool.idle, &g_pool.mu);
     pthread_mutex_unlock(&g_pool.mu);
     free(taken);
     free(item_dev);
     pthread_mutex_unlock(&g_pool.api_mu);
     return 0;
+}
+
+int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *dec, u8 *const *buf, const u32 *len, const u32 *picId,
+                                u32 *status, u32 *consumed, u32 *nErrors)
+{
+    if (!dec || !buf || !len || !status || !consumed) return -1;
+    if (!n) return 0;
+    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, NULL, NULL, 0, NULL, { 0 }, 0 };
+    return run_batch(&b);
+}
+
+/* h264bsdNextOutputPicture() of n decoder instances at once, on the parser pool's threads: every thread enqueues its pictures'
+ * way out (layout kernel + copy to pinned host memory) and waits for ITS copies only, so the transfers of the instances overlap
+ * each other and the device's remaining work.  pictures[i] = NULL when instance i has no picture to give. */
+int h264bsdmiNextOutputPictureBatch(u32 n, storage_t *const *dec, u8 **pictures, u32 *picId, u32 *isIdrPic, u32 *numErrMbs)
+{
+    if (!dec || !pictures) return -1;
+    if (!n) return 0;
+    Batch b = { n, dec, NULL, NULL, NULL, isIdrPic, picId, numErrMbs, pictures, NULL, 0, NULL, { 0 }, 0 };
+    return run_batch(&b);
 }

@@ -55,6 +55,7 @@ struct StreamCtx {
     uint8_t *h_frame[FJ_MAX_SLOTS] = {};
     uint32_t *h_conv = nullptr, *d_conv = nullptr;
     uint8_t *d_planar = nullptr;            /* a picture on its way out: tiles -> the reference's planar I420 (k_detile) */
+    hipEvent_t out_ev = nullptr;            /* recorded behind the copy of a picture on its way out: the caller waits for it OUTSIDE the engine's mutex */
     std::mutex qmu;                         /* guards pending / free_bufs (submit runs on the caller's threads) */
     PendingJob acquired = { nullptr, 0, 0, nullptr };   /* staging buffer the parser is currently filling (sink_acquire) */
     std::deque<PendingJob> pending;
@@ -570,10 +571,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
 }
 
 /* Fold the device error word into the engine's sticky error bits.  Called where the host waits for the stream anyway. */
-int poll_errors(Engine *e)
+static void fold_errors(Engine *e)                    /* h_err holds a copy of the device's words that has arrived */
 {
-    HIP_TRY(hipMemcpyAsync(e->h_err, e->d_err, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
     const uint32_t fresh = e->h_err[0] & ~e->errors;
     __atomic_store_n(&e->error_events, e->h_err[1], __ATOMIC_RELAXED);
     if (fresh) {
@@ -583,6 +582,12 @@ int poll_errors(Engine *e)
         __atomic_fetch_or(&e->errors, fresh, __ATOMIC_RELAXED);
         tickets_rezero(e->device);
     }
+}
+int poll_errors(Engine *e)
+{
+    HIP_TRY(hipMemcpyAsync(e->h_err, e->d_err, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    fold_errors(e);
     return 0;
 }
 
@@ -741,6 +746,7 @@ void stream_release(StreamCtx *s)
     if (s->h_conv) hipHostFree(s->h_conv);
     if (s->d_conv) hipFree(s->d_conv);
     if (s->d_planar) hipFree(s->d_planar);
+    if (s->out_ev) { hipEventDestroy(s->out_ev); s->out_ev = nullptr; }
     s->d_frames = nullptr; s->h_conv = nullptr; s->d_conv = nullptr; s->d_planar = nullptr;
 }
 
@@ -840,63 +846,97 @@ uint32_t sink_errors(void *user)
     return __atomic_load_n(&u->e->error_events, __ATOMIC_RELAXED);
 }
 
+/* A picture leaves the device.  Under the engine's mutex only what must be ordered: everything queued is enqueued (not awaited),
+ * the layout kernel and the copy follow on the engine's stream, an event of the INSTANCE is recorded behind them.  The wait for
+ * that event — the pixels' whole latency: the tick's kernels, 3.1 MB over PCIe — happens outside the mutex, so that the other
+ * instances of the process go on submitting, flushing and pulling meanwhile (rounds 1-4 held the mutex across a synchronous
+ * copy: one picture at a time for the whole process).  Reference: the zero-copy alias of src/h264bsd_decoder.c:599-646. */
+static int out_begin(SinkUser *u)                     /* mutex held */
+{
+    if (flush_locked(u->e, false)) return -1;
+    if (!u->s->out_ev) HIP_TRY(hipEventCreateWithFlags(&u->s->out_ev, hipEventDisableTiming));
+    return 0;
+}
+static int out_end_locked(SinkUser *u)                /* mutex held: the device's error words travel with the picture */
+{
+    HIP_TRY(hipMemcpyAsync(u->e->h_err, u->e->d_err, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, u->e->stream));
+    HIP_TRY(hipEventRecord(u->s->out_ev, u->e->stream));
+    return 0;
+}
+static int out_wait(SinkUser *u)                      /* mutex NOT held */
+{
+    if (hipEventSynchronize(u->s->out_ev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lk(u->e->mu);
+    fold_errors(u->e);                                 /* (a later copy may have overwritten h_err meanwhile: it is as good or newer) */
+    return 0;
+}
+
 uint8_t *sink_fetch(void *user, uint32_t slot)
 {
     SinkUser *u = static_cast<SinkUser *>(user);
-    std::lock_guard<std::mutex> lk(u->e->mu);
     StreamCtx *s = u->s;
-    if (slot >= s->n_slots || flush_locked(u->e)) return nullptr;
-    if (!s->h_frame[slot] && hipHostMalloc((void **)&s->h_frame[slot], s->frame_bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-    if (!s->d_planar && hipMalloc((void **)&s->d_planar, s->frame_bytes) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(h264k::k_detile, dim3(512, 1), dim3(256), 0, u->e->stream, s->d_frames + (size_t)slot * s->frame_bytes,
-                       s->d_planar, s->wmb, s->hmb, (size_t)0, (size_t)0);
-    if (hipMemcpyAsync(s->h_frame[slot], s->d_planar, s->frame_bytes, hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
-    if (hipStreamSynchronize(u->e->stream) != hipSuccess) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(u->e->mu);
+        if (slot >= s->n_slots || out_begin(u)) return nullptr;
+        if (!s->h_frame[slot] && hipHostMalloc((void **)&s->h_frame[slot], s->frame_bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (!s->d_planar && hipMalloc((void **)&s->d_planar, s->frame_bytes) != hipSuccess) return nullptr;
+        hipLaunchKernelGGL(h264k::k_detile, dim3(512, 1), dim3(256), 0, u->e->stream, s->d_frames + (size_t)slot * s->frame_bytes,
+                           s->d_planar, s->wmb, s->hmb, (size_t)0, (size_t)0);
+        if (hipMemcpyAsync(s->h_frame[slot], s->d_planar, s->frame_bytes, hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
+        if (out_end_locked(u)) return nullptr;
+    }
+    if (out_wait(u)) return nullptr;
     return s->h_frame[slot];
 }
 
 uint32_t *sink_fetch_converted(void *user, uint32_t slot, int fmt)
 {
     SinkUser *u = static_cast<SinkUser *>(user);
-    std::lock_guard<std::mutex> lk(u->e->mu);
     StreamCtx *s = u->s;
-    if (slot >= s->n_slots || flush_locked(u->e)) return nullptr;
-    const uint32_t w = s->wmb * 16, h = s->hmb * 16;
-    const size_t bytes = (size_t)w * h * 4;
-    if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
-    if (!s->h_conv && hipHostMalloc((void **)&s->h_conv, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(h264k::k_convert_tiles, dim3(1024, 1), dim3(256), 0, u->e->stream,
-                       s->d_frames + (size_t)slot * s->frame_bytes, s->d_conv, s->wmb, s->hmb, fmt, (size_t)0, (size_t)0);
-    if (hipMemcpyAsync(s->h_conv, s->d_conv, bytes, hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
-    if (hipStreamSynchronize(u->e->stream) != hipSuccess) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(u->e->mu);
+        if (slot >= s->n_slots || out_begin(u)) return nullptr;
+        const uint32_t w = s->wmb * 16, h = s->hmb * 16;
+        const size_t bytes = (size_t)w * h * 4;
+        if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
+        if (!s->h_conv && hipHostMalloc((void **)&s->h_conv, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+        hipLaunchKernelGGL(h264k::k_convert_tiles, dim3(1024, 1), dim3(256), 0, u->e->stream,
+                           s->d_frames + (size_t)slot * s->frame_bytes, s->d_conv, s->wmb, s->hmb, fmt, (size_t)0, (size_t)0);
+        if (hipMemcpyAsync(s->h_conv, s->d_conv, bytes, hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
+        if (out_end_locked(u)) return nullptr;
+    }
+    if (out_wait(u)) return nullptr;
     return s->h_conv;
 }
 
 void *sink_fetch_device(void *user, uint32_t slot, int fmt, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, void **stream)
 {
     SinkUser *u = static_cast<SinkUser *>(user);
-    std::lock_guard<std::mutex> lk(u->e->mu);
     StreamCtx *s = u->s;
-    if (slot >= s->n_slots || flush_locked(u->e)) return nullptr;
-    const uint32_t fw = s->wmb * 16, fh = s->hmb * 16;
-    if (!w || !h || x0 + w > fw || y0 + h > fh) return nullptr;
-    uint8_t *frame = s->d_frames + (size_t)slot * s->frame_bytes;
     void *ret;
-    /* frames are macroblock tiles in HBM: every picture that leaves is laid out by a kernel, the whole uncropped I420
-     * frame by k_detile, everything else (window, conversion) by k_output */
-    const size_t bytes = (size_t)fw * fh * 4;
-    if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
-    if (fmt == 3 && x0 == 0 && y0 == 0 && w == fw && h == fh) {
-        hipLaunchKernelGGL(h264k::k_detile, dim3(512, 1), dim3(256), 0, u->e->stream, frame, reinterpret_cast<uint8_t *>(s->d_conv),
-                           s->wmb, s->hmb, (size_t)0, (size_t)0);
-    } else {
-        const uint32_t n = fmt == 3 ? w * h * 3 / 8 : w * h / 4;
-        hipLaunchKernelGGL(h264k::k_output, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 + 1 : 2048), dim3(256), 0, u->e->stream,
-                           frame, reinterpret_cast<uint8_t *>(s->d_conv), fw, fh, fmt, x0, y0, w, h);
+    {
+        std::lock_guard<std::mutex> lk(u->e->mu);
+        if (slot >= s->n_slots || out_begin(u)) return nullptr;
+        const uint32_t fw = s->wmb * 16, fh = s->hmb * 16;
+        if (!w || !h || x0 + w > fw || y0 + h > fh) return nullptr;
+        uint8_t *frame = s->d_frames + (size_t)slot * s->frame_bytes;
+        /* frames are macroblock tiles in HBM: every picture that leaves is laid out by a kernel, the whole uncropped I420
+         * frame by k_detile, everything else (window, conversion) by k_output */
+        const size_t bytes = (size_t)fw * fh * 4;
+        if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
+        if (fmt == 3 && x0 == 0 && y0 == 0 && w == fw && h == fh) {
+            hipLaunchKernelGGL(h264k::k_detile, dim3(512, 1), dim3(256), 0, u->e->stream, frame, reinterpret_cast<uint8_t *>(s->d_conv),
+                               s->wmb, s->hmb, (size_t)0, (size_t)0);
+        } else {
+            const uint32_t n = fmt == 3 ? w * h * 3 / 8 : w * h / 4;
+            hipLaunchKernelGGL(h264k::k_output, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 + 1 : 2048), dim3(256), 0, u->e->stream,
+                               frame, reinterpret_cast<uint8_t *>(s->d_conv), fw, fh, fmt, x0, y0, w, h);
+        }
+        ret = s->d_conv;
+        if (out_end_locked(u)) return nullptr;
+        if (stream) *stream = u->e->stream;
     }
-    ret = s->d_conv;
-    if (hipStreamSynchronize(u->e->stream) != hipSuccess) return nullptr;
-    if (stream) *stream = u->e->stream;
+    if (out_wait(u)) return nullptr;
     return ret;
 }
 

@@ -65,7 +65,13 @@ u32 h264bsdmiDecodePicture(storage_t *pStorage, u8 *buf, u32 len, u32 picId, u32
  * status[i] / consumed[i] / nErrors[i] (nErrors may be NULL) as above.  Instances must be distinct. */
 int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *pStorage, u8 *const *buf, const u32 *len, const u32 *picId,
                                 u32 *status, u32 *consumed, u32 *nErrors);
-/* Number of parser threads (default: online CPUs, at most 64; env H264BSDMI_THREADS).  Returns the value in use. */
+/* h264bsdNextOutputPicture() (src/h264bsd_decoder.c:599-646) of n distinct instances at once, on the same threads: every thread
+ * enqueues its instances' pictures on their way out (layout kernel + copy into pinned host memory) and waits for ITS copies
+ * only — the engine's lock is held while enqueueing, never while waiting — so the 3.1 MB transfers of the instances overlap.
+ * pictures[i] = NULL when instance i has no picture to give; picId / isIdrPic / numErrMbs may be NULL.  0 = ok. */
+int h264bsdmiNextOutputPictureBatch(u32 n, storage_t *const *pStorage, u8 **pictures, u32 *picId, u32 *isIdrPic, u32 *numErrMbs);
+/* Number of parser threads (default: the CPUs the process may use — affinity mask, cgroup quota — divided by H264BSDMI_HOST_SHARE,
+ * at most 64; env H264BSDMI_THREADS).  Returns the value in use. */
 int h264bsdmiSetParserThreads(int n);
 /* INPUT BUFFERS ARE MODIFIED by h264bsdDecode() and by the two calls above, exactly as by the reference: the emulation-
  * prevention bytes of the NAL unit just parsed are removed IN the caller's buffer (src/h264bsd_byte_stream.c), so that a

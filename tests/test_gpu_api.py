@@ -3,6 +3,7 @@ driven exactly like /root/reference/posix/test_h264bsd.c:146-177."""
 import ctypes
 import hashlib
 
+import numpy as np
 import pytest
 
 from conftest import STREAMS, stream_bytes
@@ -146,6 +147,37 @@ def test_parser_pool_with_async_flush_is_exact(built, golden):
                     break
                 assert hashlib.sha256(pic[0].tobytes()).hexdigest() == golden[names[k]]["frame_sha256"][seen[k]]
                 seen[k] += 1
+    assert rounds == 73 and seen == [73] * len(names)
+    for d in decs:
+        d.close()
+
+
+def test_batch_pull_on_the_parser_threads(built, golden):
+    """h264bsdmiNextOutputPictureBatch: the pictures of all instances pulled at once on the library's threads (every thread waits
+    for its own copies outside the engine's lock): same pictures, same ids, in every round; an instance without a picture gives NULL"""
+    names = ["test_640x360"] * 5 + ["test_1920x1080", "test_1920x1080_fullRange", "test_640x360"]
+    L = built.lib()
+    L.h264bsdmiSetParserThreads(6)
+    decs = [built.Decoder() for _ in names]
+    drv = built.BatchDriver(decs, [stream_bytes(n) for n in names])
+    seen = [0] * len(names)
+    rounds = 0
+    while True:
+        ready = drv.step()
+        if not ready:
+            break
+        rounds += 1
+        ptrs, ids = built.pull_batch(decs)
+        for k in range(len(names)):
+            assert (ptrs[k] is not None and ptrs[k] != 0) == (k in ready)
+            if k in ready:
+                n_bytes = decs[k].pic_width() * 16 * decs[k].pic_height() * 16 * 3 // 2
+                frame = np.ctypeslib.as_array(ctypes.cast(ptrs[k], ctypes.POINTER(ctypes.c_uint8)), (n_bytes,))
+                assert hashlib.sha256(frame.tobytes()).hexdigest() == golden[names[k]]["frame_sha256"][seen[k]]
+                assert ids[k] == seen[k]
+                seen[k] += 1
+        ptrs, _ = built.pull_batch(decs)                         # nothing left: NULL everywhere
+        assert not any(ptrs)
     assert rounds == 73 and seen == [73] * len(names)
     for d in decs:
         d.close()

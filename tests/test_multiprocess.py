@@ -76,6 +76,17 @@ def test_gpu_bench_two_ranks_on_one_box(built):
     assert len(res["per_gpu"]["value"]) == 2 and all(v > 0 for v in res["per_gpu"]["value"])
     assert abs(res["value"] - 2 * 32 * 73 * 8160 * 1000 / res["ms_per_step"]) < 1e-3 * res["value"]
     assert res["device_errors"] == 0 and "cpu_baseline" not in res
+    # the end-to-end legs run on both ranks at once and the line carries them: the node figure, every rank's
+    # own, and parser pools that together do not oversubscribe what the container may use
+    import h264bsd_amd.capi  # noqa: F401
+    for key in ("end_to_end", "end_to_end_host_output"):
+        leg = res[key]
+        assert leg["n_gpus"] == 2 and leg["streams"] == 64 and len(leg["per_gpu"]["fps"]) == 2 and all(v > 0 for v in leg["per_gpu"]["fps"])
+        assert leg["fps"] <= sum(leg["per_gpu"]["fps"]) * 1.001
+        threads = leg["per_gpu"]["parser_threads"]
+        quota = leg["cpu_quota"] or leg["host_cores"]
+        assert sum(threads) <= max(2, int(1.25 * quota) + 2), (threads, quota)
+    assert res["end_to_end_host_output"]["d2h_bytes_per_picture"] == 8160 * 384 and res["end_to_end"]["d2h_bytes_per_picture"] == 0
 
 
 @pytest.mark.gpu
@@ -86,7 +97,7 @@ def test_gpu_bench_starts_its_own_ranks(built):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "32", "--steps", "1", "--warmup", "0",
-                          "--ramp-seconds", "0", "--no-staggered", "--no-desync", "--no-argb", "--no-full-copies-variant"],
+                          "--ramp-seconds", "0", "--no-staggered", "--no-desync", "--no-argb", "--no-full-copies-variant", "--no-end-to-end"],
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, "\n".join(l for l in out.stderr.splitlines() if "socket.cpp" not in l and "amdgpu.ids" not in l)[-6000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
