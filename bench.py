@@ -568,7 +568,8 @@ def main():
                         n_i = vfile["kernels"][k]["valu_wave_instr_per_launch"] * scale
                         t_s = breakdown[k][0] * 1e-3 / breakdown[k][1]
                         per[k] = {"wave_instr_per_launch": n_i, "avg_launch_us": t_s * 1e6, "achieved": n_i / t_s, "frac": n_i / t_s / peak,
-                                  "wave_instr_per_macroblock": n_i / (n_mbs * args.streams)}
+                                  "wave_instr_per_macroblock": n_i / (n_mbs * args.streams),
+                                  "lane_util": (vfile["kernels"][k].get("active_lanes_per_valu_instr") or 0.0) / 64.0}
                 tot_i = sum(v["wave_instr_per_launch"] for v in per.values())
                 valu = {"peak_wave_instr_per_s": peak, "cycles_per_wave_instruction": cyc, "source": os.path.relpath(vpath, ROOT),
                         "per_kernel": per, "whole_path": {"wave_instr_per_tick": tot_i, "achieved": tot_i * n_pics * args.steps / (dev_total_ms * 1e-3),

@@ -1419,55 +1419,67 @@ __device__ __noinline__ void conceal_mb(const FrameDesc &fd, uint32_t mb, int la
  * Every sample of the eight directional modes is (a + 2b + c + 2) >> 2 or (a + b + 1) >> 1 over three of the block's
  * 13 neighbour samples n[0] = corner, n[1..8] = above 0..7 (above-right replaced by above[3] when it is not available),
  * n[9..12] = left 0..3 (8.3.1.2.1-9; reference Intra4x4*Prediction, src/h264bsd_intra_prediction.c:1493-1830).  The table
- * holds, per (mode, row, sample): a byte selector for v_perm_b32 (the three neighbours out of n[0..7] resp. n[8..12]), the
- * byte mask that picks between the two, the weights (1,2,1 / 1,1,0) for v_dot4_u32_u8 and the shift (= the rounding
- * term): five instructions per sample, ONE instruction stream for all lanes whatever their modes are (a switch over the
+ * holds, per (mode, row, sample): a byte selector for v_perm_b32 (the three neighbours out of n[0..7] resp. n[8..12]) and the
+ * byte mask that picks between the two.  Weights and rounding are the same for every sample — v_dot4_u32_u8 with (1, 2, 1), + 2,
+ * >> 2 — because the two-tap form is written as (a + 2 b + a + 2) >> 2 = (a + b + 1) >> 1: the selector names a twice.  One table
+ * row (the four samples of a block row) is 32 bytes, two ds_read_b128; a lane that owns a block fetches its row ONCE, before the
+ * ten dependent steps of the macroblock (round 4 fetched four 16-byte entries — selector, mask, weights, shift — inside every
+ * step, a second LDS round trip on each link of the chain).  Five instructions per sample, ONE instruction stream for all lanes whatever their modes are (a switch over the
  * modes executes every mode that occurs among the active lanes — up to eight when four macroblocks are predicted
  * together).  DC (mode 2) is the only special case. */
-__constant__ uint4 c_i4tab[36][4] = {
-    { { 0x0C010101u, 0x00000000u, 0x00010201u, 2u }, { 0x0C020202u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030303u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040404u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C010101u, 0x00000000u, 0x00010201u, 2u }, { 0x0C020202u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030303u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040404u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C010101u, 0x00000000u, 0x00010201u, 2u }, { 0x0C020202u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030303u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040404u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C010101u, 0x00000000u, 0x00010201u, 2u }, { 0x0C020202u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030303u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040404u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C010101u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C010101u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C010101u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C010101u, 0x00FFFFFFu, 0x00010201u, 2u } },
-    { { 0x0C020202u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020202u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020202u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020202u, 0x00FFFFFFu, 0x00010201u, 2u } },
-    { { 0x0C030303u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030303u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030303u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030303u, 0x00FFFFFFu, 0x00010201u, 2u } },
-    { { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u } },
-    { { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000000u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C030201u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040302u, 0x00000000u, 0x00010201u, 2u }, { 0x0C050403u, 0x00000000u, 0x00010201u, 2u }, { 0x0C060504u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C040302u, 0x00000000u, 0x00010201u, 2u }, { 0x0C050403u, 0x00000000u, 0x00010201u, 2u }, { 0x0C060504u, 0x00000000u, 0x00010201u, 2u }, { 0x0C070605u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C050403u, 0x00000000u, 0x00010201u, 2u }, { 0x0C060504u, 0x00000000u, 0x00010201u, 2u }, { 0x0C070605u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000706u, 0x00FF0000u, 0x00010201u, 2u } },
-    { { 0x0C060504u, 0x00000000u, 0x00010201u, 2u }, { 0x0C070605u, 0x00000000u, 0x00010201u, 2u }, { 0x0C000706u, 0x00FF0000u, 0x00010201u, 2u }, { 0x0C000007u, 0x00FFFF00u, 0x00010201u, 2u } },
-    { { 0x0C010001u, 0x00FF0000u, 0x00010201u, 2u }, { 0x0C020100u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030201u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040302u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C020100u, 0x00FFFF00u, 0x00010201u, 2u }, { 0x0C010001u, 0x00FF0000u, 0x00010201u, 2u }, { 0x0C020100u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030201u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C030201u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020100u, 0x00FFFF00u, 0x00010201u, 2u }, { 0x0C010001u, 0x00FF0000u, 0x00010201u, 2u }, { 0x0C020100u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C040302u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030201u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020100u, 0x00FFFF00u, 0x00010201u, 2u }, { 0x0C010001u, 0x00FF0000u, 0x00010201u, 2u } },
-    { { 0x0C010100u, 0x00000000u, 0x00000101u, 1u }, { 0x0C020201u, 0x00000000u, 0x00000101u, 1u }, { 0x0C030302u, 0x00000000u, 0x00000101u, 1u }, { 0x0C040403u, 0x00000000u, 0x00000101u, 1u } },
-    { { 0x0C010001u, 0x000000FFu, 0x00010201u, 2u }, { 0x0C020100u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030201u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040302u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C000102u, 0x0000FFFFu, 0x00010201u, 2u }, { 0x0C010100u, 0x00000000u, 0x00000101u, 1u }, { 0x0C020201u, 0x00000000u, 0x00000101u, 1u }, { 0x0C030302u, 0x00000000u, 0x00000101u, 1u } },
-    { { 0x0C010203u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C010001u, 0x000000FFu, 0x00010201u, 2u }, { 0x0C020100u, 0x00000000u, 0x00010201u, 2u }, { 0x0C030201u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C010100u, 0x00FFFF00u, 0x00000101u, 1u }, { 0x0C010001u, 0x000000FFu, 0x00010201u, 2u }, { 0x0C000102u, 0x00000000u, 0x00010201u, 2u }, { 0x0C010203u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C020201u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C020100u, 0x00FFFF00u, 0x00010201u, 2u }, { 0x0C010100u, 0x00FFFF00u, 0x00000101u, 1u }, { 0x0C010001u, 0x000000FFu, 0x00010201u, 2u } },
-    { { 0x0C030302u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C030201u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C020201u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C020100u, 0x00FFFF00u, 0x00010201u, 2u } },
-    { { 0x0C040403u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C040302u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030302u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C030201u, 0x00FFFFFFu, 0x00010201u, 2u } },
-    { { 0x0C020201u, 0x00000000u, 0x00000101u, 1u }, { 0x0C030302u, 0x00000000u, 0x00000101u, 1u }, { 0x0C040403u, 0x00000000u, 0x00000101u, 1u }, { 0x0C050504u, 0x00000000u, 0x00000101u, 1u } },
-    { { 0x0C030201u, 0x00000000u, 0x00010201u, 2u }, { 0x0C040302u, 0x00000000u, 0x00010201u, 2u }, { 0x0C050403u, 0x00000000u, 0x00010201u, 2u }, { 0x0C060504u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C030302u, 0x00000000u, 0x00000101u, 1u }, { 0x0C040403u, 0x00000000u, 0x00000101u, 1u }, { 0x0C050504u, 0x00000000u, 0x00000101u, 1u }, { 0x0C060605u, 0x00000000u, 0x00000101u, 1u } },
-    { { 0x0C040302u, 0x00000000u, 0x00010201u, 2u }, { 0x0C050403u, 0x00000000u, 0x00010201u, 2u }, { 0x0C060504u, 0x00000000u, 0x00010201u, 2u }, { 0x0C070605u, 0x00000000u, 0x00010201u, 2u } },
-    { { 0x0C020201u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C030201u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C030302u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C040302u, 0x00FFFFFFu, 0x00010201u, 2u } },
-    { { 0x0C030302u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C040302u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040403u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C040403u, 0x00FFFFFFu, 0x00010201u, 2u } },
-    { { 0x0C040403u, 0x00FFFFFFu, 0x00000101u, 1u }, { 0x0C040403u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u } },
-    { { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u }, { 0x0C040404u, 0x00FFFFFFu, 0x00010201u, 2u } },
+__constant__ uint2 c_i4tab[36][4] = {
+    { { 0x0C010101u, 0x00000000u }, { 0x0C020202u, 0x00000000u }, { 0x0C030303u, 0x00000000u }, { 0x0C040404u, 0x00000000u } },
+    { { 0x0C010101u, 0x00000000u }, { 0x0C020202u, 0x00000000u }, { 0x0C030303u, 0x00000000u }, { 0x0C040404u, 0x00000000u } },
+    { { 0x0C010101u, 0x00000000u }, { 0x0C020202u, 0x00000000u }, { 0x0C030303u, 0x00000000u }, { 0x0C040404u, 0x00000000u } },
+    { { 0x0C010101u, 0x00000000u }, { 0x0C020202u, 0x00000000u }, { 0x0C030303u, 0x00000000u }, { 0x0C040404u, 0x00000000u } },
+    { { 0x0C010101u, 0x00FFFFFFu }, { 0x0C010101u, 0x00FFFFFFu }, { 0x0C010101u, 0x00FFFFFFu }, { 0x0C010101u, 0x00FFFFFFu } },
+    { { 0x0C020202u, 0x00FFFFFFu }, { 0x0C020202u, 0x00FFFFFFu }, { 0x0C020202u, 0x00FFFFFFu }, { 0x0C020202u, 0x00FFFFFFu } },
+    { { 0x0C030303u, 0x00FFFFFFu }, { 0x0C030303u, 0x00FFFFFFu }, { 0x0C030303u, 0x00FFFFFFu }, { 0x0C030303u, 0x00FFFFFFu } },
+    { { 0x0C040404u, 0x00FFFFFFu }, { 0x0C040404u, 0x00FFFFFFu }, { 0x0C040404u, 0x00FFFFFFu }, { 0x0C040404u, 0x00FFFFFFu } },
+    { { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u } },
+    { { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u } },
+    { { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u } },
+    { { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u }, { 0x0C000000u, 0x00000000u } },
+    { { 0x0C030201u, 0x00000000u }, { 0x0C040302u, 0x00000000u }, { 0x0C050403u, 0x00000000u }, { 0x0C060504u, 0x00000000u } },
+    { { 0x0C040302u, 0x00000000u }, { 0x0C050403u, 0x00000000u }, { 0x0C060504u, 0x00000000u }, { 0x0C070605u, 0x00000000u } },
+    { { 0x0C050403u, 0x00000000u }, { 0x0C060504u, 0x00000000u }, { 0x0C070605u, 0x00000000u }, { 0x0C000706u, 0x00FF0000u } },
+    { { 0x0C060504u, 0x00000000u }, { 0x0C070605u, 0x00000000u }, { 0x0C000706u, 0x00FF0000u }, { 0x0C000007u, 0x00FFFF00u } },
+    { { 0x0C010001u, 0x00FF0000u }, { 0x0C020100u, 0x00000000u }, { 0x0C030201u, 0x00000000u }, { 0x0C040302u, 0x00000000u } },
+    { { 0x0C020100u, 0x00FFFF00u }, { 0x0C010001u, 0x00FF0000u }, { 0x0C020100u, 0x00000000u }, { 0x0C030201u, 0x00000000u } },
+    { { 0x0C030201u, 0x00FFFFFFu }, { 0x0C020100u, 0x00FFFF00u }, { 0x0C010001u, 0x00FF0000u }, { 0x0C020100u, 0x00000000u } },
+    { { 0x0C040302u, 0x00FFFFFFu }, { 0x0C030201u, 0x00FFFFFFu }, { 0x0C020100u, 0x00FFFF00u }, { 0x0C010001u, 0x00FF0000u } },
+    { { 0x0C000100u, 0x00000000u }, { 0x0C010201u, 0x00000000u }, { 0x0C020302u, 0x00000000u }, { 0x0C030403u, 0x00000000u } },
+    { { 0x0C010001u, 0x000000FFu }, { 0x0C020100u, 0x00000000u }, { 0x0C030201u, 0x00000000u }, { 0x0C040302u, 0x00000000u } },
+    { { 0x0C000102u, 0x0000FFFFu }, { 0x0C000100u, 0x00000000u }, { 0x0C010201u, 0x00000000u }, { 0x0C020302u, 0x00000000u } },
+    { { 0x0C010203u, 0x00FFFFFFu }, { 0x0C010001u, 0x000000FFu }, { 0x0C020100u, 0x00000000u }, { 0x0C030201u, 0x00000000u } },
+    { { 0x0C000100u, 0x0000FF00u }, { 0x0C010001u, 0x000000FFu }, { 0x0C000102u, 0x00000000u }, { 0x0C010203u, 0x00000000u } },
+    { { 0x0C010201u, 0x00FFFFFFu }, { 0x0C020100u, 0x00FFFF00u }, { 0x0C000100u, 0x0000FF00u }, { 0x0C010001u, 0x000000FFu } },
+    { { 0x0C020302u, 0x00FFFFFFu }, { 0x0C030201u, 0x00FFFFFFu }, { 0x0C010201u, 0x00FFFFFFu }, { 0x0C020100u, 0x00FFFF00u } },
+    { { 0x0C030403u, 0x00FFFFFFu }, { 0x0C040302u, 0x00FFFFFFu }, { 0x0C020302u, 0x00FFFFFFu }, { 0x0C030201u, 0x00FFFFFFu } },
+    { { 0x0C010201u, 0x00000000u }, { 0x0C020302u, 0x00000000u }, { 0x0C030403u, 0x00000000u }, { 0x0C040504u, 0x00000000u } },
+    { { 0x0C030201u, 0x00000000u }, { 0x0C040302u, 0x00000000u }, { 0x0C050403u, 0x00000000u }, { 0x0C060504u, 0x00000000u } },
+    { { 0x0C020302u, 0x00000000u }, { 0x0C030403u, 0x00000000u }, { 0x0C040504u, 0x00000000u }, { 0x0C050605u, 0x00000000u } },
+    { { 0x0C040302u, 0x00000000u }, { 0x0C050403u, 0x00000000u }, { 0x0C060504u, 0x00000000u }, { 0x0C070605u, 0x00000000u } },
+    { { 0x0C010201u, 0x00FFFFFFu }, { 0x0C030201u, 0x00FFFFFFu }, { 0x0C020302u, 0x00FFFFFFu }, { 0x0C040302u, 0x00FFFFFFu } },
+    { { 0x0C020302u, 0x00FFFFFFu }, { 0x0C040302u, 0x00FFFFFFu }, { 0x0C030403u, 0x00FFFFFFu }, { 0x0C040403u, 0x00FFFFFFu } },
+    { { 0x0C030403u, 0x00FFFFFFu }, { 0x0C040403u, 0x00FFFFFFu }, { 0x0C040404u, 0x00FFFFFFu }, { 0x0C040404u, 0x00FFFFFFu } },
+    { { 0x0C040404u, 0x00FFFFFFu }, { 0x0C040404u, 0x00FFFFFFu }, { 0x0C040404u, 0x00FFFFFFu }, { 0x0C040404u, 0x00FFFFFFu } },
 };
-constexpr int I4TAB_BYTES = 36 * 4 * 16;
+constexpr int I4TAB_BYTES = 36 * 4 * 8;
 
+/* the table row of (mode, block row y): selector and mask of its four samples */
+struct I4Row { uint4 a, b; };                        /* { sel0, mask0, sel1, mask1 }, { sel2, mask2, sel3, mask3 } */
+__device__ __forceinline__ I4Row intra4_entries(const uint2 *i4tab, int mode, int y)
+{
+    const uint4 *ent = reinterpret_cast<const uint4 *>(i4tab + ((mode & 15) * 4 + y) * 4);
+    I4Row r;
+    r.a = ent[0]; r.b = ent[1];
+    return r;
+}
 /* One row (4 samples) of the Intra4x4 prediction of the block at (bx4, by4) of the macroblock whose LDS tile is `tile`.
- * i4tab: the table above in LDS.  Lanes without a block pass any valid mode and ignore the result. */
-__device__ __forceinline__ void intra4_row(const uint8_t *tile, int bx4, int by4, int y, int mode, bool has_left, bool has_top, bool has_tr,
-                                           const uint4 *i4tab, int vv[4])
+ * e: the block row's table entries (intra4_entries).  Lanes without a block pass any valid mode and ignore the result. */
+__device__ __forceinline__ void intra4_row(const uint8_t *tile, int bx4, int by4, int mode, bool has_left, bool has_top, bool has_tr,
+                                           const I4Row &e, int vv[4])
 {
     /* the 13 neighbour samples in seven INDEPENDENT LDS reads: corner | above 0..7 | left 0..3 */
     const uint8_t *trow = &tile[by4 * TS + bx4];
@@ -1475,16 +1487,15 @@ __device__ __forceinline__ void intra4_row(const uint8_t *tile, int bx4, int by4
                    w2 = *reinterpret_cast<const uint32_t *>(trow + 8);
     const uint32_t l0 = tile[(by4 + 1) * TS + 3 + bx4], l1 = tile[(by4 + 2) * TS + 3 + bx4],
                    l2 = tile[(by4 + 3) * TS + 3 + bx4], l3 = tile[(by4 + 4) * TS + 3 + bx4];
-    const uint4 *ent = i4tab + ((mode & 15) * 4 + y) * 4;
     const uint32_t tr = has_tr ? w2 : (w1 >> 24) * 0x01010101u;
     const uint32_t N0 = (w0 >> 24) | (w1 << 8), N1 = (w1 >> 24) | (tr << 8);          /* n[0..3], n[4..7] */
     const uint32_t N2 = (tr >> 24) | (l0 << 8) | (l1 << 16) | (l2 << 24), N3 = l3;      /* n[8..11], n[12] */
+    const uint32_t sel[4] = { e.a.x, e.a.z, e.b.x, e.b.z }, msk[4] = { e.a.y, e.a.w, e.b.y, e.b.w };
 #pragma unroll
     for (int x = 0; x < 4; x++) {
-        const uint4 e = ent[x];                          /* selector | mask | weights | shift */
-        const uint32_t lo = perm(N1, N0, e.x), hi = perm(N3, N2, e.x);
-        const uint32_t v = (hi & e.y) | (lo & ~e.y);
-        vv[x] = (int)(__builtin_amdgcn_udot4(v, e.z, e.w, false) >> e.w);
+        const uint32_t lo = perm(N1, N0, sel[x]), hi = perm(N3, N2, sel[x]);
+        const uint32_t v = (uint32_t)__builtin_amdgcn_bitop3_b32(hi, lo, msk[x], 0xE4);      /* (hi & mask) | (lo & ~mask) */
+        vv[x] = (int)(__builtin_amdgcn_udot4(v, 0x00010201u, 2u, false) >> 2);
     }
     if (__ballot(mode == 2) != 0ull) {
         const int st = (int)((w1 & 255u) + ((w1 >> 8) & 255u) + ((w1 >> 16) & 255u) + (w1 >> 24)), sl = (int)(l0 + l1 + l2 + l3);
@@ -1561,13 +1572,17 @@ __device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, co
     L.rows.ldc = 0;
     if (kind == FJ_MB_IPCM || kind == FJ_MB_CONCEAL_I) return;
     const uint8_t *Y = fd.cur + (size_t)mb * TILE;
+#if defined(INTRA_WHATIF) && (INTRA_WHATIF & 1)      /* timing experiment: no neighbour / coefficient loads */
+    L.nb_y = lane; L.nb_c = lane + 1; L.rows.y = L.rows.c = L.rows.cdc = make_int2(lane, 1); (void)Y; (void)cross;
+    return;
+#endif
     if (avail & lo.y_bit) L.nb_y = cross && lane < 21 ? (int)ld_agent_u8(Y + lo.y_off) : (int)Y[lo.y_off];
     if (avail & lo.c_bit) L.nb_c = cross && lane < 18 ? (int)ld_agent_u8(Y + lo.c_off) : (int)Y[lo.c_off];
     L.rows = mb_residual_fetch(coded, fd.coefs + 16 * (size_t)coef_idx, lane);
 }
 
 __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int lane, uint8_t *tile, uint8_t *ctile0,
-                                         const uint4 *i4tab, const uint32_t *rec_lds, const IntraLoads &L, const IntraLaneOffs &lo, bool wt,
+                                         const uint2 *i4tab, const uint32_t *rec_lds, const IntraLoads &L, const IntraLaneOffs &lo, bool wt,
                                          int16_t *res_defer = nullptr, unsigned long long *tp = nullptr)
 {
 #define ITICK() (tp ? __builtin_readcyclecounter() : 0ull)
@@ -1592,13 +1607,23 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
     const int nb_y = L.nb_y, nb_c = L.nb_c;
 
     int ry[4], rc[4];
+#if defined(INTRA_WHATIF) && (INTRA_WHATIF & 2)      /* timing experiment: no residual arithmetic */
+    ry[0] = ry[1] = ry[2] = ry[3] = L.rows.y.x & 7; rc[0] = rc[1] = rc[2] = rc[3] = L.rows.c.x & 7;
+#else
     report_residual_range(fd, mb_residual_compute(rec.coded, rec.qp_y, rec.qp_c, rec.kind == FJ_MB_I16x16, coef, lane, L.rows, ry, rc), lane);
+#endif
 
     if (nb_y_at >= 0) tile[nb_y_at] = (uint8_t)nb_y;
     if (nb_c_at >= 0) ctile0[nb_c_at] = (uint8_t)nb_c;
     wave_sync();
     const unsigned long long i1 = ITICK();
 
+#if defined(INTRA_WHATIF) && (INTRA_WHATIF & 4)      /* timing experiment: no luma prediction */
+    if (true) {
+        res_defer = nullptr;
+        put4(Y + (by * 4 + row) * 16 + bx * 4, pack4(ry[0] & 255, ry[1] & 255, ry[2] & 255, (ry[3] + tile[4 + lane]) & 255), wt);
+    } else
+#endif
     if (rec.kind == FJ_MB_I16x16) {
         const int mode = rec.pred & 3;
         const int y = by * 4 + row, x0 = bx * 4;
@@ -1659,10 +1684,11 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
         bool has_tr;
         if (by == 0) has_tr = bx < 3 ? av_b : av_c;
         else has_tr = bx < 3 && z_of(bx + 1, by - 1) < z;
+        const I4Row ent = intra4_entries(i4tab, mode, y);          /* the lane's table row: once, not inside the ten steps */
         for (int d = 0; d < 10; d++) {
             if (bx + 2 * by == d) {
                 int vv[4];
-                intra4_row(tile, bx4, by4, y, mode, has_left, has_top, has_tr, i4tab, vv);
+                intra4_row(tile, bx4, by4, mode, has_left, has_top, has_tr, ent, vv);
                 int pr[4];
 #pragma unroll
                 for (int x = 0; x < 4; x++) pr[x] = clip255(vv[x] + ry[x]);
@@ -1730,7 +1756,7 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
  * my_mb < 0: the group has no macroblock.  Afterwards lane s of a group stores row s of the finished macroblock. */
 constexpr int INTRA_SLOT = 1024;                     /* LDS per prepared macroblock: luma tile 17 x TS + chroma tiles 2 x 144 */
 constexpr int INTRA_WAVE_LDS = 4 * INTRA_SLOT + 4 * 512 + 128;   /* four slots + four residual blocks of 16 x 16 int16 + four records */
-__device__ __forceinline__ void intra4_joint(const FrameDesc &fd, int my_mb, int lane, uint8_t *wave_lds, const uint4 *i4tab, bool wt)
+__device__ __forceinline__ void intra4_joint(const FrameDesc &fd, int my_mb, int lane, uint8_t *wave_lds, const uint2 *i4tab, bool wt)
 {
     const int g = lane >> 4, sub = lane & 15, a = sub >> 2, y = sub & 3;
     uint8_t *tile = wave_lds + g * INTRA_SLOT;
@@ -1740,25 +1766,41 @@ __device__ __forceinline__ void intra4_joint(const FrameDesc &fd, int my_mb, int
     const uint2 mw = on ? *reinterpret_cast<const uint2 *>(&tile[24]) : make_uint2(0u, 0u);
     const unsigned long long i4modes = (unsigned long long)mw.x | ((unsigned long long)mw.y << 32);
     const bool av_a = avail & FJ_AVAIL_A, av_b = avail & FJ_AVAIL_B, av_c = avail & FJ_AVAIL_C;
-    for (int d = 0; d < 10; d++) {
+    /* what a lane does in step d — which block, its mode, its table row and its residual row — depends on nothing the steps produce:
+     * it is worked out, and its two LDS reads are issued, one step AHEAD, so that a step's own chain is neighbour reads -> 20
+     * instructions -> one LDS write */
+    /* (plain scalars, no struct: the compiler keeps a struct with bool members in scratch memory) */
+    int c_bx, c_by, c_mode, c_flags;                          /* flags: 1 active, 2 has_left, 4 has_top, 8 has_tr */
+    I4Row c_ent; uint2 c_rr;
+    auto setup = [&](int d, int &o_bx, int &o_by, int &o_mode, int &o_flags, I4Row &o_ent, uint2 &o_rr) {
         const int by = min(3, d >> 1) - a, bx = d - 2 * by;
         const bool act = on && a < 2 && by >= 0 && bx >= 0 && bx <= 3;
-        if (__ballot(act) != 0ull) {
-            const int cbx = act ? bx : 0, cby = act ? by : 0;
-            const int z = z_of(cbx, cby);
-            const int mode = act ? (int)((i4modes >> (4 * z)) & 15u) : 0;
-            const bool has_left = cbx > 0 || av_a, has_top = cby > 0 || av_b;
-            const bool has_tr = cby == 0 ? (cbx < 3 ? av_b : av_c) : (cbx < 3 && z_of(cbx + 1, cby - 1) < z);
+        o_bx = act ? bx : 0; o_by = act ? by : 0;
+        const int z = z_of(o_bx, o_by);
+        o_mode = act ? (int)((i4modes >> (4 * z)) & 15u) : 0;
+        const bool has_left = o_bx > 0 || av_a, has_top = o_by > 0 || av_b;
+        const bool has_tr = o_by == 0 ? (o_bx < 3 ? av_b : av_c) : (o_bx < 3 && z_of(o_bx + 1, o_by - 1) < z);
+        o_flags = (act ? 1 : 0) | (has_left ? 2 : 0) | (has_top ? 4 : 0) | (has_tr ? 8 : 0);
+        o_ent = intra4_entries(i4tab, o_mode, y);
+        o_rr = *reinterpret_cast<const uint2 *>(res + (o_by * 4 + y) * 16 + o_bx * 4);
+    };
+    setup(0, c_bx, c_by, c_mode, c_flags, c_ent, c_rr);
+    for (int d = 0; d < 10; d++) {
+        int n_bx = 0, n_by = 0, n_mode = 0, n_flags = 0;
+        I4Row n_ent = c_ent; uint2 n_rr = c_rr;
+        if (d < 9) setup(d + 1, n_bx, n_by, n_mode, n_flags, n_ent, n_rr);
+        if (__ballot(c_flags & 1) != 0ull) {
             int vv[4];
-            intra4_row(tile, cbx * 4, cby * 4, y, mode, has_left, has_top, has_tr, i4tab, vv);
-            if (act) {
-                const uint2 rr = *reinterpret_cast<const uint2 *>(res + (cby * 4 + y) * 16 + cbx * 4);
+            intra4_row(tile, c_bx * 4, c_by * 4, c_mode, (c_flags & 2) != 0, (c_flags & 4) != 0, (c_flags & 8) != 0, c_ent, vv);
+            if (c_flags & 1) {
+                const uint2 rr = c_rr;
                 const int r0 = (int16_t)(rr.x & 0xFFFFu), r1 = (int32_t)rr.x >> 16, r2 = (int16_t)(rr.y & 0xFFFFu), r3 = (int32_t)rr.y >> 16;
-                *reinterpret_cast<uint32_t *>(&tile[(cby * 4 + 1 + y) * TS + 4 + cbx * 4]) =
+                *reinterpret_cast<uint32_t *>(&tile[(c_by * 4 + 1 + y) * TS + 4 + c_bx * 4]) =
                     pack4(clip255(vv[0] + r0), clip255(vv[1] + r1), clip255(vv[2] + r2), clip255(vv[3] + r3));
             }
         }
         wave_sync();
+        c_bx = n_bx; c_by = n_by; c_mode = n_mode; c_flags = n_flags; c_ent = n_ent; c_rr = n_rr;
     }
     if (on) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&tile[(sub + 1) * TS + 4]);
@@ -2272,7 +2314,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
     uint16_t *queue = reinterpret_cast<uint16_t *>(dep + n_loc16);
     uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + nq8);   /* [0] head, [1] tail, [2] total, [3] producers awaited, [4] producers seen, [5] poll lock */
     uint32_t *seen = ctr + 8;
-    uint4 *i4tab = reinterpret_cast<uint4 *>(seen + ((((wmb + 31) >> 5) + 3) & ~3));
+    uint2 *i4tab = reinterpret_cast<uint2 *>(seen + ((((wmb + 31) >> 5) + 3) & ~3));
     uint8_t *done_g = scratch_done(fd, 1);
 
     for (int i = tid; i < n_loc16 / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dep)[i] = 0xFFFFFFFFu;
@@ -2425,7 +2467,11 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
             }
             /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
             if (kind == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
+#if defined(INTRA_WHATIF) && (INTRA_WHATIF & 4)
+            else if (false) {
+#else
             else if (kind == FJ_MB_I4x4 && k > 1) {
+#endif
                 intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, lane_offs, wt, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512), tp);
                 if ((uint32_t)(lane >> 4) == j) joint_mb = (int)mb;
             } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, lane_offs, wt, nullptr, tp);

@@ -28,7 +28,8 @@ out += ["# per dispatch (= one tick of 256 pictures; values of the two instantia
         "# SQ_ACTIVE_* count quad-cycles summed over wavefronts (MI355X_MICROARCH.md); WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES.",
         f"# 'valu pipe' = SQ_INSTS_VALU x {VALU_CYC} cycles (measured: tools/probes/valu_rate_probe.hip) / (1024 SIMDs x kernel time per tick from the un-profiled bench line of the same build x {GHZ} GHz).",
         f"# bench line of this build: {bl['value'] / 1e6:.1f} M MB/s, device ms per step " + json.dumps({k: round(v, 1) for k, v in ms.items() if isinstance(v, (int, float))}),
-        "kernel           dispatches  VALU instr  SALU instr   LDS instr  VMEM rd/wr   parked  issue-stall  issuing  LDS-stall  bank-confl  L2 hit  valu pipe"]
+        "# 'lanes' = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = active lanes per wave64 VALU instruction (calibrated: tools/probes/lane_util_probe.hip gives 64.0 / 32.0 / 16.0 / 8.0 / 1.0 for 64 / 32 / 16 / 8 / 1 active lanes: no further factor).",
+        "kernel           dispatches  VALU instr  SALU instr   LDS instr  VMEM rd/wr   parked  issue-stall  issuing  LDS-stall  bank-confl  L2 hit  valu pipe  lanes"]
 for k in order:
     v = {n: (t / c if c else 0.0) for n, (t, c) in vals.get(k, {}).items()}
     if not v:
@@ -40,7 +41,7 @@ for k in order:
     n = max(c for _, c in vals[k].values())
     out.append(f"{k:16s} {n:10d}  {v.get('SQ_INSTS_VALU', 0):10.3e}  {v.get('SQ_INSTS_SALU', 0):10.3e}  {v.get('SQ_INSTS_LDS', 0):10.3e}  "
                f"{v.get('SQ_INSTS_VMEM_RD', 0):.2e}/{v.get('SQ_INSTS_VMEM_WR', 0):.2e}  {v.get('SQ_WAIT_ANY', 0) / wc:5.0%}  {v.get('SQ_WAIT_INST_ANY', 0) / wc:10.0%}  "
-               f"{v.get('SQ_ACTIVE_INST_ANY', 0) / wc:6.0%}  {v.get('SQ_WAIT_INST_LDS', 0) / wc:8.1%}  {v.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, v.get('SQ_LDS_IDX_ACTIVE', 0)):9.1%}  {hit:5.0%}  {pipe:8.0%}")
+               f"{v.get('SQ_ACTIVE_INST_ANY', 0) / wc:6.0%}  {v.get('SQ_WAIT_INST_LDS', 0) / wc:8.1%}  {v.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, v.get('SQ_LDS_IDX_ACTIVE', 0)):9.1%}  {hit:5.0%}  {pipe:8.0%}  {(v.get('SQ_THREAD_CYCLES_VALU', 0) / v['SQ_INSTS_VALU']) if v.get('SQ_INSTS_VALU') else 0:5.1f}")
 out.append("")
 out.append("# raw per-dispatch values")
 for k in order:
@@ -60,7 +61,7 @@ for k in order:
     v = {n: (t / c if c else 0.0) for n, (t, c) in vals.get(k, {}).items()}
     if v:
         table["kernels"][k] = {"valu_wave_instr_per_launch": v.get("SQ_INSTS_VALU", 0.0), "salu_wave_instr_per_launch": v.get("SQ_INSTS_SALU", 0.0),
-                               "lds_wave_instr_per_launch": v.get("SQ_INSTS_LDS", 0.0), "active_lanes_per_valu_instr": (v.get("SQ_THREAD_CYCLES_VALU", 0.0) / v["SQ_INSTS_VALU"] / 4.0) if v.get("SQ_INSTS_VALU") else None}
+                               "lds_wave_instr_per_launch": v.get("SQ_INSTS_LDS", 0.0), "active_lanes_per_valu_instr": (v.get("SQ_THREAD_CYCLES_VALU", 0.0) / v["SQ_INSTS_VALU"]) if v.get("SQ_INSTS_VALU") else None}
 json.dump(table, open(os.path.join(root, "profiles", f"{tag}_sq_counters.json"), "w"), indent=1)
 print("\n".join(out[:24]))
 
