@@ -290,11 +290,15 @@ int h264bsdmiJobFinalize(u8 *job, u32 capacity, u32 n_coef_blocks)
             const u32 has_cdc = (r->coded & FJ_CODED_CHROMA_DC) ? 1u : 0u;
             if ((size_t)h->coef_off + ((size_t)r->coef_idx + n_l + has_cdc + n_c) * 32u > capacity) continue;      /* (fj_finalize rejects the job) */
             const int16_t *p = (const int16_t *)(job + h->coef_off) + 16u * (size_t)r->coef_idx;
-            u32 sl = 0, sd = 0, sc = 0;
-            for (u32 i = 0; i < 16u * n_l; i++) sl += (u32)abs(p[i]);
-            p += 16u * n_l;
-            if (has_cdc) { for (int i = 0; i < 8; i++) sd += (u32)abs(p[i]); p += 16; }
-            for (u32 i = 0; i < 16u * n_c; i++) sc += (u32)abs(p[i]);
+            u32 sl = 0, sd = 0, sc = 0;                 /* the largest block's sum of each kind, like the parser's (hd_mb.c parse_residual) */
+            for (u32 b = 0; b < n_l; b++, p += 16) { u32 t = 0; for (int i = 0; i < 16; i++) t += (u32)abs(p[i]); if (t > sl) sl = t; }
+            if (has_cdc) {
+                u32 t0 = 0, t1 = 0;
+                for (int i = 0; i < 4; i++) { t0 += (u32)abs(p[i]); t1 += (u32)abs(p[4 + i]); }
+                sd = t0 > t1 ? t0 : t1;
+                p += 16;
+            }
+            for (u32 b = 0; b < n_c; b++, p += 16) { u32 t = 0; for (int i = 0; i < 16; i++) t += (u32)abs(p[i]); if (t > sc) sc = t; }
             if (!hd_residual_bound_ok(sl, sd, sc, r->qp_y, r->qp_c)) r->coded |= FJ_CODED_WIDE;
         }
     }

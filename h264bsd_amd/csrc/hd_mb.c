@@ -343,19 +343,21 @@ static inline int16_t *next_block(HostDec *d, int16_t *coefs)
     return p;
 }
 
-static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, uint32_t *coded_out, uint32_t sums[3])
+static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, uint32_t *coded_out, uint32_t sums[4])
 {
     HostDec *d = c->d;
     BitReader *br = c->br;
     MbInfo *m = c->cur;
     uint32_t coded = 0;
     int n;
-    sums[0] = sums[1] = sums[2] = 0;                 /* level magnitudes: luma blocks, chroma DC, chroma AC (hd_residual_bound_ok) */
+    sums[0] = sums[1] = sums[2] = sums[3] = 0;       /* level magnitudes, the LARGEST block's of each kind: luma blocks, chroma DC (per plane), chroma AC (hd_residual_bound_ok:
+                                                        the bound is a property of one block — the macroblock's total cleared 130 macroblocks per 1080p picture fewer) */
 
     if (is_i16) {
         int16_t *blk = next_block(d, coefs);
         if (!blk) FAIL;
-        n = hd_cavlc_block(br, nc_luma(c, 0), 16, blk, NULL);
+        sums[3] = 0;
+        n = hd_cavlc_block_sum(br, nc_luma(c, 0), 16, blk, NULL, &sums[3]);      /* sums[3]: the Intra16x16 DC levels (every DC is a signed sum of them) */
         if (n < 0) FAIL;
         if (n) { coded |= FJ_CODED_LUMA_DC; d->coef_blocks++; }
     }
@@ -363,8 +365,10 @@ static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, ui
         if (!(cbp & (1u << (z >> 2)))) { m->tc[z] = 0; continue; }
         int16_t *blk = next_block(d, coefs);
         if (!blk) FAIL;
-        n = hd_cavlc_block_sum(br, nc_luma(c, z), is_i16 ? 15 : 16, blk, NULL, &sums[0]);
+        uint32_t bsum = 0;
+        n = hd_cavlc_block_sum(br, nc_luma(c, z), is_i16 ? 15 : 16, blk, NULL, &bsum);
         if (n < 0) FAIL;
+        if (bsum > sums[0]) sums[0] = bsum;
         m->tc[z] = (uint8_t)n;
         if (n) { coded |= 1u << z; d->coef_blocks++; }
     }
@@ -372,10 +376,12 @@ static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, ui
     if (cbp & 0x30) {
         int16_t *blk = next_block(d, coefs);
         if (!blk) FAIL;
-        int n0 = hd_cavlc_block_sum(br, -1, 4, blk, NULL, &sums[1]);
+        uint32_t s0 = 0, s1 = 0;
+        int n0 = hd_cavlc_block_sum(br, -1, 4, blk, NULL, &s0);
         if (n0 < 0) FAIL;
-        int n1 = hd_cavlc_block_sum(br, -1, 4, blk + 4, NULL, &sums[1]);
+        int n1 = hd_cavlc_block_sum(br, -1, 4, blk + 4, NULL, &s1);
         if (n1 < 0) FAIL;
+        sums[1] = s0 > s1 ? s0 : s1;
         if (n0 || n1) { coded |= FJ_CODED_CHROMA_DC; d->coef_blocks++; }
     }
     if (cbp & 0x20) {
@@ -383,8 +389,10 @@ static int parse_residual(MbCtx *c, int is_i16, uint32_t cbp, int16_t *coefs, ui
             int16_t *blk = next_block(d, coefs);
             int spill;
             if (!blk) FAIL;
-            n = hd_cavlc_block_sum(br, nc_chroma(c, k >> 2, k & 3), 15, blk, &spill, &sums[2]);
+            uint32_t bsum = 0;
+            n = hd_cavlc_block_sum(br, nc_chroma(c, k >> 2, k & 3), 15, blk, &spill, &bsum);
             if (n < 0) FAIL;
+            if (bsum > sums[2]) sums[2] = bsum;
             m->tc[16 + k] = (uint8_t)n;
             if (n) { coded |= 1u << (16 + k); d->coef_blocks++; }
             if (k == 7 && spill && is_i16) {
@@ -459,7 +467,7 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
 
     const int first_decode = d->mb_decoded[addr] == 0;
     const uint32_t coef_start = d->coef_blocks;
-    uint32_t level_sums[3] = { 0, 0, 0 };
+    uint32_t level_sums[4] = { 0, 0, 0, 0 };
     FjMbRec rec;
     memset(&rec, 0, sizeof(rec));
     rec.coef_idx = coef_start;
@@ -560,7 +568,7 @@ static int decode_mb_body(HostDec *d, BitReader *br, const SliceHdr *sh, const P
         int qi = (int)m->qp + pps->chroma_qp_index_offset;
         qi = qi < 0 ? 0 : qi > 51 ? 51 : qi;
         /* (almost every macroblock is cleared by the bound on the level magnitudes the parse has summed up) */
-        if (!((rec.coded & FJ_CODED_LUMA_DC) == 0 && hd_residual_bound_ok(level_sums[0], level_sums[1], level_sums[2], m->qp, qpc_table[qi]))) {
+        if (!((rec.coded & FJ_CODED_LUMA_DC_RAW) == 0 && hd_residual_bound_ok4(level_sums[0], level_sums[1], level_sums[2], level_sums[3], m->qp, qpc_table[qi]))) {
             /* the bound does not clear it: the kernels must not run this macroblock's transforms in 16 bits (framejob.h) */
             if (rec.kind == FJ_MB_INTER) rec.coded |= FJ_CODED_WIDE;
             if (hd_residual_out_of_range(coefs + 16u * coef_start, rec.coded, m->qp, qpc_table[qi], rec.kind == FJ_MB_I16x16)) {

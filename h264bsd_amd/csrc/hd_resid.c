@@ -58,12 +58,27 @@ static inline int block_check(const int16_t *c, int qp, int use_dc, int32_t dc)
 
 int hd_residual_bound_ok(uint32_t sum_l, uint32_t sum_d, uint32_t sum_c, int qp_y, int qp_c)
 {
-    /* the same bound as the first pass of hd_residual_out_of_range(), from sums the parser collected on the way */
+    /* the bound of block_check() for the macroblock's WORST blocks: sum_l / sum_c = the largest sum of level magnitudes of one
+     * luma / one chroma AC block, sum_d = the larger of the two planes' chroma DC sums (every DC of a plane is a signed sum of
+     * its four levels) — collected by the parser on the way.  Holds -> every block's residual is in range AND every intermediate
+     * of its transforms fits 16 bits (FJ_CODED_WIDE stays clear, framejob.h) */
     const uint64_t bound_l = (uint64_t)sum_l * ((uint32_t)level_scale[qp_y % 6][2] << (qp_y / 6));
     const int q6c = qp_c / 6;
     const uint64_t dc_max = ((uint64_t)sum_d * level_scale[qp_c % 6][0]) << (q6c >= 1 ? q6c - 1 : 0);
     const uint64_t bound_c = (uint64_t)sum_c * ((uint32_t)level_scale[qp_c % 6][2] << q6c) + dc_max;
     return bound_l <= 32735u && bound_c <= 32735u;
+}
+
+/* ... with an Intra16x16 DC block: every luma DC is a signed sum of its sixteen levels, scaled as in 8.5.10 (sum_ldc = the
+ * sum of their magnitudes; 0 without the block) and replaces element 0 of its 4x4 block */
+int hd_residual_bound_ok4(uint32_t sum_l, uint32_t sum_d, uint32_t sum_c, uint32_t sum_ldc, int qp_y, int qp_c)
+{
+    if (!sum_ldc) return hd_residual_bound_ok(sum_l, sum_d, sum_c, qp_y, qp_c);
+    const int q6 = qp_y / 6;
+    const uint64_t f = (uint64_t)sum_ldc * level_scale[qp_y % 6][0];
+    const uint64_t ldc_max = q6 >= 2 ? f << (q6 - 2) : ((f + (1u << (1 - q6))) >> (2 - q6));
+    const uint64_t bound_l = (uint64_t)sum_l * ((uint32_t)level_scale[qp_y % 6][2] << q6) + ldc_max;
+    return bound_l <= 32735u && hd_residual_bound_ok(0, sum_d, sum_c, qp_y, qp_c);
 }
 
 static const int16_t zero_block[16];

@@ -390,6 +390,7 @@ int hd_cavlc_block_sum(BitReader *br, int nc, int max_coeff, int16_t *coef, int 
 /* ... given the sums of the level magnitudes of the macroblock's luma blocks, chroma DC block and chroma AC blocks: 1 = the
  * bound proves every residual sample in range (no Intra16x16 DC block), 0 = hd_residual_out_of_range() has to look */
 int hd_residual_bound_ok(uint32_t sum_luma, uint32_t sum_cdc, uint32_t sum_cac, int qp_y, int qp_c);
+int hd_residual_bound_ok4(uint32_t sum_luma, uint32_t sum_cdc, uint32_t sum_cac, uint32_t sum_ldc, int qp_y, int qp_c);
 /* hd_resid.c */
 int hd_residual_out_of_range(const int16_t *blk, uint32_t coded, int qp_y, int qp_c, int is_i16);
 /* hd_mb.c */

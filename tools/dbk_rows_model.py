@@ -166,3 +166,43 @@ if len(sys.argv) > 3 and sys.argv[3] == "grid":
         for waves in (8, 12):
             cyc = sum(queue_model(*f, waves, 8, cf, cl) for f in F)
             print(f"ready queue, {waves} wavefronts, {cf} / {cl}: {cyc / GHZ / 1e6:.1f} ms")
+
+
+def queue_model4(hh, w, left, top, inner, any_, waves, per_mb, cost_full, cost_both, cost_one):
+    """ready lists by class: inner / both macroblock edges / left edge only / upper edge only (a step of the last two runs ONE pass)"""
+    n = hh * w
+    dep = np.zeros(n, int); succ = [[] for _ in range(n)]
+    A = any_.reshape(-1); Lf = left.reshape(-1); Tp = top.reshape(-1); In = inner.reshape(-1)
+    for y in range(hh):
+        for x in range(w):
+            i = y * w + x
+            if not A[i]: continue
+            if x and Lf[i] and A[i - 1] and (In[i - 1] or Tp[i - 1]): dep[i] += 1; succ[i - 1].append(i)
+            if y and Tp[i] and A[i - w] and (In[i - w] or Lf[i - w]): dep[i] += 1; succ[i - w].append(i)
+            if y and x + 1 < w and Tp[i] and A[i - w + 1] and Lf[i - w + 1]: dep[i] += 1; succ[i - w + 1].append(i)
+    ready = [[], [], [], []]
+    cost = [cost_full, cost_both, cost_one, cost_one]
+    def cls(i): return 0 if In[i] else 1 if (Lf[i] and Tp[i]) else 2 if Lf[i] else 3
+    for i in range(n):
+        if A[i] and dep[i] == 0: ready[cls(i)].append(i)
+    t, free, running, done = 0, waves, [], 0
+    total = int(A.sum())
+    while done < total:
+        while free and any(ready):
+            q = max(range(4), key=lambda k: (len(ready[k]), k))
+            batch, ready[q] = ready[q][:per_mb], ready[q][per_mb:]
+            heapq.heappush(running, (t + cost[q], batch)); free -= 1
+        t, batch = heapq.heappop(running)
+        free += 1
+        for i in batch:
+            done += 1
+            for s_ in succ[i]:
+                dep[s_] -= 1
+                if dep[s_] == 0: ready[cls(s_)].append(s_)
+    return t
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "lists4":
+    for cf, cb, co in ((11500, 4500, 4500), (11500, 4500, 3300), (11500, 4500, 3000), (11500, 4800, 3300)):
+        cyc = sum(queue_model4(*f, 8, 8, cf, cb, co) for f in F)
+        print(f"four ready lists, 8 wavefronts, inner {cf} / both edges {cb} / one edge {co}: {cyc / GHZ / 1e6:.1f} ms")
