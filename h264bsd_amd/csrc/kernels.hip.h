@@ -1008,9 +1008,8 @@ template <int PATH>
 __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_OCC_PART) void k_recon_inter(const FrameDesc *__restrict__ frames)
 {
 #ifdef H264K_INTER_PROFILE
-    unsigned long long ipt[6] = { 0, 0, 0, 0, 0, 0 };      /* cycle accounting of a wavefront's life (tools/inter_prof.py): start | entry here | windows staged | predicted | before the store | end */
+    unsigned long long ipt[6] = { 0, 0, 0, 0, 0, 0 };      /* cycle accounting of one list entry (tools/inter_prof.py): begin | entry here | windows staged | predicted | before the store | end */
 #endif
-    IPROF(0);
     __shared__ __attribute__((aligned(16))) uint8_t lds[INTER_WG_WAVES * INTER_WAVE_LDS];
     const FrameDesc &fd = FD_REF(frames, blockIdx.y);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform: the list entry, the record and
@@ -1026,6 +1025,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
   for (uint32_t it = 0; it < inter_per_wave<PATH>(); it++) {
     const uint32_t gi = g_first + (blockIdx.x * INTER_WG_WAVES + wave) * inter_per_wave<PATH>() + it;
     if (gi >= g_end) return;
+    IPROF(0);                                        /* (the first entry's count begins a few scalar loads into the wavefront's life) */
     /* list entry and record as whole dwords from a wave-uniform address in read-only memory: scalar loads (there is no scalar
      * byte load: a struct copy would fetch the byte-sized members with vector loads and wait for them) */
     FjGen ge;

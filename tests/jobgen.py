@@ -62,12 +62,12 @@ LS0 = [10, 11, 13, 14, 16, 18]
 
 
 def _to_bound(rng, coefs, first, n_luma, has_cdc, n_cac, qp_y, qp_c):
-    """Rescale the levels of an inter macroblock so that the parser's magnitude bound (hd_resid.c: sum of the level magnitudes x
+    """Rescale the levels of an inter macroblock so that the parser's magnitude bound (hd_resid.c: the largest block's sum of level magnitudes x
     the largest scale, <= 32735 per plane) lands within +-15 % of its limit: the macroblocks on either side of FJ_CODED_WIDE, and
     intermediates that use most of 16 bits on the packed side of it."""
     def rescale(lo, hi, scale, extra=0.0):
         blk = coefs[lo:hi].astype(np.int64)
-        tot = np.abs(blk).sum()
+        tot = np.abs(blk).reshape(-1, 16).sum(axis=1).max() if hi > lo else 0      # the bound is per block: the LARGEST block's sum
         if tot == 0:
             return
         target = rng.uniform(0.85, 1.15) * 32735.0 - extra

@@ -72,7 +72,7 @@ if os.path.exists(blp):
     line = json.loads(open(blp).read())
     rf = line.get("roofline", {})
     v0 = rf.get("valu")
-    if (v0 is None or "per_kernel" not in v0) and rf.get("device_ms_per_step") and rf.get("launches_per_step"):
+    if (v0 is None or "per_kernel" not in v0 or any("lane_util" not in p_ for p_ in v0["per_kernel"].values())) and rf.get("device_ms_per_step") and rf.get("launches_per_step"):
         peak = 1024 * 2.4e9 / VALU_CYC
         n_mbs_tick = float(rf.get("mbs_per_launch", 256 * 8160))
         per = {}
@@ -82,7 +82,7 @@ if os.path.exists(blp):
                 continue
             n_i, t_s = kv["valu_wave_instr_per_launch"], ms * 1e-3 / n
             per[k] = {"wave_instr_per_launch": n_i, "avg_launch_us": t_s * 1e6, "achieved": n_i / t_s, "frac": n_i / t_s / peak,
-                      "wave_instr_per_macroblock": n_i / n_mbs_tick}
+                      "wave_instr_per_macroblock": n_i / n_mbs_tick, "lane_util": (kv.get("active_lanes_per_valu_instr") or 0.0) / 64.0}
         tot_i = sum(p["wave_instr_per_launch"] for p in per.values())
         ticks = max(rf["launches_per_step"].values())
         total_s = rf["device_ms_per_step"]["total"] * 1e-3
