@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "h264bsdProfile", "h264bsdAlloc", "h264bsdFree", "h264bsdConvertToRGBA", "h264bsdConvertToBGRA",
     "h264bsdConvertToYCbCrA",
     "h264bsdmiInitCapture", "h264bsdmiNextOutputInfo", "h264bsdmiNextOutputPictureDevice", "h264bsdmiJobFinalize", "h264bsdmiDeviceCount", "h264bsdmiSetDevice", "h264bsdmiFlush", "h264bsdmiFlushAsync", "h264bsdmiDeviceErrors",
-    "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiNextOutputPictureBatch", "h264bsdmiSetParserThreads", "h264bsdmiSetInputReadOnly", "h264bsdmiSetCopyElision",
+    "h264bsdmiDecodePicture", "h264bsdmiDecodePictureBatch", "h264bsdmiNextOutputPictureBatch", "h264bsdmiPullAndDecodePictureBatch", "h264bsdmiSetParserThreads", "h264bsdmiSetInputReadOnly", "h264bsdmiSetCopyElision",
     "h264bsdmiReplayCreate", "h264bsdmiReplayCreateStaggered", "h264bsdmiReplayCreateDesync", "h264bsdmiReplayCreateSched", "h264bsdmiReplayReschedule", "h264bsdmiReplayDestroy", "h264bsdmiReplayRun", "h264bsdmiReplaySync",
     "h264bsdmiReplayFetch", "h264bsdmiReplayChecksums", "h264bsdmiReplayConvert", "h264bsdmiReplayFetchConverted",
     "h264bsdmiReplayTimings", "h264bsdmiReplaySetConvert", "h264bsdmiReplayConvertTimings", "h264bsdmiReplaySetStages", "h264bsdmiReplaySetTimedKernels", "h264bsdmiReplaySetGroups", "h264bsdmiDebugTailProfile", "h264bsdmiDebugSetTail", "h264bsdmiDebugDeviceErrorEvents", "h264bsdmiReplayJobBytes", "h264bsdmiReplayFrameBytes",
@@ -116,6 +116,7 @@ def lib():
     L.h264bsdmiDecodePicture.argtypes = [vp, u8p, u32, u32, P32, P32]
     L.h264bsdmiDecodePicture.restype = u32
     L.h264bsdmiDecodePictureBatch.argtypes = [u32, ctypes.POINTER(vp), ctypes.POINTER(vp), P32, P32, P32, P32, P32]
+    L.h264bsdmiPullAndDecodePictureBatch.argtypes = [u32, ctypes.POINTER(vp), ctypes.POINTER(vp), P32, P32, P32, ctypes.POINTER(vp), P32, P32, P32, P32, P32]
     L.h264bsdmiSetParserThreads.argtypes = [ctypes.c_int]
     L.h264bsdmiSetInputReadOnly.argtypes = [vp, u32]
     L.h264bsdmiSetCopyElision.argtypes = [vp, u32]
@@ -337,12 +338,36 @@ class BatchDriver:
         self._dec = VP(*[d._st for d in decoders])
         self._ptr, self._len, self._pid = VP(), U32(), U32()
         self._status, self._consumed, self._errs = U32(), U32(), U32()
+        self._out, self._oid, self._oidr, self._onerr = VP(), U32(), U32(), U32()
+        self.pulled = {}
 
-    def step(self):
-        """parse the next picture of every unfinished stream; returns the indices that produced a picture"""
+    def step(self, pull=False):
+        """parse the next picture of every unfinished stream; returns the indices that produced a picture.
+        pull=True: h264bsdmiPullAndDecodePictureBatch — every stream's next output picture is pulled first (self.pulled: stream index ->
+        (host pointer, picId, isIdrPic, numErrMbs) of the streams that had one), on the same threads, beside the parsing of the other streams."""
         live = [k for k in range(self.n) if self.off[k] < self.size[k]]
+        self.pulled = {}
         if not live:
             return []
+        if pull:
+            for i, k in enumerate(live):
+                self._dec[i] = self.decoders[k]._st
+                self._ptr[i] = ctypes.addressof(self._bufs[k]) + self.off[k]
+                self._len[i] = self.size[k] - self.off[k]
+                self._pid[i] = self.pictures[k]
+            rc = self.L.h264bsdmiPullAndDecodePictureBatch(len(live), self._dec, self._out, self._oid, self._oidr, self._onerr,
+                                                           self._ptr, self._len, self._pid, self._status, self._consumed, self._errs)
+            if rc != 0:
+                raise RuntimeError("h264bsdmiPullAndDecodePictureBatch failed")
+            ready = []
+            for i, k in enumerate(live):
+                if self._out[i]:
+                    self.pulled[k] = (self._out[i], int(self._oid[i]), int(self._oidr[i]), int(self._onerr[i]))
+                self.off[k] += self._consumed[i]
+                if self._status[i] == H264BSD_PIC_RDY:
+                    self.pictures[k] += 1
+                    ready.append(k)
+            return ready
         for i, k in enumerate(live):
             self._dec[i] = self.decoders[k]._st
             self._ptr[i] = ctypes.addressof(self._bufs[k]) + self.off[k]

@@ -340,8 +340,10 @@ typedef struct Batch {
     u8 *const *buf;
     const u32 *len, *pic_id;
     u32 *status, *consumed, *n_errors;
-    u8 **out;                               /* non-NULL: a PULL batch — item i = h264bsdNextOutputPicture(dec[i]) -> out[i], pic_id[i], n_errors[i] */
+    u8 **out;                               /* non-NULL: item i pulls first — h264bsdNextOutputPicture(dec[i]) -> out[i], out_id[i], out_idr[i], out_nerr[i] */
+    u32 *out_id, *out_idr, *out_nerr;       /* (each may be NULL) */
     atomic_uchar *taken;                    /* one flag per item */
+    unsigned char *began;                   /* per item, touched by the worker that took it only: its picture is on its way (item_pull_begin) */
     int active;                             /* pool threads currently inside this batch (guarded by g_pool.mu) */
     signed char *item_dev;                  /* device of every item's decoder instance (-1: capture mode) */
     int devs[16], n_devs;                   /* the devices in use in this batch */
@@ -358,18 +360,53 @@ static struct {
 } g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, { 0 }, 0, 0, 0, 0, 0, NULL,
              PTHREAD_MUTEX_INITIALIZER };
 
-static void batch_run_item(Batch *b, u32 i)
+/* An item of a batch that pulls (b->out) runs in two steps: item_pull_begin pops the instance's output queue and starts the picture on
+ * its way to host memory, item_finish waits for it and — if the batch decodes as well (b->buf) — parses the instance's next picture.  A
+ * worker begins its NEXT item before it finishes the current one (batch_take): while it parses, the next picture crosses the link, and
+ * its wait finds the picture there.  That is not only latency hidden: every thread that SLEEPS in the runtime's event wait is woken by
+ * every completion on the device (measured: a round of 256 pulls takes 35 + 4.1 x threads us per picture when each thread waits for
+ * its picture right after asking for it — 30 ms with 20 threads, 76 ms with 64), so the fewer waits really block, the better. */
+static void item_pull_begin(Batch *b, u32 i)
+{
+    ApiDec *a = dec_of(b->dec[i]);
+    u32 id = 0, idr = 0, nerr = 0;
+    const OutPic *o = a ? pop_output(a, &id, &idr, &nerr) : NULL;
+    b->out[i] = NULL;
+    if (b->out_id) b->out_id[i] = id;
+    if (b->out_idr) b->out_idr[i] = idr;
+    if (b->out_nerr) b->out_nerr[i] = nerr;
+    if (!o) return;
+    const JobSink *k = &a->hd->sink;
+    if (k->fetch_begin && k->fetch_end) {
+        if (k->fetch_begin(k->user, o->slot) == 0) b->began[i] = 1;        /* on its way: item_finish collects it */
+    } else if (k->fetch) b->out[i] = k->fetch(k->user, o->slot);
+}
+
+static void item_finish(Batch *b, u32 i)
 {
     if (b->out) {
-        u32 id = 0, idr = 0, nerr = 0;
-        b->out[i] = h264bsdNextOutputPicture(b->dec[i], &id, &idr, &nerr);
-        if (b->status) b->status[i] = idr;
-        if (b->consumed) b->consumed[i] = id;
-        if (b->n_errors) b->n_errors[i] = nerr;
-        return;
+        const ApiDec *a = dec_of(b->dec[i]);
+        if (b->began[i]) b->out[i] = a->hd->sink.fetch_end(a->hd->sink.user);
+        if (!b->buf) return;
+        /* pull AND decode: the reference's decoder drops what is still waiting in its output queue when the next slice arrives
+         * (src/h264bsd_dpb.c:1260-1261), so an instance with more pictures to give is not fed — the caller comes back for them */
+        if (a && a->hd->dpb.out_idx < a->hd->dpb.n_out) {
+            b->status[i] = H264BSD_RDY; b->consumed[i] = 0;
+            if (b->n_errors) b->n_errors[i] = 0;
+            return;
+        }
     }
     b->status[i] = h264bsdmiDecodePicture(b->dec[i], b->buf[i], b->len[i], b->pic_id ? b->pic_id[i] : 0,
                                           &b->consumed[i], b->n_errors ? &b->n_errors[i] : NULL);
+}
+
+/* item i has just been claimed by this worker; *held = the item it began before and has not finished (-1: none) */
+static void batch_take(Batch *b, u32 i, int *held)
+{
+    if (!b->out) { item_finish(b, i); return; }
+    item_pull_begin(b, i);
+    if (*held >= 0) item_finish(b, (u32)*held);
+    *held = (int)i;
 }
 
 /* Worker `me` of `nw`: group g = me % n_devs serves device devs[g].  It takes the items of its device i = k, k + gs,
@@ -381,15 +418,17 @@ static void batch_work(Batch *b, u32 me, u32 nw)
     const u32 g = me % nd, k = me / nd, gs = (nw - g + nd - 1) / nd;
     const int my_dev = b->n_devs > 0 ? b->devs[g] : -1;
     u32 seen = 0;
+    int held = -1;
     for (u32 i = 0; i < b->n; i++) {
         if (b->n_devs > 0 && b->item_dev[i] != my_dev) continue;
-        if (seen++ % gs == k && !atomic_exchange(&b->taken[i], 1)) batch_run_item(b, i);
+        if (seen++ % gs == k && !atomic_exchange(&b->taken[i], 1)) batch_take(b, i, &held);
     }
     for (int pass = 0; pass < 2; pass++)        /* leftovers: own device first */
         for (u32 i = 0; i < b->n; i++) {
             if (pass == 0 && b->n_devs > 0 && b->item_dev[i] != my_dev) continue;
-            if (!atomic_load(&b->taken[i]) && !atomic_exchange(&b->taken[i], 1)) batch_run_item(b, i);
+            if (!atomic_load(&b->taken[i]) && !atomic_exchange(&b->taken[i], 1)) batch_take(b, i, &held);
         }
+    if (held >= 0) item_finish(b, (u32)held);
 }
 
 static void pin_worker(u32 me, int device, int *pinned_to)
@@ -519,9 +558,10 @@ static int run_batch(Batch *b)
     pthread_mutex_lock(&g_pool.api_mu);
     if (!g_pool.n_threads) h264bsdmiSetParserThreads(0);
     atomic_uchar *taken = (atomic_uchar *)calloc(n, sizeof(atomic_uchar));
+    unsigned char *began = (unsigned char *)calloc(n, 1);
     signed char *item_dev = (signed char *)malloc(n);
-    if (!taken || !item_dev) { free(taken); free(item_dev); pthread_mutex_unlock(&g_pool.api_mu); return -1; }
-    b->taken = taken; b->item_dev = item_dev; b->active = 0; b->n_devs = 0;
+    if (!taken || !began || !item_dev) { free(taken); free(began); free(item_dev); pthread_mutex_unlock(&g_pool.api_mu); return -1; }
+    b->taken = taken; b->began = began; b->item_dev = item_dev; b->active = 0; b->n_devs = 0;
     for (u32 i = 0; i < n; i++) {
         const ApiDec *a = dec_of(b->dec[i]);
         const int dv = a && a->hd ? eng_sink_device(&a->hd->sink) : -1;
@@ -542,6 +582,7 @@ static int run_batch(Batch *b)
     while (b->active) pthread_cond_wait(&g_pool.idle, &g_pool.mu);
     pthread_mutex_unlock(&g_pool.mu);
     free(taken);
+    free(began);
     free(item_dev);
     pthread_mutex_unlock(&g_pool.api_mu);
     return 0;
@@ -552,7 +593,7 @@ int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *dec, u8 *const *buf, co
 {
     if (!dec || !buf || !len || !status || !consumed) return -1;
     if (!n) return 0;
-    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, NULL, NULL, 0, NULL, { 0 }, 0 };
+    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL, { 0 }, 0 };
     return run_batch(&b);
 }
 
@@ -563,6 +604,19 @@ int h264bsdmiNextOutputPictureBatch(u32 n, storage_t *const *dec, u8 **pictures,
 {
     if (!dec || !pictures) return -1;
     if (!n) return 0;
-    Batch b = { n, dec, NULL, NULL, NULL, isIdrPic, picId, numErrMbs, pictures, NULL, 0, NULL, { 0 }, 0 };
+    Batch b = { n, dec, NULL, NULL, NULL, NULL, NULL, NULL, pictures, picId, isIdrPic, numErrMbs, NULL, NULL, 0, NULL, { 0 }, 0 };
+    return run_batch(&b);
+}
+
+/* One round of the reference's per-stream loop (posix/test_h264bsd.c:146-177: pull what is ready, then decode on) for n instances
+ * at once: every pool thread pulls ITS instance's next picture and then parses that instance's next picture, so the transfers of
+ * some instances run beside the parsing of others — with h264bsdmiNextOutputPictureBatch + h264bsdmiDecodePictureBatch the
+ * CPUs idle while the pictures cross the link and the link idles while the CPUs parse. */
+int h264bsdmiPullAndDecodePictureBatch(u32 n, storage_t *const *dec, u8 **pictures, u32 *outPicId, u32 *outIsIdrPic, u32 *outNumErrMbs,
+                                       u8 *const *buf, const u32 *len, const u32 *picId, u32 *status, u32 *consumed, u32 *nErrors)
+{
+    if (!dec || !pictures || !buf || !len || !status || !consumed) return -1;
+    if (!n) return 0;
+    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, pictures, outPicId, outIsIdrPic, outNumErrMbs, NULL, NULL, 0, NULL, { 0 }, 0 };
     return run_batch(&b);
 }

@@ -52,9 +52,11 @@ struct StreamCtx {
     uint32_t wmb = 0, hmb = 0, n_slots = 0, frame_bytes = 0;
     uint8_t *d_frames = nullptr;
     uint8_t *d_dbk = nullptr;
-    uint8_t *h_frame[FJ_MAX_SLOTS] = {};
-    uint32_t *h_conv = nullptr, *d_conv = nullptr;
-    uint8_t *d_planar = nullptr;            /* a picture on its way out: tiles -> the reference's planar I420 (k_detile) */
+    uint8_t *h_frame[FJ_MAX_SLOTS] = {};      /* pinned host mirrors of the frame buffers, written by the layout kernel itself ... */
+    uint8_t *hd_frame[FJ_MAX_SLOTS] = {};     /* ... through these device pointers (no staging copy in HBM, no copy engine: out_begin) */
+    int out_slot = -1;                      /* the frame buffer whose picture is on its way to host memory (sink_fetch_begin .. sink_fetch_end) */
+    std::vector<uint8_t *> retired_host;    /* host mirrors of the frame buffers a new parameter set replaced: a picture pulled just before lives in one (freed at the next pull) */
+    uint32_t *h_conv = nullptr, *hd_conv = nullptr, *d_conv = nullptr;      /* converted picture: host mirror + its device pointer; device copy (device-resident output) */
     hipEvent_t out_ev = nullptr;            /* recorded behind the copy of a picture on its way out: the caller waits for it OUTSIDE the engine's mutex */
     std::mutex qmu;                         /* guards pending / free_bufs (submit runs on the caller's threads) */
     PendingJob acquired = { nullptr, 0, 0, nullptr };   /* staging buffer the parser is currently filling (sink_acquire) */
@@ -119,6 +121,7 @@ struct Engine {
     std::mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t out_stream = nullptr;        /* pictures on their way to host memory (out_begin): behind the picture's OWN tick, not behind every lane */
     std::vector<Lane> lanes;                 /* [0, n_light) light lanes, then n_heavy heavy lanes */
     unsigned n_light = 1, n_heavy = 0, heavy_rr = 0, group_rr = 0;
     std::vector<StreamCtx *> streams;
@@ -129,7 +132,7 @@ struct Engine {
     SideLane side;
     /* device error word (DEVERR_* bits, kernels.hip.h): the kernels OR into d_err, poll_errors() folds it into `errors`
      * whenever the host has waited for the device anyway */
-    uint32_t *d_err = nullptr, *h_err = nullptr;
+    uint32_t *d_err = nullptr, *h_err = nullptr, *hd_err = nullptr;      /* device error words, their pinned host copy, the device pointer of that copy */
     uint32_t errors = 0;                       /* sticky bits (written with __atomic_fetch_or under mu, read without the lock) */
     uint32_t error_events = 0;                 /* how often a tripwire fired, ever: monotonic, so that a NEW occurrence of a bit that is
                                                   already set is visible (per-decoder copy-elision guard, the tests' delta) */
@@ -166,6 +169,8 @@ __attribute__((constructor)) static void lib_init() { setenv("GPU_MAX_HW_QUEUES"
  * with, which the library cannot see (and can only influence when it is loaded first): it is measured.  One workgroup
  * that spins for ~500 us on each of eight fresh streams: side by side they take about as long as one, on shared queues
  * several times as long.  Returns 1 when the eight ran concurrently. */
+/* the device's two error words into their pinned host copy, in stream order behind a picture on its way out (out_end_locked) */
+__global__ void k_err_words(const uint32_t *__restrict__ d_err, uint32_t *__restrict__ host) { if (threadIdx.x < 2) host[threadIdx.x] = d_err[threadIdx.x]; }
 __global__ void k_spin(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) { } }
 
 static int streams_run_concurrently(Engine *e)
@@ -269,6 +274,7 @@ Engine *engine_get(int device = -1)
         hipMalloc((void **)&e->d_err, 256) != hipSuccess || hipMemset(e->d_err, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||   /* (hipMemset returns before the fill has run) */
         hipHostMalloc((void **)&e->h_err, 64, hipHostMallocDefault) != hipSuccess) { delete e; return nullptr; }
     e->h_err[0] = e->h_err[1] = 0;
+    if (hipHostGetDevicePointer((void **)&e->hd_err, e->h_err, 0) != hipSuccess) { delete e; return nullptr; }
     g_engines[device] = e;
     return e;
 }
@@ -731,7 +737,13 @@ int flush_locked(Engine *e, bool wait = true)
 /* ---- JobSink implementation ---- */
 struct SinkUser { Engine *e; StreamCtx *s; };
 
-void stream_release(StreamCtx *s)
+static void free_retired(StreamCtx *s)
+{
+    for (uint8_t *p : s->retired_host) hipHostFree(p);
+    s->retired_host.clear();
+}
+
+void stream_release(StreamCtx *s, bool keep_pulled = false)
 {
     for (auto &j : s->pending) hipHostFree(j.host);
     s->pending.clear();
@@ -742,12 +754,15 @@ void stream_release(StreamCtx *s)
     if (s->d_frames) hipFree(s->d_frames);
     if (s->d_dbk) hipFree(s->d_dbk);
     s->d_dbk = nullptr;
-    for (auto &p : s->h_frame) if (p) { hipHostFree(p); p = nullptr; }
+    /* keep_pulled (a new sequence re-allocates the frame buffers, sink_configure): h264bsdmiPullAndDecodePictureBatch hands out a picture and
+     * parses on in the same call — the picture must outlive the activation of a parameter set that the parsing may bring */
+    for (auto &p : s->h_frame) if (p) { if (keep_pulled) s->retired_host.push_back(p); else hipHostFree(p); p = nullptr; }
+    for (auto &p : s->hd_frame) p = nullptr;
+    if (!keep_pulled) free_retired(s);
     if (s->h_conv) hipHostFree(s->h_conv);
     if (s->d_conv) hipFree(s->d_conv);
-    if (s->d_planar) hipFree(s->d_planar);
     if (s->out_ev) { hipEventDestroy(s->out_ev); s->out_ev = nullptr; }
-    s->d_frames = nullptr; s->h_conv = nullptr; s->d_conv = nullptr; s->d_planar = nullptr;
+    s->d_frames = nullptr; s->h_conv = nullptr; s->hd_conv = nullptr; s->d_conv = nullptr;
 }
 
 int sink_configure(void *user, uint32_t wmb, uint32_t hmb, uint32_t n_slots)
@@ -756,7 +771,8 @@ int sink_configure(void *user, uint32_t wmb, uint32_t hmb, uint32_t n_slots)
     std::lock_guard<std::mutex> lk(u->e->mu);
     if (flush_locked(u->e)) return -1;
     HIP_TRY(hipSetDevice(u->e->device));
-    stream_release(u->s);
+    if (u->e->out_stream) HIP_TRY(hipStreamSynchronize(u->e->out_stream));
+    stream_release(u->s, true);
     u->s->wmb = wmb; u->s->hmb = hmb; u->s->n_slots = n_slots;
     u->s->frame_bytes = fj_frame_bytes(wmb, hmb);
     const size_t total = (size_t)n_slots * u->s->frame_bytes + 256;
@@ -846,21 +862,48 @@ uint32_t sink_errors(void *user)
     return __atomic_load_n(&u->e->error_events, __ATOMIC_RELAXED);
 }
 
-/* A picture leaves the device.  Under the engine's mutex only what must be ordered: everything queued is enqueued (not awaited),
- * the layout kernel and the copy follow on the engine's stream, an event of the INSTANCE is recorded behind them.  The wait for
- * that event — the pixels' whole latency: the tick's kernels, 3.1 MB over PCIe — happens outside the mutex, so that the other
+/* A picture leaves the device.  Under the engine's mutex only what must be ordered: the instance's queued pictures are enqueued (not
+ * awaited), the layout kernel — which writes pinned host memory itself — follows behind the picture's tick, an event of the INSTANCE is
+ * recorded behind it.  The wait for that event — the pixels' whole latency: the tick's kernels, 3.1 MB over PCIe — happens outside the mutex, so that the other
  * instances of the process go on submitting, flushing and pulling meanwhile (rounds 1-4 held the mutex across a synchronous
  * copy: one picture at a time for the whole process).  Reference: the zero-copy alias of src/h264bsd_decoder.c:599-646. */
-static int out_begin(SinkUser *u)                     /* mutex held */
+#ifndef OUT_EVENT_FLAGS
+#define OUT_EVENT_FLAGS (hipEventDisableTiming | hipEventBlockingSync)    /* the waiter sleeps: under a CPU quota a spinning waiter takes the time the parser threads need */
+#endif
+static int out_begin(SinkUser *u, bool to_host, hipStream_t *st)          /* mutex held */
 {
-    if (flush_locked(u->e, false)) return -1;
-    if (!u->s->out_ev) HIP_TRY(hipEventCreateWithFlags(&u->s->out_ev, hipEventDisableTiming));
+    /* Only an instance whose OWN pictures are still queued makes the engine enqueue (everything: ticks are formed across instances).
+     * One whose pictures are all on the device already leaves the other instances' queues alone — when the pulls of one round run
+     * beside the parsing of the next (h264bsdmiPullAndDecodePictureBatch), a flush per pull would cut that round's tick into as many
+     * straggler ticks as there are pulls. */
+    Engine *e = u->e;
+    StreamCtx *s = u->s;
+    bool mine;
+    { std::lock_guard<std::mutex> ql(s->qmu); mine = !s->pending.empty(); }
+    if (mine && flush_locked(e, false)) return -1;
+    if (!mine) HIP_TRY(hipSetDevice(e->device));
+    if (!s->out_ev) HIP_TRY(hipEventCreateWithFlags(&s->out_ev, OUT_EVENT_FLAGS));
+    *st = e->stream;                                   /* device-resident output: on the engine's stream, which is behind every lane since the last flush */
+    if (to_host) {
+        /* A picture bound for host memory waits for the tick that made it (or a later one of its lane), not for whatever else the engine's
+         * stream is behind: instances whose tick is done hand their pictures over while other instances' ticks still run.  Nothing the
+         * device does later can touch the frame before the call returns — the instance's next job is submitted after that. */
+        if (!e->out_stream) HIP_TRY(hipStreamCreateWithFlags(&e->out_stream, hipStreamNonBlocking));
+        if (s->last_lane >= 0) {
+            hipEvent_t made = e->lanes[s->last_lane].ring[s->last_launch % Lane::RING];
+            if (hipEventQuery(made) != hipSuccess) HIP_TRY(hipStreamWaitEvent(e->out_stream, made, 0));      /* (long done, usually: no barrier packet then) */
+        }
+        *st = e->out_stream;
+    }
     return 0;
 }
-static int out_end_locked(SinkUser *u)                /* mutex held: the device's error words travel with the picture */
+static int out_end_locked(SinkUser *u, hipStream_t st)  /* mutex held: the device's error words travel with the picture */
 {
-    HIP_TRY(hipMemcpyAsync(u->e->h_err, u->e->d_err, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, u->e->stream));
-    HIP_TRY(hipEventRecord(u->s->out_ev, u->e->stream));
+#ifndef OUT_WHATIF_NO_ERR_WORDS      /* (timing experiment: what does the second launch per picture cost?) */
+    hipLaunchKernelGGL(k_err_words, dim3(1), dim3(64), 0, st, u->e->d_err, u->e->hd_err);
+    HIP_TRY(hipGetLastError());
+#endif
+    HIP_TRY(hipEventRecord(u->s->out_ev, st));
     return 0;
 }
 static int out_wait(SinkUser *u)                      /* mutex NOT held */
@@ -871,23 +914,37 @@ static int out_wait(SinkUser *u)                      /* mutex NOT held */
     return 0;
 }
 
-uint8_t *sink_fetch(void *user, uint32_t slot)
+int sink_fetch_begin(void *user, uint32_t slot)
 {
     SinkUser *u = static_cast<SinkUser *>(user);
     StreamCtx *s = u->s;
-    {
-        std::lock_guard<std::mutex> lk(u->e->mu);
-        if (slot >= s->n_slots || out_begin(u)) return nullptr;
-        if (!s->h_frame[slot] && hipHostMalloc((void **)&s->h_frame[slot], s->frame_bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-        if (!s->d_planar && hipMalloc((void **)&s->d_planar, s->frame_bytes) != hipSuccess) return nullptr;
-        hipLaunchKernelGGL(h264k::k_detile, dim3(512, 1), dim3(256), 0, u->e->stream, s->d_frames + (size_t)slot * s->frame_bytes,
-                           s->d_planar, s->wmb, s->hmb, (size_t)0, (size_t)0);
-        if (hipMemcpyAsync(s->h_frame[slot], s->d_planar, s->frame_bytes, hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
-        if (out_end_locked(u)) return nullptr;
+    std::lock_guard<std::mutex> lk(u->e->mu);
+    hipStream_t st;
+    s->out_slot = -1;
+    if (slot >= s->n_slots || out_begin(u, true, &st)) return -1;
+    free_retired(s);
+    if (!s->h_frame[slot]) {
+        if (hipHostMalloc((void **)&s->h_frame[slot], s->frame_bytes, hipHostMallocDefault) != hipSuccess) return -1;
+        if (hipHostGetDevicePointer((void **)&s->hd_frame[slot], s->h_frame[slot], 0) != hipSuccess) return -1;
     }
-    if (out_wait(u)) return nullptr;
-    return s->h_frame[slot];
+    /* the layout kernel writes the host mirror itself: 16-byte pieces over the link run at 49 GB/s (tools/probes/d2h_probe.hip: as fast as
+     * whole rows, and as fast as the copy engine moves one large buffer), and a picture costs ONE launch on the compute queue instead
+     * of a kernel, two copy-engine transfers and the hand-overs between the engines */
+    hipLaunchKernelGGL(h264k::k_detile, dim3(512, 1), dim3(256), 0, st, s->d_frames + (size_t)slot * s->frame_bytes,
+                       s->hd_frame[slot], s->wmb, s->hmb, (size_t)0, (size_t)0);
+    if (hipGetLastError() != hipSuccess) return -1;
+    if (out_end_locked(u, st)) return -1;
+    s->out_slot = (int)slot;
+    return 0;
 }
+uint8_t *sink_fetch_end(void *user)
+{
+    SinkUser *u = static_cast<SinkUser *>(user);
+    StreamCtx *s = u->s;
+    if (s->out_slot < 0 || out_wait(u)) return nullptr;
+    return s->h_frame[s->out_slot];
+}
+uint8_t *sink_fetch(void *user, uint32_t slot) { return sink_fetch_begin(user, slot) ? nullptr : sink_fetch_end(user); }
 
 uint32_t *sink_fetch_converted(void *user, uint32_t slot, int fmt)
 {
@@ -895,15 +952,18 @@ uint32_t *sink_fetch_converted(void *user, uint32_t slot, int fmt)
     StreamCtx *s = u->s;
     {
         std::lock_guard<std::mutex> lk(u->e->mu);
-        if (slot >= s->n_slots || out_begin(u)) return nullptr;
+        hipStream_t st;
+        if (slot >= s->n_slots || out_begin(u, true, &st)) return nullptr;
         const uint32_t w = s->wmb * 16, h = s->hmb * 16;
         const size_t bytes = (size_t)w * h * 4;
-        if (!s->d_conv && hipMalloc((void **)&s->d_conv, bytes) != hipSuccess) return nullptr;
-        if (!s->h_conv && hipHostMalloc((void **)&s->h_conv, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-        hipLaunchKernelGGL(h264k::k_convert_tiles, dim3(1024, 1), dim3(256), 0, u->e->stream,
-                           s->d_frames + (size_t)slot * s->frame_bytes, s->d_conv, s->wmb, s->hmb, fmt, (size_t)0, (size_t)0);
-        if (hipMemcpyAsync(s->h_conv, s->d_conv, bytes, hipMemcpyDeviceToHost, u->e->stream) != hipSuccess) return nullptr;
-        if (out_end_locked(u)) return nullptr;
+        if (!s->h_conv) {
+            if (hipHostMalloc((void **)&s->h_conv, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+            if (hipHostGetDevicePointer((void **)&s->hd_conv, s->h_conv, 0) != hipSuccess) return nullptr;
+        }
+        hipLaunchKernelGGL(h264k::k_convert_tiles, dim3(1024, 1), dim3(256), 0, st,
+                           s->d_frames + (size_t)slot * s->frame_bytes, s->hd_conv, s->wmb, s->hmb, fmt, (size_t)0, (size_t)0);
+        if (hipGetLastError() != hipSuccess) return nullptr;
+        if (out_end_locked(u, st)) return nullptr;
     }
     if (out_wait(u)) return nullptr;
     return s->h_conv;
@@ -916,7 +976,8 @@ void *sink_fetch_device(void *user, uint32_t slot, int fmt, uint32_t x0, uint32_
     void *ret;
     {
         std::lock_guard<std::mutex> lk(u->e->mu);
-        if (slot >= s->n_slots || out_begin(u)) return nullptr;
+        hipStream_t st;
+        if (slot >= s->n_slots || out_begin(u, false, &st)) return nullptr;
         const uint32_t fw = s->wmb * 16, fh = s->hmb * 16;
         if (!w || !h || x0 + w > fw || y0 + h > fh) return nullptr;
         uint8_t *frame = s->d_frames + (size_t)slot * s->frame_bytes;
@@ -933,8 +994,8 @@ void *sink_fetch_device(void *user, uint32_t slot, int fmt, uint32_t x0, uint32_
                                frame, reinterpret_cast<uint8_t *>(s->d_conv), fw, fh, fmt, x0, y0, w, h);
         }
         ret = s->d_conv;
-        if (out_end_locked(u)) return nullptr;
-        if (stream) *stream = u->e->stream;
+        if (out_end_locked(u, st)) return nullptr;
+        if (stream) *stream = st;
     }
     if (out_wait(u)) return nullptr;
     return ret;
@@ -948,6 +1009,7 @@ void sink_close(void *user)
         hipSetDevice(u->e->device);
         reap_locked(u->e, true);
         hipStreamSynchronize(u->e->stream);
+        if (u->e->out_stream) hipStreamSynchronize(u->e->out_stream);      /* (a pull that failed half way may have left its kernel behind) */
         stream_release(u->s);
         auto &v = u->e->streams;
         v.erase(std::remove(v.begin(), v.end(), u->s), v.end());
@@ -976,6 +1038,8 @@ int eng_attach(JobSink *sink)
     sink->acquire = sink_acquire;
     sink->submit = sink_submit;
     sink->fetch = sink_fetch;
+    sink->fetch_begin = sink_fetch_begin;
+    sink->fetch_end = sink_fetch_end;
     sink->fetch_converted = sink_fetch_converted;
     sink->fetch_device = sink_fetch_device;
     sink->close = sink_close;

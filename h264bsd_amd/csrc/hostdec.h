@@ -228,6 +228,11 @@ typedef struct JobSink {
     int  (*submit)(void *user, const uint8_t *blob, uint32_t bytes);
     /* make slot's pixels available at host address; returns pointer or NULL */
     uint8_t *(*fetch)(void *user, uint32_t slot);
+    /* optional: fetch() in two steps, for callers that have other work between them (the batch calls of api.c: a parser thread starts the
+     * next instance's picture on its way before it waits for this one's).  begin enqueues and returns at once (0 = ok); end waits and
+     * returns what fetch() would have.  One begin per sink at a time, every begin is followed by its end. */
+    int  (*fetch_begin)(void *user, uint32_t slot);
+    uint8_t *(*fetch_end)(void *user);
     /* colour conversion of a slot into a host buffer of width*height u32; fmt 0 RGBA 1 BGRA 2 YCbCrA */
     uint32_t *(*fetch_converted)(void *user, uint32_t slot, int fmt);
     /* slot (cropped to x0,y0,w,h; fmt 0..2 converted, 3 = I420) as a DEVICE pointer; *stream = the HIP stream used */

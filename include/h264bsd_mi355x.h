@@ -70,6 +70,18 @@ int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *pStorage, u8 *const *bu
  * only — the engine's lock is held while enqueueing, never while waiting — so the 3.1 MB transfers of the instances overlap.
  * pictures[i] = NULL when instance i has no picture to give; picId / isIdrPic / numErrMbs may be NULL.  0 = ok. */
 int h264bsdmiNextOutputPictureBatch(u32 n, storage_t *const *pStorage, u8 **pictures, u32 *picId, u32 *isIdrPic, u32 *numErrMbs);
+/* Both in one call — one round of the reference harness's per-stream loop (posix/test_h264bsd.c:146-177: take the pictures that are
+ * ready, then decode on) for n distinct instances: every thread FIRST pulls its instance's next output picture (as above:
+ * pictures[i], outPicId[i], outIsIdrPic[i], outNumErrMbs[i]; the last three may be NULL) and THEN parses that instance's next
+ * picture (as h264bsdmiDecodePicture: buf / len / picId -> status / consumed / nErrors).  The pictures of some instances cross the
+ * link while other instances are parsed; with the two calls above the CPUs wait for the link and the link for the CPUs.
+ * An instance that still has FURTHER pictures waiting in its output queue is not fed — the next slice would discard them, as in the
+ * reference (src/h264bsd_dpb.c:1260-1261): status[i] = H264BSD_RDY, consumed[i] = 0, call again.  len[i] = 0: pull only.
+ * pictures[i] stays valid until the next pull from instance i (it is the pinned host mirror of the picture's DPB slot, which the
+ * parsing of later pictures does not touch, and which survives the activation of a new sequence parameter set) — longer than the
+ * reference's "until the next h264bsdDecode()"; its dimensions are those the instance reported BEFORE the call.  0 = ok. */
+int h264bsdmiPullAndDecodePictureBatch(u32 n, storage_t *const *pStorage, u8 **pictures, u32 *outPicId, u32 *outIsIdrPic, u32 *outNumErrMbs,
+                                       u8 *const *buf, const u32 *len, const u32 *picId, u32 *status, u32 *consumed, u32 *nErrors);
 /* Number of parser threads (default: the CPUs the process may use — affinity mask, cgroup quota — divided by H264BSDMI_HOST_SHARE,
  * at most 64; env H264BSDMI_THREADS).  Returns the value in use. */
 int h264bsdmiSetParserThreads(int n);

@@ -102,3 +102,56 @@ def test_shared_read_only_input_buffer(built):
         assert traces[0] == want_trace and traces[1] == want_trace
     finally:
         libc.mprotect(ctypes.c_void_p(addr), ctypes.c_size_t((len(data) + page - 1) // page * page), mmap.PROT_READ | mmap.PROT_WRITE)
+
+
+def test_pull_and_decode_batch_parses_like_the_harness_loop(built):
+    """h264bsdmiPullAndDecodePictureBatch (capture mode: the pull pops the output queue, there are no pixels): which frame buffer a
+    picture is decoded into depends on what has left the output queue (src/h264bsd_dpb.c: a picture waiting for display keeps its
+    buffer; the next slice discards the queue, :1260-1261), so the frame jobs only equal those of the reference harness's loop —
+    decode, drain the queue, decode — if an instance with pictures still waiting is not fed"""
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from h264writer import StreamWriter
+    from synth_configs import CONFIGS
+    datas = [StreamWriter(**CONFIGS[n]).build() for n in ("poc0_display_reorder", "everything", "mmco_long_term", "multi_ref")] + [stream_bytes("test_640x360")]
+
+    def harness_loop(data):
+        jobs = []
+        dec = built.Decoder(capture=lambda b: jobs.append(hashlib.sha1(b).hexdigest()))
+        buf = ctypes.create_string_buffer(data, len(data))
+        off, stall, outs = 0, 0, []
+        while off < len(data):
+            r, rb = dec.decode(ctypes.addressof(buf) + off, len(data) - off, len(jobs))
+            off += rb
+            if r == 1:
+                while True:
+                    o = dec.next_output_info()
+                    if o is None:
+                        break
+                    outs.append(o[1])
+            stall = stall + 1 if rb == 0 else 0
+            if stall > 3 or r >= 3:
+                break
+        dec.close()
+        return jobs, outs
+    want = [harness_loop(d) for d in datas]
+    built.lib().h264bsdmiSetParserThreads(3)
+    got = [[] for _ in datas]
+    decs = [built.Decoder(capture=(lambda b, k=k: got[k].append(hashlib.sha1(b).hexdigest()))) for k in range(len(datas))]
+    drv = built.BatchDriver(decs, datas)
+    held_back = 0
+    for _ in range(4000):
+        before = list(drv.off)
+        drv.step(pull=True)
+        held_back += sum(1 for k in range(len(datas)) if before[k] < drv.size[k] and drv.off[k] == before[k])
+        if all(o >= s for o, s in zip(drv.off, drv.size)):
+            break
+    else:
+        raise AssertionError("the streams were not consumed")
+    for k in range(len(datas)):
+        assert got[k] == want[k][0], k
+    assert held_back > 0
+    for d in decs:
+        d.close()

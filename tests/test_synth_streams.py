@@ -8,13 +8,16 @@ repeated IDRs.  The expected answers (h264bsdDecode call trace, output order, pi
 every output frame) come from the compiled reference decoder (tests/golden/make_synth_golden.py).
 
 CPU test: host parser + CPU oracle.  GPU test: the product (h264bsdInit + HIP engine) through the C ABI."""
+import ctypes
 import hashlib
 import json
 import os
 
+import numpy as np
 import pytest
 
 import synth
+from h264bsd_amd import capi
 from h264writer import StreamWriter
 from synth_configs import CONFIGS
 
@@ -140,3 +143,45 @@ def test_gpu_random_streams_match_live_reference(built):
     _live_sweep(92000, 120, False, "gpu")
     _live_sweep(92500, 160, True, "gpu")
     _live_sweep(93500, 60, True, "gpu", concat=3)     # the engine re-allocates (zeroed) frame buffers at every activation
+
+
+@pytest.mark.gpu
+def test_gpu_pull_and_decode_batch_follows_the_call_protocol(built):
+    """h264bsdmiPullAndDecodePictureBatch on streams whose pictures leave in another order than they are decoded (display
+    reordering, MMCO, frame_num gaps, a new SPS): every round pulls ONE picture per instance and then parses on — unless the
+    instance still has pictures waiting, which the next slice would discard (src/h264bsd_dpb.c:1260-1261): then it is not fed.
+    Same pictures, ids, IDR flags and error counts as the one-call-at-a-time loop of the reference harness."""
+    names = ["poc0_display_reorder", "everything", "multi_ref", "mmco_long_term", "frame_num_gaps", "poc1_nonref_idr", "fmo_dispersed"]
+    datas = [stream_of(n) for n in names] + [_concat(("fmo_dispersed", "multi_ref", "poc0_display_reorder"))]
+    want = [synth.decode_ours(d, "gpu")[1] for d in datas]
+    capi.lib().h264bsdmiSetParserThreads(4)
+    decs = [capi.Decoder() for _ in datas]
+    drv = capi.BatchDriver(decs, datas)
+    got = [[] for _ in datas]
+
+    def take(k, n_bytes, ptr, pid, idr, nerr):
+        frame = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), (n_bytes,))
+        got[k].append((hashlib.sha1(frame.tobytes()).hexdigest(), pid, idr, nerr))
+    held_back = 0
+    for _ in range(4000):
+        before = list(drv.off)
+        size_before = [d.frame_bytes() for d in decs]       # a pulled picture has the size its instance reported BEFORE the call: the parsing
+        drv.step(pull=True)                                  # behind the pull may activate another sequence parameter set
+        for k, p in drv.pulled.items():
+            take(k, size_before[k], *p)
+        held_back += sum(1 for k in range(len(datas)) if before[k] < drv.size[k] and drv.off[k] == before[k] and k in drv.pulled)
+        if all(o >= s for o, s in zip(drv.off, drv.size)):
+            break
+    else:
+        raise AssertionError("the streams were not consumed")
+    for k, d in enumerate(decs):
+        d.flush_buffer()
+        while True:
+            o = d.next_output_picture()
+            if o is None:
+                break
+            got[k].append((hashlib.sha1(np.ascontiguousarray(o[0]).tobytes()).hexdigest(), o[1], o[2], o[3]))
+        d.close()
+    for k in range(len(datas)):
+        assert got[k] == [tuple(p) for p in want[k]], k
+    assert held_back > 0            # the reordering streams did hand out several pictures after one decode
