@@ -363,9 +363,8 @@ static struct {
 /* An item of a batch that pulls (b->out) runs in two steps: item_pull_begin pops the instance's output queue and starts the picture on
  * its way to host memory, item_finish waits for it and — if the batch decodes as well (b->buf) — parses the instance's next picture.  A
  * worker begins its NEXT item before it finishes the current one (batch_take): while it parses, the next picture crosses the link, and
- * its wait finds the picture there.  That is not only latency hidden: every thread that SLEEPS in the runtime's event wait is woken by
- * every completion on the device (measured: a round of 256 pulls takes 35 + 4.1 x threads us per picture when each thread waits for
- * its picture right after asking for it — 30 ms with 20 threads, 76 ms with 64), so the fewer waits really block, the better. */
+ * its wait finds the picture there (8.5 -> 8.8 k fps with 256 instances and 20 threads; DESIGN.md §5 has the whole account of the
+ * host-output path, including what is still unexplained about it: a round gets LONGER with more pool threads). */
 static void item_pull_begin(Batch *b, u32 i)
 {
     ApiDec *a = dec_of(b->dec[i]);
