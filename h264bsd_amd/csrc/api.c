@@ -347,6 +347,7 @@ typedef struct Batch {
     int active;                             /* pool threads currently inside this batch (guarded by g_pool.mu) */
     signed char *item_dev;                  /* device of every item's decoder instance (-1: capture mode) */
     int devs[16], n_devs;                   /* the devices in use in this batch */
+    u32 workers;                            /* threads that work on this batch (run_batch): all of the pool, or fewer when the batch pulls */
 } Batch;
 
 static struct {
@@ -354,10 +355,11 @@ static struct {
     pthread_cond_t wake, idle;
     pthread_t th[64];
     int n_threads, started, want, pin;
+    int chosen;                             /* the application (or H264BSDMI_THREADS) named the number of threads: batches that pull use them all */
     unsigned generation;
     Batch *batch;
     pthread_mutex_t api_mu;                 /* one batch at a time */
-} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, { 0 }, 0, 0, 0, 0, 0, NULL,
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, { 0 }, 0, 0, 0, 0, 0, 0, NULL,
              PTHREAD_MUTEX_INITIALIZER };
 
 /* An item of a batch that pulls (b->out) runs in two steps: item_pull_begin pops the instance's output queue and starts the picture on
@@ -470,10 +472,12 @@ static void *pool_main(void *arg)
         Batch *b = g_pool.batch;
         if (!b) continue;
         b->active++;
-        const u32 nw = (u32)g_pool.n_threads;
+        const u32 nw = b->workers;
         pthread_mutex_unlock(&g_pool.mu);
-        pin_worker(me, b->n_devs > 0 ? b->devs[me % (u32)b->n_devs] : -1, &pinned_to);
-        batch_work(b, me, nw);
+        if (me < nw) {
+            pin_worker(me, b->n_devs > 0 ? b->devs[me % (u32)b->n_devs] : -1, &pinned_to);
+            batch_work(b, me, nw);
+        }
         pthread_mutex_lock(&g_pool.mu);
         if (--b->active == 0) pthread_cond_broadcast(&g_pool.idle);
     }
@@ -484,7 +488,7 @@ static void *pool_main(void *arg)
  * (containers: /sys/fs/cgroup/cpu.max, or cpu.cfs_quota_us / cpu.cfs_period_us under cgroup v1).  Parser threads
  * beyond that only take turns: on a box with 256 hardware threads and a quota of 16 CPUs, 64 threads parse 24 % fewer
  * pictures per second than 16. */
-static long usable_cpus(void)
+static long usable_cpus_q(int quota_bonus)
 {
     long n = sysconf(_SC_NPROCESSORS_ONLN);
     cpu_set_t set;
@@ -506,10 +510,11 @@ static long usable_cpus(void)
          * of a round).  A quarter more threads than CPUs of quota measured best on the GPU box (256 hardware threads, quota
          * 16: 16 / 20 / 24 / 28 / 32 threads -> 17.5 / 18.7 / 16.8 / 16.9 / 16.0 k pictures per second end to end). */
         const long q = (long)((quota + period - 1) / period), q125 = q + q / 4;
-        if (q >= 1 && q < n) n = q125 < n ? q125 : n;
+        if (q >= 1 && q < n) n = !quota_bonus ? q : q125 < n ? q125 : n;
     }
     return n < 1 ? 1 : n;
 }
+static long usable_cpus(void) { return usable_cpus_q(1); }
 
 /* Processes that share this host's CPUs, one per GPU (the usual multi-GPU launch): every one of them sizes its
  * parser pool for ITS share of the CPUs the container may use — eight ranks that each start usable_cpus() threads only take
@@ -535,6 +540,7 @@ static int pool_default_threads(void)
 int h264bsdmiSetParserThreads(int n)
 {
     pthread_mutex_lock(&g_pool.mu);
+    g_pool.chosen = n >= 1 || getenv("H264BSDMI_THREADS") != NULL;
     if (n < 1) n = pool_default_threads();
     if (n > 64) n = 64;
     g_pool.want = n;
@@ -570,10 +576,19 @@ static int run_batch(Batch *b)
         if (!known && b->n_devs < 16) b->devs[b->n_devs++] = dv;
     }
     pthread_mutex_lock(&g_pool.mu);
+    /* A batch that pulls pictures runs on no more threads than the process may have running at once.  The pool is a quarter larger than a
+     * CPU quota (usable_cpus_q: that uses the budget up when threads only parse); threads that also wait for the device in between burn a
+     * period's budget in bursts, and while the cgroup is throttled nothing feeds the link: 256 pulls + parses take 26.5 ms on 16 threads,
+     * 29.5 on 20, 52 on 40 under a quota of 16 CPUs. */
+    u32 nw = (u32)g_pool.n_threads;
+    if (b->out && !g_pool.chosen) {
+        const long lim = (usable_cpus_q(0) + host_share() - 1) / host_share();
+        if (lim >= 1 && (u32)lim < nw) nw = (u32)lim;
+    }
+    b->workers = nw;
     g_pool.batch = b;
     g_pool.generation++;
     pthread_cond_broadcast(&g_pool.wake);
-    const u32 nw = (u32)g_pool.n_threads;
     pthread_mutex_unlock(&g_pool.mu);
     batch_work(b, 0, nw);
     pthread_mutex_lock(&g_pool.mu);
@@ -592,7 +607,7 @@ int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *dec, u8 *const *buf, co
 {
     if (!dec || !buf || !len || !status || !consumed) return -1;
     if (!n) return 0;
-    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL, { 0 }, 0 };
+    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL, { 0 }, 0, 0 };
     return run_batch(&b);
 }
 
@@ -603,7 +618,7 @@ int h264bsdmiNextOutputPictureBatch(u32 n, storage_t *const *dec, u8 **pictures,
 {
     if (!dec || !pictures) return -1;
     if (!n) return 0;
-    Batch b = { n, dec, NULL, NULL, NULL, NULL, NULL, NULL, pictures, picId, isIdrPic, numErrMbs, NULL, NULL, 0, NULL, { 0 }, 0 };
+    Batch b = { n, dec, NULL, NULL, NULL, NULL, NULL, NULL, pictures, picId, isIdrPic, numErrMbs, NULL, NULL, 0, NULL, { 0 }, 0, 0 };
     return run_batch(&b);
 }
 
@@ -616,6 +631,6 @@ int h264bsdmiPullAndDecodePictureBatch(u32 n, storage_t *const *dec, u8 **pictur
 {
     if (!dec || !pictures || !buf || !len || !status || !consumed) return -1;
     if (!n) return 0;
-    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, pictures, outPicId, outIsIdrPic, outNumErrMbs, NULL, NULL, 0, NULL, { 0 }, 0 };
+    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, pictures, outPicId, outIsIdrPic, outNumErrMbs, NULL, NULL, 0, NULL, { 0 }, 0, 0 };
     return run_batch(&b);
 }

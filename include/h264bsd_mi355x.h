@@ -82,8 +82,9 @@ int h264bsdmiNextOutputPictureBatch(u32 n, storage_t *const *pStorage, u8 **pict
  * reference's "until the next h264bsdDecode()"; its dimensions are those the instance reported BEFORE the call.  0 = ok. */
 int h264bsdmiPullAndDecodePictureBatch(u32 n, storage_t *const *pStorage, u8 **pictures, u32 *outPicId, u32 *outIsIdrPic, u32 *outNumErrMbs,
                                        u8 *const *buf, const u32 *len, const u32 *picId, u32 *status, u32 *consumed, u32 *nErrors);
-/* Number of parser threads (default: the CPUs the process may use — affinity mask, cgroup quota — divided by H264BSDMI_HOST_SHARE,
- * at most 64; env H264BSDMI_THREADS).  Returns the value in use. */
+/* Number of parser threads (default: the CPUs the process may use — affinity mask, cgroup quota + a quarter — divided by H264BSDMI_HOST_SHARE,
+ * at most 64; env H264BSDMI_THREADS).  Returns the value in use.  With the default, batches that PULL pictures run on at most as many of
+ * these threads as the process may have running at once (the quota itself); a count named here or in the environment is used as it is. */
 int h264bsdmiSetParserThreads(int n);
 /* INPUT BUFFERS ARE MODIFIED by h264bsdDecode() and by the two calls above, exactly as by the reference: the emulation-
  * prevention bytes of the NAL unit just parsed are removed IN the caller's buffer (src/h264bsd_byte_stream.c), so that a
