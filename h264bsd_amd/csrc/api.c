@@ -355,7 +355,8 @@ static struct {
     pthread_cond_t wake, idle;
     pthread_t th[64];
     int n_threads, started, want, pin;
-    int chosen;                             /* the application (or H264BSDMI_THREADS) named the number of threads: batches that pull use them all */
+    int pull_workers;                       /* threads a batch that pulls pictures runs on (run_batch): the CPUs the process may have running at once — or
+                                               all of the pool when the application (or H264BSDMI_THREADS) named the number of threads */
     unsigned generation;
     Batch *batch;
     pthread_mutex_t api_mu;                 /* one batch at a time */
@@ -540,7 +541,7 @@ static int pool_default_threads(void)
 int h264bsdmiSetParserThreads(int n)
 {
     pthread_mutex_lock(&g_pool.mu);
-    g_pool.chosen = n >= 1 || getenv("H264BSDMI_THREADS") != NULL;
+    const int chosen = n >= 1 || getenv("H264BSDMI_THREADS") != NULL;
     if (n < 1) n = pool_default_threads();
     if (n > 64) n = 64;
     g_pool.want = n;
@@ -552,6 +553,10 @@ int h264bsdmiSetParserThreads(int n)
         g_pool.started++;
     }
     g_pool.n_threads = g_pool.started + 1;
+    {
+        const long lim = (usable_cpus_q(0) + host_share() - 1) / host_share();
+        g_pool.pull_workers = chosen || lim < 1 || lim > g_pool.n_threads ? g_pool.n_threads : (int)lim;
+    }
     const int r = g_pool.n_threads;
     pthread_mutex_unlock(&g_pool.mu);
     return r;
@@ -580,11 +585,7 @@ static int run_batch(Batch *b)
      * CPU quota (usable_cpus_q: that uses the budget up when threads only parse); threads that also wait for the device in between burn a
      * period's budget in bursts, and while the cgroup is throttled nothing feeds the link: 256 pulls + parses take 26.5 ms on 16 threads,
      * 29.5 on 20, 52 on 40 under a quota of 16 CPUs. */
-    u32 nw = (u32)g_pool.n_threads;
-    if (b->out && !g_pool.chosen) {
-        const long lim = (usable_cpus_q(0) + host_share() - 1) / host_share();
-        if (lim >= 1 && (u32)lim < nw) nw = (u32)lim;
-    }
+    const u32 nw = (u32)(b->out ? g_pool.pull_workers : g_pool.n_threads);
     b->workers = nw;
     g_pool.batch = b;
     g_pool.generation++;

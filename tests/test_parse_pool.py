@@ -104,7 +104,8 @@ def test_shared_read_only_input_buffer(built):
         libc.mprotect(ctypes.c_void_p(addr), ctypes.c_size_t((len(data) + page - 1) // page * page), mmap.PROT_READ | mmap.PROT_WRITE)
 
 
-def test_pull_and_decode_batch_parses_like_the_harness_loop(built):
+@pytest.mark.parametrize("threads", [3, 0])       # 0: the library's default (batches that pull then run on the CPUs of quota, api.c run_batch)
+def test_pull_and_decode_batch_parses_like_the_harness_loop(built, threads):
     """h264bsdmiPullAndDecodePictureBatch (capture mode: the pull pops the output queue, there are no pixels): which frame buffer a
     picture is decoded into depends on what has left the output queue (src/h264bsd_dpb.c: a picture waiting for display keeps its
     buffer; the next slice discards the queue, :1260-1261), so the frame jobs only equal those of the reference harness's loop —
@@ -137,7 +138,7 @@ def test_pull_and_decode_batch_parses_like_the_harness_loop(built):
         dec.close()
         return jobs, outs
     want = [harness_loop(d) for d in datas]
-    built.lib().h264bsdmiSetParserThreads(3)
+    assert built.lib().h264bsdmiSetParserThreads(threads) >= 1
     got = [[] for _ in datas]
     decs = [built.Decoder(capture=(lambda b, k=k: got[k].append(hashlib.sha1(b).hexdigest()))) for k in range(len(datas))]
     drv = built.BatchDriver(decs, datas)
