@@ -187,7 +187,7 @@ def end_to_end(data, streams, threads, laps=2, pull=False, barrier=None):
                 d2h_bytes_per_picture=info["width_mbs"] * info["height_mbs"] * 384 if pull else 0, seconds=dt,
                 device_errors=h.device_errors(),
                 sample=f"{streams} decoder instances x {timed} pictures through h264bsdDecode-equivalent batch calls, PCIe inclusive, "
-                       f"{dt:.1f} s; " + ("every picture pulled to host memory (h264bsdNextOutputPicture semantics)" if pull else "pictures left in HBM"))
+                       f"{dt:.1f} s; " + ("every picture pulled to host memory (h264bsdNextOutputPicture semantics; h264bsdmiPullAndDecodePictureBatch, which runs on min(parser_threads, CPUs the process may have running at once) threads)" if pull else "pictures left in HBM"))
 
 
 def main():
