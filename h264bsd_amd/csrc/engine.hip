@@ -923,10 +923,8 @@ int sink_fetch_begin(void *user, uint32_t slot)
     s->out_slot = -1;
     if (slot >= s->n_slots || out_begin(u, true, &st)) return -1;
     free_retired(s);
-    if (!s->h_frame[slot]) {
-        if (hipHostMalloc((void **)&s->h_frame[slot], s->frame_bytes, hipHostMallocDefault) != hipSuccess) return -1;
-        if (hipHostGetDevicePointer((void **)&s->hd_frame[slot], s->h_frame[slot], 0) != hipSuccess) return -1;
-    }
+    if (!s->h_frame[slot] && hipHostMalloc((void **)&s->h_frame[slot], s->frame_bytes, hipHostMallocDefault) != hipSuccess) { s->h_frame[slot] = nullptr; return -1; }
+    if (!s->hd_frame[slot] && hipHostGetDevicePointer((void **)&s->hd_frame[slot], s->h_frame[slot], 0) != hipSuccess) { s->hd_frame[slot] = nullptr; return -1; }
     /* the layout kernel writes the host mirror itself: 16-byte pieces over the link run at 49 GB/s (tools/probes/d2h_probe.hip: as fast as
      * whole rows, and as fast as the copy engine moves one large buffer), and a picture costs ONE launch on the compute queue instead
      * of a kernel, two copy-engine transfers and the hand-overs between the engines */
@@ -956,10 +954,8 @@ uint32_t *sink_fetch_converted(void *user, uint32_t slot, int fmt)
         if (slot >= s->n_slots || out_begin(u, true, &st)) return nullptr;
         const uint32_t w = s->wmb * 16, h = s->hmb * 16;
         const size_t bytes = (size_t)w * h * 4;
-        if (!s->h_conv) {
-            if (hipHostMalloc((void **)&s->h_conv, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-            if (hipHostGetDevicePointer((void **)&s->hd_conv, s->h_conv, 0) != hipSuccess) return nullptr;
-        }
+        if (!s->h_conv && hipHostMalloc((void **)&s->h_conv, bytes, hipHostMallocDefault) != hipSuccess) { s->h_conv = nullptr; return nullptr; }
+        if (!s->hd_conv && hipHostGetDevicePointer((void **)&s->hd_conv, s->h_conv, 0) != hipSuccess) { s->hd_conv = nullptr; return nullptr; }
         hipLaunchKernelGGL(h264k::k_convert_tiles, dim3(1024, 1), dim3(256), 0, st,
                            s->d_frames + (size_t)slot * s->frame_bytes, s->hd_conv, s->wmb, s->hmb, fmt, (size_t)0, (size_t)0);
         if (hipGetLastError() != hipSuccess) return nullptr;
