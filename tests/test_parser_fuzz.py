@@ -144,3 +144,31 @@ def test_sanitizer_harness_builds_and_runs(tmp_path):
                        capture_output=True, text=True, timeout=900, env=dict(env, ASAN_OPTIONS="detect_leaks=0"))
     out = "\n".join(ln for ln in (r.stdout + r.stderr).splitlines() if "left shift of negative" not in ln)   # (mirrors the reference's arithmetic)
     assert "cases 150" in out and "ERROR: AddressSanitizer" not in out and "runtime error" not in out, out[-1500:]
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_batch_calls_under_sanitizers(tmp_path, sanitizer):
+    """The threaded host paths — parser pool, h264bsdmiDecodePictureBatch, h264bsdmiNextOutputPictureBatch and
+    h264bsdmiPullAndDecodePictureBatch with its look-ahead pulls — under ThreadSanitizer and under Address/UB/LeakSanitizer, bound to a
+    device stand-in (tests/fuzz_asan/mock_engine.c) whose pictures are the running number of the job decoded into a frame buffer: every
+    pull must hand out the successor of the instance's previous picture, no report from the sanitizer."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    C = os.path.join(root, "h264bsd_amd", "csrc")
+    exe = str(tmp_path / "batch_san")
+    srcs = [os.path.join(root, "tests", "fuzz_asan", f) for f in ("batch_tsan.c", "mock_engine.c")] + \
+           [os.path.join(C, f) for f in ("hd_nal.c", "hd_params.c", "hd_slice.c", "hd_dpb.c", "hd_cavlc.c", "hd_resid.c", "hd_mb.c", "hd_core.c", "api.c")]
+    b = subprocess.run(["gcc", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer", "-std=gnu11", f"-I{C}", "-DH264BSD_BUILD"] + srcs +
+                       ["-lpthread", "-o", exe], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe, os.path.join(root, "tests", "golden", "test_640x360.h264"), "12", "6"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", TSAN_OPTIONS="halt_on_error=0"))
+    out = "\n".join(ln for ln in (r.stdout + r.stderr).splitlines() if "left shift of negative" not in ln)   # (mirrors the reference's arithmetic)
+    if "FATAL: ThreadSanitizer" in out and "unexpected memory mapping" in out:
+        pytest.skip("ThreadSanitizer cannot run in this container (address space layout)")
+    assert r.returncode == 0 and "ok: 12 instances x 2 styles, 1752 pictures pulled" in out, out[-2000:]
+    assert "WARNING: ThreadSanitizer" not in out and "ERROR: AddressSanitizer" not in out and "ERROR: LeakSanitizer" not in out and "runtime error" not in out, out[-2000:]
