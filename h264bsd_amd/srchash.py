@@ -1,11 +1,12 @@
 """Identity of the kernel sources for measurements that cannot be repeated inside bench.py (the PMC traffic table,
-profiles/rNN_traffic.json): sha256 over kernels.hip.h + framejob.h with comments and white space removed, so that a
+profiles/rNN_traffic.json): sha256 over kernels.hip.h, kernels/*.hip.h + framejob.h with comments and white space removed, so that a
 table stays valid across comment edits and goes stale with any change of code."""
 import hashlib
 import os
 import re
 
-_FILES = ("kernels.hip.h", "framejob.h")
+_FILES = ("kernels.hip.h", "kernels/common.hip.h", "kernels/k_dbk.hip.h", "kernels/k_copy.hip.h", "kernels/k_recon_inter.hip.h",
+          "kernels/tail_common.hip.h", "kernels/k_frame_intra.hip.h", "kernels/k_frame_dbk.hip.h", "kernels/k_pixels_io.hip.h", "framejob.h")
 
 
 def _code_only(text):
