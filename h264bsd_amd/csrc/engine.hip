@@ -284,7 +284,8 @@ Engine *engine_get(int device = -1)
  * workgroup, and a cap on the bands of one launch.  H264BSDMI_TAIL="dbk_rows_light,dbk_rows_heavy,dbk_waves,intra_rows_light,
  * intra_rows_heavy,intra_waves" overrides the defaults (0 rows = one band); h264bsdmiDebugSetTail() does the same for tests. */
 struct TailConfig {
-    uint32_t dbk_rows_light = 17, dbk_rows_heavy = 9, dbk_waves = 8;
+    uint32_t dbk_rows_light = 17, dbk_rows_heavy = 9, dbk_waves = 12;
+    uint32_t dbk_chroma_waves = 0;        /* wavefronts of a k_frame_dbk workgroup that start on the chroma graph; 0 = a third */
     uint32_t intra_rows_light = 0, intra_rows_heavy = 9, intra_waves = 12;
     /* A picture is only split where that puts idle compute units to work: a launch gets at most band_budget workgroups
      * (bands per picture <= band_budget / pictures of the tick, at least 1).  256 pictures in lock-step: one workgroup per
@@ -305,11 +306,12 @@ TailConfig tail_config()
     if (!g_tail.from_env) {
         g_tail.from_env = true;
         if (const char *cfg = getenv("H264BSDMI_TAIL")) {
-            unsigned v[6];
-            if (sscanf(cfg, "%u,%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
+            unsigned v[7] = { 0, 0, 0, 0, 0, 0, 0 };
+            if (sscanf(cfg, "%u,%u,%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) >= 6) {
                 g_tail.dbk_rows_light = v[0]; g_tail.dbk_rows_heavy = v[1]; g_tail.dbk_waves = v[2];
                 g_tail.intra_rows_light = v[3]; g_tail.intra_rows_heavy = v[4]; g_tail.intra_waves = v[5];
-            } else fprintf(stderr, "h264bsd-mi355x: H264BSDMI_TAIL=%s ignored (expected six numbers)\n", cfg);
+                g_tail.dbk_chroma_waves = v[6];          /* optional seventh number; 0 = a third of dbk_waves */
+            } else fprintf(stderr, "h264bsd-mi355x: H264BSDMI_TAIL=%s ignored (expected six or seven numbers)\n", cfg);
         }
         if (const char *cfg = getenv("H264BSDMI_BAND_BUDGET")) g_tail.band_budget = (uint32_t)strtoul(cfg, nullptr, 10);
         if (const char *cfg = getenv("H264BSDMI_HEAVY_BUDGET")) g_tail.heavy_budget = (uint32_t)strtoul(cfg, nullptr, 10);
@@ -551,6 +553,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
             fprintf(stderr, "h264bsd-mi355x: picture %u macroblocks wide is too large for k_frame_dbk\n", s.max_w); return -1;
         }
         const uint32_t bands = bp.bands, rows = bp.rows, waves = bp.waves;
+        /* the last third of a workgroup's wavefronts starts on the chroma graph (k_frame_dbk.hip.h); the seventh number of H264BSDMI_TAIL overrides */
+        const uint32_t chroma_waves = tc.dbk_chroma_waves ? tc.dbk_chroma_waves : std::max<uint32_t>(1u, waves / 3u);
         const size_t lds = bp.lds;
         uint32_t *tickets = bands > 1 ? tickets_for(st) : nullptr;
         if (bands > 1 && !tickets) return -1;
@@ -566,8 +570,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
                 lds_enabled[bands > 1][dev] = lds;
             }
         }
-        if (bands > 1) hipLaunchKernelGGL(h264k::k_frame_dbk<true>, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets, bands, rows, light_cap);
-        else hipLaunchKernelGGL(h264k::k_frame_dbk<false>, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof, nullptr, 1u, rows, 1u);
+        if (bands > 1) hipLaunchKernelGGL(h264k::k_frame_dbk<true>, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets, bands, rows, light_cap, chroma_waves);
+        else hipLaunchKernelGGL(h264k::k_frame_dbk<false>, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof, nullptr, 1u, rows, 1u, chroma_waves);
         if (launches) launches[4]++;
     }
     if (EV_NEEDED(5)) HIP_TRY(hipEventRecord(tt->ev[5], st));

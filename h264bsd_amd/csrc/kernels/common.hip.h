@@ -50,9 +50,13 @@ struct FrameDesc {
                           edge) and / or rows -3..2 (upper edge): its right-hand neighbour has to wait for it only if its UPPER edge is
                           filtered, the macroblock below only if its LEFT edge is (k_frame_dbk, dependency rule) */
 /* Per-stream deblocking scratch (FrameDesc.dbk): n_mbs records | n4 flag bytes (DBKF_*) | n4 "done" bytes of k_frame_dbk's row
- * bands | n4 "done" bytes of k_frame_intra's row bands | exit counters of the two kernels (u32 each) — n4 = n_mbs rounded up
- * to a multiple of 4.  Flags, done bytes and counters are zero between pictures (the last band to leave cleans up). */
-#define DBK_SCRATCH_BYTES(n_mbs) ((size_t)(n_mbs) * (DBK_REC_BYTES + 3) + 64)
+ * bands for its luma graph | n4 for its chroma graph | n4 "done" bytes of k_frame_intra's row bands | exit counters of the two
+ * kernels (u32 each) — n4 = n_mbs rounded up to a multiple of 4.  Flags, done bytes and counters are zero between pictures (the
+ * last band to leave cleans up). */
+#define DBK_SCRATCH_BYTES(n_mbs) ((size_t)(n_mbs) * (DBK_REC_BYTES + 4) + 64)
+#define SCRATCH_DONE_DBK_LUMA 0
+#define SCRATCH_DONE_DBK_CHROMA 1
+#define SCRATCH_DONE_INTRA 2
 
 
 namespace h264k {
@@ -197,13 +201,13 @@ __device__ __forceinline__ uint2 ld8g(const H264K_GLOBAL uint8_t *p) { const u32
 __device__ __forceinline__ void st16g(H264K_GLOBAL uint8_t *p, uint4 v) { *(H264K_GLOBAL u32x4 *)p = (u32x4){ v.x, v.y, v.z, v.w }; }
 __device__ __forceinline__ uint4 ld16c(const H264K_CONST void *p) { const u32x4 v = *(const H264K_CONST u32x4 *)p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint8_t *scratch_flags(const FrameDesc &fd) { return fd.dbk + (size_t)fd.n_mbs * DBK_REC_BYTES; }
-__device__ __forceinline__ uint8_t *scratch_done(const FrameDesc &fd, int which)      /* 0: k_frame_dbk, 1: k_frame_intra */
+__device__ __forceinline__ uint8_t *scratch_done(const FrameDesc &fd, int which)      /* SCRATCH_DONE_* */
 {
     return scratch_flags(fd) + (size_t)(1 + which) * ((fd.n_mbs + 3u) & ~3u);
 }
 __device__ __forceinline__ uint32_t *scratch_exits(const FrameDesc &fd, int which)
 {
-    return reinterpret_cast<uint32_t *>(scratch_flags(fd) + (size_t)3 * ((fd.n_mbs + 3u) & ~3u)) + which;
+    return reinterpret_cast<uint32_t *>(scratch_flags(fd) + (size_t)4 * ((fd.n_mbs + 3u) & ~3u)) + which;
 }
 
 /* 4x4 transpose across the 4 lanes of a quad: lane q holds row q in v[0..3] -> holds column q */

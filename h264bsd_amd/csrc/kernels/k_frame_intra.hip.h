@@ -487,7 +487,7 @@ __device__ __forceinline__ void intra4_joint(const FrameDesc &fd, int my_mb, int
  * ROW BANDS as in k_frame_dbk (which see): up to max_bands workgroups per picture, band-local state for rows r0-1 .. r1-1.
  * Intra prediction only looks up and to the left, so the only dependencies that cross a band boundary are those of a band's
  * first row on the last row of the band above (FJ_NEED_UL / U / UR): the producers write their tiles write-through and set
- * a "done" byte (scratch_done(fd, 1)), an idle wavefront of the band below polls, the consumers read the row above past
+ * a "done" byte (scratch_done(fd, SCRATCH_DONE_INTRA)), an idle wavefront of the band below polls, the consumers read the row above past
  * the L1 (intra_issue, cross).  Pictures with concealed macroblocks (which may wait for the macroblock BELOW them) are never
  * split (FjHeader.intra_down_deps -> FrameDesc.intra_bands = 1).
  * Dynamic LDS: per wavefront INTRA_WAVE_LDS (4 macroblock slots + deferred residuals + records) | need | dep |
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
     uint32_t *ctr = reinterpret_cast<uint32_t *>(queue + nq8);   /* [0] head, [1] tail, [2] total, [3] producers awaited, [4] producers seen, [5] poll lock */
     uint32_t *seen = ctr + 8;
     uint2 *i4tab = reinterpret_cast<uint2 *>(seen + ((((wmb + 31) >> 5) + 3) & ~3));
-    uint8_t *done_g = scratch_done(fd, 1);
+    uint8_t *done_g = scratch_done(fd, SCRATCH_DONE_INTRA);
 
     for (int i = tid; i < n_loc16 / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dep)[i] = 0xFFFFFFFFu;
     for (int i = tid; i < nq8 / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(queue)[i] = 0xFFFFFFFFu;

@@ -22,7 +22,7 @@ def main():
     path = sys.argv[1]
     subs = sys.argv[2:]
     lines = open(path).read().split('\n')
-    starts = [(i, l.split(':')[0]) for i, l in enumerate(lines) if re.match(r'^_Z[A-Za-z0-9_]+:', l)]
+    starts = [(i, l.split(':')[0]) for i, l in enumerate(lines) if re.match(r'^[A-Za-z_][A-Za-z0-9_]*:', l)]
     starts.append((len(lines), None))
     for (a, name), (b, _) in zip(starts, starts[1:]):
         if subs and not any(s in name for s in subs): continue
