@@ -19,16 +19,21 @@ namespace h264k {
  * reference: h264bsdFilterPicture and below, src/h264bsd_deblocking.c:575-1745 (FilterLuma order :1551-1623). */
 constexpr int DBK_LANES = 8;                         /* lanes per worker */
 /* worker-private exchange buffers.  Luma: two 128-byte halves (block columns 0..3 | 4..7 of every lane's row) 144 bytes
- * apart; a worker's buffer 288 bytes.  For one ds_read_b32 phase the eight lanes of a worker then read eight consecutive
- * banks and the four workers of a 32-lane group start 8 banks apart (288 / 4 = 72 = 8 mod 32).  Chroma: 128 bytes + 16. */
-constexpr int DBK_LW = 288, DBK_LW_HI = 144, DBK_CW = 144;
-constexpr int DBK_WAVE_LDS = 8 * DBK_LW;             /* 2304 bytes per wavefront, whichever role it plays */
+ * apart, then the 64-byte strip area (four rows of the upper neighbour); a worker's buffer 352 bytes.  For one ds_read_b32 phase
+ * the eight lanes of a worker then read eight consecutive banks and the four workers of a 32-lane group start 24, 16 and 8
+ * banks apart (352 / 4 = 88 = 24 mod 32).  Chroma: 128 bytes, 16 free, a 32-byte strip area (two rows per plane); 176 bytes. */
+constexpr int DBK_LW = 352, DBK_LW_HI = 144, DBK_LW_STRIP = 288, DBK_CW = 176, DBK_CW_STRIP = 144;
+constexpr int DBK_WAVE_LDS = 8 * DBK_LW;             /* 2816 bytes per wavefront, whichever role it plays */
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const H264K_LDS uint8_t *)p; }
 /* LDS accesses by 32-bit address (ds_write_b128 / ds_read_b32 / ds_read_u16; the compiler pairs neighbouring reads into ds_read2_b32) */
 __device__ __forceinline__ void lds_st128(uint32_t a, uint32_t x, uint32_t y, uint32_t z, uint32_t w) { *(H264K_LDS u32x4 *)(uintptr_t)a = (u32x4){ x, y, z, w }; }
 __device__ __forceinline__ uint32_t lds_ld32(uint32_t a) { return *(const H264K_LDS uint32_t *)(uintptr_t)a; }
 __device__ __forceinline__ uint32_t lds_ld16(uint32_t a) { return *(const H264K_LDS uint16_t *)(uintptr_t)a; }
+__device__ __forceinline__ uint2 lds_ld64(uint32_t a) { const u32x2 v = *(const H264K_LDS u32x2 *)(uintptr_t)a; return make_uint2(v.x, v.y); }
+__device__ __forceinline__ void lds_st64(uint32_t a, uint32_t x, uint32_t y) { *(H264K_LDS u32x2 *)(uintptr_t)a = (u32x2){ x, y }; }
+__device__ __forceinline__ void lds_st32(uint32_t a, uint32_t x) { *(H264K_LDS uint32_t *)(uintptr_t)a = x; }
+__device__ __forceinline__ void lds_st16(uint32_t a, uint32_t x) { *(H264K_LDS uint16_t *)(uintptr_t)a = (uint16_t)x; }
 
 __device__ __forceinline__ s2 pk_splat_byte(uint32_t w, int byte)   /* (byte, byte) as two 16-bit halves: one v_perm_b32 */
 {
@@ -122,6 +127,10 @@ __device__ __forceinline__ void stg_u32(uint8_t *cur, uint32_t o, uint32_t v, bo
 {
     if (wt) st_agent_u32(cur + o, v); else *(H264K_GLOBAL uint32_t *)((H264K_GLOBAL uint8_t *)cur + o) = v;
 }
+__device__ __forceinline__ void stg_b64(uint8_t *cur, uint32_t o, uint2 v, bool wt)
+{
+    if (wt) put8(cur + o, v, true); else *(H264K_GLOBAL u32x2 *)((H264K_GLOBAL uint8_t *)cur + o) = (u32x2){ v.x, v.y };
+}
 __device__ __forceinline__ void stg_b128(uint8_t *cur, uint32_t o, uint4 v, bool wt)
 {
     if (wt) put16(cur + o, v, true); else st16g((H264K_GLOBAL uint8_t *)cur + o, v);
@@ -153,11 +162,23 @@ __device__ __forceinline__ s2 pair_hi(uint32_t blk) { return as_s2(perm(0u, blk,
 #endif
 
 /* ================================================================== luma */
+/* What a vector memory instruction costs the compute unit (tools/probes/vmem_issue_probe.hip, 12 wavefronts per CU, cycles of the
+ * CU's address path per wave-level instruction): it grows with the 32-byte SECTORS and 128-byte lines the 64 lanes touch, hardly
+ * with the bytes — a dword per lane out of every second row of eight tiles (the left strips) 52 as a load and 62 as a store,
+ * 16 bits per lane out of one row of eight tiles 17 / 20, a 16-byte row piece per lane 18 / 56, eight lanes reading the same 16
+ * bytes 14.  Twelve wavefronts walking chains share that path, and a step used to open with 13 loads and end with 7-9 stores.
+ * So the strips travel WIDE and in as few instructions as possible, and what a pass needs in another shape is reshaped in LDS:
+ *   left strip   loaded as the 8-byte row halves that hold it; stored as dwords, lanes regrouped by DPP so that one instruction
+ *                covers rows 0..7 (one 128-byte line per tile) and the other rows 8..15;
+ *   upper strip  loaded as 8 bytes per lane (the four rows are 64 contiguous bytes), turned into column pairs through the
+ *                worker's strip area in LDS; rows 13..15 return the same way and leave as 8 bytes from six lanes;
+ *   own rows     the second transposition hands every lane the rows that make instruction A write rows 0..7 (a full line per
+ *                tile, every sector whole) and instruction B rows 8..15. */
 /* Everything a luma worker loads, all of it requested before the first use (one memory round trip per step). */
 struct DbkLumaLoads {
     uint4 y0, y1;             /* rows 2l, 2l+1: 32 contiguous bytes of the tile                                          */
-    uint32_t l0, l1;          /* the last four columns of the tile to the left, same rows                                 */
-    uint32_t t[4];            /* columns 2l, 2l+1 of the last four rows of the tile above (16 bits each)                  */
+    uint2 l0, l1;             /* columns 8..15 of the same rows of the tile to the left (.y = its last four columns)       */
+    uint2 t;                  /* dwords 2l, 2l+1 of the last four rows of the tile above (row 12 + l/2, columns 8 (l&1) ..) */
     uint4 r0, r1; uint2 r2;   /* the record: strengths | class dwords luma left / top / inner (, chroma left) | bytes 40..47 */
 };
 
@@ -168,6 +189,7 @@ __device__ __forceinline__ void dbk_luma_load(const FrameDesc &fd, int mb, int l
 {
     if (mb < 0) return;
     const uint8_t *cur = fd.cur;
+    const H264K_GLOBAL uint8_t *curg = (const H264K_GLOBAL uint8_t *)cur;
     const H264K_GLOBAL uint8_t *recs = (const H264K_GLOBAL uint8_t *)fd.dbk;
     const uint32_t umb = (uint32_t)mb, wmb = fd.wmb;
     const uint32_t t = umb * TILE, tl = (umb ? umb - 1u : 0u) * TILE, tu = (umb >= wmb ? umb - wmb : umb) * TILE;     /* stand-ins where there is no neighbour: never used (k_dbk: LEFT / TOP only where it exists) */
@@ -175,20 +197,14 @@ __device__ __forceinline__ void dbk_luma_load(const FrameDesc &fd, int mb, int l
     p.r0 = ld16g(recs + ro);
     p.r1 = ld16g(recs + ro + 16u);
     p.r2 = ld8g(recs + ro + 40u);
-    p.y0 = ld16g((const H264K_GLOBAL uint8_t *)cur + t + 32u * l);
-    p.y1 = ld16g((const H264K_GLOBAL uint8_t *)cur + t + 32u * l + 16u);
-    p.l0 = ldg_u32(cur, tl + 32u * l + 12u);
-    p.l1 = ldg_u32(cur, tl + 32u * l + 28u);
-    const uint32_t uy = tu + 192u + 2u * l;
-#pragma unroll
-    for (int i = 0; i < 4; i++) p.t[i] = 0u;
-    if (!cross) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) p.t[i] = ldg_u16(cur, uy + 16u * i);
-    } else if (want_top) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) p.t[i] = ld_agent_u16(cur + uy + 16u * i);
-    }
+    p.y0 = ld16g(curg + t + 32u * l);
+    p.y1 = ld16g(curg + t + 32u * l + 16u);
+    p.l0 = ld8g(curg + tl + 32u * l + 8u);
+    p.l1 = ld8g(curg + tl + 32u * l + 24u);
+    const uint32_t uy = tu + 192u + 8u * l;
+    p.t = make_uint2(0u, 0u);
+    if (!cross) p.t = ld8g(curg + uy);
+    else if (want_top) p.t = make_uint2(ld_agent_u32(cur + uy), ld_agent_u32(cur + uy + 4u));
 }
 
 /* In-loop filter of the luma of one macroblock by one worker = 8 lanes: vertical edges, then horizontal edges (8.7).
@@ -215,17 +231,20 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
     /* thresholds per class: A / B = alpha / beta in both halves, t4 = { 0, tc0(1), tc0(2), tc0(3) } */
     const uint32_t w_ll = p.r1.x, w_lt = p.r1.y, w_li = p.r1.z, t3a = p.r2.x;      /* t3a: bytes 40..43 = tc0(3) of luma left / top / inner */
     const int k = l >> 1;                                          /* both lines of a lane lie in segment k of every edge */
+    const uint32_t sb = wb + DBK_LW_STRIP;                         /* the strip area: four rows of 16 bytes */
+    const bool lo4 = l < 4;
     s2 one = pk(1);
     asm volatile("" : "+v"(one));
 #ifdef H264K_TAIL_PROFILE
     if (tp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     const unsigned long long d1 = DTICK();
+    lds_st64(sb + 8u * l, p.t.x, p.t.y);                           /* the upper strip as rows; read back as column pairs below */
 
     /* ---- vertical edges: rows 2l (low halves) and 2l+1 (high halves); px[0..3] = the left neighbour's last columns ---- */
     s2 px[NPX];
-    px[0] = as_s2(perm(p.l1, p.l0, 0x0C040C00u)); px[1] = as_s2(perm(p.l1, p.l0, 0x0C050C01u));
-    px[2] = as_s2(perm(p.l1, p.l0, 0x0C060C02u)); px[3] = as_s2(perm(p.l1, p.l0, 0x0C070C03u));
+    px[0] = as_s2(perm(p.l1.y, p.l0.y, 0x0C040C00u)); px[1] = as_s2(perm(p.l1.y, p.l0.y, 0x0C050C01u));
+    px[2] = as_s2(perm(p.l1.y, p.l0.y, 0x0C060C02u)); px[3] = as_s2(perm(p.l1.y, p.l0.y, 0x0C070C03u));
     {
         const uint32_t ra[4] = { p.y0.x, p.y0.y, p.y0.z, p.y0.w }, rb[4] = { p.y1.x, p.y1.y, p.y1.z, p.y1.w };
 #pragma unroll
@@ -257,7 +276,6 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
     /* ---- to columns: hx[r + 4] = row r, columns 2l (low half), 2l+1 (high half); hx[0..3] = the upper neighbour's last rows ---- */
     s2 hx[NPX];
     uint32_t own0 = 0u, own1 = 0u;                                 /* SLOTS = 1: columns 0..3 of rows 2l, 2l+1 after the vertical pass */
-    const uint32_t ra_ = wb + (l < 4 ? 4u * l : (uint32_t)DBK_LW_HI + 4u * (l - 4));     /* this lane's column of blocks in the exchange buffer */
     if constexpr (SLOTS == 4) {
         /* block (row pair l, column pair j) = (row 2l col 2j, row 2l+1 col 2j, row 2l col 2j+1, row 2l+1 col 2j+1) */
         uint32_t D[8];
@@ -266,6 +284,7 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
         lds_st128(wb + 16u * l, D[0], D[1], D[2], D[3]);
         lds_st128(wb + DBK_LW_HI + 16u * l, D[4], D[5], D[6], D[7]);
         wave_sync();
+        const uint32_t ra_ = wb + (lo4 ? 4u * l : (uint32_t)DBK_LW_HI + 4u * (l - 4));     /* this lane's column of blocks */
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t e = lds_ld32(ra_ + 16u * r);            /* block (row pair r, column pair l) */
@@ -281,11 +300,10 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
         lds_st128(wb + 32u * l + 16u, own1, p.y1.y, p.y1.z, p.y1.w);
         wave_sync();
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            hx[4 + r] = as_s2(perm(0u, lds_ld16(wb + 16u * r + 2u * l), 0x0C010C00u));
+        for (int r = 0; r < 4; r++) hx[4 + r] = as_s2(perm(0u, lds_ld16(wb + 16u * r + 2u * l), 0x0C010C00u));
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) hx[r] = as_s2(perm(0u, p.t[r], 0x0C010C00u));
+    for (int r = 0; r < 4; r++) hx[r] = as_s2(perm(0u, lds_ld16(sb + 16u * r + 2u * l), 0x0C010C00u));
 
     /* ---- horizontal edges ---- */
     if (any_h) {
@@ -303,49 +321,64 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
     /* ---- store ---- */
     uint8_t *cur = fd.cur;
     const uint32_t t = (uint32_t)mb * TILE;
+    /* rows 13..15 of the upper neighbour (row 12 = p3 never changes) go back through the strip area ... */
+#pragma unroll
+    for (int r = 1; r < 4; r++) lds_st16(sb + 16u * r + 2u * l, perm(0u, as_u32(hx[r]), 0x0C0C0200u));
     if constexpr (SLOTS == 4) {
         /* back to rows: block (row pair r, column pair l) = (row 2r col 2l, row 2r+1 col 2l, row 2r col 2l+1, row 2r+1 col 2l+1) */
         uint32_t F[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) F[r] = blk_t_of(hx[4 + 2 * r], hx[5 + 2 * r]);
-        wave_sync();                                               /* (every lane has read the first trip) */
-        lds_st128(wb + 16u * l, F[0], F[1], F[2], F[3]);
+        lds_st128(wb + 16u * l, F[0], F[1], F[2], F[3]);           /* (every lane has read the first trip: LDS operations of a wavefront execute in order) */
         lds_st128(wb + DBK_LW_HI + 16u * l, F[4], F[5], F[6], F[7]);
         wave_sync();
-        uint32_t G[8];
+        /* instruction A stores rows 0..7, instruction B rows 8..15 — one whole 128-byte line per tile each: lanes 0..3 take the even
+         * row of row pair l & 3 (+ 4 for B), lanes 4..7 the odd one (two lanes read the same blocks: an LDS broadcast) */
+        const uint32_t rsel = lo4 ? 0x06040200u : 0x07050301u;
+        const uint32_t rq = wb + 4u * (l & 3);
+        uint32_t Ga[8], Gb[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) G[j] = lds_ld32(ra_ + 16u * j);      /* block (row pair l, column pair j) */
+        for (int j = 0; j < 8; j++) { Ga[j] = lds_ld32(rq + 16u * j); Gb[j] = lds_ld32(rq + DBK_LW_HI + 16u * j); }      /* blocks (row pair l & 3 (+ 4), column pair j) */
         if (act) {
-            uint4 ya, yb;
-            ya.x = perm(G[1], G[0], 0x06040200u); ya.y = perm(G[3], G[2], 0x06040200u); ya.z = perm(G[5], G[4], 0x06040200u); ya.w = perm(G[7], G[6], 0x06040200u);
-            yb.x = perm(G[1], G[0], 0x07050301u); yb.y = perm(G[3], G[2], 0x07050301u); yb.z = perm(G[5], G[4], 0x07050301u); yb.w = perm(G[7], G[6], 0x07050301u);
-            stg_b128(cur, t + 32u * l, ya, wt);
-            stg_b128(cur, t + 32u * l + 16u, yb, wt);
+            const uint32_t o = t + 32u * (l & 3) + (lo4 ? 0u : 16u);
+            stg_b128(cur, o, make_uint4(perm(Ga[1], Ga[0], rsel), perm(Ga[3], Ga[2], rsel), perm(Ga[5], Ga[4], rsel), perm(Ga[7], Ga[6], rsel)), wt);
+            stg_b128(cur, o + 128u, make_uint4(perm(Gb[1], Gb[0], rsel), perm(Gb[3], Gb[2], rsel), perm(Gb[5], Gb[4], rsel), perm(Gb[7], Gb[6], rsel)), wt);
         }
     } else {
+        /* columns 0..3 of the rows the upper edge does not rewrite: lanes regrouped so that one instruction covers rows 0..7, the
+         * other rows 8..15 (DPP row_shr:4 / row_shl:4 with a bank mask: the other half of the worker keeps its own dword) */
+        const uint32_t va = (uint32_t)__builtin_amdgcn_update_dpp((int)own0, (int)own1, 0x114, 0xF, 0xA, false);   /* lanes 4..7: row 2(l-4)+1 of lane l-4 */
+        const uint32_t vb = (uint32_t)__builtin_amdgcn_update_dpp((int)own1, (int)own0, 0x104, 0xF, 0x5, false);   /* lanes 0..3: row 2(l+4) of lane l+4 */
         if (f_left) {
-            /* rows 0..2 leave with the horizontal pass when the upper edge is filtered */
-            if (!(f_top && l <= 1)) stg_u32(cur, t + 32u * l, own0, wt);          /* rows 0 and 2 */
-            if (!(f_top && l == 0)) stg_u32(cur, t + 32u * l + 16u, own1, wt);    /* row 1 (row 3 = q3 of the upper edge stays a row store) */
+            const int row_a = lo4 ? 2 * l : 2 * (l - 4) + 1;      /* rows 0..2 leave with the horizontal pass when the upper edge is filtered */
+            if (!(f_top && row_a < 3)) stg_u32(cur, t + 16u * row_a, va, wt);
+            stg_u32(cur, t + 128u + 32u * (l & 3) + (lo4 ? 0u : 16u), vb, wt);
         }
-        if (f_top) {
+        /* rows 0..2 after both passes: as rows again through LDS, 8 bytes from each of six lanes */
 #pragma unroll
-            for (int r = 0; r < 3; r++) stg_u16(cur, t + 16u * r + 2u * l, perm(0u, as_u32(hx[4 + r]), 0x0C0C0200u), wt);
+        for (int r = 0; r < 3; r++) lds_st16(wb + 16u * r + 2u * l, perm(0u, as_u32(hx[4 + r]), 0x0C0C0200u));
+        wave_sync();
+        if (f_top && l < 6) {
+            const uint2 v = lds_ld64(wb + 8u * l);
+            stg_b64(cur, t + 8u * l, v, wt);
         }
     }
     if (f_left) {
         const uint32_t tl = t - TILE;
-        stg_u32(cur, tl + 32u * l + 12u, lo0, wt);
-        stg_u32(cur, tl + 32u * l + 28u, lo1, wt);
+        const uint32_t va = (uint32_t)__builtin_amdgcn_update_dpp((int)lo0, (int)lo1, 0x114, 0xF, 0xA, false);
+        const uint32_t vb = (uint32_t)__builtin_amdgcn_update_dpp((int)lo1, (int)lo0, 0x104, 0xF, 0x5, false);
+        const uint32_t o = tl + 32u * (l & 3) + (lo4 ? 12u : 28u);
+        stg_u32(cur, o, va, wt);
+        stg_u32(cur, o + 128u, vb, wt);
     }
-    if (f_top) {
-        const uint32_t tu = t - (uint32_t)fd.wmb * TILE;
-#pragma unroll
-        for (int r = 1; r < 4; r++) stg_u16(cur, tu + 192u + 16u * r + 2u * l, perm(0u, as_u32(hx[r]), 0x0C0C0200u), wt);     /* rows 13..15 (row 12 = p3 never changes) */
+    wave_sync();
+    if (f_top && l < 6) {
+        const uint2 v = lds_ld64(sb + 16u + 8u * l);               /* ... and leave as 8 bytes from each of six lanes */
+        stg_b64(cur, t - (uint32_t)fd.wmb * TILE + 208u + 8u * l, v, wt);
     }
     wave_sync();          /* the exchange buffer is reused by this worker's next macroblock */
 #ifdef H264K_TAIL_PROFILE
-    if (tp) { const unsigned long long d4 = DTICK(); tp[8] += d1 - d0; tp[9] += d2 - d1; tp[10] += d3 - d2; tp[11] += d4 - d3; }
+    if (tp) { const unsigned long long d4 = DTICK(); tp[0] += d1 - d0; tp[1] += d2 - d1; tp[2] += d3 - d2; tp[3] += d4 - d3; }
 #endif
     (void)d0; (void)d1; (void)d2; (void)d3; (void)tp;
 }
@@ -353,8 +386,8 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
 /* ================================================================== chroma */
 struct DbkChromaLoads {
     uint4 c;                  /* rows 2 c4, 2 c4 + 1 of plane l >> 2 (16 contiguous bytes: x, y = row 2 c4; z, w = row 2 c4 + 1) */
-    uint32_t l0, l1;          /* the last four columns of the tile to the left, same rows                                 */
-    uint32_t t[2];            /* columns 2 c4, 2 c4 + 1 of the last two rows of the tile above, same plane                */
+    uint4 lc;                 /* the same rows of the tile to the left (.y, .w = its last four columns)                  */
+    uint32_t t;               /* dword l & 3 of the last two rows of the tile above, same plane (row 6 + (l & 3) / 2)     */
     uint4 r0; uint32_t w_cl; uint2 w_ci; uint2 r2;     /* strengths | chroma left | chroma top, inner | bytes 40..47     */
 };
 
@@ -362,6 +395,7 @@ __device__ __forceinline__ void dbk_chroma_load(const FrameDesc &fd, int mb, int
 {
     if (mb < 0) return;
     const uint8_t *cur = fd.cur;
+    const H264K_GLOBAL uint8_t *curg = (const H264K_GLOBAL uint8_t *)cur;
     const H264K_GLOBAL uint8_t *recs = (const H264K_GLOBAL uint8_t *)fd.dbk;
     const uint32_t umb = (uint32_t)mb, wmb = fd.wmb;
     const uint32_t t = umb * TILE, tl = (umb ? umb - 1u : 0u) * TILE, tu = (umb >= wmb ? umb - wmb : umb) * TILE;
@@ -370,16 +404,12 @@ __device__ __forceinline__ void dbk_chroma_load(const FrameDesc &fd, int mb, int
     p.w_cl = *(const H264K_GLOBAL uint32_t *)(recs + ro + 28u);
     p.w_ci = ld8g(recs + ro + 32u);
     p.r2 = ld8g(recs + ro + 40u);
-    p.c = ld16g((const H264K_GLOBAL uint8_t *)cur + t + T_CB + 16u * l);
-    p.l0 = ldg_u32(cur, tl + T_CB + 16u * l + 4u);
-    p.l1 = ldg_u32(cur, tl + T_CB + 16u * l + 12u);
-    const uint32_t uc = tu + T_CB + 64u * (l >> 2) + 48u + 2u * (l & 3);
-    p.t[0] = p.t[1] = 0u;
-    if (!cross) {
-        p.t[0] = ldg_u16(cur, uc); p.t[1] = ldg_u16(cur, uc + 8u);
-    } else if (want_top) {
-        p.t[0] = ld_agent_u16(cur + uc); p.t[1] = ld_agent_u16(cur + uc + 8u);
-    }
+    p.c = ld16g(curg + t + T_CB + 16u * l);
+    p.lc = ld16g(curg + tl + T_CB + 16u * l);
+    const uint32_t uc = tu + T_CB + 64u * (l >> 2) + 48u + 4u * (l & 3);
+    p.t = 0u;
+    if (!cross) p.t = ldg_u32(cur, uc);
+    else if (want_top) p.t = ld_agent_u32(cur + uc);
 }
 
 /* Chroma of one macroblock: both planes, edges at columns / rows 0 and 4 (= luma edges 0 and 2).  SLOTS = 2: both; SLOTS = 1:
@@ -397,14 +427,16 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
     const bool any_v = __ballot(act && (SLOTS == 2 ? ((p.r0.x | p.r0.y) & 0xFFFFu) : (p.r0.x & 0xFFFFu))) != 0ull;
     const bool any_h = __ballot(act && (SLOTS == 2 ? ((p.r0.z | p.r0.w) & 0xFFFFu) : (p.r0.z & 0xFFFFu))) != 0ull;
     const uint32_t w_cl = p.w_cl, w_ctp = p.w_ci.x, w_ci = p.w_ci.y, t3a = p.r2.x, t3b = p.r2.y;    /* byte 43: tc0(3) chroma left; bytes 44, 45: top, inner */
+    const uint32_t sb = wb + DBK_CW_STRIP + 16u * pl;              /* the strip area of this plane: two rows of 8 bytes */
 #ifdef H264K_TAIL_PROFILE
     if (tp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     const unsigned long long d1 = DTICK();
+    lds_st32(sb + 4u * c4, p.t);
 
     /* ---- vertical edges: px[0], px[1] = columns 6, 7 of the left neighbour; px[2 + c] = column c ---- */
     s2 px[NPX];
-    px[0] = as_s2(perm(p.l1, p.l0, 0x0C060C02u)); px[1] = as_s2(perm(p.l1, p.l0, 0x0C070C03u));
+    px[0] = as_s2(perm(p.lc.w, p.lc.y, 0x0C060C02u)); px[1] = as_s2(perm(p.lc.w, p.lc.y, 0x0C070C03u));
     px[2] = as_s2(perm(p.c.z, p.c.x, 0x0C040C00u)); px[3] = as_s2(perm(p.c.z, p.c.x, 0x0C050C01u));
     if constexpr (SLOTS == 2) {
         px[4] = as_s2(perm(p.c.z, p.c.x, 0x0C060C02u)); px[5] = as_s2(perm(p.c.z, p.c.x, 0x0C070C03u));
@@ -424,7 +456,6 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
     /* ---- to columns: hx[2 + r] = row r, columns 2 c4, 2 c4 + 1; hx[0], hx[1] = rows 6, 7 of the upper neighbour ---- */
     s2 hx[NPX];
     const uint32_t ra_ = wb + 64u * pl + 4u * c4;
-    uint32_t own0 = 0u, own1 = 0u;
     if constexpr (SLOTS == 2) {
         lds_st128(wb + 16u * l, blk_of(px[2], px[3]), blk_of(px[4], px[5]), blk_of(px[6], px[7]), blk_of(px[8], px[9]));
         wave_sync();
@@ -436,14 +467,13 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
     } else {
         /* rows as rows (8 bytes each, plane after plane): the upper edge reads rows 0, 1 */
         const uint32_t a = blk_of(px[2], px[3]);                   /* (row 2 c4 col 0, row 2 c4 + 1 col 0, row 2 c4 col 1, row 2 c4 + 1 col 1) */
-        own0 = perm(p.c.x, a, 0x07060200u); own1 = perm(p.c.z, a, 0x07060301u);       /* columns 0, 1 filtered, 2, 3 as loaded */
+        const uint32_t own0 = perm(p.c.x, a, 0x07060200u), own1 = perm(p.c.z, a, 0x07060301u);       /* columns 0, 1 filtered, 2, 3 as loaded */
         lds_st128(wb + 16u * l, own0, p.c.y, own1, p.c.w);
         wave_sync();
 #pragma unroll
-        for (int r = 0; r < 2; r++)
-            hx[2 + r] = as_s2(perm(0u, lds_ld16(wb + 64u * pl + 8u * r + 2u * c4), 0x0C010C00u));
+        for (int r = 0; r < 2; r++) hx[2 + r] = as_s2(perm(0u, lds_ld16(wb + 64u * pl + 8u * r + 2u * c4), 0x0C010C00u));
     }
-    hx[0] = as_s2(perm(0u, p.t[0], 0x0C010C00u)); hx[1] = as_s2(perm(0u, p.t[1], 0x0C010C00u));
+    hx[0] = as_s2(perm(0u, lds_ld16(sb + 2u * c4), 0x0C010C00u)); hx[1] = as_s2(perm(0u, lds_ld16(sb + 8u + 2u * c4), 0x0C010C00u));
 
     /* ---- horizontal edges ---- */
     if (any_h) {
@@ -463,7 +493,6 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
         uint32_t F[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) F[r] = blk_t_of(hx[2 + 2 * r], hx[3 + 2 * r]);
-        wave_sync();
         lds_st128(wb + 16u * l, F[0], F[1], F[2], F[3]);
         wave_sync();
         uint32_t G[4];
@@ -476,24 +505,31 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
             stg_b128(cur, t + T_CB + 16u * l, v, wt);
         }
     } else {
+        /* column 0 of rows 2 c4, 2 c4 + 1 (q0 of the left edge), lanes regrouped (quad_perm [2,3,0,1]) so that one instruction covers
+         * rows 0..3 of both planes and the other rows 4..7; row 0 leaves with the horizontal pass when the upper edge is filtered */
+        const uint32_t q0 = as_u32(px[2]), q0x = (uint32_t)quad_xor2((int)q0);
+        const uint32_t va = c4 < 2 ? (q0 & 255u) : (q0x >> 16), vb = c4 < 2 ? (q0x & 255u) : (q0 >> 16);
+        const uint32_t row_a = c4 < 2 ? 2u * c4 : 2u * (c4 - 2) + 1u;
         if (f_left) {
-            /* column 0 of rows 2 c4, 2 c4 + 1 (q0 of the left edge); row 0 leaves with the horizontal pass when the upper edge is filtered */
-            if (!(f_top && c4 == 0)) stg_u8(cur, tp_ + 16u * c4, as_u32(px[2]) & 255u, wt);
-            stg_u8(cur, tp_ + 16u * c4 + 8u, as_u32(px[2]) >> 16, wt);
+            if (!(f_top && row_a == 0u)) stg_u8(cur, tp_ + 8u * row_a, va, wt);
+            stg_u8(cur, tp_ + 8u * (row_a + 4u), vb, wt);
         }
         if (f_top) stg_u16(cur, tp_ + 2u * c4, perm(0u, as_u32(hx[2]), 0x0C0C0200u), wt);
     }
     if (f_left) {
-        const uint32_t tl = tp_ - TILE;
-        stg_u8(cur, tl + 16u * c4 + 7u, as_u32(px[1]) & 255u, wt);                /* p0 of the left edge: column 7 of the left neighbour */
-        stg_u8(cur, tl + 16u * c4 + 15u, as_u32(px[1]) >> 16, wt);
+        /* p0 of the left edge: column 7 of the left neighbour, regrouped the same way */
+        const uint32_t p0 = as_u32(px[1]), p0x = (uint32_t)quad_xor2((int)p0);
+        const uint32_t va = c4 < 2 ? (p0 & 255u) : (p0x >> 16), vb = c4 < 2 ? (p0x & 255u) : (p0 >> 16);
+        const uint32_t row_a = c4 < 2 ? 2u * c4 : 2u * (c4 - 2) + 1u;
+        stg_u8(cur, tp_ - TILE + 8u * row_a + 7u, va, wt);
+        stg_u8(cur, tp_ - TILE + 8u * (row_a + 4u) + 7u, vb, wt);
     }
     if (f_top) stg_u16(cur, tp_ - (uint32_t)fd.wmb * TILE + 56u + 2u * c4, perm(0u, as_u32(hx[1]), 0x0C0C0200u), wt);    /* p0 of the upper edge: row 7 of the upper neighbour */
     wave_sync();
 #ifdef H264K_TAIL_PROFILE
-    if (tp) { const unsigned long long d4 = DTICK(); tp[8] += d1 - d0; tp[9] += d2 - d1; tp[10] += d3 - d2; tp[11] += d4 - d3; }
+    if (tp) { const unsigned long long d4 = DTICK(); tp[0] += d1 - d0; tp[1] += d2 - d1; tp[2] += d3 - d2; tp[3] += d4 - d3; }
 #endif
-    (void)d0; (void)d1; (void)d2; (void)d3; (void)tp; (void)own0; (void)own1;
+    (void)d0; (void)d1; (void)d2; (void)d3; (void)tp;
 }
 #undef DTICK
 
@@ -544,7 +580,7 @@ struct DbkGraph {
     uint8_t *done_g;                                  /* this graph's "done" bytes in the stream's scratch area */
 };
 #ifndef DBK_OCC
-#define DBK_OCC 4
+#define DBK_OCC 3
 #endif
 #ifndef DBK_CHROMA_PRIO
 #define DBK_CHROMA_PRIO 1
@@ -593,6 +629,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
     (void)prof;
 #endif
     unsigned long long t_idle = 0, t_work = 0, t_store = 0, n_done = 0, n_steps = 0;
+    unsigned long long acc[6] = { 0, 0, 0, 0, 0, 0 };       /* inside the steps: load wait, vertical, horizontal, store; claim won -> queue slot read, -> loads issued */
     const unsigned long long t_begin = tp ? __builtin_readcyclecounter() : 0ull;
     unsigned long long t_mark = t_begin;
 
@@ -731,20 +768,29 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
                 run = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef H264K_TAIL_PROFILE
+            if (tp) acc[4] += __builtin_readcyclecounter() - t_mark;      /* claim won -> queue slot read */
+#endif
             const bool cross = has_up && run >= 0 && run < lo_mb + wmb;  /* first row: the tile above belongs to the band above */
             const bool wt = has_down && run >= hi_mb - wmb;              /* last row: the band below reads what this macroblock writes */
             const uint32_t fm = run >= 0 ? anyf[run - base] : 0u;
             bool want_top = true;
             if (BANDED && __ballot(cross) != 0ull) want_top = !cross || (fm & DBKF_TOP);
-            unsigned long long *stp = (tp && lane == 0) ? tp : nullptr;
+            unsigned long long *stp = tp ? acc : nullptr;
             if (role == 0) {
                 DbkLumaLoads cp;
                 dbk_luma_load(fd, run, l, cp, BANDED && cross, want_top);
+#ifdef H264K_TAIL_PROFILE
+                if (tp) acc[5] += __builtin_readcyclecounter() - t_mark;  /* ... -> loads issued */
+#endif
                 if (cls) dbk_luma_step<BANDED, 1>(fd, run, l, cp, wb + (uint32_t)grp * DBK_LW, wt, stp);
                 else dbk_luma_step<BANDED, 4>(fd, run, l, cp, wb + (uint32_t)grp * DBK_LW, wt, stp);
             } else {
                 DbkChromaLoads cp;
                 dbk_chroma_load(fd, run, l, cp, BANDED && cross, want_top);
+#ifdef H264K_TAIL_PROFILE
+                if (tp) acc[5] += __builtin_readcyclecounter() - t_mark;
+#endif
                 if (cls) dbk_chroma_step<BANDED, 1>(fd, run, l, cp, wb + (uint32_t)grp * DBK_CW, wt, stp);
                 else dbk_chroma_step<BANDED, 2>(fd, run, l, cp, wb + (uint32_t)grp * DBK_CW, wt, stp);
             }
@@ -770,6 +816,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
     }
     if (tp && lane == 0) {
         tp[0] += t_idle; tp[1] += t_work; tp[2] += t_store; tp[3] += n_done; tp[4] += __builtin_readcyclecounter() - t_begin; tp[5] += n_steps;
+        for (int i = 0; i < 6; i++) tp[8 + i] += acc[i];
     }
     /* the last band of the picture to leave zeroes the flags (k_dbk only visits non-trivial macroblocks) and the done bytes
      * of both graphs for the next picture of this stream */
