@@ -46,10 +46,20 @@ __device__ __forceinline__ s2 pk_splat_byte(uint32_t w, int byte)   /* (byte, by
  * reference FilterVerLumaEdge / FilterHorLuma / FilterVerChromaEdge ... src/h264bsd_deblocking.c:643-1180.
  * bs = 0 switches the lane off (alpha 0: |p0 - q0| < 0 never holds). */
 __device__ __forceinline__ s2 pk_absdiff(s2 a, s2 b) { return __builtin_elementwise_max(a - b, b - a); }
-
-__device__ __forceinline__ void filter_luma_pk(s2 v[8], int bs, s2 A, s2 B, int tc0, s2 one)
+/* (m & a) | (~m & b) in ONE instruction.  (Written in C the compiler shares sub-terms between the six selects of an edge and ends
+ * up with two instructions for most of them.) */
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b)
 {
-    const s2 p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+/* The sample registers of a pass are plain 32-bit values that the filters read and write as packed pairs: kept as <2 x i16>
+ * across the branches that skip inactive edges, every register that passes a branch is taken apart into its halves and put
+ * together again (v_lshrrev_b32 + v_perm_b32 per register and edge: a quarter of a full step's vector instructions). */
+__device__ __forceinline__ void filter_luma_pk(uint32_t v[8], int bs, s2 A, s2 B, int tc0, s2 one)
+{
+    const s2 p3 = as_s2(v[0]), p2 = as_s2(v[1]), p1 = as_s2(v[2]), p0 = as_s2(v[3]), q0 = as_s2(v[4]), q1 = as_s2(v[5]), q2 = as_s2(v[6]), q3 = as_s2(v[7]);
     const s2 zero = pk(0);
     const s2 Aon = bs != 0 ? A : zero;
     const s2 d0 = pk_absdiff(p0, q0);
@@ -84,19 +94,19 @@ __device__ __forceinline__ void filter_luma_pk(s2 v[8], int bs, s2 A, s2 B, int 
             r_q2 = ((q3 << pk(1)) + q2 + (q2 << pk(1)) + q1 + p0q0 + pk(4)) >> pk(3);
             m_p1 = sp; m_q1 = sq; m_p2 = sp; m_q2 = sq;
         }
+        v[1] = bfi(as_u32(fs & m_p2), as_u32(r_p2), v[1]);
+        v[6] = bfi(as_u32(fs & m_q2), as_u32(r_q2), v[6]);
     }
-    v[3] = pk_sel(fs, r_p0, p0);
-    v[4] = pk_sel(fs, r_q0, q0);
-    v[2] = pk_sel(fs & m_p1, r_p1, p1);
-    v[5] = pk_sel(fs & m_q1, r_q1, q1);
-    v[1] = pk_sel(fs & m_p2, r_p2, p2);
-    v[6] = pk_sel(fs & m_q2, r_q2, q2);
+    v[3] = bfi(as_u32(fs), as_u32(r_p0), v[3]);
+    v[4] = bfi(as_u32(fs), as_u32(r_q0), v[4]);
+    v[2] = bfi(as_u32(fs & m_p1), as_u32(r_p1), v[2]);
+    v[5] = bfi(as_u32(fs & m_q1), as_u32(r_q1), v[5]);
 }
 
 /* chroma (chromaEdgeFlag = 1): only p0 and q0 change; v = p1, p0, q0, q1 */
-__device__ __forceinline__ void filter_chroma_pk(s2 v[4], int bs, s2 A, s2 B, int tc0)
+__device__ __forceinline__ void filter_chroma_pk(uint32_t v[4], int bs, s2 A, s2 B, int tc0)
 {
-    const s2 p1 = v[0], p0 = v[1], q0 = v[2], q1 = v[3];
+    const s2 p1 = as_s2(v[0]), p0 = as_s2(v[1]), q0 = as_s2(v[2]), q1 = as_s2(v[3]);
     const s2 zero = pk(0);
     const s2 Aon = bs != 0 ? A : zero;
     s2 fs = ((pk_absdiff(p0, q0) - Aon) & (pk_absdiff(p1, p0) - B) & (pk_absdiff(q1, q0) - B)) >> pk(15);
@@ -109,8 +119,8 @@ __device__ __forceinline__ void filter_chroma_pk(s2 v[4], int bs, s2 A, s2 B, in
         const s2 s_p0 = ((p1 << pk(1)) + p0 + q1 + pk(2)) >> pk(2), s_q0 = ((q1 << pk(1)) + q0 + p1 + pk(2)) >> pk(2);
         if (strong) { r_p0 = s_p0; r_q0 = s_q0; }
     }
-    v[1] = pk_sel(fs, r_p0, p0);
-    v[2] = pk_sel(fs, r_q0, q0);
+    v[1] = bfi(as_u32(fs), as_u32(r_p0), v[1]);
+    v[2] = bfi(as_u32(fs), as_u32(r_q0), v[2]);
 }
 
 /* ---- stores into the picture: plain, or write-through (agent scope) for samples another row band will read ---- */
@@ -149,17 +159,20 @@ __device__ __forceinline__ int bs_of(uint32_t w0s, uint32_t w1s, int e) { return
 __device__ __forceinline__ int tc0_of(uint32_t t4, int bs) { return (int)((t4 >> (8 * (bs & 3))) & 255u); }
 
 /* the 2 x 2 block dword (a.lo, a.hi, b.lo, b.hi) of two packed pairs a, b (samples are < 256: byte 0 and byte 2 of each) */
-__device__ __forceinline__ uint32_t blk_of(s2 a, s2 b) { return perm(as_u32(b), as_u32(a), 0x06040200u); }
+__device__ __forceinline__ uint32_t blk_of(uint32_t a, uint32_t b) { return perm(b, a, 0x06040200u); }
 /* ... and the other way round: (a.lo, b.lo, a.hi, b.hi) — the block of two COLUMN pairs a, b in (row-major pair, column) order */
-__device__ __forceinline__ uint32_t blk_t_of(s2 a, s2 b) { return perm(as_u32(b), as_u32(a), 0x06020400u); }
-__device__ __forceinline__ s2 pair_lo(uint32_t blk) { return as_s2(perm(0u, blk, 0x0C020C00u)); }     /* (byte 0, byte 2) */
-__device__ __forceinline__ s2 pair_hi(uint32_t blk) { return as_s2(perm(0u, blk, 0x0C030C01u)); }     /* (byte 1, byte 3) */
+__device__ __forceinline__ uint32_t blk_t_of(uint32_t a, uint32_t b) { return perm(b, a, 0x06020400u); }
+__device__ __forceinline__ uint32_t pair_lo(uint32_t blk) { return perm(0u, blk, 0x0C020C00u); }     /* (byte 0, byte 2) */
+__device__ __forceinline__ uint32_t pair_hi(uint32_t blk) { return perm(0u, blk, 0x0C030C01u); }     /* (byte 1, byte 3) */
 
 #ifdef H264K_TAIL_PROFILE
-#define DTICK() (tp ? __builtin_readcyclecounter() : 0ull)
+#define DTICK() (tp ? (uint32_t)__builtin_readcyclecounter() : 0u)
 #else
-#define DTICK() 0ull
+#define DTICK() 0u
 #endif
+
+/* cycle accounting of a wavefront's steps (debug builds with -DH264K_TAIL_PROFILE; members, not an array: registers, not scratch memory) */
+struct DbkProf { uint32_t wait, v, h, st, q, ld; };       /* (32 bits: a tick is a million cycles) */
 
 /* ================================================================== luma */
 /* What a vector memory instruction costs the compute unit (tools/probes/vmem_issue_probe.hip, 12 wavefronts per CU, cycles of the
@@ -218,12 +231,12 @@ __device__ __forceinline__ void dbk_luma_load(const FrameDesc &fd, int mb, int l
  *   very samples concern them (k_frame_dbk, dependency rule) and may be rewriting the rest of its tile at the same time.
  * wt: the macroblock lies in the last row of a row band, the band below reads what it writes: everything goes write-through. */
 template <bool BANDED, int SLOTS>
-__device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l, const DbkLumaLoads &p, uint32_t wb, bool wt_, unsigned long long *tp)
+__device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l, const DbkLumaLoads &p, uint32_t wb, bool wt_, DbkProf *tp)
 {
     constexpr int NPX = SLOTS == 4 ? 20 : 8;
     const bool wt = BANDED && wt_;
     const bool act = mb >= 0;
-    const unsigned long long d0 = DTICK();
+    const uint32_t d0 = DTICK();
     const uint32_t flags = p.r2.y >> 16;                          /* byte 46: FJ_DBK_*, byte 47: any */
     const bool f_left = act && (flags & FJ_DBK_LEFT) && (p.r0.x & 0xFFFFu), f_top = act && (flags & FJ_DBK_TOP) && (p.r0.z & 0xFFFFu);
     const bool any_v = __ballot(act && (SLOTS == 4 ? (p.r0.x | p.r0.y) : (p.r0.x & 0xFFFFu))) != 0ull;   /* wave-wide phase skips */
@@ -238,21 +251,21 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
 #ifdef H264K_TAIL_PROFILE
     if (tp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    const unsigned long long d1 = DTICK();
+    const uint32_t d1 = DTICK();
     lds_st64(sb + 8u * l, p.t.x, p.t.y);                           /* the upper strip as rows; read back as column pairs below */
 
     /* ---- vertical edges: rows 2l (low halves) and 2l+1 (high halves); px[0..3] = the left neighbour's last columns ---- */
-    s2 px[NPX];
-    px[0] = as_s2(perm(p.l1.y, p.l0.y, 0x0C040C00u)); px[1] = as_s2(perm(p.l1.y, p.l0.y, 0x0C050C01u));
-    px[2] = as_s2(perm(p.l1.y, p.l0.y, 0x0C060C02u)); px[3] = as_s2(perm(p.l1.y, p.l0.y, 0x0C070C03u));
+    uint32_t px[NPX];
+    px[0] = perm(p.l1.y, p.l0.y, 0x0C040C00u); px[1] = perm(p.l1.y, p.l0.y, 0x0C050C01u);
+    px[2] = perm(p.l1.y, p.l0.y, 0x0C060C02u); px[3] = perm(p.l1.y, p.l0.y, 0x0C070C03u);
     {
         const uint32_t ra[4] = { p.y0.x, p.y0.y, p.y0.z, p.y0.w }, rb[4] = { p.y1.x, p.y1.y, p.y1.z, p.y1.w };
 #pragma unroll
         for (int g = 0; g < NPX / 4 - 1; g++) {
-            px[4 + 4 * g + 0] = as_s2(perm(rb[g], ra[g], 0x0C040C00u));
-            px[4 + 4 * g + 1] = as_s2(perm(rb[g], ra[g], 0x0C050C01u));
-            px[4 + 4 * g + 2] = as_s2(perm(rb[g], ra[g], 0x0C060C02u));
-            px[4 + 4 * g + 3] = as_s2(perm(rb[g], ra[g], 0x0C070C03u));
+            px[4 + 4 * g + 0] = perm(rb[g], ra[g], 0x0C040C00u);
+            px[4 + 4 * g + 1] = perm(rb[g], ra[g], 0x0C050C01u);
+            px[4 + 4 * g + 2] = perm(rb[g], ra[g], 0x0C060C02u);
+            px[4 + 4 * g + 3] = perm(rb[g], ra[g], 0x0C070C03u);
         }
     }
     if (any_v) {
@@ -271,10 +284,10 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
         const uint32_t a = blk_of(px[0], px[1]), b = blk_of(px[2], px[3]);
         lo0 = perm(b, a, 0x06040200u); lo1 = perm(b, a, 0x07050301u);
     }
-    const unsigned long long d2 = DTICK();
+    const uint32_t d2 = DTICK();
 
     /* ---- to columns: hx[r + 4] = row r, columns 2l (low half), 2l+1 (high half); hx[0..3] = the upper neighbour's last rows ---- */
-    s2 hx[NPX];
+    uint32_t hx[NPX];
     uint32_t own0 = 0u, own1 = 0u;                                 /* SLOTS = 1: columns 0..3 of rows 2l, 2l+1 after the vertical pass */
     if constexpr (SLOTS == 4) {
         /* block (row pair l, column pair j) = (row 2l col 2j, row 2l+1 col 2j, row 2l col 2j+1, row 2l+1 col 2j+1) */
@@ -300,10 +313,10 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
         lds_st128(wb + 32u * l + 16u, own1, p.y1.y, p.y1.z, p.y1.w);
         wave_sync();
 #pragma unroll
-        for (int r = 0; r < 4; r++) hx[4 + r] = as_s2(perm(0u, lds_ld16(wb + 16u * r + 2u * l), 0x0C010C00u));
+        for (int r = 0; r < 4; r++) hx[4 + r] = perm(0u, lds_ld16(wb + 16u * r + 2u * l), 0x0C010C00u);
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) hx[r] = as_s2(perm(0u, lds_ld16(sb + 16u * r + 2u * l), 0x0C010C00u));
+    for (int r = 0; r < 4; r++) hx[r] = perm(0u, lds_ld16(sb + 16u * r + 2u * l), 0x0C010C00u);
 
     /* ---- horizontal edges ---- */
     if (any_h) {
@@ -316,14 +329,14 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
             if (__ballot(bs != 0)) filter_luma_pk(hx + 4 * e, bs, e ? A_i : A_t, e ? B_i : B_t, tc0_of(e ? t4_i : t4_t, bs), one);
         }
     }
-    const unsigned long long d3 = DTICK();
+    const uint32_t d3 = DTICK();
 
     /* ---- store ---- */
     uint8_t *cur = fd.cur;
     const uint32_t t = (uint32_t)mb * TILE;
     /* rows 13..15 of the upper neighbour (row 12 = p3 never changes) go back through the strip area ... */
 #pragma unroll
-    for (int r = 1; r < 4; r++) lds_st16(sb + 16u * r + 2u * l, perm(0u, as_u32(hx[r]), 0x0C0C0200u));
+    for (int r = 1; r < 4; r++) lds_st16(sb + 16u * r + 2u * l, perm(0u, hx[r], 0x0C0C0200u));
     if constexpr (SLOTS == 4) {
         /* back to rows: block (row pair r, column pair l) = (row 2r col 2l, row 2r+1 col 2l, row 2r col 2l+1, row 2r+1 col 2l+1) */
         uint32_t F[8];
@@ -356,7 +369,7 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
         }
         /* rows 0..2 after both passes: as rows again through LDS, 8 bytes from each of six lanes */
 #pragma unroll
-        for (int r = 0; r < 3; r++) lds_st16(wb + 16u * r + 2u * l, perm(0u, as_u32(hx[4 + r]), 0x0C0C0200u));
+        for (int r = 0; r < 3; r++) lds_st16(wb + 16u * r + 2u * l, perm(0u, hx[4 + r], 0x0C0C0200u));
         wave_sync();
         if (f_top && l < 6) {
             const uint2 v = lds_ld64(wb + 8u * l);
@@ -378,7 +391,7 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
     }
     wave_sync();          /* the exchange buffer is reused by this worker's next macroblock */
 #ifdef H264K_TAIL_PROFILE
-    if (tp) { const unsigned long long d4 = DTICK(); tp[0] += d1 - d0; tp[1] += d2 - d1; tp[2] += d3 - d2; tp[3] += d4 - d3; }
+    if (tp) { const uint32_t d4 = DTICK(); tp->wait += d1 - d0; tp->v += d2 - d1; tp->h += d3 - d2; tp->st += d4 - d3; }
 #endif
     (void)d0; (void)d1; (void)d2; (void)d3; (void)tp;
 }
@@ -415,12 +428,12 @@ __device__ __forceinline__ void dbk_chroma_load(const FrameDesc &fd, int mb, int
 /* Chroma of one macroblock: both planes, edges at columns / rows 0 and 4 (= luma edges 0 and 2).  SLOTS = 2: both; SLOTS = 1:
  * the macroblock edges only (partial stores as in dbk_luma_step: column 0 and row 0 of the own planes). */
 template <bool BANDED, int SLOTS>
-__device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int l, const DbkChromaLoads &p, uint32_t wb, bool wt_, unsigned long long *tp)
+__device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int l, const DbkChromaLoads &p, uint32_t wb, bool wt_, DbkProf *tp)
 {
     constexpr int NPX = SLOTS == 2 ? 10 : 4;
     const bool wt = BANDED && wt_;
     const bool act = mb >= 0;
-    const unsigned long long d0 = DTICK();
+    const uint32_t d0 = DTICK();
     const int c4 = l & 3, pl = l >> 2;
     const uint32_t flags = p.r2.y >> 16;
     const bool f_left = act && (flags & FJ_DBK_LEFT) && (p.r0.x & 0xFFFFu), f_top = act && (flags & FJ_DBK_TOP) && (p.r0.z & 0xFFFFu);
@@ -431,17 +444,17 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
 #ifdef H264K_TAIL_PROFILE
     if (tp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    const unsigned long long d1 = DTICK();
+    const uint32_t d1 = DTICK();
     lds_st32(sb + 4u * c4, p.t);
 
     /* ---- vertical edges: px[0], px[1] = columns 6, 7 of the left neighbour; px[2 + c] = column c ---- */
-    s2 px[NPX];
-    px[0] = as_s2(perm(p.lc.w, p.lc.y, 0x0C060C02u)); px[1] = as_s2(perm(p.lc.w, p.lc.y, 0x0C070C03u));
-    px[2] = as_s2(perm(p.c.z, p.c.x, 0x0C040C00u)); px[3] = as_s2(perm(p.c.z, p.c.x, 0x0C050C01u));
+    uint32_t px[NPX];
+    px[0] = perm(p.lc.w, p.lc.y, 0x0C060C02u); px[1] = perm(p.lc.w, p.lc.y, 0x0C070C03u);
+    px[2] = perm(p.c.z, p.c.x, 0x0C040C00u); px[3] = perm(p.c.z, p.c.x, 0x0C050C01u);
     if constexpr (SLOTS == 2) {
-        px[4] = as_s2(perm(p.c.z, p.c.x, 0x0C060C02u)); px[5] = as_s2(perm(p.c.z, p.c.x, 0x0C070C03u));
-        px[6] = as_s2(perm(p.c.w, p.c.y, 0x0C040C00u)); px[7] = as_s2(perm(p.c.w, p.c.y, 0x0C050C01u));
-        px[8] = as_s2(perm(p.c.w, p.c.y, 0x0C060C02u)); px[9] = as_s2(perm(p.c.w, p.c.y, 0x0C070C03u));
+        px[4] = perm(p.c.z, p.c.x, 0x0C060C02u); px[5] = perm(p.c.z, p.c.x, 0x0C070C03u);
+        px[6] = perm(p.c.w, p.c.y, 0x0C040C00u); px[7] = perm(p.c.w, p.c.y, 0x0C050C01u);
+        px[8] = perm(p.c.w, p.c.y, 0x0C060C02u); px[9] = perm(p.c.w, p.c.y, 0x0C070C03u);
     }
     if (any_v) {
         const uint32_t w0s = p.r0.x >> (4 * c4), w1s = p.r0.y >> (4 * c4);     /* chroma rows 2 c4, 2 c4 + 1 = luma rows 4 c4 .. 4 c4 + 3: segment c4 */
@@ -451,10 +464,10 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
         if constexpr (SLOTS == 2) if (__ballot(bs1 != 0))
             filter_chroma_pk(px + 4, bs1, pk_splat_byte(w_ci, 0), pk_splat_byte(w_ci, 1), tc0_of(perm(t3b, w_ci, 0x0503020Cu), bs1));
     }
-    const unsigned long long d2 = DTICK();
+    const uint32_t d2 = DTICK();
 
     /* ---- to columns: hx[2 + r] = row r, columns 2 c4, 2 c4 + 1; hx[0], hx[1] = rows 6, 7 of the upper neighbour ---- */
-    s2 hx[NPX];
+    uint32_t hx[NPX];
     const uint32_t ra_ = wb + 64u * pl + 4u * c4;
     if constexpr (SLOTS == 2) {
         lds_st128(wb + 16u * l, blk_of(px[2], px[3]), blk_of(px[4], px[5]), blk_of(px[6], px[7]), blk_of(px[8], px[9]));
@@ -471,9 +484,9 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
         lds_st128(wb + 16u * l, own0, p.c.y, own1, p.c.w);
         wave_sync();
 #pragma unroll
-        for (int r = 0; r < 2; r++) hx[2 + r] = as_s2(perm(0u, lds_ld16(wb + 64u * pl + 8u * r + 2u * c4), 0x0C010C00u));
+        for (int r = 0; r < 2; r++) hx[2 + r] = perm(0u, lds_ld16(wb + 64u * pl + 8u * r + 2u * c4), 0x0C010C00u);
     }
-    hx[0] = as_s2(perm(0u, lds_ld16(sb + 2u * c4), 0x0C010C00u)); hx[1] = as_s2(perm(0u, lds_ld16(sb + 8u + 2u * c4), 0x0C010C00u));
+    hx[0] = perm(0u, lds_ld16(sb + 2u * c4), 0x0C010C00u); hx[1] = perm(0u, lds_ld16(sb + 8u + 2u * c4), 0x0C010C00u);
 
     /* ---- horizontal edges ---- */
     if (any_h) {
@@ -484,7 +497,7 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
         if constexpr (SLOTS == 2) if (__ballot(bs1 != 0))
             filter_chroma_pk(hx + 4, bs1, pk_splat_byte(w_ci, 0), pk_splat_byte(w_ci, 1), tc0_of(perm(t3b, w_ci, 0x0503020Cu), bs1));
     }
-    const unsigned long long d3 = DTICK();
+    const uint32_t d3 = DTICK();
 
     /* ---- store ---- */
     uint8_t *cur = fd.cur;
@@ -507,27 +520,27 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
     } else {
         /* column 0 of rows 2 c4, 2 c4 + 1 (q0 of the left edge), lanes regrouped (quad_perm [2,3,0,1]) so that one instruction covers
          * rows 0..3 of both planes and the other rows 4..7; row 0 leaves with the horizontal pass when the upper edge is filtered */
-        const uint32_t q0 = as_u32(px[2]), q0x = (uint32_t)quad_xor2((int)q0);
+        const uint32_t q0 = px[2], q0x = (uint32_t)quad_xor2((int)q0);
         const uint32_t va = c4 < 2 ? (q0 & 255u) : (q0x >> 16), vb = c4 < 2 ? (q0x & 255u) : (q0 >> 16);
         const uint32_t row_a = c4 < 2 ? 2u * c4 : 2u * (c4 - 2) + 1u;
         if (f_left) {
             if (!(f_top && row_a == 0u)) stg_u8(cur, tp_ + 8u * row_a, va, wt);
             stg_u8(cur, tp_ + 8u * (row_a + 4u), vb, wt);
         }
-        if (f_top) stg_u16(cur, tp_ + 2u * c4, perm(0u, as_u32(hx[2]), 0x0C0C0200u), wt);
+        if (f_top) stg_u16(cur, tp_ + 2u * c4, perm(0u, hx[2], 0x0C0C0200u), wt);
     }
     if (f_left) {
         /* p0 of the left edge: column 7 of the left neighbour, regrouped the same way */
-        const uint32_t p0 = as_u32(px[1]), p0x = (uint32_t)quad_xor2((int)p0);
+        const uint32_t p0 = px[1], p0x = (uint32_t)quad_xor2((int)p0);
         const uint32_t va = c4 < 2 ? (p0 & 255u) : (p0x >> 16), vb = c4 < 2 ? (p0x & 255u) : (p0 >> 16);
         const uint32_t row_a = c4 < 2 ? 2u * c4 : 2u * (c4 - 2) + 1u;
         stg_u8(cur, tp_ - TILE + 8u * row_a + 7u, va, wt);
         stg_u8(cur, tp_ - TILE + 8u * (row_a + 4u) + 7u, vb, wt);
     }
-    if (f_top) stg_u16(cur, tp_ - (uint32_t)fd.wmb * TILE + 56u + 2u * c4, perm(0u, as_u32(hx[1]), 0x0C0C0200u), wt);    /* p0 of the upper edge: row 7 of the upper neighbour */
+    if (f_top) stg_u16(cur, tp_ - (uint32_t)fd.wmb * TILE + 56u + 2u * c4, perm(0u, hx[1], 0x0C0C0200u), wt);    /* p0 of the upper edge: row 7 of the upper neighbour */
     wave_sync();
 #ifdef H264K_TAIL_PROFILE
-    if (tp) { const unsigned long long d4 = DTICK(); tp[0] += d1 - d0; tp[1] += d2 - d1; tp[2] += d3 - d2; tp[3] += d4 - d3; }
+    if (tp) { const uint32_t d4 = DTICK(); tp->wait += d1 - d0; tp->v += d2 - d1; tp->h += d3 - d2; tp->st += d4 - d3; }
 #endif
     (void)d0; (void)d1; (void)d2; (void)d3; (void)tp;
 }
@@ -628,10 +641,10 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
     unsigned long long *const tp = nullptr;
     (void)prof;
 #endif
-    unsigned long long t_idle = 0, t_work = 0, t_store = 0, n_done = 0, n_steps = 0;
-    unsigned long long acc[6] = { 0, 0, 0, 0, 0, 0 };       /* inside the steps: load wait, vertical, horizontal, store; claim won -> queue slot read, -> loads issued */
-    const unsigned long long t_begin = tp ? __builtin_readcyclecounter() : 0ull;
-    unsigned long long t_mark = t_begin;
+    uint32_t t_idle = 0, t_work = 0, t_store = 0, n_done = 0, n_steps = 0;
+    DbkProf acc = { 0, 0, 0, 0, 0, 0 };       /* inside the steps: load wait, vertical, horizontal, store; claim won -> queue slot read, -> loads issued */
+    const uint32_t t_begin = tp ? (uint32_t)__builtin_readcyclecounter() : 0u;
+    uint32_t t_mark = t_begin;
 
     {
         /* flags of rows r0-1 .. r1-1 (row -1 of band 0: zeros) */
@@ -759,7 +772,7 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
                 if (polled) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
                 continue;
             }
-            if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
+            if (tp) { const uint32_t t = (uint32_t)__builtin_readcyclecounter(); t_idle += t - t_mark; t_mark = t; }
             int run = -1;
             if ((uint32_t)grp < k) {
                 int v;
@@ -769,19 +782,19 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #ifdef H264K_TAIL_PROFILE
-            if (tp) acc[4] += __builtin_readcyclecounter() - t_mark;      /* claim won -> queue slot read */
+            if (tp) acc.q += (uint32_t)__builtin_readcyclecounter() - t_mark;      /* claim won -> queue slot read */
 #endif
             const bool cross = has_up && run >= 0 && run < lo_mb + wmb;  /* first row: the tile above belongs to the band above */
             const bool wt = has_down && run >= hi_mb - wmb;              /* last row: the band below reads what this macroblock writes */
             const uint32_t fm = run >= 0 ? anyf[run - base] : 0u;
             bool want_top = true;
             if (BANDED && __ballot(cross) != 0ull) want_top = !cross || (fm & DBKF_TOP);
-            unsigned long long *stp = tp ? acc : nullptr;
+            DbkProf *stp = tp ? &acc : nullptr;
             if (role == 0) {
                 DbkLumaLoads cp;
                 dbk_luma_load(fd, run, l, cp, BANDED && cross, want_top);
 #ifdef H264K_TAIL_PROFILE
-                if (tp) acc[5] += __builtin_readcyclecounter() - t_mark;  /* ... -> loads issued */
+                if (tp) acc.ld += (uint32_t)__builtin_readcyclecounter() - t_mark;  /* ... -> loads issued */
 #endif
                 if (cls) dbk_luma_step<BANDED, 1>(fd, run, l, cp, wb + (uint32_t)grp * DBK_LW, wt, stp);
                 else dbk_luma_step<BANDED, 4>(fd, run, l, cp, wb + (uint32_t)grp * DBK_LW, wt, stp);
@@ -789,12 +802,12 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
                 DbkChromaLoads cp;
                 dbk_chroma_load(fd, run, l, cp, BANDED && cross, want_top);
 #ifdef H264K_TAIL_PROFILE
-                if (tp) acc[5] += __builtin_readcyclecounter() - t_mark;
+                if (tp) acc.ld += (uint32_t)__builtin_readcyclecounter() - t_mark;
 #endif
                 if (cls) dbk_chroma_step<BANDED, 1>(fd, run, l, cp, wb + (uint32_t)grp * DBK_CW, wt, stp);
                 else dbk_chroma_step<BANDED, 2>(fd, run, l, cp, wb + (uint32_t)grp * DBK_CW, wt, stp);
             }
-            if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && l == 0)); n_steps++; }
+            if (tp) { const uint32_t t = (uint32_t)__builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && l == 0)); n_steps++; }
             /* release: stores done -> dependants */
             release_stores(BANDED && wt && run >= 0);
             if (BANDED && wt && l == 3) st_agent_u8(g.done_g + run, 1u);   /* hand-over to the band below */
@@ -811,12 +824,12 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
                 }
                 if (waits) release(g, dmb - base);
             }
-            if (tp) { const unsigned long long t = __builtin_readcyclecounter(); t_store += t - t_mark; t_mark = t; }
+            if (tp) { const uint32_t t = (uint32_t)__builtin_readcyclecounter(); t_store += t - t_mark; t_mark = t; }
         }
     }
     if (tp && lane == 0) {
-        tp[0] += t_idle; tp[1] += t_work; tp[2] += t_store; tp[3] += n_done; tp[4] += __builtin_readcyclecounter() - t_begin; tp[5] += n_steps;
-        for (int i = 0; i < 6; i++) tp[8 + i] += acc[i];
+        tp[0] += t_idle; tp[1] += t_work; tp[2] += t_store; tp[3] += n_done; tp[4] += (uint32_t)__builtin_readcyclecounter() - t_begin; tp[5] += n_steps;
+        tp[8] += acc.wait; tp[9] += acc.v; tp[10] += acc.h; tp[11] += acc.st; tp[12] += acc.q; tp[13] += acc.ld;
     }
     /* the last band of the picture to leave zeroes the flags (k_dbk only visits non-trivial macroblocks) and the done bytes
      * of both graphs for the next picture of this stream */
