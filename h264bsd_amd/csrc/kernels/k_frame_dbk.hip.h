@@ -252,7 +252,6 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
     if (tp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     const uint32_t d1 = DTICK();
-    lds_st64(sb + 8u * l, p.t.x, p.t.y);                           /* the upper strip as rows; read back as column pairs below */
 
     /* ---- vertical edges: rows 2l (low halves) and 2l+1 (high halves); px[0..3] = the left neighbour's last columns ---- */
     uint32_t px[NPX];
@@ -278,6 +277,7 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
             if (__ballot(bs != 0)) filter_luma_pk(px + 4 * e, bs, e ? A_i : A_l, e ? B_i : B_l, tc0_of(e ? t4_i : t4_l, bs), one);
         }
     }
+    lds_st64(sb + 8u * l, p.t.x, p.t.y);                           /* the upper strip as rows; read back as column pairs below */
     /* the left neighbour's columns 12..15 as the two row dwords they are stored as */
     uint32_t lo0, lo1;
     {
@@ -445,7 +445,6 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
     if (tp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     const uint32_t d1 = DTICK();
-    lds_st32(sb + 4u * c4, p.t);
 
     /* ---- vertical edges: px[0], px[1] = columns 6, 7 of the left neighbour; px[2 + c] = column c ---- */
     uint32_t px[NPX];
@@ -469,6 +468,7 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
     /* ---- to columns: hx[2 + r] = row r, columns 2 c4, 2 c4 + 1; hx[0], hx[1] = rows 6, 7 of the upper neighbour ---- */
     uint32_t hx[NPX];
     const uint32_t ra_ = wb + 64u * pl + 4u * c4;
+    lds_st32(sb + 4u * c4, p.t);
     if constexpr (SLOTS == 2) {
         lds_st128(wb + 16u * l, blk_of(px[2], px[3]), blk_of(px[4], px[5]), blk_of(px[6], px[7]), blk_of(px[8], px[9]));
         wave_sync();
@@ -544,7 +544,6 @@ __device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int
 #endif
     (void)d0; (void)d1; (void)d2; (void)d3; (void)tp;
 }
-#undef DTICK
 
 /* ================================================================== the per-picture scheduler */
 /* In-loop deblocking of one picture.  The filter of macroblock (x,y) touches its own samples, the last
@@ -736,6 +735,8 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
                     k = 0xFFFFFFFFu;                                    /* everything has been claimed */
                 }
             }
+            /* (through the LDS crossbar on purpose: handing lane 0's values over with v_readfirstlane — one LDS round trip less —
+             * costs the kernel 12 %, 31.7 -> 35.6 ms per step, with or without a pause of the same length in its place) */
             cbase = __shfl(cbase, 0); k = __shfl(k, 0); cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(cls, 0));
             if (k == 0xFFFFFFFFu) break;
             if (++spins > (1u << 24)) { if (lane == 0) report_device_error(fd, DEVERR_DBK_SCHED); break; }
@@ -789,6 +790,10 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
             const uint32_t fm = run >= 0 ? anyf[run - base] : 0u;
             bool want_top = true;
             if (BANDED && __ballot(cross) != 0ull) want_top = !cross || (fm & DBKF_TOP);
+            /* the dependants' flags (release, below), read while the loads are in flight: l = 0: (x+1, y), l = 1: (x, y+1), l = 2: (x-1, y+1) */
+            const int dmb = l == 0 ? run + 1 : l == 1 ? run + wmb : run + wmb - 1;
+            uint32_t fdep = 0u;
+            if (run >= 0 && l < 3 && dmb < hi_mb) fdep = anyf[dmb - base];
             DbkProf *stp = tp ? &acc : nullptr;
             if (role == 0) {
                 DbkLumaLoads cp;
@@ -814,10 +819,9 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
             if (run >= 0 && l < 3) {
                 /* dependants: l = 0: (x+1, y), l = 1: (x, y+1), l = 2: (x-1, y+1) — the mirror image of the dependency rule above.  The
                  * "neighbours" of the first / last column that lie in another row never qualify: a macroblock of column 0 has no LEFT */
-                const int dmb = l == 0 ? run + 1 : l == 1 ? run + wmb : run + wmb - 1;
                 bool waits = false;
                 if (dmb < hi_mb) {
-                    const uint32_t fd_ = anyf[dmb - base];
+                    const uint32_t fd_ = fdep;
                     waits = (fd_ & DBKF_ANY) && (l == 0 ? ((fd_ & DBKF_LEFT) != 0u && (fm & (DBKF_INNER | DBKF_TOP)) != 0u)
                                                       : l == 1 ? ((fd_ & DBKF_TOP) != 0u && (fm & (DBKF_INNER | DBKF_LEFT)) != 0u)
                                                                : ((fd_ & DBKF_TOP) != 0u && (fm & DBKF_LEFT) != 0u));
