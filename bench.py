@@ -147,6 +147,8 @@ def end_to_end(data, streams, threads, laps=2, pull=False, barrier=None):
     reference's call protocol demands (posix/test_h264bsd.c:146-177) — h264bsdmiPullAndDecodePictureBatch: a parser thread pulls
     an instance's picture and then parses that instance's next one, so the link works while other instances are parsed.
     pull = "barrier": the two separate batch calls (every picture pulled, THEN the next round parsed), as measured earlier in round 5."""
+    import hashlib
+    import numpy as np
     import h264bsd_amd as h
     L = h.lib()
     decs = [h.Decoder() for _ in range(streams)]
@@ -172,12 +174,27 @@ def end_to_end(data, streams, threads, laps=2, pull=False, barrier=None):
             ptrs, _ = h.pull_batch(decs)
             assert all(ptrs)
         timed += pic >= 73
+    jobs, _, info = h.capture_stream(data, copy_elision=os.environ.get("H264BSDMI_COPY_ELISION", "1")[:1] != "0")
+    frame_bytes = info["width_mbs"] * info["height_mbs"] * 384
+    last = None
     if combined:
-        ptrs, _ = h.pull_batch(decs)                          # the last round's pictures
-        assert all(ptrs)
+        last, _ = h.pull_batch(decs, frame_bytes)             # the last round's pictures
+        assert all(v is not None for v in last)
     assert L.h264bsdmiFlush() == 0
     dt = time.perf_counter() - t0
-    jobs, _, info = h.capture_stream(data, copy_elision=os.environ.get("H264BSDMI_COPY_ELISION", "1")[:1] != "0")
+    # Verification (outside the timed region): the LAST picture of every instance — pulled to host memory through
+    # the same batch call — must be the reference's picture 72 (sha256 of the first instance's, byte-for-byte equality of all the
+    # others with it).  Every picture of the final group of pictures feeds it through inter prediction, and the kernel-only legs
+    # check every single picture of every stream on the device.
+    if last is None:
+        last, _ = h.pull_batch(decs, frame_bytes)
+        assert all(v is not None for v in last)
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))[STREAM]["frame_sha256"][-1]
+    if hashlib.sha256(last[0].tobytes()).hexdigest() != want:
+        raise SystemExit("end_to_end: the last picture of instance 0 is not the reference's (sha256)")
+    bad = [i for i in range(1, streams) if not np.array_equal(last[i], last[0])]
+    if bad:
+        raise SystemExit(f"end_to_end: the last picture of {len(bad)} instances differs from the reference's (first: instance {bad[0]})")
     h2d = sum(len(j) for j in jobs) * streams * laps
     for d in decs:
         d.close()
@@ -185,7 +202,7 @@ def end_to_end(data, streams, threads, laps=2, pull=False, barrier=None):
     return dict(value=pics * 8160 / dt, unit="macroblocks/s", fps=pics / dt, streams=streams, parser_threads=int(threads),
                 host_cores=os.cpu_count(), cpu_quota=cpu_quota(), h2d_bytes_per_picture=h2d / pics,
                 d2h_bytes_per_picture=info["width_mbs"] * info["height_mbs"] * 384 if pull else 0, seconds=dt,
-                device_errors=h.device_errors(),
+                device_errors=h.device_errors(), verified=f"last picture of all {streams} instances sha256 / byte-equal to the reference's picture 72",
                 sample=f"{streams} decoder instances x {timed} pictures through h264bsdDecode-equivalent batch calls, PCIe inclusive, "
                        f"{dt:.1f} s; " + ("every picture pulled to host memory (h264bsdNextOutputPicture semantics; h264bsdmiPullAndDecodePictureBatch, which runs on min(parser_threads, CPUs the process may have running at once) threads)" if pull else "pictures left in HBM"))
 
@@ -537,6 +554,18 @@ def main():
         units_per_launch = n_mbs * n_pics * args.streams * args.steps / launches
         achieved = alg_per_mb * units_per_launch / (avg_launch_us * 1e-6) / 1e9       # GB/s
         path_gbs = alg_bytes_stream * args.streams * args.steps / (dev_total_ms * 1e-3) / 1e9
+        # `frac` above charges the WHOLE path's algorithmic bytes to the dominant kernel's time (the contract's formula).  frac_own prices
+        # every kernel against the bytes ITS OWN work has to move: tiles read and written by the macroblocks on
+        # its list, the records and coefficient blocks it consumes — per stream pass, from the frame-job headers.
+        n_coef_blocks = sum(h["n_coef_blocks"] for h in heads)
+        gen_mbs, intra_mbs, dbk_mbs = sum(h["n_gen"] for h in heads), sum(h["n_intra"] for h in heads), sum(h["n_dbk"] for h in heads)
+        coded_share = 32.0 * n_coef_blocks / max(1, gen_mbs + intra_mbs)         # coefficient bytes per reconstructed (non-copy) macroblock
+        own_bytes = {"k_copy": 768.0 * copy_mbs,
+                     "k_recon_inter": gen_mbs * (768.0 + 32.0 + coded_share),       # reference window + tile out + record + coefficients
+                     "k_dbk": dbk_mbs * (3 * 32.0 + 48.0 + 1.0),                     # own and two neighbour records in, deblocking record + flag out
+                     "k_frame_intra": intra_mbs * (384.0 + 32.0 + coded_share),
+                     "k_frame_dbk": 2 * dbk_mbs * 48.0 + dbk_mbs * 768.0}           # tile in and out (luma and chroma graph), the record for each graph
+        frac_own = {k: (own_bytes[k] * args.streams / (breakdown[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS if breakdown[k][0] > 0 else None) for k in kernels}
         # HBM bytes per launch of the dominant kernel: PMC counters need rocprofv3 (separate --pmc passes,
         # tools/refresh_profiles.sh), so they cannot be collected inside this run; the committed table is only used
         # while it belongs to the kernels that just ran (sha256 of the kernel sources), otherwise traffic is null
@@ -608,7 +637,12 @@ def main():
                                                 "same pictures, verified on device; alg_bytes_per_mb below still counts them (SURVEY 8d formula), "
                                                 "alg_bytes_per_mb_moved does not"}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "frac_note": "`frac` = the contract's formula: the WHOLE path's algorithmic bytes per launch / the dominant kernel's launch time / peak; "
+                                      "`frac_own` = the dominant kernel's OWN algorithmic bytes / its own time / peak; `whole_path_frac` = the whole path's bytes / the whole step / peak",
+                         "frac_own": frac_own[dom], "frac_own_per_kernel": frac_own,
+                         "own_alg_bytes_per_stream_pass": own_bytes,
+                         "traffic": traffic, "traffic_source": traffic_note,
                          "traffic_per_kernel": traffic_all, "traffic_whole_path": traffic_whole,
                          "traffic_ratio": (traffic_whole / (alg_per_mb * units_per_launch)) if traffic_whole else None,
                          "alg_bytes_per_launch": alg_per_mb * units_per_launch,

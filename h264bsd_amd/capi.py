@@ -77,6 +77,30 @@ def _share_torch_hip_runtime():
                 return
 
 
+_api = None
+_use_product = False
+
+
+def use_product_library(on=True):
+    """Decoder / BatchDriver / pull_batch / convert / device_* go through libh264bsd_mi355x.so — what a C application links — instead
+    of the harness library (same objects plus the replay exports).  tests/test_gpu_api.py switches it on for its module."""
+    global _use_product
+    _use_product = bool(on)
+
+
+def api_lib():
+    """the library the drop-in API is called through: the product library when use_product_library() is on, else the harness one"""
+    global _api
+    if not _use_product:
+        return lib()
+    if _api is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _share_torch_hip_runtime()
+        _api = _declare(ctypes.CDLL(LIB_PATH), harness=False)
+    return _api
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -84,7 +108,11 @@ def lib():
     if not os.path.exists(LIB_PATH) or not os.path.exists(BENCH_LIB_PATH):
         build()
     _share_torch_hip_runtime()
-    L = ctypes.CDLL(BENCH_LIB_PATH)
+    _lib = _declare(ctypes.CDLL(BENCH_LIB_PATH), harness=True)
+    return _lib
+
+
+def _declare(L, harness):
     vp, u32, u8p = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p
     L.h264bsdAlloc.restype = vp
     L.h264bsdFree.argtypes = [vp]
@@ -121,8 +149,12 @@ def lib():
     L.h264bsdmiSetInputReadOnly.argtypes = [vp, u32]
     L.h264bsdmiSetCopyElision.argtypes = [vp, u32]
     L.h264bsdmiSetCopyElision.restype = ctypes.c_int
-    L.h264bsdmiJobFinalize.argtypes = [ctypes.c_void_p, u32, u32]
     L.h264bsdmiSetDevice.argtypes = [ctypes.c_int]
+    L.h264bsdmiDeviceErrors.restype = ctypes.c_uint
+    L.h264bsdmiNextOutputPictureBatch.argtypes = [u32, ctypes.POINTER(vp), ctypes.POINTER(vp), P32, P32, P32]
+    if not harness:
+        return L
+    L.h264bsdmiJobFinalize.argtypes = [ctypes.c_void_p, u32, u32]
     L.h264bsdmiReplayCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32]
     L.h264bsdmiReplayCreate.restype = vp
     L.h264bsdmiReplayCreateStaggered.argtypes = [ctypes.POINTER(ctypes.c_void_p), P32, u32, u32, u32]
@@ -143,7 +175,6 @@ def lib():
     L.h264bsdmiReplayTimings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), P32]
     L.h264bsdmiReplaySetConvert.argtypes = [vp, ctypes.c_int]
     L.h264bsdmiReplayConvertTimings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), P32]
-    L.h264bsdmiDeviceErrors.restype = ctypes.c_uint
     L.h264bsdmiReplaySetStages.argtypes = [vp, ctypes.c_uint]
     L.h264bsdmiReplaySetTimedKernels.argtypes = [vp, ctypes.c_uint]
     L.h264bsdmiReplaySetGroups.argtypes = [vp, u32]
@@ -152,12 +183,11 @@ def lib():
     L.h264bsdmiReplayJobBytes.restype = ctypes.c_ulonglong
     L.h264bsdmiReplayFrameBytes.argtypes = [vp]
     L.h264bsdmiReplayFrameBytes.restype = u32
-    _lib = L
     return L
 
 
 def device_count():
-    return int(lib().h264bsdmiDeviceCount())
+    return int(api_lib().h264bsdmiDeviceCount())
 
 
 KEEP = 0xFFFFFFFF
@@ -172,9 +202,7 @@ def set_tail(dbk_rows_light=KEEP, dbk_rows_heavy=KEEP, dbk_waves=KEEP, intra_row
 
 def device_errors():
     """sticky DEVERR_* bits of the engine (0 = none): tripwires of the kernels that must never fire"""
-    L = lib()
-    L.h264bsdmiDeviceErrors.restype = ctypes.c_uint
-    return int(L.h264bsdmiDeviceErrors())
+    return int(api_lib().h264bsdmiDeviceErrors())
 
 
 def device_error_events():
@@ -191,7 +219,7 @@ class Decoder:
         """capture: None -> pixels on the GPU (h264bsdInit; raises when there is no device);
         a callable(bytes) -> parser only, every picture's frame job is handed to it.
         copy_elision: None -> the library's default (on with a device, off in capture mode), else h264bsdmiSetCopyElision."""
-        L = lib()
+        L = api_lib()
         self._L = L
         self._st = L.h264bsdAlloc()
         self._cb = None
@@ -326,7 +354,7 @@ class BatchDriver:
 
     def __init__(self, decoders, streams):
         """streams: one bytes object per decoder (each is copied once into a private buffer)"""
-        self.L = lib()
+        self.L = api_lib()
         self.n = len(decoders)
         self.decoders = decoders
         self._bufs = [ctypes.create_string_buffer(b, len(b)) for b in streams]
@@ -390,7 +418,7 @@ def pull_batch(decoders, frame_bytes=None):
     """h264bsdmiNextOutputPictureBatch: the next output picture of every decoder, pulled on the library's threads.
     Returns (pointers, pic ids); with frame_bytes also numpy views of the pinned host pictures (valid until the next decode call)."""
     import numpy as np
-    L = lib()
+    L = api_lib()
     n = len(decoders)
     VP = ctypes.c_void_p * n
     U32 = ctypes.c_uint32 * n
@@ -461,7 +489,7 @@ def convert(fmt, width, height, yuv):
     """h264bsdConvertToRGBA/BGRA/YCbCrA (fmt 0/1/2) of one host I420 frame, computed on the GPU."""
     if device_count() <= 0:
         raise RuntimeError("h264bsdConvertTo*: no HIP device (no CPU pixel path exists)")
-    L = lib()
+    L = api_lib()
     fn = (L.h264bsdConvertToRGBA, L.h264bsdConvertToBGRA, L.h264bsdConvertToYCbCrA)[fmt]
     src = np.ascontiguousarray(yuv, dtype=np.uint8)
     out = np.zeros(width * height, dtype=np.uint32)

@@ -11,6 +11,15 @@ from conftest import STREAMS, stream_bytes
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _through_the_product_library(built):
+    """this module drives libh264bsd_mi355x.so itself — the library a C application links (exports.map) — not the harness
+    library with the replay exports that the kernel tests use"""
+    built.use_product_library(True)
+    yield
+    built.use_product_library(False)
+
+
 @pytest.mark.parametrize("name", STREAMS)
 def test_decode_loop_matches_reference(name, built, golden):
     g = golden[name]
@@ -128,7 +137,7 @@ def test_parser_pool_with_async_flush_is_exact(built, golden):
     """h264bsdmiDecodePictureBatch + h264bsdmiFlushAsync: 6 instances advance picture by picture on the parser threads,
     reconstruction is enqueued without waiting; every 5th round all queued output pictures are pulled and compared"""
     names = ["test_640x360"] * 4 + ["test_1920x1080", "test_1920x1080_fullRange"]
-    L = built.lib()
+    L = built.api_lib()
     L.h264bsdmiSetParserThreads(4)
     decs = [built.Decoder() for _ in names]
     drv = built.BatchDriver(decs, [stream_bytes(n) for n in names])
@@ -156,7 +165,7 @@ def test_batch_pull_on_the_parser_threads(built, golden):
     """h264bsdmiNextOutputPictureBatch: the pictures of all instances pulled at once on the library's threads (every thread waits
     for its own copies outside the engine's lock): same pictures, same ids, in every round; an instance without a picture gives NULL"""
     names = ["test_640x360"] * 5 + ["test_1920x1080", "test_1920x1080_fullRange", "test_640x360"]
-    L = built.lib()
+    L = built.api_lib()
     L.h264bsdmiSetParserThreads(6)
     decs = [built.Decoder() for _ in names]
     drv = built.BatchDriver(decs, [stream_bytes(n) for n in names])
@@ -186,7 +195,7 @@ def test_batch_pull_on_the_parser_threads(built, golden):
 def test_lifecycle_edge_cases(built, golden):
     """things an application may do in any order: pull before anything was decoded, flush an empty decoder, shut down
     with pictures still queued and never pulled, re-init the same storage, decode again after h264bsdFlushBuffer"""
-    L = built.lib()
+    L = built.api_lib()
     name = "test_640x360"
     g = golden[name]
     data = stream_bytes(name)
@@ -269,10 +278,10 @@ def test_72_different_streams_through_the_batch_api(built, golden):
         streams.append(data); want.append([tuple(p) for p in gold[n]["pics"]]); kind.append("synth")
     for n in ["test_640x360", "test_1920x1080", "test_1920x1080_fullRange"] * 4:
         streams.append(stream_bytes(n)); want.append(golden[n]["frame_sha256"]); kind.append("bundled")
-    errs_before = built.device_error_events()    # (a counter, not the sticky bits: a bit that a hand-built test job set earlier firing AGAIN would show)
+    errs_before = built.device_errors()          # (the product library's engine: no hand-built job ever ran through it, the sticky word must stay 0)
     N = len(streams)
     assert N == 72
-    L = built.lib()
+    L = built.api_lib()
     L.h264bsdmiSetParserThreads(8)
     decs = [built.Decoder() for _ in range(N)]
     drv = built.BatchDriver(decs, streams)
@@ -309,7 +318,7 @@ def test_72_different_streams_through_the_batch_api(built, golden):
         decs[k].flush_buffer()
         pull(k)
         assert got[k] == want[k], f"instance {k} ({kind[k]}) differs from the reference"
-    assert built.device_error_events() == errs_before
+    assert built.device_errors() == errs_before == 0
     for d in decs:
         d.close()
 
