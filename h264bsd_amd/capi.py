@@ -368,6 +368,7 @@ class BatchDriver:
         self._status, self._consumed, self._errs = U32(), U32(), U32()
         self._out, self._oid, self._oidr, self._onerr = VP(), U32(), U32(), U32()
         self.pulled = {}
+        self._draining = set()
 
     def step(self, pull=False):
         """parse the next picture of every unfinished stream; returns the indices that produced a picture.
@@ -375,12 +376,16 @@ class BatchDriver:
         (host pointer, picId, isIdrPic, numErrMbs) of the streams that had one), on the same threads, beside the parsing of the other streams."""
         live = [k for k in range(self.n) if self.off[k] < self.size[k]]
         self.pulled = {}
+        if pull:
+            # a stream that has consumed its input stays in the batch with len = 0 ("pull only", include/h264bsd_mi355x.h) until a
+            # pull comes back empty: the pictures still in its output queue are not silently dropped (ADVICE r5)
+            live = live + [k for k in sorted(self._draining) if k not in live]
         if not live:
             return []
         if pull:
             for i, k in enumerate(live):
                 self._dec[i] = self.decoders[k]._st
-                self._ptr[i] = ctypes.addressof(self._bufs[k]) + self.off[k]
+                self._ptr[i] = ctypes.addressof(self._bufs[k]) + min(self.off[k], self.size[k] - 1)
                 self._len[i] = self.size[k] - self.off[k]
                 self._pid[i] = self.pictures[k]
             rc = self.L.h264bsdmiPullAndDecodePictureBatch(len(live), self._dec, self._out, self._oid, self._oidr, self._onerr,
@@ -391,7 +396,11 @@ class BatchDriver:
             for i, k in enumerate(live):
                 if self._out[i]:
                     self.pulled[k] = (self._out[i], int(self._oid[i]), int(self._oidr[i]), int(self._onerr[i]))
+                elif k in self._draining:
+                    self._draining.discard(k)                  # its queue is empty: done
                 self.off[k] += self._consumed[i]
+                if self.off[k] >= self.size[k] and k not in self._draining and (self._out[i] or self._status[i] == H264BSD_PIC_RDY):
+                    self._draining.add(k)                      # input finished: come back for what is still queued
                 if self._status[i] == H264BSD_PIC_RDY:
                     self.pictures[k] += 1
                     ready.append(k)

@@ -348,6 +348,7 @@ typedef struct Batch {
     signed char *item_dev;                  /* device of every item's decoder instance (-1: capture mode) */
     int devs[16], n_devs;                   /* the devices in use in this batch */
     u32 workers;                            /* threads that work on this batch (run_batch): all of the pool, or fewer when the batch pulls */
+    atomic_int pull_failed;                 /* a picture was popped from an instance's output queue and could not be fetched (HIP failure): the batch returns -1 */
 } Batch;
 
 static struct {
@@ -381,14 +382,21 @@ static void item_pull_begin(Batch *b, u32 i)
     const JobSink *k = &a->hd->sink;
     if (k->fetch_begin && k->fetch_end) {
         if (k->fetch_begin(k->user, o->slot) == 0) b->began[i] = 1;        /* on its way: item_finish collects it */
-    } else if (k->fetch) b->out[i] = k->fetch(k->user, o->slot);
+        else atomic_store(&b->pull_failed, 1);
+    } else if (k->fetch) {
+        b->out[i] = k->fetch(k->user, o->slot);
+        if (!b->out[i]) atomic_store(&b->pull_failed, 1);
+    }
 }
 
 static void item_finish(Batch *b, u32 i)
 {
     if (b->out) {
         const ApiDec *a = dec_of(b->dec[i]);
-        if (b->began[i]) b->out[i] = a->hd->sink.fetch_end(a->hd->sink.user);
+        if (b->began[i]) {
+            b->out[i] = a->hd->sink.fetch_end(a->hd->sink.user);
+            if (!b->out[i]) atomic_store(&b->pull_failed, 1);
+        }
         if (!b->buf) return;
         /* pull AND decode: the reference's decoder drops what is still waiting in its output queue when the next slice arrives
          * (src/h264bsd_dpb.c:1260-1261), so an instance with more pictures to give is not fed — the caller comes back for them */
@@ -524,9 +532,28 @@ static long usable_cpus(void) { return usable_cpus_q(1); }
 static long host_share(void)
 {
     const char *e = getenv("H264BSDMI_HOST_SHARE");
-    if (!e || !*e) e = getenv("LOCAL_WORLD_SIZE");
-    const long n = e ? atol(e) : 1;
-    return n < 1 ? 1 : n > 64 ? 64 : n;
+    int from_launcher = 0;
+    if (!e || !*e) {
+        /* The launcher's LOCAL_WORLD_SIZE only says that N processes run on this host — not that they share CPUs.  Where the launcher
+         * (SLURM / mpirun binding, numactl or a cgroup per rank) has already given this process its own CPUs, usable_cpus() IS the
+         * share, and dividing again would leave a CPU-bound pipeline with 1 / N of its threads.  The fallback therefore applies
+         * only while the process's affinity mask is the whole host.  A cgroup CPU quota does not count as a partition:
+         * a container's quota is normally shared by all the ranks started inside it (the GPU boxes of this project: 256 hardware
+         * threads online, quota 16 for the container) — a launcher that gives every rank its own cgroup sets H264BSDMI_HOST_SHARE=1. */
+        e = getenv("LOCAL_WORLD_SIZE");
+        const long online = sysconf(_SC_NPROCESSORS_ONLN);
+        cpu_set_t set;
+        if (e && online > 0 && sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < online) e = NULL;
+        from_launcher = e != NULL;
+    }
+    long n = e ? atol(e) : 1;
+    n = n < 1 ? 1 : n > 64 ? 64 : n;
+    static int said;
+    if (from_launcher && n > 1 && !said) {
+        said = 1;
+        fprintf(stderr, "h264bsd-mi355x: parser pool sized for 1 / %ld of this host's CPUs (LOCAL_WORLD_SIZE=%ld; H264BSDMI_HOST_SHARE or H264BSDMI_THREADS override)\n", n, n);
+    }
+    return n;
 }
 
 static int pool_default_threads(void)
@@ -572,6 +599,7 @@ static int run_batch(Batch *b)
     signed char *item_dev = (signed char *)malloc(n);
     if (!taken || !began || !item_dev) { free(taken); free(began); free(item_dev); pthread_mutex_unlock(&g_pool.api_mu); return -1; }
     b->taken = taken; b->began = began; b->item_dev = item_dev; b->active = 0; b->n_devs = 0;
+    atomic_store(&b->pull_failed, 0);
     for (u32 i = 0; i < n; i++) {
         const ApiDec *a = dec_of(b->dec[i]);
         const int dv = a && a->hd ? eng_sink_device(&a->hd->sink) : -1;
@@ -600,7 +628,7 @@ static int run_batch(Batch *b)
     free(began);
     free(item_dev);
     pthread_mutex_unlock(&g_pool.api_mu);
-    return 0;
+    return atomic_load(&b->pull_failed) ? -1 : 0;      /* -1: a picture left an output queue and could not be fetched (its out[] entry is NULL) */
 }
 
 int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *dec, u8 *const *buf, const u32 *len, const u32 *picId,
@@ -608,7 +636,7 @@ int h264bsdmiDecodePictureBatch(u32 n, storage_t *const *dec, u8 *const *buf, co
 {
     if (!dec || !buf || !len || !status || !consumed) return -1;
     if (!n) return 0;
-    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL, { 0 }, 0, 0 };
+    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL, { 0 }, 0, 0, 0 };
     return run_batch(&b);
 }
 
@@ -619,7 +647,7 @@ int h264bsdmiNextOutputPictureBatch(u32 n, storage_t *const *dec, u8 **pictures,
 {
     if (!dec || !pictures) return -1;
     if (!n) return 0;
-    Batch b = { n, dec, NULL, NULL, NULL, NULL, NULL, NULL, pictures, picId, isIdrPic, numErrMbs, NULL, NULL, 0, NULL, { 0 }, 0, 0 };
+    Batch b = { n, dec, NULL, NULL, NULL, NULL, NULL, NULL, pictures, picId, isIdrPic, numErrMbs, NULL, NULL, 0, NULL, { 0 }, 0, 0, 0 };
     return run_batch(&b);
 }
 
@@ -632,6 +660,6 @@ int h264bsdmiPullAndDecodePictureBatch(u32 n, storage_t *const *dec, u8 **pictur
 {
     if (!dec || !pictures || !buf || !len || !status || !consumed) return -1;
     if (!n) return 0;
-    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, pictures, outPicId, outIsIdrPic, outNumErrMbs, NULL, NULL, 0, NULL, { 0 }, 0, 0 };
+    Batch b = { n, dec, buf, len, picId, status, consumed, nErrors, pictures, outPicId, outIsIdrPic, outNumErrMbs, NULL, NULL, 0, NULL, { 0 }, 0, 0, 0 };
     return run_batch(&b);
 }

@@ -584,7 +584,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
 static void fold_errors(Engine *e)                    /* h_err holds a copy of the device's words that has arrived */
 {
     const uint32_t fresh = e->h_err[0] & ~e->errors;
-    __atomic_store_n(&e->error_events, e->h_err[1], __ATOMIC_RELAXED);
+    /* monotonic: the pinned words are written by copies on two streams, an older snapshot may land last */
+    if (e->h_err[1] > __atomic_load_n(&e->error_events, __ATOMIC_RELAXED)) __atomic_store_n(&e->error_events, e->h_err[1], __ATOMIC_RELAXED);
     if (fresh) {
         fprintf(stderr, "h264bsd-mi355x: DEVICE ERROR 0x%x:%s%s%s — pixels of the affected pictures are not trustworthy\n", fresh,
                 (fresh & DEVERR_RESIDUAL_RANGE) ? " residual outside [-512,511] reached the kernels (host check missed it)" : "",
