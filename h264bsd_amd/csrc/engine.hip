@@ -285,7 +285,7 @@ Engine *engine_get(int device = -1)
  * intra_rows_heavy,intra_waves" overrides the defaults (0 rows = one band); h264bsdmiDebugSetTail() does the same for tests. */
 struct TailConfig {
     uint32_t dbk_rows_light = 17, dbk_rows_heavy = 9, dbk_waves = 12;
-    uint32_t dbk_chroma_waves = 0;        /* wavefronts of a k_frame_dbk workgroup that start on the chroma graph; 0 = a third */
+    uint32_t dbk_chroma_waves = 0;        /* wavefronts of a k_frame_dbk workgroup that start on the chroma graph; 0 = five twelfths */
     uint32_t intra_rows_light = 0, intra_rows_heavy = 9, intra_waves = 12;
     /* A picture is only split where that puts idle compute units to work: a launch gets at most band_budget workgroups
      * (bands per picture <= band_budget / pictures of the tick, at least 1).  256 pictures in lock-step: one workgroup per
@@ -310,7 +310,7 @@ TailConfig tail_config()
             if (sscanf(cfg, "%u,%u,%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) >= 6) {
                 g_tail.dbk_rows_light = v[0]; g_tail.dbk_rows_heavy = v[1]; g_tail.dbk_waves = v[2];
                 g_tail.intra_rows_light = v[3]; g_tail.intra_rows_heavy = v[4]; g_tail.intra_waves = v[5];
-                g_tail.dbk_chroma_waves = v[6];          /* optional seventh number; 0 = a third of dbk_waves */
+                g_tail.dbk_chroma_waves = v[6];          /* optional seventh number; 0 = five twelfths of dbk_waves */
             } else fprintf(stderr, "h264bsd-mi355x: H264BSDMI_TAIL=%s ignored (expected six or seven numbers)\n", cfg);
         }
         if (const char *cfg = getenv("H264BSDMI_BAND_BUDGET")) g_tail.band_budget = (uint32_t)strtoul(cfg, nullptr, 10);
@@ -553,8 +553,8 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
             fprintf(stderr, "h264bsd-mi355x: picture %u macroblocks wide is too large for k_frame_dbk\n", s.max_w); return -1;
         }
         const uint32_t bands = bp.bands, rows = bp.rows, waves = bp.waves;
-        /* the last third of a workgroup's wavefronts starts on the chroma graph (k_frame_dbk.hip.h); the seventh number of H264BSDMI_TAIL overrides */
-        const uint32_t chroma_waves = tc.dbk_chroma_waves ? tc.dbk_chroma_waves : std::max<uint32_t>(1u, waves / 3u);
+        /* five twelfths of a workgroup's wavefronts start on the chroma graph (k_frame_dbk.hip.h); the seventh number of H264BSDMI_TAIL overrides */
+        const uint32_t chroma_waves = tc.dbk_chroma_waves ? tc.dbk_chroma_waves : std::max<uint32_t>(1u, (waves * 5u + 6u) / 12u);     /* 12 -> 5 (4 / 5 / 6: 31.6 / 30.3 / 30.3 ms per step), 8 -> 3 */
         const size_t lds = bp.lds;
         uint32_t *tickets = bands > 1 ? tickets_for(st) : nullptr;
         if (bands > 1 && !tickets) return -1;
