@@ -156,7 +156,8 @@ __device__ __forceinline__ uint32_t ld_agent_u16(const void *p)
  * right by 4 * (segment of the lane): nibble n = 4 * e + k sits at bit 16 * (e & 1) of dword e >> 1 */
 __device__ __forceinline__ int bs_of(uint32_t w0s, uint32_t w1s, int e) { return (int)(((e & 2 ? w1s : w0s) >> (16 * (e & 1))) & 15u); }
 /* tc0 of a class for strength bs: t4 = { 0, tc0(1), tc0(2), tc0(3) } as bytes; bs 0 and 4 give 0 */
-__device__ __forceinline__ int tc0_of(uint32_t t4, int bs) { return (int)((t4 >> (8 * (bs & 3))) & 255u); }
+/* (one v_perm_b32 with the strength as the selector: byte bs of { t4, 0 }; the selector's upper bytes pick byte 0 = 0) */
+__device__ __forceinline__ int tc0_of(uint32_t t4, int bs) { return (int)perm(0u, t4, (uint32_t)bs); }
 
 /* the 2 x 2 block dword (a.lo, a.hi, b.lo, b.hi) of two packed pairs a, b (samples are < 256: byte 0 and byte 2 of each) */
 __device__ __forceinline__ uint32_t blk_of(uint32_t a, uint32_t b) { return perm(b, a, 0x06040200u); }
@@ -254,6 +255,8 @@ __device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l
     const uint32_t d1 = DTICK();
 
     /* ---- vertical edges: rows 2l (low halves) and 2l+1 (high halves); px[0..3] = the left neighbour's last columns ---- */
+    asm volatile("" :: "v"(p.l0.x), "v"(p.l1.x));            /* (the unused halves keep the two loads 8 bytes wide: as dword loads of every second row's last
+                                                                 columns they cost the CU's address path 52 cycles each instead of 18) */
     uint32_t px[NPX];
     px[0] = perm(p.l1.y, p.l0.y, 0x0C040C00u); px[1] = perm(p.l1.y, p.l0.y, 0x0C050C01u);
     px[2] = perm(p.l1.y, p.l0.y, 0x0C060C02u); px[3] = perm(p.l1.y, p.l0.y, 0x0C070C03u);
