@@ -175,6 +175,21 @@ __device__ __forceinline__ uint32_t pair_hi(uint32_t blk) { return perm(0u, blk,
 /* cycle accounting of a wavefront's steps (debug builds with -DH264K_TAIL_PROFILE; members, not an array: registers, not scratch memory) */
 struct DbkProf { uint32_t wait, v, h, st, q, ld; };       /* (32 bits: a tick is a million cycles) */
 
+/* The descriptor fields the steps use, fetched ONCE per workgroup.  (Read through the FrameDesc reference, the picture's address is a
+ * scalar load in front of every step's loads and another one in front of its stores — the compiler re-materialises loads from the
+ * constant address space instead of keeping two scalar registers — and each waits for the scalar cache, which 256 pictures' descriptors
+ * and twelve wavefronts' kernel arguments do not fit.) */
+struct DbkCtx { uint8_t *cur; const uint8_t *recs; uint32_t wmb; };
+__device__ __forceinline__ DbkCtx dbk_ctx(const FrameDesc &fd)
+{
+    DbkCtx c;
+    unsigned long long a = (unsigned long long)(uintptr_t)fd.cur, b = (unsigned long long)(uintptr_t)fd.dbk;
+    uint32_t w = fd.wmb;
+    asm volatile("" : "+s"(a), "+s"(b), "+s"(w));                  /* opaque: values, not reloadable expressions */
+    c.cur = (uint8_t *)(uintptr_t)a; c.recs = (const uint8_t *)(uintptr_t)b; c.wmb = w;
+    return c;
+}
+
 /* ================================================================== luma */
 /* What a vector memory instruction costs the compute unit (tools/probes/vmem_issue_probe.hip, 12 wavefronts per CU, cycles of the
  * CU's address path per wave-level instruction): it grows with the 32-byte SECTORS and 128-byte lines the 64 lanes touch, hardly
@@ -199,12 +214,12 @@ struct DbkLumaLoads {
 /* cross: the macroblock lies in the first row of a row band: the tile above belongs to another workgroup, its last rows are
  * read past the L1 — and only when this macroblock's upper edge is filtered at all (want_top), because an unconditional
  * load could run ahead of the other band's stores. */
-__device__ __forceinline__ void dbk_luma_load(const FrameDesc &fd, int mb, int l, DbkLumaLoads &p, bool cross, bool want_top)
+__device__ __forceinline__ void dbk_luma_load(const DbkCtx &fd, int mb, int l, DbkLumaLoads &p, bool cross, bool want_top)
 {
     if (mb < 0) return;
     const uint8_t *cur = fd.cur;
     const H264K_GLOBAL uint8_t *curg = (const H264K_GLOBAL uint8_t *)cur;
-    const H264K_GLOBAL uint8_t *recs = (const H264K_GLOBAL uint8_t *)fd.dbk;
+    const H264K_GLOBAL uint8_t *recs = (const H264K_GLOBAL uint8_t *)fd.recs;
     const uint32_t umb = (uint32_t)mb, wmb = fd.wmb;
     const uint32_t t = umb * TILE, tl = (umb ? umb - 1u : 0u) * TILE, tu = (umb >= wmb ? umb - wmb : umb) * TILE;     /* stand-ins where there is no neighbour: never used (k_dbk: LEFT / TOP only where it exists) */
     const uint32_t ro = umb * DBK_REC_BYTES;
@@ -232,7 +247,7 @@ __device__ __forceinline__ void dbk_luma_load(const FrameDesc &fd, int mb, int l
  *   very samples concern them (k_frame_dbk, dependency rule) and may be rewriting the rest of its tile at the same time.
  * wt: the macroblock lies in the last row of a row band, the band below reads what it writes: everything goes write-through. */
 template <bool BANDED, int SLOTS>
-__device__ __forceinline__ void dbk_luma_step(const FrameDesc &fd, int mb, int l, const DbkLumaLoads &p, uint32_t wb, bool wt_, DbkProf *tp)
+__device__ __forceinline__ void dbk_luma_step(const DbkCtx &fd, int mb, int l, const DbkLumaLoads &p, uint32_t wb, bool wt_, DbkProf *tp)
 {
     constexpr int NPX = SLOTS == 4 ? 20 : 8;
     const bool wt = BANDED && wt_;
@@ -407,12 +422,12 @@ struct DbkChromaLoads {
     uint4 r0; uint32_t w_cl; uint2 w_ci; uint2 r2;     /* strengths | chroma left | chroma top, inner | bytes 40..47     */
 };
 
-__device__ __forceinline__ void dbk_chroma_load(const FrameDesc &fd, int mb, int l, DbkChromaLoads &p, bool cross, bool want_top)
+__device__ __forceinline__ void dbk_chroma_load(const DbkCtx &fd, int mb, int l, DbkChromaLoads &p, bool cross, bool want_top)
 {
     if (mb < 0) return;
     const uint8_t *cur = fd.cur;
     const H264K_GLOBAL uint8_t *curg = (const H264K_GLOBAL uint8_t *)cur;
-    const H264K_GLOBAL uint8_t *recs = (const H264K_GLOBAL uint8_t *)fd.dbk;
+    const H264K_GLOBAL uint8_t *recs = (const H264K_GLOBAL uint8_t *)fd.recs;
     const uint32_t umb = (uint32_t)mb, wmb = fd.wmb;
     const uint32_t t = umb * TILE, tl = (umb ? umb - 1u : 0u) * TILE, tu = (umb >= wmb ? umb - wmb : umb) * TILE;
     const uint32_t ro = umb * DBK_REC_BYTES;
@@ -431,7 +446,7 @@ __device__ __forceinline__ void dbk_chroma_load(const FrameDesc &fd, int mb, int
 /* Chroma of one macroblock: both planes, edges at columns / rows 0 and 4 (= luma edges 0 and 2).  SLOTS = 2: both; SLOTS = 1:
  * the macroblock edges only (partial stores as in dbk_luma_step: column 0 and row 0 of the own planes). */
 template <bool BANDED, int SLOTS>
-__device__ __forceinline__ void dbk_chroma_step(const FrameDesc &fd, int mb, int l, const DbkChromaLoads &p, uint32_t wb, bool wt_, DbkProf *tp)
+__device__ __forceinline__ void dbk_chroma_step(const DbkCtx &fd, int mb, int l, const DbkChromaLoads &p, uint32_t wb, bool wt_, DbkProf *tp)
 {
     constexpr int NPX = SLOTS == 2 ? 10 : 4;
     const bool wt = BANDED && wt_;
@@ -611,7 +626,8 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
     const FrameDesc &fd = FD_REF(frames, pic);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane / DBK_LANES, l = lane % DBK_LANES;
     const int n_waves = (int)(blockDim.x >> 6);
-    const int wmb = fd.wmb, hmb = fd.hmb;
+    const DbkCtx cx = dbk_ctx(fd);
+    const int wmb = (int)cx.wmb, hmb = fd.hmb;
     int R = hmb, nb = 1;
     if (BANDED) band_split(hmb, fd.dbk_bands, fd.heavy, max_bands, light_cap, rows_cap, R, nb);
     if (!fd.any_deblock || (int)band >= nb) { if (BANDED) return_ticket(tickets); return; }
@@ -800,20 +816,20 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
             DbkProf *stp = tp ? &acc : nullptr;
             if (role == 0) {
                 DbkLumaLoads cp;
-                dbk_luma_load(fd, run, l, cp, BANDED && cross, want_top);
+                dbk_luma_load(cx, run, l, cp, BANDED && cross, want_top);
 #ifdef H264K_TAIL_PROFILE
                 if (tp) acc.ld += (uint32_t)__builtin_readcyclecounter() - t_mark;  /* ... -> loads issued */
 #endif
-                if (cls) dbk_luma_step<BANDED, 1>(fd, run, l, cp, wb + (uint32_t)grp * DBK_LW, wt, stp);
-                else dbk_luma_step<BANDED, 4>(fd, run, l, cp, wb + (uint32_t)grp * DBK_LW, wt, stp);
+                if (cls) dbk_luma_step<BANDED, 1>(cx, run, l, cp, wb + (uint32_t)grp * DBK_LW, wt, stp);
+                else dbk_luma_step<BANDED, 4>(cx, run, l, cp, wb + (uint32_t)grp * DBK_LW, wt, stp);
             } else {
                 DbkChromaLoads cp;
-                dbk_chroma_load(fd, run, l, cp, BANDED && cross, want_top);
+                dbk_chroma_load(cx, run, l, cp, BANDED && cross, want_top);
 #ifdef H264K_TAIL_PROFILE
                 if (tp) acc.ld += (uint32_t)__builtin_readcyclecounter() - t_mark;
 #endif
-                if (cls) dbk_chroma_step<BANDED, 1>(fd, run, l, cp, wb + (uint32_t)grp * DBK_CW, wt, stp);
-                else dbk_chroma_step<BANDED, 2>(fd, run, l, cp, wb + (uint32_t)grp * DBK_CW, wt, stp);
+                if (cls) dbk_chroma_step<BANDED, 1>(cx, run, l, cp, wb + (uint32_t)grp * DBK_CW, wt, stp);
+                else dbk_chroma_step<BANDED, 2>(cx, run, l, cp, wb + (uint32_t)grp * DBK_CW, wt, stp);
             }
             if (tp) { const uint32_t t = (uint32_t)__builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; n_done += __popcll(__ballot(run >= 0 && l == 0)); n_steps++; }
             /* release: stores done -> dependants */
