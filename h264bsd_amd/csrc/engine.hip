@@ -904,10 +904,8 @@ static int out_begin(SinkUser *u, bool to_host, hipStream_t *st)          /* mut
 }
 static int out_end_locked(SinkUser *u, hipStream_t st)  /* mutex held: the device's error words travel with the picture */
 {
-#ifndef OUT_WHATIF_NO_ERR_WORDS      /* (timing experiment: what does the second launch per picture cost?) */
     hipLaunchKernelGGL(k_err_words, dim3(1), dim3(64), 0, st, u->e->d_err, u->e->hd_err);
     HIP_TRY(hipGetLastError());
-#endif
     HIP_TRY(hipEventRecord(u->s->out_ev, st));
     return 0;
 }

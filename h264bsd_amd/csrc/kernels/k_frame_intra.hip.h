@@ -240,10 +240,6 @@ __device__ __forceinline__ void intra_issue(const FrameDesc &fd, uint32_t mb, co
     L.rows.ldc = 0;
     if (kind == FJ_MB_IPCM || kind == FJ_MB_CONCEAL_I) return;
     const uint8_t *Y = fd.cur + (size_t)mb * TILE;
-#if defined(INTRA_WHATIF) && (INTRA_WHATIF & 1)      /* timing experiment: no neighbour / coefficient loads */
-    L.nb_y = lane; L.nb_c = lane + 1; L.rows.y = L.rows.c = L.rows.cdc = make_int2(lane, 1); (void)Y; (void)cross;
-    return;
-#endif
     if (avail & lo.y_bit) L.nb_y = cross && lane < 21 ? (int)ld_agent_u8(Y + lo.y_off) : (int)Y[lo.y_off];
     if (avail & lo.c_bit) L.nb_c = cross && lane < 18 ? (int)ld_agent_u8(Y + lo.c_off) : (int)Y[lo.c_off];
     L.rows = mb_residual_fetch(coded, fd.coefs + 16 * (size_t)coef_idx, lane);
@@ -275,23 +271,13 @@ __device__ __forceinline__ void intra_mb(const FrameDesc &fd, uint32_t mb, int l
     const int nb_y = L.nb_y, nb_c = L.nb_c;
 
     int ry[4], rc[4];
-#if defined(INTRA_WHATIF) && (INTRA_WHATIF & 2)      /* timing experiment: no residual arithmetic */
-    ry[0] = ry[1] = ry[2] = ry[3] = L.rows.y.x & 7; rc[0] = rc[1] = rc[2] = rc[3] = L.rows.c.x & 7;
-#else
     report_residual_range(fd, mb_residual_compute(rec.coded, rec.qp_y, rec.qp_c, rec.kind == FJ_MB_I16x16, coef, lane, L.rows, ry, rc), lane);
-#endif
 
     if (nb_y_at >= 0) tile[nb_y_at] = (uint8_t)nb_y;
     if (nb_c_at >= 0) ctile0[nb_c_at] = (uint8_t)nb_c;
     wave_sync();
     const unsigned long long i1 = ITICK();
 
-#if defined(INTRA_WHATIF) && (INTRA_WHATIF & 4)      /* timing experiment: no luma prediction */
-    if (true) {
-        res_defer = nullptr;
-        put4(Y + (by * 4 + row) * 16 + bx * 4, pack4(ry[0] & 255, ry[1] & 255, ry[2] & 255, (ry[3] + tile[4 + lane]) & 255), wt);
-    } else
-#endif
     if (rec.kind == FJ_MB_I16x16) {
         const int mode = rec.pred & 3;
         const int y = by * 4 + row, x0 = bx * 4;
@@ -684,11 +670,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, INTRA_OCC) void k_frame_intra(cons
             }
             /* lost macroblocks (error path) are a call, so that they cost the intra path no registers */
             if (kind == FJ_MB_CONCEAL_I) conceal_mb(fd, mb, lane, head >> 24);
-#if defined(INTRA_WHATIF) && (INTRA_WHATIF & 4)
-            else if (false) {
-#else
             else if (kind == FJ_MB_I4x4 && k > 1) {
-#endif
                 intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, lane_offs, wt, reinterpret_cast<int16_t *>(my + 4 * INTRA_SLOT + j * 512), tp);
                 if ((uint32_t)(lane >> 4) == j) joint_mb = (int)mb;
             } else intra_mb(fd, mb, lane, slot, slot + 17 * TS, i4tab, rec_lds + 8 * j, cur_loads, lane_offs, wt, nullptr, tp);

@@ -357,31 +357,11 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
         /* (the window's 21 columns reach into the third tile only when they start in the last four columns of the first:
          * in three cases out of four that tile is not requested at all — nothing reads the bytes it would have filled) */
         const bool l_on = lfast && lane < 63 && lx < W && (lk < 2 || xi - xs >= 12);
-#if defined(INTER_WHATIF) && (INTER_WHATIF & 4)
-        if (ge.coded != 0xFFFFFFFFu) continue;
-#endif
-#if defined(INTER_WHATIF) && (INTER_WHATIF & 1)
-        const uint4 vl = make_uint4(lane, mb, ge.coded, lx);
-#else
         const uint4 vl = ld16g(ref + (l_on ? luma_at(wmb, lx, yi + lr) : (size_t)0));
-#endif
         const int cp = lane >= 18, rem = cp ? lane - 18 : lane, cr = rem >> 1, ck = rem & 1, cx = cxs + 8 * ck;
         const bool c_on = cfast && lane < 36 && cx < CW;
-#if defined(INTER_WHATIF) && (INTER_WHATIF & 1)
-        const uint2 vc = make_uint2(lane, cx);
-        rrows.y = rrows.c = rrows.cdc = make_int2(lane, mb); rrows.ldc = 0;
-#else
         const uint2 vc = ld8g(ref + (c_on ? chroma_at(wmb, cp, cx, cyi + cr) : (size_t)0));
         rrows = mb_residual_fetch(ge.coded, coef, lane);
-#endif
-#if defined(INTER_WHATIF) && (INTER_WHATIF & 2)
-        {
-            H264K_GLOBAL uint8_t *T2 = cur + (size_t)mb * TILE;
-            *reinterpret_cast<H264K_GLOBAL uint32_t *>(T2 + (by * 4 + row) * 16 + bx * 4) = vl.x ^ vl.y ^ vl.z ^ vl.w ^ (uint32_t)rrows.y.x ^ (uint32_t)rrows.c.x ^ (uint32_t)rrows.cdc.x;
-            if (lane < 32) *reinterpret_cast<H264K_GLOBAL uint32_t *>(T2 + T_CB + 4 * lane) = vc.x ^ vc.y;
-            continue;
-        }
-#endif
         if (l_on) {
             uint32_t *d32 = reinterpret_cast<uint32_t *>(lw + lr * IW_STRIDE + 16 * lk);
             d32[0] = vl.x; d32[1] = vl.y; d32[2] = vl.z; d32[3] = vl.w;
