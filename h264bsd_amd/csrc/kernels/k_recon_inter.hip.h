@@ -190,6 +190,31 @@ __device__ __forceinline__ void chroma_from_rows(const int a[3], const int b[3],
     out[0] = (w00 * a[0] + w10 * a[1] + w01 * b[0] + w11 * b[1] + 32) >> 6;
     out[1] = (w00 * a[1] + w10 * a[2] + w01 * b[1] + w11 * b[2] + 32) >> 6;
 }
+/* The same two samples from STAGED rows in packed 16-bit: s0 points at the first of three consecutive bytes of the upper row, s1 at
+ * those of the row below (any byte alignment; the dword behind them belongs to the row's stride).  Weights are at most 64 and
+ * samples at most 255: every partial sum fits a signed 16-bit half.  Round 6: the chroma prediction of a macroblock used to be
+ * 32 lanes x 4 samples in 32-bit arithmetic from ten ds_read_u8 each — about 56 of the 257 vector instructions of a one-vector
+ * macroblock; it is 64 lanes x 2 samples now (lanes 32..63 hand their pair to lanes 0..31 with v_permlane32_swap). */
+__device__ __forceinline__ s2 chroma_pair_lds(const uint8_t *s0, const uint8_t *s1, int fx, int fy)
+{
+    auto three = [](const uint8_t *p) -> uint32_t {
+        const uint32_t sh = (uint32_t)(uintptr_t)p & 3u;
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh);
+        return __builtin_amdgcn_alignbyte(q[1], q[0], sh);
+    };
+    const uint32_t ra = three(s0), rb = three(s1);
+    const s2 P0 = as_s2(perm(0u, ra, 0x0C010C00u)), P1 = as_s2(perm(0u, ra, 0x0C020C01u));
+    const s2 Q0 = as_s2(perm(0u, rb, 0x0C010C00u)), Q1 = as_s2(perm(0u, rb, 0x0C020C01u));
+    const int w00 = (8 - fx) * (8 - fy), w10 = fx * (8 - fy), w01 = (8 - fx) * fy, w11 = fx * fy;
+    return (P0 * pk(w00) + P1 * pk(w10) + Q0 * pk(w01) + Q1 * pk(w11) + pk(32)) >> pk(6);
+}
+/* lanes 0..31 receive the pair of lane + 32 (theirs is samples 0, 1 of the row, that one samples 2, 3) */
+__device__ __forceinline__ s2 pair_from_upper_half(s2 mine)
+{
+    const uint32_t x = as_u32(mine);
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return as_s2(r[1]);
+}
 /* 2 chroma samples (x, x+1 ; y) of plane `plane` straight from global memory (w, h: chroma plane size) */
 __device__ __forceinline__ void chroma_pred2(const uint8_t *__restrict__ f, int wmb, int plane, int w, int h, int x, int y, int fx, int fy, int out[2])
 {
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
     ResidRows rrows;
     if (!uniform) rrows = mb_residual_fetch(ge.coded, coef, lane);
     s2 pl01 = pk(0), pl23 = pk(0);               /* the lane's four luma prediction samples, two packed pairs */
-    int pc[4] = { 0, 0, 0, 0 };
+    s2 pc01 = pk(0), pc23 = pk(0);               /* lanes 0..31: the four chroma prediction samples of the lane's row */
     if (uniform) {
         const int mvx = (int16_t)(mv0 & 0xFFFFu), mvy = (int32_t)mv0 >> 16;
         const H264K_GLOBAL uint8_t *ref = (const H264K_GLOBAL uint8_t *)slot_ptr(fd, refs & 255u);
@@ -393,15 +418,12 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
             luma_pred_lds(lw + (4 * by + row) * IW_STRIDE + (o & ~3), IW_STRIDE, sh, mvx & 3, mvy & 3, pl01, pl23);
         }
         /* ---- chroma: lanes 0..31, 4 samples of one row = two pairs ---- */
-        if (lane < 32) {
-            const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
-            const int cy = cby * 4 + row, cx0 = cbx * 4;
-            const uint8_t *s0 = lc + plane * 9 * IC_STRIDE + cy * IC_STRIDE + (cxi - cxs) + cx0, *s1 = s0 + IC_STRIDE;
-            int a[5], b[5];
-#pragma unroll
-            for (int i = 0; i < 5; i++) { a[i] = s0[i]; b[i] = s1[i]; }
-            chroma_from_rows(a, b, mvx & 7, mvy & 7, pc);
-            chroma_from_rows(a + 2, b + 2, mvx & 7, mvy & 7, pc + 2);
+        {
+            const int k = (lane & 31) >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
+            const int cy = cby * 4 + row, cx0 = cbx * 4 + 2 * (lane >> 5);
+            const uint8_t *s0 = lc + plane * 9 * IC_STRIDE + cy * IC_STRIDE + (cxi - cxs) + cx0;
+            pc01 = chroma_pair_lds(s0, s0 + IC_STRIDE, mvx & 7, mvy & 7);
+            pc23 = pair_from_upper_half(pc01);
         }
     } else if (quadwise) {
         /* ---- one motion vector per 8x8 quadrant (16x8, 8x16, 8x8 partitions): four 13x13 luma and four 5x5 (x2 planes)
@@ -482,18 +504,15 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
             const int o = (xi & 15) + 4 * (bx & 1), sh = 8 * (o & 3);
             luma_pred_lds(lq + q * 13 * QW_STRIDE + (4 * (by & 1) + row) * QW_STRIDE + (o & ~3), QW_STRIDE, sh, mvx & 3, mvy & 3, pl01, pl23);
         }
-        if (lane < 32) {
-            const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
+        {
+            const int k = (lane & 31) >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
             const int q = cby * 2 + cbx;                             /* a 4x4 chroma block = one luma quadrant */
             const uint32_t mvm = q == 0 ? mvq[0] : q == 1 ? mvq[1] : q == 2 ? mvq[2] : mvq[3];
             const int mvx = (int16_t)(mvm & 0xFFFFu), mvy = (int32_t)mvm >> 16;
             const int cxi = mbx * 8 + 4 * (q & 1) + (mvx >> 3);
-            const uint8_t *s0 = cq + (q * 2 + plane) * 5 * QC_STRIDE + row * QC_STRIDE + (cxi & 7), *s1 = s0 + QC_STRIDE;
-            int a[5], b[5];
-#pragma unroll
-            for (int i = 0; i < 5; i++) { a[i] = s0[i]; b[i] = s1[i]; }
-            chroma_from_rows(a, b, mvx & 7, mvy & 7, pc);
-            chroma_from_rows(a + 2, b + 2, mvx & 7, mvy & 7, pc + 2);
+            const uint8_t *s0 = cq + (q * 2 + plane) * 5 * QC_STRIDE + row * QC_STRIDE + (cxi & 7) + 2 * (lane >> 5);
+            pc01 = chroma_pair_lds(s0, s0 + QC_STRIDE, mvx & 7, mvy & 7);
+            pc23 = pair_from_upper_half(pc01);
         }
     } else {
         /* ---- per-lane windows straight from global memory ---- */
@@ -513,6 +532,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
             pl01 = as_s2((uint32_t)pl[0] | ((uint32_t)pl[1] << 16)); pl23 = as_s2((uint32_t)pl[2] | ((uint32_t)pl[3] << 16));
         }
         if (lane < 32) {
+            int pc[4];
             const int k = lane >> 2, plane = k >> 2, cbx = k & 1, cby = (k >> 1) & 1;
             const int cy = cby * 4 + row, cx0 = cbx * 4;
 #pragma unroll
@@ -523,6 +543,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
                 const uint8_t *ref = slot_ptr(fd, (refs >> (8 * ((cy >> 2) * 2 + (cx >> 2)))) & 255u);
                 chroma_pred2(ref, wmb, plane, CW, CH, mbx * 8 + cx + (mvx >> 3), mby * 8 + cy + (mvy >> 3), mvx & 7, mvy & 7, pc + 2 * pair);
             }
+            pc01 = as_s2((uint32_t)pc[0] | ((uint32_t)pc[1] << 16)); pc23 = as_s2((uint32_t)pc[2] | ((uint32_t)pc[3] << 16));
         }
     }
 
@@ -530,7 +551,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
      * into the residual code, where every coded macroblock would wait for a second memory round trip) */
     asm volatile("" :: "v"(rrows.y.x), "v"(rrows.y.y), "v"(rrows.c.x), "v"(rrows.c.y), "v"(rrows.cdc.x), "v"(rrows.cdc.y));
 #ifdef H264K_INTER_PROFILE
-    asm volatile("" :: "v"(pl01), "v"(pl23), "v"(pc[0]), "v"(pc[1]), "v"(pc[2]), "v"(pc[3]));
+    asm volatile("" :: "v"(pl01), "v"(pl23), "v"(pc01), "v"(pc23));
 #endif
     IPROF(3);
     /* ---- residual add, clip, store.  Lane (block, row) holds 4 samples of row 4*by+row at column 4*bx: the 64 dwords of the
@@ -541,20 +562,20 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
     uint32_t luma_dw, chroma_dw;
     if ((ge.coded & 0x03FFFFFFu) == 0u) {                        /* wave-uniform */
         luma_dw = perm(as_u32(pl23), as_u32(pl01), 0x06040200u);
-        chroma_dw = pack4(pc[0], pc[1], pc[2], pc[3]);
+        chroma_dw = perm(as_u32(pc23), as_u32(pc01), 0x06040200u);
     } else if (!(ge.coded & FJ_CODED_WIDE)) {                    /* wave-uniform: the host proved that 16 bits hold every intermediate */
         s2 y01, y23, c01, c23;
         mb_residual_pk(ge.coded, rec.qp_y, rec.qp_c, lane, rrows, y01, y23, c01, c23);
         const s2 lo = pk(0), hi = pk(255);
         const s2 l01 = pk_clip(lo, hi, pl01 + y01), l23 = pk_clip(lo, hi, pl23 + y23);
-        const s2 k01 = pk_clip(lo, hi, as_s2((uint32_t)pc[0] | ((uint32_t)pc[1] << 16)) + c01), k23 = pk_clip(lo, hi, as_s2((uint32_t)pc[2] | ((uint32_t)pc[3] << 16)) + c23);
+        const s2 k01 = pk_clip(lo, hi, pc01 + c01), k23 = pk_clip(lo, hi, pc23 + c23);
         luma_dw = perm(as_u32(l23), as_u32(l01), 0x06040200u);
         chroma_dw = perm(as_u32(k23), as_u32(k01), 0x06040200u);
     } else {
         int ry[4], rc[4];
         report_residual_range(fd, mb_residual_compute<false>(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc), lane);
         luma_dw = pack4(clip255(pl01.x + ry[0]), clip255(pl01.y + ry[1]), clip255(pl23.x + ry[2]), clip255(pl23.y + ry[3]));
-        chroma_dw = pack4(clip255(pc[0] + rc[0]), clip255(pc[1] + rc[1]), clip255(pc[2] + rc[2]), clip255(pc[3] + rc[3]));
+        chroma_dw = pack4(clip255(pc01.x + rc[0]), clip255(pc01.y + rc[1]), clip255(pc23.x + rc[2]), clip255(pc23.y + rc[3]));
     }
 #ifdef H264K_INTER_PROFILE
     asm volatile("" :: "v"(luma_dw), "v"(chroma_dw));
