@@ -179,9 +179,15 @@ typedef struct FjGen {
                                  quadrant (references in FjMbRec.ref_slot); 0: anything else                   */
     uint8_t  slot;            /* reference slot when uniform                                  */
     int16_t  mvx, mvy;        /* the motion vector when uniform (quarter samples)             */
-    uint32_t coef_idx;        /* = FjMbRec.coef_idx                                           */
+    uint32_t coef_idx;        /* bits 0..19 = FjMbRec.coef_idx (at most 27 blocks x 36864 macroblocks), bits 20..25 = FjMbRec.qp_y,
+                                 bits 26..31 = FjMbRec.qp_c: a one-vector macroblock is reconstructed from its list entry alone — the
+                                 record, a second dependent scalar load in front of every macroblock of k_recon_inter, is not fetched */
     uint32_t coded;           /* = FjMbRec.coded                                              */
 } FjGen;                      /* 16 bytes */
+#define FJ_GEN_COEF(idx, qp_y, qp_c) (((uint32_t)(idx) & 0xFFFFFu) | ((uint32_t)((qp_y) & 63u) << 20) | ((uint32_t)((qp_c) & 63u) << 26))
+#define FJ_GEN_COEF_IDX(w) ((w) & 0xFFFFFu)
+#define FJ_GEN_QP_Y(w) (((w) >> 20) & 63u)
+#define FJ_GEN_QP_C(w) ((w) >> 26)
 
 typedef struct FjMbRec {
     uint8_t  kind;

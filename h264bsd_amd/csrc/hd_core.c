@@ -175,7 +175,7 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
             if (recon && !whole) {
                 FjGen *gi = &gen_tmp[n_gen++];
                 gi->mb = (uint16_t)a; gi->uniform = 1; gi->slot = r->ref_slot[0];
-                gi->mvx = r->mv[0]; gi->mvy = r->mv[1]; gi->coef_idx = r->coef_idx; gi->coded = 0;
+                gi->mvx = r->mv[0]; gi->mvy = r->mv[1]; gi->coef_idx = FJ_GEN_COEF(r->coef_idx, r->qp_y, r->qp_c); gi->coded = 0;
             }
             goto deblock_index;
         }
@@ -278,7 +278,7 @@ int fj_finalize_ex(uint8_t *job, uint32_t cap, uint32_t coef_blocks, FjElide *el
                     }
                 }
                 gi->mb = (uint16_t)a; gi->uniform = (uint8_t)(same_mv ? 1 : quad ? 2 : 0); gi->slot = r->ref_slot[0];
-                gi->mvx = m0[0]; gi->mvy = m0[1]; gi->coef_idx = r->coef_idx; gi->coded = r->coded;
+                gi->mvx = m0[0]; gi->mvy = m0[1]; gi->coef_idx = FJ_GEN_COEF(r->coef_idx, r->qp_y, r->qp_c); gi->coded = r->coded;
                 if (!same_mv) memcpy(&gi->mvx, &r->mvx, 4);      /* partitioned: the two fields hold the index of its sixteen vectors */
             }
         }

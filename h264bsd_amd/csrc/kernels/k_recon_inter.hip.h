@@ -329,8 +329,10 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
     if (PATH == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #endif
     IPROF(1);
-    FjMbRec rec;                                     /* only the QPs (and, partitioned, the references) are needed from it */
-    {
+    /* the QPs travel in the list entry (framejob.h); only the partitioned paths need the record, for their four references */
+    const int qp_y = (int)FJ_GEN_QP_Y(ge.coef_idx), qp_c = (int)FJ_GEN_QP_C(ge.coef_idx);
+    FjMbRec rec;
+    if (PATH != 0) {
         const uint4 w = ld16c((const H264K_CONST FjMbRec *)fd.recs + mb), w2 = ld16c((const H264K_CONST uint8_t *)((const H264K_CONST FjMbRec *)fd.recs + mb) + 16);
         __builtin_memcpy(&rec, &w, 16);
         __builtin_memcpy(reinterpret_cast<uint8_t *>(&rec) + 16, &w2, 16);
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
     /* partitioned macroblocks: the list entry's vector fields hold the index of their sixteen vectors in the sparse section */
     const uint32_t mvx_idx = PATH == 0 ? 0u : (uint32_t)(uint16_t)ge.mvx | ((uint32_t)(uint16_t)ge.mvy << 16);
     const int16_t *mvs = (const int16_t *)((const H264K_CONST int16_t *)fd.mvx + 32 * (size_t)mvx_idx);
-    const int16_t *coef = (const int16_t *)((const H264K_CONST int16_t *)fd.coefs + 16 * (size_t)ge.coef_idx);
+    const int16_t *coef = (const int16_t *)((const H264K_CONST int16_t *)fd.coefs + 16 * (size_t)FJ_GEN_COEF_IDX(ge.coef_idx));
     H264K_GLOBAL uint8_t *cur = (H264K_GLOBAL uint8_t *)fd.cur;
     const int blk = lane >> 2, row = lane & 3, bx = blk & 3, by = blk >> 2;
     const bool uniform = PATH == 0, quadwise = PATH == 1;
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
         chroma_dw = perm(as_u32(pc23), as_u32(pc01), 0x06040200u);
     } else if (!(ge.coded & FJ_CODED_WIDE)) {                    /* wave-uniform: the host proved that 16 bits hold every intermediate */
         s2 y01, y23, c01, c23;
-        mb_residual_pk(ge.coded, rec.qp_y, rec.qp_c, lane, rrows, y01, y23, c01, c23);
+        mb_residual_pk(ge.coded, qp_y, qp_c, lane, rrows, y01, y23, c01, c23);
         const s2 lo = pk(0), hi = pk(255);
         const s2 l01 = pk_clip(lo, hi, pl01 + y01), l23 = pk_clip(lo, hi, pl23 + y23);
         const s2 k01 = pk_clip(lo, hi, pc01 + c01), k23 = pk_clip(lo, hi, pc23 + c23);
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
         chroma_dw = perm(as_u32(k23), as_u32(k01), 0x06040200u);
     } else {
         int ry[4], rc[4];
-        report_residual_range(fd, mb_residual_compute<false>(ge.coded, rec.qp_y, rec.qp_c, false, coef, lane, rrows, ry, rc), lane);
+        report_residual_range(fd, mb_residual_compute<false>(ge.coded, qp_y, qp_c, false, coef, lane, rrows, ry, rc), lane);
         luma_dw = pack4(clip255(pl01.x + ry[0]), clip255(pl01.y + ry[1]), clip255(pl23.x + ry[2]), clip255(pl23.y + ry[3]));
         chroma_dw = pack4(clip255(pc01.x + rc[0]), clip255(pc01.y + rc[1]), clip255(pc23.x + rc[2]), clip255(pc23.y + rc[3]));
     }
