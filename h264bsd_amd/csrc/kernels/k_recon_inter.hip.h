@@ -331,12 +331,8 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
     IPROF(1);
     /* the QPs travel in the list entry (framejob.h); only the partitioned paths need the record, for their four references */
     const int qp_y = (int)FJ_GEN_QP_Y(ge.coef_idx), qp_c = (int)FJ_GEN_QP_C(ge.coef_idx);
-    FjMbRec rec;
-    if (PATH != 0) {
-        const uint4 w = ld16c((const H264K_CONST FjMbRec *)fd.recs + mb), w2 = ld16c((const H264K_CONST uint8_t *)((const H264K_CONST FjMbRec *)fd.recs + mb) + 16);
-        __builtin_memcpy(&rec, &w, 16);
-        __builtin_memcpy(reinterpret_cast<uint8_t *>(&rec) + 16, &w2, 16);
-    }
+    uint32_t rec_refs = 0u;                          /* FjMbRec.ref_slot[4]: one scalar dword instead of the 32-byte record */
+    if (PATH != 0) rec_refs = *(const H264K_CONST uint32_t *)((const H264K_CONST uint8_t *)((const H264K_CONST FjMbRec *)fd.recs + mb) + offsetof(FjMbRec, ref_slot));
     int lane = threadIdx.x & 63;
     if (inter_per_wave<PATH>() > 1) asm volatile("" : "+v"(lane));                   /* (everything a lane derives from its number is worked out again for every entry: hoisted out of
                                                         the loop it would live in registers the kernel does not have at 8 wavefronts per SIMD) */
@@ -354,7 +350,7 @@ __global__ __launch_bounds__(64 * INTER_WG_WAVES, PATH == 0 ? INTER_OCC : INTER_
     uint32_t refs = ge.slot * 0x01010101u, mv_mine = 0;
     const uint32_t mv0 = (uint32_t)(uint16_t)ge.mvx | ((uint32_t)(uint16_t)ge.mvy << 16);
     if (!uniform) {
-        __builtin_memcpy(&refs, rec.ref_slot, 4);
+        refs = rec_refs;
         if (!quadwise) mv_mine = *reinterpret_cast<const uint32_t *>(mvs + 2 * blk);
     }
 
