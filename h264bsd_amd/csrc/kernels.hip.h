@@ -43,6 +43,7 @@
 #include "kernels/k_dbk.hip.h"
 #include "kernels/k_copy.hip.h"
 #include "kernels/k_recon_inter.hip.h"
+#include "kernels/convert.hip.h"
 #include "kernels/tail_common.hip.h"
 #include "kernels/k_frame_intra.hip.h"
 #include "kernels/k_frame_dbk.hip.h"

@@ -77,45 +77,21 @@ __global__ __launch_bounds__(256) void k_convert(const uint8_t *__restrict__ yuv
     }
 }
 
-/* Whole frames, tiles -> 32-bit pixels: ONE WAVEFRONT PER MACROBLOCK, lane = (row, quad of 4 pixels).  The 256 luma bytes
- * of the tile are one contiguous 4-byte-per-lane load, the 2 x 64 chroma bytes one 4-byte load of lanes 0..31 that is
- * handed round with two shuffles, and the four wavefronts of a workgroup take four neighbouring macroblocks, so that a
- * store instruction of the workgroup covers 256 contiguous bytes of 16 picture rows.  The chroma terms of the conversion
- * are computed once per pixel pair.  Same arithmetic as k_convert / yuv_pixel (reference decoder.c:1163-1370). */
+/* Whole frames, tiles -> 32-bit pixels: one wavefront per PAIR of horizontally adjacent macroblocks (conv_tile_pair,
+ * kernels/convert.hip.h: packed 16-bit arithmetic, two rows x four columns per lane).  Same results as k_convert / yuv_pixel
+ * (reference decoder.c:1163-1370). */
 __global__ __launch_bounds__(256) void k_convert_tiles(const uint8_t *__restrict__ yuv, uint32_t *__restrict__ out, uint32_t wmb, uint32_t hmb,
                                                        int fmt, size_t in_stride, size_t out_stride)
 {
     const uint8_t *src = yuv + blockIdx.y * in_stride;
     uint32_t *dst = out + blockIdx.y * out_stride;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_mbs = wmb * hmb, W = wmb * 16;
-    const uint32_t r = lane >> 2, q = lane & 3u;
-    for (uint32_t mb = (blockIdx.x * 4u + wave); mb < n_mbs; mb += gridDim.x * 4u) {
-        const uint8_t *T = src + (size_t)mb * TILE;
-        const uint32_t yy = reinterpret_cast<const uint32_t *>(T)[lane];
-        uint32_t cw = 0;
-        if (lane < 32u) cw = reinterpret_cast<const uint32_t *>(T + T_CB)[lane];          /* lanes 0-15 Cb, 16-31 Cr */
-        const int ci = (int)((r >> 1) * 2u + (q >> 1));                                    /* dword of chroma row r/2 holding samples 2q, 2q+1 */
-        const uint32_t cbw = (uint32_t)__shfl((int)cw, ci) >> (16u * (q & 1u)), crw = (uint32_t)__shfl((int)cw, 16 + ci) >> (16u * (q & 1u));
-        uint32_t px[4];
-        if (fmt == 2) {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                px[k] = 0xFF000000u | (((crw >> (8 * (k >> 1))) & 255u) << 16) | (((cbw >> (8 * (k >> 1))) & 255u) << 8) | ((yy >> (8 * k)) & 255u);
-        } else {
-#pragma unroll
-            for (int h2 = 0; h2 < 2; h2++) {
-                const int d = (int)((cbw >> (8 * h2)) & 255u) - 128, e = (int)((crw >> (8 * h2)) & 255u) - 128;
-                const int tr = 409 * e + 128, tg = -100 * d - 208 * e + 128, tb = 516 * d + 128;
-#pragma unroll
-                for (int k2 = 0; k2 < 2; k2++) {
-                    const int k = 2 * h2 + k2, c = 298 * ((int)((yy >> (8 * k)) & 255u) - 16);
-                    const uint32_t R = (uint32_t)clip255((c + tr) >> 8), G = (uint32_t)clip255((c + tg) >> 8), B = (uint32_t)clip255((c + tb) >> 8);
-                    px[k] = fmt == 0 ? 0xFF000000u | (B << 16) | (G << 8) | R : 0xFF000000u | (R << 16) | (G << 8) | B;
-                }
-            }
-        }
-        const uint32_t mbx = mb % wmb, mby = mb / wmb;
-        *reinterpret_cast<uint4 *>(dst + (size_t)(mby * 16u + r) * W + mbx * 16u + q * 4u) = make_uint4(px[0], px[1], px[2], px[3]);
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t ppr = (wmb + 1u) >> 1, n_pairs = ppr * hmb, magic = ppr == 1u ? 0u : 0xFFFFFFFFu / ppr + 1u;   /* p / ppr = mulhi(p, magic): exact for p * ppr < 2^32 */
+    const uint32_t W = wmb * 16u;
+    const ConvLane cl = conv_lane(W, lane);
+    for (uint32_t p = blockIdx.x * 4u + wave; p < n_pairs; p += gridDim.x * 4u) {
+        const uint32_t mby = ppr == 1u ? p : __umulhi(p, magic), mbx = 2u * (p - mby * ppr);
+        conv_tile_pair(src + ((size_t)mby * wmb + mbx) * TILE, dst + (size_t)mby * 16u * W + mbx * 16u, W, mbx + 1u < wmb, fmt, cl, lane);
     }
 }
 
