@@ -226,6 +226,7 @@ def main():
     ap.add_argument("--no-desync", action="store_true", help="skip the fully desynchronised variants (reported next to the lock-step value)")
     ap.add_argument("--no-staggered", action="store_true", help="skip the staggered-start variant (reported next to the lock-step value)")
     ap.add_argument("--no-argb", action="store_true", help="skip the config-3 variant (colour conversion of every picture inside the timed region)")
+    ap.add_argument("--argb-no-hosting", action="store_true", help="config-3 variant with a k_convert_tiles launch behind every tick instead of the conversion hosted by the next tick's k_frame_dbk (A/B)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end leg through the drop-in C API (host parse + H2D + kernels)")
     args = ap.parse_args()
 
@@ -406,9 +407,12 @@ def main():
             staggered = dict(odd_stream_offset=idr[0], elapsed=st_elapsed, breakdown=st_breakdown, dev_ms=st_dev_ms)
 
     # ---- BASELINE.json config 3: the same lock-step work with the colour conversion of every produced picture inside
-    # the timed region (k_convert, BGRA = the reference's "ARGB" word, h264bsdConvertToBGRA semantics): +1024 B written
-    # per macroblock.  The converted pictures 0, 1 and 72 of one stream are checked against the reference's own
-    # conversion (golden.json convert_sha256) in an untimed pass first.
+    # the timed region (BGRA = the reference's "ARGB" word, h264bsdConvertToBGRA semantics): +1024 B written per macroblock.
+    # The pictures of tick i - 1 are converted by wavefronts of tick i's k_frame_dbk workgroups, beside the filtering of
+    # picture i (kernels/convert.hip.h); the last picture of a step, and a picture whose successor is decoded into the
+    # same frame buffer, by a k_convert_tiles launch.  Checked against the reference's own conversion (golden.json
+    # convert_sha256) in untimed passes first: pictures 0, 1 and 72 through the launch, pictures 0 and 1 as the hosts of
+    # ticks 1 and 2 leave them in the conversion buffer.
     argb = None
     if not args.no_argb:
         import hashlib
@@ -421,7 +425,18 @@ def main():
                 got = rep.fetch_converted(args.streams - 1, w_px * h_px)
                 if hashlib.sha256(got.tobytes()).hexdigest() != golden["convert_sha256"][str(i)][h264bsd_amd.FMT_BGRA]:
                     raise SystemExit(f"rank {rank}: BGRA conversion of picture {i} differs from the reference")
-        rep.set_convert(h264bsd_amd.FMT_BGRA)
+        hosted_checked = []
+        for i in sorted(int(k) for k in golden["convert_sha256"]):
+            if i + 1 >= n_pics or heads[i + 1]["cur_slot"] == heads[i]["cur_slot"]:
+                continue
+            rep.set_convert(h264bsd_amd.FMT_BGRA, trailing=False)     # ticks 0 .. i + 1, no launch behind the last: the buffer holds picture i as tick i + 1's hosts wrote it
+            rep.run(0, i + 2); rep.sync()
+            for s_ in (0, args.streams - 1):
+                got = rep.fetch_converted(s_, w_px * h_px)
+                if hashlib.sha256(got.tobytes()).hexdigest() != golden["convert_sha256"][str(i)][h264bsd_amd.FMT_BGRA]:
+                    raise SystemExit(f"rank {rank}: BGRA conversion of picture {i} by the hosts of tick {i + 1} differs from the reference (stream {s_})")
+            hosted_checked.append(i)
+        rep.set_convert(h264bsd_amd.FMT_BGRA, hosting=not args.argb_no_hosting)
         rep.run(); rep.sync()
         barrier()
         t0 = time.perf_counter()
@@ -436,7 +451,7 @@ def main():
         sums = rep.checksums(heads[-1]["cur_slot"])
         if not (sums == golden_sums[-1]).all():
             raise SystemExit(f"rank {rank}: ARGB variant: final pictures are not bit-exact")
-        # ... and what the timed region converted last (on its own HIP stream, beside the next tick's per-picture kernels) is the reference's conversion
+        # ... and what the timed region converted last (the launch behind the step's last tick) is the reference's conversion
         if str(n_pics - 1) in golden["convert_sha256"]:
             got = rep.fetch_converted(0, w_px * h_px)
             if hashlib.sha256(got.tobytes()).hexdigest() != golden["convert_sha256"][str(n_pics - 1)][h264bsd_amd.FMT_BGRA]:
@@ -447,7 +462,7 @@ def main():
             tt = torch.tensor([a_elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             a_elapsed = float(tt.item())
-        argb = dict(elapsed=a_elapsed, conv_ms=conv_ms, conv_n=conv_n, dev_ms=a_dev_ms)
+        argb = dict(elapsed=a_elapsed, conv_ms=conv_ms, conv_n=conv_n, dev_ms=a_dev_ms, hosted_checked=hosted_checked)
 
     # ---- streams that are not in step at all: stream s starts at picture s * n_pics / n_streams.  Every tick then
     # holds I pictures AND the heaviest P pictures of the stream, and a tick lasts as long as its slowest picture:
@@ -692,6 +707,8 @@ def main():
                            "ms_per_step": argb["elapsed"] * 1e3 / side_steps, "steps": side_steps, "format": "BGRA (the reference's ARGB word, h264bsdConvertToBGRA)",
                            "alg_bytes_per_mb": alg_per_mb + 1024,
                            "whole_path_GBs": (alg_bytes_stream + 1024 * n_mbs * n_pics) * args.streams * side_steps / (argb["dev_ms"] * 1e-3) / 1e9,
+                           "conversion": {"ticks_hosted_by_the_next_ticks_k_frame_dbk": n_pics * side_steps - argb["conv_n"], "ticks_followed_by_a_k_convert_tiles_launch": argb["conv_n"],
+                                          "hosted_pictures_checked_against_the_reference": argb["hosted_checked"]},
                            "k_convert": {"avg_launch_us": conv_us, "launches": argb["conv_n"], "alg_bytes_per_launch": conv_bytes,
                                          "achieved_GBs": conv_bytes / (conv_us * 1e-6) / 1e9, "frac": conv_bytes / (conv_us * 1e-6) / 1e9 / HBM_PEAK_GBS}}
         if per_gpu is not None:

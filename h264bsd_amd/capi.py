@@ -570,8 +570,12 @@ class Replay:
             raise RuntimeError("h264bsdmiReplayChecksums failed")
         return out
 
-    def set_convert(self, fmt):
-        """fmt 0..2: every tick of run() is followed by the colour conversion of the produced pictures; -1: off"""
+    def set_convert(self, fmt, trailing=True, hosting=True, conv_waves=0):
+        """fmt 0..2: every picture run() produces is converted (hosted by the next tick's k_frame_dbk where possible, a launch of
+        its own otherwise); -1: off.  trailing=False: no launch behind the last tick of a run; hosting=False: launches only;
+        conv_waves: conversion wavefronts per k_frame_dbk workgroup (0 = the default)."""
+        if fmt >= 0:
+            fmt |= (0 if trailing else 0x100) | (0 if hosting else 0x200) | ((conv_waves & 15) << 16)
         if self._L.h264bsdmiReplaySetConvert(self._h, fmt) != 0:
             raise RuntimeError("h264bsdmiReplaySetConvert failed")
 

@@ -106,9 +106,13 @@ struct Lane {
 constexpr unsigned HEAVY_DELAY = 4;
 constexpr unsigned MAX_LANES_TOTAL = 10;     /* light + heavy lanes of an engine (the engine's own stream and the side stream come on top) */
 #ifndef CONVERT_WGS_N
-#define CONVERT_WGS_N 512       /* 64: 808, 128: 744, 256: 703, 512: 680 us per tick of 256 pictures */
+#define CONVERT_WGS_N 128       /* a wavefront converts batches of CONV_BATCH tile pairs: 128 workgroups x 4 wavefronts = the 510 batches of a 1080p picture */
 #endif
 constexpr unsigned CONVERT_WGS = CONVERT_WGS_N;      /* workgroups per picture of k_convert_tiles in batched launches */
+#ifndef CONV_WAVES_N
+#define CONV_WAVES_N 4          /* wavefronts of a k_frame_dbk workgroup that convert another picture before they filter (TickShape.conv) */
+#endif
+#define CONVERT_GRID(n) dim3(CONVERT_WGS, (n))
 /* Under lane scheduling a k_frame_dbk workgroup shares its compute unit with the other lanes' kernels: 8 wavefronts
  * hold less of the register file than the 12 that are best when a tick has the GPU to itself (desynchronised replay
  * with 9 groups: 763 vs 734 M MB/s; lock-step, single lane: 12 wavefronts 54.9 ms per step, 8: 56.8). */
@@ -375,6 +379,9 @@ struct TickShape {
     bool intra_whole = false;
     uint32_t load = 0;               /* pictures the device works on at the same time as this tick (other lanes' ticks included): the
                                         band budget is shared between them; 0 = this tick only */
+    /* hosted colour conversion (FrameDesc.conv_*): descriptors of this tick name a finished picture to convert */
+    bool conv = false;
+    uint32_t conv_waves = 0;         /* wavefronts of a k_frame_dbk workgroup that convert before they filter; 0 = CONV_WAVES_N */
 };
 
 /* descriptor of one picture: device addresses of the sections of its (device-resident) frame job */
@@ -413,6 +420,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
         d.intra_bands = h->intra_down_deps ? 1 : bands_for(h->height_mbs, heavy ? tc.intra_rows_heavy : tc.intra_rows_light);
     }
     d.err = dev_err;
+    d.conv_src = nullptr; d.conv_dst = nullptr; d.conv_fmt = 0; d.conv_pad = 0;
     for (uint32_t k = 0; k < FJ_MAX_SLOTS; k++) d.slot[k] = k < h->n_slots ? dev_frames + (size_t)k * frame_bytes : nullptr;
     if (shape) {
         shape->n_frames++;
@@ -570,10 +578,13 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
                 lds_enabled[bands > 1][dev] = lds;
             }
         }
-        if (bands > 1) hipLaunchKernelGGL(h264k::k_frame_dbk<true>, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets, bands, rows, light_cap, chroma_waves);
-        else hipLaunchKernelGGL(h264k::k_frame_dbk<false>, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof, nullptr, 1u, rows, 1u, chroma_waves);
+        const uint32_t conv_waves = !s.conv ? 0u : std::min<uint32_t>(s.conv_waves ? s.conv_waves : (uint32_t)CONV_WAVES_N, waves > chroma_waves + 1u ? waves - chroma_waves - 1u : 0u);
+        if (bands > 1) hipLaunchKernelGGL(h264k::k_frame_dbk<true>, dim3(s.n_frames * bands), dim3(64 * waves), lds, st, d_desc, prof, tickets, bands, rows, light_cap, chroma_waves, conv_waves);
+        else hipLaunchKernelGGL(h264k::k_frame_dbk<false>, dim3(s.n_frames), dim3(64 * waves), lds, st, d_desc, prof, nullptr, 1u, rows, 1u, chroma_waves, conv_waves);
         if (launches) launches[4]++;
     }
+    if (s.conv && !(s.any_deblock && (stages & 4u)))             /* no k_frame_dbk in this tick: nobody hosted the conversion */
+        hipLaunchKernelGGL(h264k::k_convert_rest, dim3(CONVERT_WGS, s.n_frames), dim3(256), 0, st, d_desc);
     if (EV_NEEDED(5)) HIP_TRY(hipEventRecord(tt->ev[5], st));
 #undef EV_NEEDED
     HIP_TRY(hipGetLastError());
@@ -1227,6 +1238,13 @@ struct h264bsdmi_replay {
     /* config 3 ("ARGB conversion on-GPU"): colour conversion of every produced picture inside the run, timed */
     int convert_fmt = -1;
     std::vector<hipEvent_t> cev;      /* 2 per tick */
+    /* ... hosted by the NEXT tick's k_frame_dbk where that is possible (kernels/convert.hip.h, conv_drain): descriptors with the
+     * conversion of the stream's previous picture written in, which ticks host */
+    FrameDesc *d_desc_conv = nullptr;
+    std::vector<uint8_t> hosted;      /* tick i converts the pictures of tick i - 1 while it filters its own */
+    std::vector<uint8_t> cev_on;      /* tick i was followed by a stand-alone conversion launch in the last run */
+    bool host_convert = true, convert_trailing = true;
+    uint32_t conv_waves = 0;
 };
 
 h264bsdmi_replay *h264bsdmiReplayCreateSched(const u8 *const *blobs, const u32 *bytes, u32 n_pics, u32 n_streams,
@@ -1491,6 +1509,7 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     hipStreamSynchronize(r->e->stream);
     hipFree(r->d_blobs); hipFree(r->d_frames); hipFree(r->d_desc); hipFree(r->d_sums); hipFree(r->d_dbk);
     if (r->d_conv) hipFree(r->d_conv);
+    if (r->d_desc_conv) hipFree(r->d_desc_conv);
     if (r->d_planar) hipFree(r->d_planar);
     for (auto &t : r->timers) for (auto &ev : t.ev) hipEventDestroy(ev);
     hipEventDestroy(r->ev_begin); hipEventDestroy(r->ev_end); if (r->gdone_any) hipEventDestroy(r->gdone_any);
@@ -1572,16 +1591,23 @@ int h264bsdmiReplayRun(h264bsdmi_replay *r, u32 first, u32 count)
         }
     } else if (r->n_groups <= 1) {
         for (u32 i = first; i < first + count; i++) { r->timers[i].on = true; r->timers[i].mask = r->timed_mask; }
+        r->cev_on.assign(r->n_pics, 0);
         for (u32 i = first; i < first + count; i++) {
-            if (launch_tick(r->e->stream, r->d_desc + (size_t)i * r->n_streams, r->shapes[i], &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr, r->e->tail_prof)) return -1;
-            if (r->convert_fmt >= 0) {
+            /* config 3: the pictures of tick i - 1 are converted by tick i's k_frame_dbk workgroups where the schedule allows it */
+            const bool host = r->convert_fmt >= 0 && r->host_convert && i > first && r->hosted[i];
+            TickShape shape = r->shapes[i];
+            shape.conv = host; shape.conv_waves = r->conv_waves;
+            if (launch_tick(r->e->stream, (host ? r->d_desc_conv : r->d_desc) + (size_t)i * r->n_streams, shape, &r->timers[i], r->launches, r->stages, (r->overlap_dbk && !(r->stages & 8u)) ? &r->e->side : nullptr, r->e->tail_prof)) return -1;
+            const bool next_hosts = r->convert_fmt >= 0 && r->host_convert && i + 1 < first + count && r->hosted[i + 1];
+            if (r->convert_fmt >= 0 && !next_hosts && (r->convert_trailing || i + 1 < first + count)) {
                 /* the picture every stream has just produced, converted where it lies (tiles -> packed 32-bit pixels) */
                 const uint32_t w = r->wmb * 16, h = r->hmb * 16;
                 HIP_TRY(hipEventRecord(r->cev[2 * i], r->e->stream));
-                hipLaunchKernelGGL(h264k::k_convert_tiles, dim3(CONVERT_WGS, r->n_streams), dim3(256), 0, r->e->stream,
+                hipLaunchKernelGGL(h264k::k_convert_tiles, CONVERT_GRID(r->n_streams), dim3(256), 0, r->e->stream,
                                    r->d_frames + (size_t)r->cur_slot[i] * r->frame_bytes, r->d_conv, r->wmb, r->hmb, r->convert_fmt,
                                    (size_t)r->n_slots * r->frame_bytes, (size_t)w * h);
                 HIP_TRY(hipEventRecord(r->cev[2 * i + 1], r->e->stream));
+                r->cev_on[i] = 1;
             }
         }
     } else {
@@ -1698,7 +1724,7 @@ int h264bsdmiReplayConvert(h264bsdmi_replay *r, u32 slot, int fmt)
     HIP_TRY(hipSetDevice(r->e->device));
     const uint32_t w = r->wmb * 16, h = r->hmb * 16;
     if (!r->d_conv) HIP_TRY(hipMalloc((void **)&r->d_conv, (size_t)w * h * 4 * r->n_streams));
-    hipLaunchKernelGGL(h264k::k_convert_tiles, dim3(CONVERT_WGS, r->n_streams), dim3(256), 0, r->e->stream,
+    hipLaunchKernelGGL(h264k::k_convert_tiles, CONVERT_GRID(r->n_streams), dim3(256), 0, r->e->stream,
                        r->d_frames + (size_t)slot * r->frame_bytes, r->d_conv, r->wmb, r->hmb, fmt,
                        (size_t)r->n_slots * r->frame_bytes, (size_t)w * h);
     HIP_TRY(hipGetLastError());
@@ -1717,8 +1743,12 @@ int h264bsdmiReplayFetchConverted(h264bsdmi_replay *r, u32 stream, u32 *dst)
 
 /* fmt 0..2: every h264bsdmiReplayRun() tick (lock-step sets, one group) is followed by the colour conversion of the
  * pictures it produced, inside the timed region; fmt < 0: off.  h264bsdmiReplayConvertTimings: k_convert time of the last run. */
-int h264bsdmiReplaySetConvert(h264bsdmi_replay *r, int fmt)
+int h264bsdmiReplaySetConvert(h264bsdmi_replay *r, int fmt_and_flags)
 {
+    /* flags (tests and A/B runs): 0x100 = no conversion launch behind the LAST tick of a run (what the conversion buffer then holds
+     * is the work of the last tick's hosts), 0x200 = no hosting (every tick followed by its own conversion launch) */
+    const int fmt = fmt_and_flags < 0 ? -1 : (fmt_and_flags & 0xFF);
+    const bool no_trailing = fmt_and_flags >= 0 && (fmt_and_flags & 0x100), no_hosting = fmt_and_flags >= 0 && (fmt_and_flags & 0x200);
     if (!r || fmt > 2 || !r->sched.empty()) return -1;
     std::lock_guard<std::mutex> lk(r->e->mu);
     HIP_TRY(hipSetDevice(r->e->device));
@@ -1726,6 +1756,30 @@ int h264bsdmiReplaySetConvert(h264bsdmi_replay *r, int fmt)
         const size_t n = (size_t)r->wmb * 16 * r->hmb * 16;
         if (!r->d_conv) HIP_TRY(hipMalloc((void **)&r->d_conv, n * 4 * r->n_streams));
         while (r->cev.size() < 2 * (size_t)r->n_pics) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); r->cev.push_back(ev); }
+        /* Hosting.  Tick i can
+         * convert the pictures of tick i - 1 while it decodes its own if no stream decodes INTO the frame buffer its previous
+         * picture lies in (an IDR picture may); the stand-alone launch converts one frame buffer number for all streams, so the
+         * streams have to be in step. */
+        HIP_TRY(hipStreamSynchronize(r->e->stream));
+        r->host_convert = !no_hosting;
+        r->convert_trailing = !no_trailing;
+        r->conv_waves = ((uint32_t)fmt_and_flags >> 16) & 15u;
+        bool in_step = true;
+        for (u32 s = 1; s < r->n_streams; s++) if (r->offsets[s] != r->offsets[0]) in_step = false;
+        r->hosted.assign(r->n_pics, 0);
+        for (u32 i = 1; in_step && i < r->n_pics; i++) r->hosted[i] = r->cur_slot[i] != r->cur_slot[i - 1];
+        const size_t n_desc = (size_t)r->n_pics * r->n_streams;
+        if (!r->d_desc_conv) HIP_TRY(hipMalloc((void **)&r->d_desc_conv, sizeof(FrameDesc) * n_desc));
+        std::vector<FrameDesc> descs(n_desc);
+        HIP_TRY(hipMemcpy(descs.data(), r->d_desc, sizeof(FrameDesc) * n_desc, hipMemcpyDeviceToHost));
+        for (u32 i = 1; i < r->n_pics; i++)
+            for (u32 s = 0; s < r->n_streams && r->hosted[i]; s++) {
+                FrameDesc &d = descs[(size_t)i * r->n_streams + s];
+                d.conv_src = r->d_frames + (size_t)s * r->frames_per_stream + (size_t)r->cur_slot[i - 1] * r->frame_bytes;
+                d.conv_dst = r->d_conv + (size_t)s * n;
+                d.conv_fmt = (uint32_t)fmt;
+            }
+        HIP_TRY(hipMemcpy(r->d_desc_conv, descs.data(), sizeof(FrameDesc) * n_desc, hipMemcpyHostToDevice));
     }
     r->convert_fmt = fmt;
     return 0;
@@ -1739,6 +1793,7 @@ int h264bsdmiReplayConvertTimings(h264bsdmi_replay *r, float *ms, u32 *launches)
     *ms = 0.f; *launches = 0;
     for (u32 i = r->timed_first; i < r->timed_first + r->timed_count; i++) {
         float t;
+        if (i >= r->cev_on.size() || !r->cev_on[i]) continue;      /* converted by the next tick's k_frame_dbk: no launch of its own */
         HIP_TRY(hipEventElapsedTime(&t, r->cev[2 * i], r->cev[2 * i + 1]));
         *ms += t; (*launches)++;
     }

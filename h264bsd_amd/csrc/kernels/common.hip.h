@@ -24,6 +24,13 @@ struct FrameDesc {
     uint16_t        heavy;                    /* 1: mostly intra coded — several times the work of the other pictures of its tick */
     uint32_t       *err;          /* device error word of the engine (DEVERR_* bits, atomicOr: must stay 0), err[1] = number of times a tripwire fired */
     uint8_t        *slot[FJ_MAX_SLOTS];
+    /* Hosted colour conversion (kernels/convert.hip.h, conv_drain): while this picture is filtered, wavefronts of its k_frame_dbk
+     * workgroup convert ANOTHER, finished picture of the stream (conv_src: its tiles) into conv_dst (32-bit pixels, conv_fmt 0 RGBA /
+     * 1 BGRA / 2 YCbCrA).  conv_src == nullptr: nothing to convert.  A tick whose pictures need no filtering launches
+     * k_convert_rest instead (engine.hip, launch_tick). */
+    const uint8_t  *conv_src;
+    uint32_t       *conv_dst;
+    uint32_t        conv_fmt, conv_pad;
 };
 
 /* Bits of the device error word.  None of them can be set by a frame job the host parser built: they are tripwires. */

@@ -612,12 +612,16 @@ struct DbkGraph {
 #ifndef DBK_OCC
 #define DBK_OCC 3
 #endif
+#ifndef CONV_PRIO
+#define CONV_PRIO 0            /* issue priority of the wavefronts that convert beside the chains */
+#endif
 #ifndef DBK_CHROMA_PRIO
 #define DBK_CHROMA_PRIO 1
 #endif
 template <bool BANDED>
 __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_dbk(const FrameDesc *__restrict__ frames, unsigned long long *prof,
-                                                              uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap, uint32_t light_cap, uint32_t chroma_waves)
+                                                              uint32_t *tickets, uint32_t max_bands, uint32_t rows_cap, uint32_t light_cap, uint32_t chroma_waves,
+                                                              uint32_t conv_waves)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint32_t s_misc[4];
@@ -630,8 +634,21 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
     const int wmb = (int)cx.wmb, hmb = fd.hmb;
     int R = hmb, nb = 1;
     if (BANDED) band_split(hmb, fd.dbk_bands, fd.heavy, max_bands, light_cap, rows_cap, R, nb);
-    if (!fd.any_deblock || (int)band >= nb) { if (BANDED) return_ticket(tickets); return; }
+    /* hosted colour conversion (FrameDesc.conv_src, kernels/convert.hip.h): a workgroup with nothing to filter converts */
+    const bool conv_on = fd.conv_src != nullptr;
+    if (!fd.any_deblock || (int)band >= nb) {
+        if (conv_on && band == 0) {                              /* (a picture without filtering: ONE workgroup, its first, converts all of it) */
+            if (tid == 0) s_misc[2] = 0u;
+            __syncthreads();
+            conv_drain(fd, lds_addr(&s_misc[2]), ((uint32_t)wmb + 1u) / 2u * (uint32_t)hmb, (uint32_t)lane);
+        }
+        if (BANDED) return_ticket(tickets);
+        return;
+    }
     const int r0 = (int)band * R, r1 = min(hmb, r0 + R);
+    /* the workgroup's share of the other picture: the tile pairs of its own rows */
+    const uint32_t conv_ppr = ((uint32_t)wmb + 1u) / 2u, conv_end = (uint32_t)r1 * conv_ppr;
+    if (conv_on && tid == 0) s_misc[2] = (uint32_t)r0 * conv_ppr;             /* (the barriers below publish it) */
     const int base = (r0 - 1) * wmb;                        /* band-local index of macroblock mb: mb - base (row r0-1 first) */
     const int n_loc = (R + 1) * wmb, n_loc16 = (n_loc + 15) & ~15, nq8 = (R * wmb + 7) & ~7;
     const int seen_words = (((wmb + 31) >> 5) + 3) & ~3;
@@ -732,6 +749,12 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
     const int n_chroma = n_waves >= 2 ? min(max((int)chroma_waves, 1), n_waves - 1) : 0;
     int role = wave >= n_waves - n_chroma ? 1 : 0;
     const int lo_mb = r0 * wmb, hi_mb = r1 * wmb;                /* the band's own macroblocks */
+    /* the last conv_waves of the luma wavefronts convert first (at the lowest issue priority: they take the slots the chains leave)
+     * and join the luma graph when the other picture is done */
+    if (conv_on && wave >= n_waves - n_chroma - (int)conv_waves && wave < n_waves - n_chroma) {
+        __builtin_amdgcn_s_setprio(CONV_PRIO);
+        conv_drain(fd, lds_addr(&s_misc[2]), conv_end, (uint32_t)lane);
+    }
     for (int pass = 0; pass < 2; pass++, role ^= 1) {
         const DbkGraph g = graph(role);
         /* these wavefronts walk dependency chains: whatever shares their SIMDs takes the issue slots they leave, not the ones they need */
@@ -849,6 +872,10 @@ __global__ __launch_bounds__(64 * DBK_WAVES, BANDED ? 3 : DBK_OCC) void k_frame_
             }
             if (tp) { const uint32_t t = (uint32_t)__builtin_readcyclecounter(); t_store += t - t_mark; t_mark = t; }
         }
+    }
+    if (conv_on) {                                               /* both graphs exhausted: what is left of the other picture */
+        __builtin_amdgcn_s_setprio(0);
+        conv_drain(fd, lds_addr(&s_misc[2]), conv_end, (uint32_t)lane);
     }
     if (tp && lane == 0) {
         tp[0] += t_idle; tp[1] += t_work; tp[2] += t_store; tp[3] += n_done; tp[4] += (uint32_t)__builtin_readcyclecounter() - t_begin; tp[5] += n_steps;

@@ -83,16 +83,31 @@ __global__ __launch_bounds__(256) void k_convert(const uint8_t *__restrict__ yuv
 __global__ __launch_bounds__(256) void k_convert_tiles(const uint8_t *__restrict__ yuv, uint32_t *__restrict__ out, uint32_t wmb, uint32_t hmb,
                                                        int fmt, size_t in_stride, size_t out_stride)
 {
-    const uint8_t *src = yuv + blockIdx.y * in_stride;
-    uint32_t *dst = out + blockIdx.y * out_stride;
+    const uint32_t pic = blockIdx.y, chunk = blockIdx.x, n_chunks = gridDim.x;
+    const uint8_t *src = yuv + pic * in_stride;
+    uint32_t *dst = out + pic * out_stride;
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t ppr = (wmb + 1u) >> 1, n_pairs = ppr * hmb, magic = ppr == 1u ? 0u : 0xFFFFFFFFu / ppr + 1u;   /* p / ppr = mulhi(p, magic): exact for p * ppr < 2^32 */
-    const uint32_t W = wmb * 16u;
-    const ConvLane cl = conv_lane(W, lane);
-    for (uint32_t p = blockIdx.x * 4u + wave; p < n_pairs; p += gridDim.x * 4u) {
-        const uint32_t mby = ppr == 1u ? p : __umulhi(p, magic), mbx = 2u * (p - mby * ppr);
-        conv_tile_pair(src + ((size_t)mby * wmb + mbx) * TILE, dst + (size_t)mby * 16u * W + mbx * 16u, W, mbx + 1u < wmb, fmt, cl, lane);
-    }
+    const ConvPic c = conv_pic(src, dst, wmb);
+    const uint32_t n_pairs = c.ppr * hmb;
+    const ConvLane cl = conv_lane(c.W, lane);
+    uint32_t p = (chunk * 4u + wave) * CONV_BATCH;
+    const uint32_t stride = n_chunks * 4u * CONV_BATCH;
+    conv_pipeline(c, n_pairs, fmt, cl, lane, [&]() -> uint32_t { const uint32_t r = p; p += stride; return r; });
+}
+
+/* The hosted conversion (FrameDesc.conv_src, kernels/convert.hip.h) of a tick that does not launch k_frame_dbk at all (none of its
+ * pictures is filtered): the same work as a launch of its own, gridDim.x workgroups per picture. */
+__global__ __launch_bounds__(256) void k_convert_rest(const FrameDesc *__restrict__ frames)
+{
+    const FrameDesc &fd = FD_REF(frames, blockIdx.y);
+    if (!fd.conv_src) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const ConvPic c = conv_pic(fd.conv_src, fd.conv_dst, fd.wmb);
+    const uint32_t n_pairs = c.ppr * fd.hmb;
+    const ConvLane cl = conv_lane(c.W, lane);
+    uint32_t p = (blockIdx.x * 4u + wave) * CONV_BATCH;
+    const uint32_t stride = gridDim.x * 4u * CONV_BATCH;
+    conv_pipeline(c, n_pairs, (int)fd.conv_fmt, cl, lane, [&]() -> uint32_t { const uint32_t r = p; p += stride; return r; });
 }
 
 /* Whole frames, tiles -> planar I420 (what h264bsdNextOutputPicture() returns): 16 bytes per thread, a luma row piece

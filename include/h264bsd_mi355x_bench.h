@@ -82,9 +82,12 @@ int  h264bsdmiReplaySetStages(h264bsdmi_replay *r, unsigned mask);
  * default 31 = all).  Every event is a barrier packet between two kernels; the bench times all five kernels in
  * its warm-up steps and only the dominant one in the timed steps. */
 int  h264bsdmiReplaySetTimedKernels(h264bsdmi_replay *r, unsigned mask);
-/* BASELINE.json config 3 ("ARGB conversion on-GPU"): fmt 0 RGBA, 1 BGRA (= the ARGB word), 2 YCbCrA: every tick of
- * h264bsdmiReplayRun() is followed, inside the timed region, by the colour conversion of the pictures it produced
- * (k_convert, 1024 B written per macroblock); fmt < 0 switches it off.  ConvertTimings: HIP-event time of those launches. */
+/* BASELINE.json config 3 ("ARGB conversion on-GPU"): fmt 0 RGBA, 1 BGRA (= the ARGB word), 2 YCbCrA: every picture a tick of
+ * h264bsdmiReplayRun() produces is converted inside the timed region (1024 B written per macroblock) — by wavefronts of the NEXT
+ * tick's k_frame_dbk workgroups, beside that picture's filtering, where the schedule allows it (streams in step, the next picture
+ * is not decoded into the same frame buffer), by a k_convert_tiles launch behind its own tick otherwise (always for the last tick
+ * of a run); fmt < 0 switches it off.  Flags or-ed into fmt (tests, A/B): 0x100 = no launch behind the last tick of a run,
+ * 0x200 = no hosting, bits 16..19 = conversion wavefronts per k_frame_dbk workgroup (0 = the default).  ConvertTimings: HIP-event time and number of the k_convert_tiles launches of the last run. */
 int  h264bsdmiReplaySetConvert(h264bsdmi_replay *r, int fmt);
 int  h264bsdmiReplayConvertTimings(h264bsdmi_replay *r, float *ms, u32 *launches);
 /* Debug hook: cycle accounting of the per-picture kernels (k_frame_intra, k_frame_dbk) for workgroup 0 of every launch between

@@ -222,3 +222,39 @@ def test_config4_at_full_size_256_streams(built, captured, golden):
         assert sums.shape == (256,) and (sums == np.uint64(g["frame_checksum64"][i])).all(), f"picture {i}"
     assert built.device_error_events() == errs_before           # no event: frame jobs of the parser never trip a wire
     rep.close()
+
+
+@pytest.mark.parametrize("name,streams", [("test_640x360", 5), ("test_1920x1080", 3)])
+def test_hosted_colour_conversion_equals_the_launch(name, streams, built, captured, golden):
+    """Config 3 inside a run: the pictures of tick i - 1 are converted by wavefronts of tick i's k_frame_dbk workgroups
+    (kernels/convert.hip.h, conv_drain) — what they leave in the conversion buffer must be what the k_convert_tiles launch
+    writes for the same picture, for every picture of the stream, every stream and every format, and the decoded pictures
+    must not notice.  The launch itself is pinned to the reference's conversion by test_on_device_colour_conversion."""
+    jobs, _, info = captured(name)
+    g = golden[name]
+    w, h = info["width_mbs"] * 16, info["height_mbs"] * 16
+    heads = [pyoracle.blob_header(j) for j in jobs]
+    n = len(jobs)
+    rep = built.Replay(jobs, n_streams=streams)
+    try:
+        launches_seen = ticks_seen = 0
+        for fmt in (1, 0, 2):
+            for k in ([0, 1, 2, 17, n - 2] if fmt != 1 else range(n - 1)):
+                # ticks 0 .. k + 1, no launch behind the last one: the buffer holds picture k as tick k + 1's hosts converted it
+                rep.set_convert(fmt, trailing=False)
+                rep.run(0, k + 2); rep.sync()
+                _, launches = rep.convert_timings()
+                got = [rep.fetch_converted(s, w * h).copy() for s in range(streams)]
+                assert [int(x) for x in rep.checksums(heads[k + 1]["cur_slot"])] == [g["frame_checksum64"][k + 1]] * streams
+                rep.set_convert(-1)
+                # the same picture through the launch
+                rep.run(0, k + 1)
+                rep.convert(heads[k]["cur_slot"], fmt)
+                for s in range(streams):
+                    assert np.array_equal(got[s], rep.fetch_converted(s, w * h)), f"picture {k}, stream {s}, format {fmt}"
+                if str(k) in g["convert_sha256"]:
+                    assert hashlib.sha256(got[streams - 1].tobytes()).hexdigest() == g["convert_sha256"][str(k)][fmt]
+                launches_seen += launches; ticks_seen += k + 1
+        assert launches_seen * 2 < ticks_seen          # most pictures really were converted by hosts, not by launches
+    finally:
+        rep.close()
