@@ -258,3 +258,39 @@ def test_hosted_colour_conversion_equals_the_launch(name, streams, built, captur
         assert launches_seen * 2 < ticks_seen          # most pictures really were converted by hosts, not by launches
     finally:
         rep.close()
+
+
+@pytest.mark.parametrize("cfg", [dict(n_pics=9, wmb=5, hmb=4, seed=41, idc=(1,)),                          # no picture is filtered: no k_frame_dbk launch, k_convert_rest converts
+                                 dict(n_pics=10, wmb=6, hmb=5, seed=42, slices_per_pic=1, idc=(0, 1)),        # filtered and unfiltered pictures: a workgroup with nothing to filter converts
+                                 dict(n_pics=8, wmb=7, hmb=3, seed=43, idc=(0,))])                            # odd width: the last tile pair of a row has no right-hand tile
+def test_hosted_colour_conversion_on_synthetic_streams(cfg, built):
+    """the hosted conversion where k_frame_dbk has nothing to do for a picture, or is not launched at all, and on a picture an
+    odd number of macroblocks wide: every picture of the stream against the k_convert_tiles launch, which is pinned to the
+    oracle's conversion (the reference's formula) here"""
+    from h264writer import StreamWriter
+    data = StreamWriter(**cfg).build()
+    jobs, _, info = built.capture_stream(data)
+    w, h = info["width_mbs"] * 16, info["height_mbs"] * 16
+    heads = [pyoracle.blob_header(j) for j in jobs]
+    if cfg["idc"] == (1,):
+        assert not any(hd["any_deblock"] for hd in heads)
+    streams = 3
+    rep = built.Replay(jobs, n_streams=streams)
+    try:
+        for fmt in range(3):
+            for k in range(len(jobs) - 1):
+                if heads[k + 1]["cur_slot"] == heads[k]["cur_slot"]:
+                    continue
+                rep.set_convert(fmt, trailing=False)
+                rep.run(0, k + 2); rep.sync()
+                got = [rep.fetch_converted(s, w * h).copy() for s in range(streams)]
+                rep.set_convert(-1)
+                rep.run(0, k + 1)
+                yuv = rep.fetch(streams - 1, heads[k]["cur_slot"])
+                want = pyoracle.oracle_convert(fmt, w, h, yuv)
+                rep.convert(heads[k]["cur_slot"], fmt)
+                for s in range(streams):
+                    assert np.array_equal(rep.fetch_converted(s, w * h), want), f"launch: picture {k}, stream {s}, format {fmt}"
+                    assert np.array_equal(got[s], want), f"hosted: picture {k}, stream {s}, format {fmt}"
+    finally:
+        rep.close()
