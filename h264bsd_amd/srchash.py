@@ -5,7 +5,7 @@ import hashlib
 import os
 import re
 
-_FILES = ("kernels.hip.h", "kernels/common.hip.h", "kernels/k_dbk.hip.h", "kernels/k_copy.hip.h", "kernels/k_recon_inter.hip.h",
+_FILES = ("kernels.hip.h", "kernels/common.hip.h", "kernels/k_dbk.hip.h", "kernels/k_copy.hip.h", "kernels/k_recon_inter.hip.h", "kernels/convert.hip.h",
           "kernels/tail_common.hip.h", "kernels/k_frame_intra.hip.h", "kernels/k_frame_dbk.hip.h", "kernels/k_pixels_io.hip.h", "framejob.h")
 
 
