@@ -630,7 +630,7 @@ def main():
                 valu = {"peak_wave_instr_per_s": peak, "cycles_per_wave_instruction": cyc, "source": os.path.relpath(vpath, ROOT),
                         "per_kernel": per, "whole_path": {"wave_instr_per_tick": tot_i, "achieved": tot_i * n_pics * args.steps / (dev_total_ms * 1e-3),
                                                           "frac": tot_i * n_pics * args.steps / (dev_total_ms * 1e-3) / peak,
-                                                          "note": "every kernel runs once per tick; k_dbk runs next to the others, its time is not in the total"}}
+                                                          "note": "every kernel runs once per tick; k_copy and k_dbk run on streams of their own beside k_recon_inter, so the kernel times add up to more than the total"}}
         except (OSError, KeyError, ValueError, IndexError, ZeroDivisionError):
             pass
         moved_per_mb = alg_per_mb - 768.0 * (copy_mbs_full - copy_mbs) / (n_mbs * n_pics)
@@ -670,7 +670,7 @@ def main():
                          "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
                          "whole_path_frac_of_copy_ceiling": path_gbs / copy_gbs,
                          "device_ms_per_step": dict({k: breakdown[k][0] for k in kernels}, total=dev_total_ms / args.steps,
-                                                    note="per-kernel: last untimed warm-up pass (all kernels bracketed by events); total: timed steps"),
+                                                    note="per-kernel: last untimed warm-up pass (all kernels bracketed by events); total: timed steps; k_copy and k_dbk run on streams of their own beside k_recon_inter (its time includes their interference), so the kernel times add up to more than the total"),
                          "launches_per_step": {k: k_n[k] // args.steps for k in kernels}},
         }
         if "groups4_elapsed" in lock_extra:

@@ -71,11 +71,30 @@ struct StreamCtx {
 };
 
 /* k_dbk (boundary strengths) needs only the frame job, not pixels: it runs on a second HIP stream next to the
- * reconstruction kernels of the same tick and joins before k_frame_dbk (measured: 245.2 -> 237.5 ms per step).  Every other
- * placement that was measured — k_copy on the side stream as well, k_dbk forked behind k_copy or behind the inter kernels,
- * k_dbk of the NEXT tick next to this tick's per-picture kernels — kept the sum or lost (docs/EXPERIMENTS.md); those
- * variants are not in the product. */
-struct SideLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+ * reconstruction kernels of the same tick and joins before k_frame_dbk (measured: 245.2 -> 237.5 ms per step).  k_copy runs on a
+ * THIRD stream beside both and joins before k_frame_intra (round 6: 87.5-88.5 -> 84.4-85.0 ms per step; on the SAME stream as
+ * k_dbk, in front of it or behind it, it gains a third of that; k_recon_inter<1> behind it on that stream loses 2.4 ms again).  Other placements that were measured — k_dbk forked behind k_copy or
+ * behind the inter kernels, k_dbk of the NEXT tick next to this tick's per-picture kernels — kept the sum or lost
+ * (docs/EXPERIMENTS.md); those variants are not in the product. */
+struct SideLane {
+    hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr;            /* k_dbk */
+    hipStream_t copy_stream = nullptr; hipEvent_t copy_join = nullptr;                 /* k_copy (launch_tick) */
+    bool create(int dbk_priority, bool with_priority)
+    {
+        if ((with_priority ? hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, dbk_priority) : hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return false;
+        return hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess &&
+               hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&copy_join, hipEventDisableTiming) == hipSuccess;
+    }
+    void destroy()
+    {
+        if (stream) hipStreamDestroy(stream);
+        if (copy_stream) hipStreamDestroy(copy_stream);
+        if (fork) hipEventDestroy(fork);
+        if (join) hipEventDestroy(join);
+        if (copy_join) hipEventDestroy(copy_join);
+        *this = SideLane();
+    }
+};
 
 /* A lane = one HIP stream that runs ticks one after the other, with its own device arena for the frame jobs of a tick
  * and its own descriptor staging.  Light lanes: one per stream group (decoder instances are dealt round-robin to the
@@ -267,14 +286,12 @@ Engine *engine_get(int device = -1)
     if (hipSetDevice(e->device) != hipSuccess) { delete e; return nullptr; }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return nullptr; }
     if (hipEventCreateWithFlags(&e->inflight_done, hipEventDisableTiming) != hipSuccess ||
-        [&] {   /* the side stream (k_dbk next to the copy and inter kernels) gets the highest priority the device has: its few workgroups
-                  * must not queue behind the hundred thousand of k_recon_inter */
+        ![&] {   /* the side stream (k_dbk next to the copy and inter kernels) gets the highest priority the device has: its few workgroups
+                   * must not queue behind the hundred thousand of k_recon_inter */
             int lo = 0, hi = 0;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(&e->side.stream, hipStreamNonBlocking);
-            return hipStreamCreateWithPriority(&e->side.stream, hipStreamNonBlocking, hi);
-        }() != hipSuccess ||
-        hipEventCreateWithFlags(&e->side.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->side.join, hipEventDisableTiming) != hipSuccess ||
+            const bool prio = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+            return e->side.create(hi, prio);
+        }() ||
         hipMalloc((void **)&e->d_err, 256) != hipSuccess || hipMemset(e->d_err, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||   /* (hipMemset returns before the fill has run) */
         hipHostMalloc((void **)&e->h_err, 64, hipHostMallocDefault) != hipSuccess) { delete e; return nullptr; }
     e->h_err[0] = e->h_err[1] = 0;
@@ -443,7 +460,7 @@ void make_desc(FrameDesc &d, const uint8_t *host_blob, const uint8_t *dev_blob, 
     }
 }
 
-struct TickTimers { hipEvent_t ev[6]; hipEvent_t sev[3] = { nullptr, nullptr, nullptr }; bool on = false; unsigned mask = 31u; };   /* mask bit k: kernel k of KERNELS is timed */   /* boundaries of the 5 kernels of a tick; sev = k_copy, k_dbk on the side stream */
+struct TickTimers { hipEvent_t ev[6]; hipEvent_t sev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr }; bool on = false; bool copy_timed = false; unsigned mask = 31u; };   /* copy_timed: sev[3..4] were recorded by the latest launch_tick */   /* mask bit k: kernel k of KERNELS is timed */   /* boundaries of the 5 kernels of a tick; sev[1..2] = k_dbk on the side stream, sev[3..4] = k_copy on the copy stream */
 
 /* k_dbk of one tick on the side stream (which must already wait for whatever frees the tick's deblocking scratch);
  * records the join event behind it */
@@ -471,15 +488,30 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
     const bool do_dbk = (stages & 4u) && s.any_deblock && s.max_dbk;
     const bool do_copy = (stages & 1u) && s.max_copy;
     const bool aside = side && side->stream && do_dbk;
+    /* k_copy on a stream of its own beside k_recon_inter (and k_dbk): the copies are HBM-bound, the inter kernel is bound by
+     * instruction issue, and they write different macroblocks of the picture; both are joined in front of k_frame_intra, whose
+     * macroblocks read them.  84.5-85.2 against 87.5-88.5 ms per step (docs/EXPERIMENTS.md, "k_copy beside the inter kernels"). */
+    const bool copy_aside = aside && do_copy && side->copy_stream;
+    if (tt) tt->copy_timed = false;
+    auto launch_copy = [&](hipStream_t cs) {
+        hipLaunchKernelGGL(h264k::k_copy, dim3(std::min<uint32_t>((s.max_copy + 3) / 4, COPY_WGS), s.n_frames), dim3(256), 0, cs, d_desc);   /* COPY_WGS workgroups per picture walk its run list */
+        if (launches) launches[0]++;
+    };
     if (aside) {
         HIP_TRY(hipEventRecord(side->fork, st));                 /* after the previous tick's k_frame_dbk: the records are free */
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        if (copy_aside) {
+            const bool ctimed = timed && (tmask & 1u) && tt->sev[3] && tt->sev[4];
+            if (tt) tt->copy_timed = ctimed;
+            HIP_TRY(hipStreamWaitEvent(side->copy_stream, side->fork, 0));
+            if (ctimed) HIP_TRY(hipEventRecord(tt->sev[3], side->copy_stream));
+            launch_copy(side->copy_stream);
+            if (ctimed) HIP_TRY(hipEventRecord(tt->sev[4], side->copy_stream));
+            HIP_TRY(hipEventRecord(side->copy_join, side->copy_stream));
+        }
         if (launch_kdbk_aside(side, d_desc, s, tt, launches, stages)) return -1;
     }
-    if (do_copy) {
-        hipLaunchKernelGGL(h264k::k_copy, dim3(std::min<uint32_t>((s.max_copy + 3) / 4, COPY_WGS), s.n_frames), dim3(256), 0, st, d_desc);   /* COPY_WGS workgroups per picture walk its run list */
-        if (launches) launches[0]++;
-    }
+    if (do_copy && !copy_aside) launch_copy(st);
     if (EV_NEEDED(1)) HIP_TRY(hipEventRecord(tt->ev[1], st));
     if ((stages & 1u) && s.max_gen) {
         if (s.max_gen_uni) hipLaunchKernelGGL(h264k::k_recon_inter<0>, dim3((s.max_gen_uni + INTER_WG_WAVES * h264k::inter_per_wave<0>() - 1) / (INTER_WG_WAVES * h264k::inter_per_wave<0>()), s.n_frames), dim3(64 * INTER_WG_WAVES), 0, st, d_desc);
@@ -526,6 +558,7 @@ int launch_tick(hipStream_t st, const FrameDesc *d_desc, const TickShape &s, Tic
         bp.bands = std::max<uint32_t>(std::max(s.n_heavy < s.n_frames ? eff_l : 1u, s.n_heavy ? eff_h : 1u), (s.max_h + rows - 1) / rows);
         return 0;
     };
+    if (copy_aside) HIP_TRY(hipStreamWaitEvent(st, side->copy_join, 0));      /* (the copies have to be there before the intra macroblocks read them) */
     if (s.max_levels && (stages & 2u)) {
         BandPlan bp;
         /* a picture with concealed macroblocks must stay in one band (FjHeader.intra_down_deps): fewer wavefronts, never
@@ -1382,9 +1415,7 @@ static bool replay_schedule(h264bsdmi_replay *r, u32 heavy_lanes, u32 heavy_dela
                 if (k < groups) {
                     ok = hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking) == hipSuccess;
                     if (ok && groups <= 2)        /* with more groups the other groups are the overlap, and busy HIP streams are scarce (Lane, above) */
-                        ok = hipStreamCreateWithFlags(&r->lane_side[k].stream, hipStreamNonBlocking) == hipSuccess &&
-                         hipEventCreateWithFlags(&r->lane_side[k].fork, hipEventDisableTiming) == hipSuccess &&
-                         hipEventCreateWithFlags(&r->lane_side[k].join, hipEventDisableTiming) == hipSuccess;
+                        ok = r->lane_side[k].create(0, false);
                 } else ok = hipStreamCreateWithPriority(&r->lanes[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
             }
             for (auto &ev : r->sched_ev) if (ok) ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
@@ -1517,7 +1548,7 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
     for (auto &ev : r->cev) hipEventDestroy(ev);
     for (auto &st : r->lanes) if (st) { tickets_release(st); hipStreamDestroy(st); }
-    for (auto &sl : r->lane_side) { if (sl.stream) hipStreamDestroy(sl.stream); if (sl.fork) hipEventDestroy(sl.fork); if (sl.join) hipEventDestroy(sl.join); }
+    for (auto &sl : r->lane_side) sl.destroy();
     delete r;
 }
 
@@ -1541,12 +1572,7 @@ int h264bsdmiReplayReschedule(h264bsdmi_replay *r, const u32 *offsets, u32 heavy
     for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
     r->sched_ev.clear(); r->sched.clear();
     for (auto &st : r->lanes) if (st) { tickets_release(st); hipStreamDestroy(st); st = nullptr; }
-    for (auto &sl : r->lane_side) {
-        if (sl.stream) hipStreamDestroy(sl.stream);
-        if (sl.fork) hipEventDestroy(sl.fork);
-        if (sl.join) hipEventDestroy(sl.join);
-        sl = SideLane();
-    }
+    for (auto &sl : r->lane_side) sl.destroy();
     r->n_lanes = r->n_light = 0;
     r->n_groups = 1;                                  /* (h264bsdmiReplaySetGroups: a property of the schedule it was set for) */
     r->convert_fmt = -1; r->timed_mask = 31u; r->stages = 7u;
@@ -1683,8 +1709,12 @@ int h264bsdmiReplayTimings(h264bsdmi_replay *r, float out_ms[6], u32 launches[5]
             }
             if ((r->timed_mask & 4u) && r->overlap_dbk && !(r->stages & 8u) && r->n_groups == 1 && r->timers[i].sev[0] &&
                 hipEventQuery(r->timers[i].sev[2]) == hipSuccess) {
-                float ms;                                /* k_copy and k_dbk ran on the side stream, next to the kernels above */
+                float ms;                                /* k_dbk ran on the side stream, next to the kernels above */
                 if (hipEventElapsedTime(&ms, r->timers[i].sev[1], r->timers[i].sev[2]) == hipSuccess) out_ms[2] += ms;
+            }
+            if (r->timers[i].copy_timed && hipEventQuery(r->timers[i].sev[4]) == hipSuccess) {
+                float ms;                                /* and so did k_copy, on a stream of its own (zero when the tick had no copy to launch) */
+                if (hipEventElapsedTime(&ms, r->timers[i].sev[3], r->timers[i].sev[4]) == hipSuccess) out_ms[0] += ms;
             }
         }
     if (r->timed_count || !r->sched.empty()) HIP_TRY(hipEventElapsedTime(&out_ms[5], r->ev_begin, r->ev_end));
