@@ -1573,6 +1573,9 @@ int h264bsdmiReplayReschedule(h264bsdmi_replay *r, const u32 *offsets, u32 heavy
     r->sched_ev.clear(); r->sched.clear();
     for (auto &st : r->lanes) if (st) { tickets_release(st); hipStreamDestroy(st); st = nullptr; }
     for (auto &sl : r->lane_side) sl.destroy();
+    /* the stream groups' HIP streams go as well (h264bsdmiReplaySetGroups makes them again): a schedule with many lanes needs every
+     * hardware queue the runtime has — idle streams hold on to theirs, and past ~12 busy streams on shared queues the runtime crawls */
+    for (int g = 0; g < 8; g++) if (r->gstream[g]) { tickets_release(r->gstream[g]); hipStreamDestroy(r->gstream[g]); r->gstream[g] = nullptr; }
     r->n_lanes = r->n_light = 0;
     r->n_groups = 1;                                  /* (h264bsdmiReplaySetGroups: a property of the schedule it was set for) */
     r->convert_fmt = -1; r->timed_mask = 31u; r->stages = 7u;

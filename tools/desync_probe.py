@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Desynchronised streams (every stream at its own picture index): lap time of the common-tick schedule and of the
 heavy-lane schedules, verified against the golden checksums at the end of a lap.
-usage: desync_probe.py [streams] [K,D[,G] ...]   K heavy lanes, D rejoin delay in ticks, G stream groups"""
+usage: desync_probe.py [streams] [K,D[,G] ...]   K heavy lanes, D rejoin delay in ticks, G stream groups
+OFFSETS=staggered: the staggered set of bench.py (odd streams start at the second IDR) instead of every stream at its own index"""
 import sys, os, json, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +15,9 @@ heads = [h.job_header(j) for j in jobs]
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 P = len(jobs)
 offsets = [(s * P) // S for s in range(S)]
+if os.environ.get("OFFSETS") == "staggered":
+    idr = [i for i, hd in enumerate(heads) if hd["is_idr"] and i > 0][0]
+    offsets = [idr if s & 1 else 0 for s in range(S)]
 cfgs = ([] if os.environ.get("NOBASE") else [(0, 0, 1)]) + [tuple(int(x) for x in a.split(",")) for a in sys.argv[2:]]
 for cfg in cfgs:
     K, D = cfg[0], cfg[1]
