@@ -5,11 +5,12 @@
  *
  * Execution model.  A tick holds at most one picture per stream (pictures of one stream depend on each other
  * through the DPB; pictures of different streams never do).  A tick of N pictures is SIX launches (launch_tick):
- *     k_copy            grid (32, N)          x 256  whole-sample copy macroblocks, one run of <= 8 tiles per wavefront
+ *     k_copy            grid (32, N)          x 256  whole-sample copy macroblocks, one run of <= 8 tiles per wavefront; on a HIP stream of its own
+ *                                                    next to the inter kernels (single-lane engine and replay sets: SideLane), joined before k_frame_intra
  *     k_recon_inter<0>  grid (n_uni/4, N)     x 256  inter macroblocks with one motion vector, one wavefront each
  *     k_recon_inter<1>  grid (n_quad/4, N)    x 256  inter macroblocks with one motion vector per 8x8 quadrant
  *     k_recon_inter<2>  grid (n_rest/4, N)    x 256  finer partitions
- *     k_dbk             grid (32, N)          x 256  boundary strengths from metadata; on a second HIP stream, next to the three above
+ *     k_dbk             grid (32, N)          x 256  boundary strengths from metadata; on a third HIP stream, next to the four above, joined before k_frame_dbk
  *     k_frame_intra     grid (N)              x 768  one workgroup per picture: intra macroblocks, dataflow-scheduled in LDS
  *     k_frame_dbk       grid (N)              x 768  one workgroup per picture: in-loop filter, dataflow-scheduled in LDS
  * Occupancy of the two per-picture kernels comes from batching streams: 256 pictures = one workgroup per CU.

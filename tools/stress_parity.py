@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test of the per-picture schedulers (hand-over inside a workgroup without a wait for the stores): the
 256-stream 1080p replay, every picture of every stream checked against the reference's checksum after EVERY tick, lap
-after lap, in the lock-step schedule and in the banded / desynchronised ones.  usage: stress_parity.py [laps]"""
+after lap, in the lock-step schedule and in the banded ones; then whole laps without a host synchronisation between ticks.  usage: stress_parity.py [laps]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -36,6 +36,22 @@ for S2 in (4, 16):
             if not (sums == np.uint64(g[i])).all():
                 bad += 1; print(f"{S2} streams, lap {lap} picture {i}: differ")
     print(f"{S2} streams (row bands): {ticks} ticks verified, {bad} bad in total, {time.time() - t0:.0f} s")
+rep.close()
+# whole laps at full speed (no host synchronisation between the ticks: k_copy and k_dbk of tick i + 1 run on their own HIP streams
+# right behind tick i's k_frame_dbk): after every lap, the picture every frame-buffer slot was written with last
+rep = h.Replay(jobs, n_streams=S)
+last_in_slot = {}
+for i in range(n):
+    last_in_slot[heads[i]["cur_slot"]] = i
+t0 = time.time(); checked = 0
+for lap in range(laps):
+    rep.run(); rep.sync()
+    for slot, i in last_in_slot.items():
+        sums = rep.checksums(slot)
+        checked += 1
+        if not (sums == np.uint64(g[i])).all():
+            bad += 1; print(f"full-speed lap {lap}: slot {slot} (picture {i}): {(sums != np.uint64(g[i])).sum()} streams differ")
+print(f"full-speed laps: {laps} laps of {n} ticks x {S} streams, {checked} slot checks ({len(last_in_slot)} slots per lap), {bad} bad in total, {time.time() - t0:.0f} s")
 rep.close()
 print("device errors", h.device_errors())
 sys.exit(1 if bad else 0)
