@@ -224,6 +224,31 @@ def test_config4_at_full_size_256_streams(built, captured, golden):
     rep.close()
 
 
+@pytest.mark.parametrize("name,streams,laps", [("test_1920x1080", 256, 3), ("test_640x360", 48, 6)])
+def test_whole_laps_without_a_host_synchronisation_between_ticks(name, streams, laps, built, captured, golden):
+    """The lock-step schedule as bench.py times it: all ticks of a lap enqueued back to back — k_copy and k_dbk of tick i + 1 on HIP
+    streams of their own right behind tick i's k_frame_dbk (engine.hip launch_tick) — and only then the device-computed checksums
+    of the picture every frame-buffer slot was written with last, for all streams.  (The per-tick tests above put a host
+    synchronisation between two ticks.)"""
+    jobs, _, _ = captured(name)
+    g = golden[name]["frame_checksum64"]
+    last_in_slot = {}
+    for i, job in enumerate(jobs):
+        last_in_slot[pyoracle.blob_header(job)["cur_slot"]] = i
+    errs_before = built.device_error_events()
+    rep = built.Replay(jobs, n_streams=streams)
+    try:
+        for lap in range(laps):
+            rep.run()
+            rep.sync()
+            for slot, i in last_in_slot.items():
+                sums = rep.checksums(slot)
+                assert sums.shape == (streams,) and (sums == np.uint64(g[i])).all(), f"lap {lap}: slot {slot}, picture {i}"
+        assert built.device_error_events() == errs_before
+    finally:
+        rep.close()
+
+
 @pytest.mark.parametrize("name,streams", [("test_640x360", 5), ("test_1920x1080", 3)])
 def test_hosted_colour_conversion_equals_the_launch(name, streams, built, captured, golden):
     """Config 3 inside a run: the pictures of tick i - 1 are converted by wavefronts of tick i's k_frame_dbk workgroups
