@@ -1264,6 +1264,29 @@ struct h264bsdmi_replay {
     hipStream_t lanes[MAX_LANES] = {};
     SideLane lane_side[MAX_LANES];        /* k_dbk next to the reconstruction kernels, per light lane */
     uint32_t n_lanes = 0, n_light = 0;
+    /* HIP streams of earlier schedules of this set, reused by the next one (normal priority: light lanes and stream groups; highest: heavy
+     * lanes; side-stream pairs).  A process that creates and destroys a dozen streams per schedule falls off the runtime's stream cliff after
+     * a few of them (a 12-lane schedule then takes seconds per lap, the same schedule in a fresh process 0.13 s): nothing is destroyed before the set is. */
+    std::vector<hipStream_t> pool_normal, pool_high;
+    std::vector<SideLane> pool_side;
+    void retire_streams()
+    {
+        for (uint32_t k = 0; k < (uint32_t)MAX_LANES; k++) {
+            if (lanes[k]) { (k < n_light ? pool_normal : pool_high).push_back(lanes[k]); lanes[k] = nullptr; }
+            if (lane_side[k].stream) { pool_side.push_back(lane_side[k]); lane_side[k] = SideLane(); }
+        }
+    }
+    bool take_stream(hipStream_t *st, bool high, int prio)
+    {
+        std::vector<hipStream_t> &pool = high ? pool_high : pool_normal;
+        if (!pool.empty()) { *st = pool.back(); pool.pop_back(); return true; }
+        return (high ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(st, hipStreamNonBlocking)) == hipSuccess;
+    }
+    bool take_side(SideLane *sl)
+    {
+        if (!pool_side.empty()) { *sl = pool_side.back(); pool_side.pop_back(); return true; }
+        return sl->create(0, false);
+    }
     std::vector<uint32_t> offsets;    /* first picture of every stream */
     /* what a schedule is built from (replay_schedule: at creation and again for every h264bsdmiReplayReschedule) */
     std::vector<FjHeader> heads;      /* the headers of the n_pics jobs (host copies) */
@@ -1414,10 +1437,10 @@ static bool replay_schedule(h264bsdmi_replay *r, u32 heavy_lanes, u32 heavy_dela
             if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
             for (u32 k = 0; ok && k < r->n_lanes; k++) {
                 if (k < groups) {
-                    ok = hipStreamCreateWithFlags(&r->lanes[k], hipStreamNonBlocking) == hipSuccess;
+                    ok = r->take_stream(&r->lanes[k], false, 0);
                     if (ok && groups <= 2)        /* with more groups the other groups are the overlap, and busy HIP streams are scarce (Lane, above) */
-                        ok = r->lane_side[k].create(0, false);
-                } else ok = hipStreamCreateWithPriority(&r->lanes[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
+                        ok = r->take_side(&r->lane_side[k]);
+                } else ok = r->take_stream(&r->lanes[k], true, prio_greatest);
             }
             for (auto &ev : r->sched_ev) if (ok) ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
         }
@@ -1548,8 +1571,9 @@ void h264bsdmiReplayDestroy(h264bsdmi_replay *r)
     for (int g = 0; g < 8; g++) { if (r->gstream[g]) { tickets_release(r->gstream[g]); hipStreamDestroy(r->gstream[g]); } if (r->gdone[g]) hipEventDestroy(r->gdone[g]); }
     for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
     for (auto &ev : r->cev) hipEventDestroy(ev);
-    for (auto &st : r->lanes) if (st) { tickets_release(st); hipStreamDestroy(st); }
-    for (auto &sl : r->lane_side) sl.destroy();
+    r->retire_streams();
+    for (auto *pool : { &r->pool_normal, &r->pool_high }) for (auto &st : *pool) { tickets_release(st); hipStreamDestroy(st); }
+    for (auto &sl : r->pool_side) sl.destroy();
     delete r;
 }
 
@@ -1572,11 +1596,8 @@ int h264bsdmiReplayReschedule(h264bsdmi_replay *r, const u32 *offsets, u32 heavy
     if (poll_errors(e)) return -1;
     for (auto &ev : r->sched_ev) if (ev) hipEventDestroy(ev);
     r->sched_ev.clear(); r->sched.clear();
-    for (auto &st : r->lanes) if (st) { tickets_release(st); hipStreamDestroy(st); st = nullptr; }
-    for (auto &sl : r->lane_side) sl.destroy();
-    /* the stream groups' HIP streams go as well (h264bsdmiReplaySetGroups makes them again): a schedule with many lanes needs every
-     * hardware queue the runtime has — idle streams hold on to theirs, and past ~12 busy streams on shared queues the runtime crawls */
-    for (int g = 0; g < 8; g++) if (r->gstream[g]) { tickets_release(r->gstream[g]); hipStreamDestroy(r->gstream[g]); r->gstream[g] = nullptr; }
+    r->retire_streams();                               /* (kept for the next schedule: h264bsdmi_replay::pool_*) */
+    for (int g = 0; g < 8; g++) if (r->gstream[g]) { r->pool_normal.push_back(r->gstream[g]); r->gstream[g] = nullptr; }      /* h264bsdmiReplaySetGroups takes them back */
     r->n_lanes = r->n_light = 0;
     r->n_groups = 1;                                  /* (h264bsdmiReplaySetGroups: a property of the schedule it was set for) */
     r->convert_fmt = -1; r->timed_mask = 31u; r->stages = 7u;
@@ -1681,7 +1702,7 @@ int h264bsdmiReplaySetGroups(h264bsdmi_replay *r, u32 n_groups)
         r->timers.push_back(t);
     }
     for (u32 g = 0; g < n_groups; g++) {
-        if (!r->gstream[g]) HIP_TRY(hipStreamCreateWithFlags(&r->gstream[g], hipStreamNonBlocking));
+        if (!r->gstream[g] && !r->take_stream(&r->gstream[g], false, 0)) return -1;
         if (!r->gdone[g]) HIP_TRY(hipEventCreateWithFlags(&r->gdone[g], hipEventDisableTiming));
     }
     r->n_groups = n_groups;
