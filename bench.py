@@ -535,6 +535,8 @@ def main():
                 desync["heavy_lanes_stream_groups"] = leg
                 break
             fell.append({"stream_groups": groups, "lap_ms": leg["lap_ms"]})
+        if "heavy_lanes_stream_groups" not in desync:
+            desync["stream_cliff"] = fell                       # (a list, not a leg: every schedule with stream groups took seconds per lap)
 
     if shared["rep"] is not None:
         shared["rep"].close()
