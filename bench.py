@@ -489,13 +489,11 @@ def main():
                     last = (offsets[st] - 1) % n_pics
                     if int(sums[heads[last]["cur_slot"]][st]) != golden_sums[last]:
                         raise SystemExit(f"rank {rank}: desynchronised set ({key}): stream {st} is not bit-exact")
-            rep.run(); rep.run(); rep.sync()
-            verify_lap()
+            t0 = time.perf_counter()
+            rep.run(); rep.sync()
+            lap_ms = (time.perf_counter() - t0) * 1e3               # (the first lap: a schedule on the cliff is given up after one of them)
             if cliff_ms is not None:
-                t0 = time.perf_counter()
-                rep.run(); rep.sync()
-                lap_ms = (time.perf_counter() - t0) * 1e3
-                slow = lap_ms > cliff_ms
+                slow = lap_ms > max(cliff_ms, 1500.0)      # (a first lap also pays for new HIP streams: cliff laps measured 2-21 s, good ones 0.13-0.4 s)
                 if dist is not None:                      # (every rank takes the same branch)
                     tt = torch.tensor([1.0 if slow else 0.0], dtype=torch.float64, device=red_dev)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -503,6 +501,8 @@ def main():
                 if slow:
                     release(rep)
                     return {"lap_ms": lap_ms}
+            rep.run(); rep.sync()
+            verify_lap()
             barrier()
             t0 = time.perf_counter()
             for _ in range(side_steps):
